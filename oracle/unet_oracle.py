@@ -1,0 +1,372 @@
+"""CPU oracle for the U-Net hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+This file is a *functional* restatement (plain PyTorch CPU fp32, ``torch.nn.functional`` only) of the
+forward dataflow of the four reference models and of the loss / train-step arithmetic that sits on the
+hot path.  It exists so that the HIP engine can be checked on the GPU box, where ``/root/reference`` does
+not exist.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import it; the product package (``bio_image_unet_amd``) never does.
+
+Pinned by: ``tests/golden/*.npz`` -- vectors produced by importing the reference model files by path
+(``tests/golden/make_golden.py``) -- and asserted equal in ``tests/test_oracle_golden.py``.
+
+Every model is expressed over a flat ``dict[str, Tensor]`` that uses the reference's ``state_dict`` key
+schema, so a reference checkpoint, a golden fixture and the product's ``state_dict()`` are all
+interchangeable inputs.
+
+Reference citations (relative to /root/reference/bio_image_unet):
+  * conv->BN->LeakyReLU(0.1)->Dropout(0) block ........ unet/unet.py:54-60, unet3d/unet3d.py:52-58,
+                                                        siam_unet/siam_unet.py:59-65,
+                                                        multi_output_unet3d/multi_output_unet3d.py:84-92
+  * Unet.forward ...................................... unet/unet.py:69-104
+  * UNet3D.forward .................................... unet3d/unet3d.py:63-99
+  * Siam_UNet.forward / depthwise_xcorr ............... siam_unet/siam_unet.py:85-148, 75-83
+  * MultiOutputUnet3D.forward / apply_activation ...... multi_output_unet3d/multi_output_unet3d.py:106-170, 97-104
+  * BCELoss2d / SoftDiceLoss / BCEDiceLoss / Tversky .. unet/losses.py:5-37, 40-75, 78-112, 145-191
+  * 2D Trainer loss expression (batch-axis quirk) ..... unet/train.py:133-134
+  * 3D Trainer loss (SmoothL1 "time" term) ............ unet3d/train.py:140-145
+  * init_weights ...................................... utils/utils.py:76-78
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5        # nn.BatchNorm default (unet/unet.py:57 uses defaults)
+BN_MOMENTUM = 0.1
+LRELU_SLOPE = 0.1    # unet/unet.py:58
+
+State = Dict[str, torch.Tensor]
+
+
+# --------------------------------------------------------------------------------------------------
+# building blocks
+# --------------------------------------------------------------------------------------------------
+def conv_block(sd: State, name: str, x: torch.Tensor, *, training: bool, dilation: int = 1) -> torch.Tensor:
+    """``nn.Sequential(ConvNd(k=3, padding=d, dilation=d), BatchNormNd, LeakyReLU(0.1), Dropout(0))``.
+
+    Train mode: batch statistics (biased var) normalise, running stats updated with unbiased var and
+    momentum 0.1, ``num_batches_tracked += 1`` -- exactly what ``F.batch_norm`` does when handed the
+    running buffers.  Eval mode: running statistics.
+    """
+    w = sd[f"{name}.0.weight"]
+    b = sd[f"{name}.0.bias"]
+    conv = F.conv3d if w.dim() == 5 else F.conv2d
+    y = conv(x, w, b, padding=dilation, dilation=dilation)
+    rm, rv = sd[f"{name}.1.running_mean"], sd[f"{name}.1.running_var"]
+    if training:
+        nbt = sd.get(f"{name}.1.num_batches_tracked")
+        if nbt is not None:
+            nbt += 1
+    y = F.batch_norm(y, rm, rv, sd[f"{name}.1.weight"], sd[f"{name}.1.bias"],
+                     training=training, momentum=BN_MOMENTUM, eps=BN_EPS)
+    return F.leaky_relu(y, LRELU_SLOPE)
+
+
+def up_conv_t(sd: State, name: str, x: torch.Tensor) -> torch.Tensor:
+    """``nn.ConvTranspose{2,3}d(k=2, stride=2)`` (unet/unet.py:38, unet3d/unet3d.py:40)."""
+    w = sd[f"{name}.weight"]
+    f = F.conv_transpose3d if w.dim() == 5 else F.conv_transpose2d
+    return f(x, w, sd[f"{name}.bias"], stride=2)
+
+
+def checked_concat(x1: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """unet/unet.py:62-67 -- order is (upsampled, skip); mismatch raises ValueError."""
+    if x1.shape != x2.shape:
+        raise ValueError("concatenation failed: wrong dimensions")
+    return torch.cat((x1, x2), 1)
+
+
+def head_activation(x: torch.Tensor, activation: Optional[str]) -> torch.Tensor:
+    """multi_output_unet3d/multi_output_unet3d.py:97-104."""
+    if activation == "sigmoid":
+        return torch.sigmoid(x)
+    if activation == "tanh":
+        return torch.tanh(x)
+    if activation == "relu":
+        return F.relu(x)
+    return x
+
+
+# --------------------------------------------------------------------------------------------------
+# models
+# --------------------------------------------------------------------------------------------------
+def _decoder2d(sd: State, mid2, skips, training: bool):
+    """Shared 2-D decoder of Unet and Siam_UNet (unet/unet.py:87-104)."""
+    e2, e4, e6, e8 = skips
+    t = mid2
+    for lvl, skip in zip((1, 2, 3, 4), (e8, e6, e4, e2)):
+        t = checked_concat(up_conv_t(sd, f"up{lvl}", t), skip)
+        t = conv_block(sd, f"decode{2 * lvl - 1}", t, training=training)
+        t = conv_block(sd, f"decode{2 * lvl}", t, training=training)
+    logits = F.conv2d(t, sd["final.0.weight"], sd["final.0.bias"])
+    return torch.sigmoid(logits), logits
+
+
+def _encoder2d(sd: State, x, training: bool, dilation: int):
+    """encode1..8 with 2x2 max-pools; returns (pooled bottleneck input, skips)."""
+    skips = []
+    t = x
+    for lvl in range(4):
+        t = conv_block(sd, f"encode{2 * lvl + 1}", t, training=training, dilation=dilation)
+        t = conv_block(sd, f"encode{2 * lvl + 2}", t, training=training, dilation=dilation)
+        skips.append(t)
+        t = F.max_pool2d(t, 2, 2)
+    return t, skips
+
+
+def unet2d_forward(sd: State, x: torch.Tensor, *, dilation: int = 1, training: bool = True):
+    """``Unet.forward`` -> (sigmoid(logits), logits)."""
+    m4, skips = _encoder2d(sd, x, training, dilation)
+    mid = conv_block(sd, "middle_conv1", m4, training=training, dilation=dilation)
+    mid = conv_block(sd, "middle_conv2", mid, training=training, dilation=dilation)
+    return _decoder2d(sd, mid, skips, training)
+
+
+def depthwise_xcorr(cur: torch.Tensor, prev: torch.Tensor) -> torch.Tensor:
+    """siam_unet/siam_unet.py:75-83: per-sample, per-channel correlation with padding='same'."""
+    b, c, h, w = prev.shape
+    out = F.conv2d(cur.reshape(1, b * c, h, w), prev.reshape(b * c, 1, h, w), groups=b * c, padding="same")
+    return out.view(b, c, out.size(2), out.size(3))
+
+
+def siam_forward(sd: State, x: torch.Tensor, prev_x: torch.Tensor, *, mode: str = "concat",
+                 training: bool = True):
+    """``Siam_UNet.forward``: weight-shared encoder applied to x then prev_x (BN stats per call)."""
+    m4, skips = _encoder2d(sd, x, training, 1)
+    mm4, _ = _encoder2d(sd, prev_x, training, 1)
+    if mode == "corr":
+        join = depthwise_xcorr(m4, mm4)
+    elif mode == "max":
+        join = torch.maximum(m4, mm4)
+    elif mode == "concat":
+        join = conv_block(sd, "conv_concat", checked_concat(m4, mm4), training=training)
+    elif mode == "control":
+        join = m4
+    else:
+        raise NotImplementedError("Unknown mode: {}".format(mode))
+    mid = conv_block(sd, "middle_conv1", join, training=training)
+    mid = conv_block(sd, "middle_conv2", mid, training=training)
+    return _decoder2d(sd, mid, skips, training)
+
+
+def _body3d(sd: State, x, *, training: bool, down: str, up: str):
+    """Shared trunk of UNet3D and MultiOutputUnet3D; returns d6 (F//2 channels, full resolution).
+
+    down: 'maxpool' | 'nearest' ; up: 'convT' | 'trilinear' | 'nearest_conv'.
+    """
+    def pool(t):
+        if down == "maxpool":
+            return F.max_pool3d(t, 2, 2)
+        return F.interpolate(t, scale_factor=0.5, mode="nearest")
+
+    def upsample(t, lvl):
+        if up == "convT":
+            return up_conv_t(sd, f"up{lvl}", t)
+        if up == "trilinear":
+            return F.interpolate(t, scale_factor=2, mode="trilinear", align_corners=False)
+        t = F.interpolate(t, scale_factor=2, mode="nearest")
+        return conv_block(sd, f"up{lvl}_conv", t, training=training)
+
+    skips = []
+    t = x
+    for lvl in range(3):
+        t = conv_block(sd, f"encode{2 * lvl + 1}", t, training=training)
+        t = conv_block(sd, f"encode{2 * lvl + 2}", t, training=training)
+        skips.append(t)
+        t = pool(t)
+    t = conv_block(sd, "middle_conv1", t, training=training)
+    t = conv_block(sd, "middle_conv2", t, training=training)
+    for lvl, skip in zip((1, 2, 3), reversed(skips)):
+        t = torch.cat((upsample(t, lvl), skip), 1)          # bare torch.cat in 3-D (unet3d.py:60-61)
+        t = conv_block(sd, f"decode{2 * lvl - 1}", t, training=training)
+        t = conv_block(sd, f"decode{2 * lvl}", t, training=training)
+    return t
+
+
+def unet3d_forward(sd: State, x: torch.Tensor, *, use_interpolation: bool = False, training: bool = True):
+    """``UNet3D.forward`` -> (sigmoid(logits), logits); head key is ``final.weight``."""
+    d6 = _body3d(sd, x, training=training, down="maxpool",
+                 up="trilinear" if use_interpolation else "convT")
+    logits = F.conv3d(d6, sd["final.weight"], sd["final.bias"])
+    return torch.sigmoid(logits), logits
+
+
+def mo3d_forward(sd: State, x: torch.Tensor, output_heads: Dict[str, dict], *,
+                 use_interpolation: bool = True, training: bool = True) -> Dict[str, torch.Tensor]:
+    """``MultiOutputUnet3D.forward`` -> dict of *activated* head outputs (no logits)."""
+    d6 = _body3d(sd, x, training=training,
+                 down="nearest" if use_interpolation else "maxpool",
+                 up="nearest_conv" if use_interpolation else "convT")
+    out = {}
+    for name, cfg in output_heads.items():
+        logits = F.conv3d(d6, sd[f"output_layers.{name}.weight"], sd[f"output_layers.{name}.bias"])
+        out[name] = head_activation(logits, cfg.get("activation"))
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# losses (unet/losses.py)
+# --------------------------------------------------------------------------------------------------
+def soft_dice_loss(logits, targets, smooth: float = 1.0):
+    p = torch.sigmoid(logits)
+    n = targets.size(0)
+    m1, m2 = p.reshape(n, -1), targets.reshape(n, -1)
+    inter = (m1 * m2).sum(1)
+    score = 2.0 * (inter + smooth) / (m1.sum(1) + m2.sum(1) + smooth)
+    return 1 - score.mean()
+
+
+def bce_dice_loss(logits, targets, alpha: float = 0.5, beta: float = 0.5):
+    return alpha * F.binary_cross_entropy_with_logits(logits, targets) + beta * soft_dice_loss(logits, targets)
+
+
+def tversky_loss(logits, targets, alpha: float = 0.5, beta: float = 0.5, smooth: float = 1.0):
+    p = torch.sigmoid(logits).reshape(-1)
+    t = targets.reshape(-1)
+    tp = (p * t).sum()
+    fp = ((1 - t) * p).sum()
+    fn = (t * (1 - p)).sum()
+    return 1 - (tp + smooth) / (tp + alpha * fp + beta * fn + smooth)
+
+
+def logcosh_tversky_loss(logits, targets, alpha: float = 0.5, beta: float = 0.5, smooth: float = 1.0):
+    return torch.log(torch.cosh(tversky_loss(logits, targets, alpha, beta, smooth)))
+
+
+def trainer2d_loss(logits, y, out_channels: int, channel_weights=None, criterion=bce_dice_loss):
+    """unet/train.py:133-134 -- NOTE the quirk: ``y_logits[ch]`` indexes the *batch* axis."""
+    cw = torch.ones(out_channels) if channel_weights is None else torch.as_tensor(channel_weights)
+    return sum(criterion(logits[ch], y[ch]) * cw[j] for j, ch in enumerate(range(out_channels))) / cw.sum()
+
+
+def trainer3d_loss(logits, y, time_loss_weight: float = 0.1, criterion=bce_dice_loss):
+    """unet3d/train.py:140-145 -- SmoothL1 between neighbouring *batch* entries."""
+    # batch == 1 gives empty slices -> nan, exactly as the reference does
+    return criterion(logits, y) + F.smooth_l1_loss(logits[1:], logits[:-1]) * time_loss_weight
+
+
+# --------------------------------------------------------------------------------------------------
+# parameter construction (reference key schema, PyTorch default init)
+# --------------------------------------------------------------------------------------------------
+def _conv_default_init(shape, fan_in, gen):
+    bound = 1.0 / math.sqrt(fan_in)      # kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), +1/sqrt(fan_in))
+    w = (torch.rand(shape, generator=gen) * 2 - 1) * bound
+    return w
+
+
+def _add_block(sd: State, name: str, cin: int, cout: int, nd: int, gen, kaiming_normal: bool):
+    k = (3,) * nd
+    fan_in = cin * 3 ** nd
+    if kaiming_normal:   # utils/utils.py:76-78: kaiming_normal_(nonlinearity='leaky_relu') => std = sqrt(2/fan_in)
+        sd[f"{name}.0.weight"] = torch.randn((cout, cin) + k, generator=gen) * math.sqrt(2.0 / fan_in)
+    else:
+        sd[f"{name}.0.weight"] = _conv_default_init((cout, cin) + k, fan_in, gen)
+    sd[f"{name}.0.bias"] = _conv_default_init((cout,), fan_in, gen)
+    sd[f"{name}.1.weight"] = torch.ones(cout)
+    sd[f"{name}.1.bias"] = torch.zeros(cout)
+    sd[f"{name}.1.running_mean"] = torch.zeros(cout)
+    sd[f"{name}.1.running_var"] = torch.ones(cout)
+    sd[f"{name}.1.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+
+
+def _add_up(sd: State, name: str, cin: int, cout: int, nd: int, gen):
+    # ConvTranspose weight (Cin, Cout, 2, 2[,2]); torch computes fan_in from dim 1 => cout * 2**nd
+    fan_in = cout * 2 ** nd
+    sd[f"{name}.weight"] = _conv_default_init((cin, cout) + (2,) * nd, fan_in, gen)
+    sd[f"{name}.bias"] = _conv_default_init((cout,), fan_in, gen)
+
+
+def _add_head(sd: State, name: str, cin: int, cout: int, nd: int, gen, kaiming_normal: bool = False):
+    if kaiming_normal:
+        sd[f"{name}.weight"] = torch.randn((cout, cin) + (1,) * nd, generator=gen) * math.sqrt(2.0 / cin)
+    else:
+        sd[f"{name}.weight"] = _conv_default_init((cout, cin) + (1,) * nd, cin, gen)
+    sd[f"{name}.bias"] = _conv_default_init((cout,), cin, gen)
+
+
+def init_unet2d(in_channels=1, out_channels=1, n_filter=32, *, seed=0, init_weights=True, siam_mode=None) -> State:
+    """Keys/shapes of ``Unet`` (unet/unet.py:16-52) or ``Siam_UNet`` (siam_unet.py:18-57, in=out=1)."""
+    g = torch.Generator().manual_seed(seed)
+    f = n_filter
+    sd: State = {}
+    chans = [in_channels, f, f, 2 * f, 2 * f, 4 * f, 4 * f, 8 * f, 8 * f]
+    for i in range(8):
+        _add_block(sd, f"encode{i + 1}", chans[i], chans[i + 1], 2, g, init_weights)
+    if siam_mode == "concat":
+        _add_block(sd, "conv_concat", 16 * f, 8 * f, 2, g, init_weights)
+    _add_block(sd, "middle_conv1", 8 * f, 16 * f, 2, g, init_weights)
+    _add_block(sd, "middle_conv2", 16 * f, 16 * f, 2, g, init_weights)
+    c = 16 * f
+    for lvl in (1, 2, 3, 4):
+        _add_up(sd, f"up{lvl}", c, c // 2, 2, g)
+        _add_block(sd, f"decode{2 * lvl - 1}", c, c // 2, 2, g, init_weights)
+        _add_block(sd, f"decode{2 * lvl}", c // 2, c // 2, 2, g, init_weights)
+        c //= 2
+    _add_head(sd, "final.0", f, out_channels, 2, g, init_weights)
+    return sd
+
+
+def _init_body3d(sd: State, in_channels, f, g, *, convT: bool, up_convs: bool):
+    plan = [("encode1", in_channels, f // 2), ("encode2", f // 2, f), ("encode3", f, f), ("encode4", f, 2 * f),
+            ("encode5", 2 * f, 2 * f), ("encode6", 2 * f, 4 * f), ("middle_conv1", 4 * f, 4 * f),
+            ("middle_conv2", 4 * f, 8 * f)]
+    for name, ci, co in plan:
+        _add_block(sd, name, ci, co, 3, g, False)
+    if convT:
+        for lvl, c in ((1, 8 * f), (2, 4 * f), (3, 2 * f)):
+            _add_up(sd, f"up{lvl}", c, c, 3, g)
+    if up_convs:
+        for lvl, c in ((1, 8 * f), (2, 4 * f), (3, 2 * f)):
+            _add_block(sd, f"up{lvl}_conv", c, c, 3, g, False)
+    for name, ci, co in [("decode1", 12 * f, 4 * f), ("decode2", 4 * f, 4 * f), ("decode3", 6 * f, 2 * f),
+                         ("decode4", 2 * f, 2 * f), ("decode5", 3 * f, f), ("decode6", f, f // 2)]:
+        _add_block(sd, name, ci, co, 3, g, False)
+
+
+def init_unet3d(in_channels=1, out_channels=1, n_filter=16, use_interpolation=False, *, seed=0) -> State:
+    """Keys/shapes of ``UNet3D`` (unet3d/unet3d.py:18-50); PyTorch default init (init_weights skips Conv3d)."""
+    g = torch.Generator().manual_seed(seed)
+    sd: State = {}
+    _init_body3d(sd, in_channels, n_filter, g, convT=not use_interpolation, up_convs=False)
+    _add_head(sd, "final", n_filter // 2, out_channels, 3, g)
+    return sd
+
+
+def init_mo3d(in_channels=1, output_heads=None, n_filter=16, use_interpolation=True, *, seed=0) -> State:
+    """Keys/shapes of ``MultiOutputUnet3D`` (multi_output_unet3d.py:13-82)."""
+    heads = output_heads or {"default": {"channels": 1, "activation": "sigmoid"}}
+    g = torch.Generator().manual_seed(seed)
+    sd: State = {}
+    _init_body3d(sd, in_channels, n_filter, g, convT=not use_interpolation, up_convs=use_interpolation)
+    for name, cfg in heads.items():
+        _add_head(sd, f"output_layers.{name}", n_filter // 2, cfg["channels"], 3, g)
+    return sd
+
+
+# --------------------------------------------------------------------------------------------------
+# helpers for tests / bench
+# --------------------------------------------------------------------------------------------------
+PARAM_SUFFIXES = (".weight", ".bias")
+
+
+def is_param(key: str) -> bool:
+    return key.endswith(PARAM_SUFFIXES)
+
+
+def clone_state(sd: State, requires_grad: bool = False) -> State:
+    out = {}
+    for k, v in sd.items():
+        t = v.detach().clone()
+        if requires_grad and is_param(k) and t.is_floating_point():
+            t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+def grads_of(loss: torch.Tensor, sd: State) -> Dict[str, torch.Tensor]:
+    keys = [k for k, v in sd.items() if v.requires_grad]
+    gs = torch.autograd.grad(loss, [sd[k] for k in keys], allow_unused=True)
+    return {k: (g if g is not None else torch.zeros_like(sd[k])) for k, g in zip(keys, gs)}

@@ -1,0 +1,162 @@
+"""Generate the golden fixtures in this directory from the REFERENCE implementation.
+
+Run in the build container only (``/root/reference`` is absent on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference's model files (and ``unet/losses.py``) import nothing but torch, so they are loaded *by file
+path* (the package ``__init__`` files pull in tifffile/skimage, which are not installed -- SURVEY.md 8c).
+Only tensors leave this script: inputs, state_dict, outputs, loss, gradients, BN buffers.  No reference
+source or bytecode is written anywhere.
+
+Each fixture ``<case>.npz`` holds:
+  meta_json                         ctor kwargs, seeds, loss description
+  in.<name>                         inputs (x, prev_x, target)
+  sd.<key>                          initial state_dict (float32 / int64)
+  train.<out>                       outputs of a train-mode forward (BN batch stats) from the initial state
+  loss                              scalar loss driven through the reference's own loss code
+  grad.<key>                        d loss / d parameter for every parameter
+  sd1.<key>                         BN buffers after that one train-mode forward
+  eval.<out>                        outputs of an eval-mode forward from the *post-step-1* buffers
+"""
+import importlib.util
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference/bio_image_unet"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+
+
+def load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+unet_mod = load("ref_unet", "unet/unet.py")
+unet3d_mod = load("ref_unet3d", "unet3d/unet3d.py")
+siam_mod = load("ref_siam", "siam_unet/siam_unet.py")
+mo3d_mod = load("ref_mo3d", "multi_output_unet3d/multi_output_unet3d.py")
+losses_mod = load("ref_losses", "unet/losses.py")
+
+
+def ref_init_weights(m):
+    # restated from utils/utils.py:76-78 (that module imports tifffile at top level, so it cannot be imported here)
+    if isinstance(m, torch.nn.Conv2d):
+        torch.nn.init.kaiming_normal_(m.weight, nonlinearity="leaky_relu")
+
+
+def dump(case, meta, model, inputs, target, loss_fn, out_names, call):
+    """Drive one reference train-mode step (forward + loss + backward), then an eval forward."""
+    arrays = {"meta_json": np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)}
+    for k, v in inputs.items():
+        arrays[f"in.{k}"] = v.numpy()
+    if target is not None:
+        if isinstance(target, dict):
+            for k, v in target.items():
+                arrays[f"in.target.{k}"] = v.numpy()
+        else:
+            arrays["in.target"] = target.numpy()
+    for k, v in model.state_dict().items():
+        arrays[f"sd.{k}"] = v.detach().clone().numpy()
+    model.train()
+    outs = call(model)
+    if isinstance(outs, dict):
+        outs_t = [outs[n] for n in out_names]
+    else:
+        outs_t = list(outs)
+    for n, t in zip(out_names, outs_t):
+        arrays[f"train.{n}"] = t.detach().numpy()
+    loss = loss_fn(outs)
+    arrays["loss"] = loss.detach().numpy()
+    model.zero_grad()
+    loss.backward()
+    for k, p in model.named_parameters():
+        arrays[f"grad.{k}"] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    for k, v in model.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            arrays[f"sd1.{k}"] = v.detach().clone().numpy()
+    model.eval()
+    with torch.no_grad():
+        outs = call(model)
+    outs_t = [outs[n] for n in out_names] if isinstance(outs, dict) else list(outs)
+    for n, t in zip(out_names, outs_t):
+        arrays[f"eval.{n}"] = t.detach().numpy()
+    path = os.path.join(HERE, f"{case}.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{case}: {os.path.getsize(path) / 1e6:.2f} MB, loss={float(loss):.6f}")
+
+
+def main():
+    bce_dice = losses_mod.BCEDiceLoss(0.5, 0.5)
+    tversky = losses_mod.TverskyLoss(0.5, 0.5)
+
+    # ---- (i) Unet 2-D ------------------------------------------------------------------------
+    for case, kw, hw, crit, crit_name in [
+        ("unet2d_f4", dict(in_channels=1, out_channels=1, n_filter=4, dilation=1), (32, 48), bce_dice, "BCEDice(0.5,0.5)"),
+        ("unet2d_f4_o2_dil2", dict(in_channels=2, out_channels=2, n_filter=4, dilation=2), (32, 32), tversky, "Tversky(0.5,0.5)"),
+    ]:
+        torch.manual_seed(0)
+        m = unet_mod.Unet(**kw)
+        m.apply(ref_init_weights)
+        x = torch.rand(2, kw["in_channels"], *hw)
+        y = (torch.rand(2, kw["out_channels"], *hw) > 0.5).float()
+        oc = kw["out_channels"]
+        # the reference Trainer's loss expression, verbatim semantics of unet/train.py:133-134
+        loss_fn = lambda outs, y=y, oc=oc, crit=crit: sum(
+            crit(outs[1][ch], y[ch]) * torch.ones(oc)[j] for j, ch in enumerate(range(oc))) / sum(torch.ones(oc))
+        dump(case, dict(model="Unet", ctor=kw, seed=0, loss=f"unet/train.py:133-134 with {crit_name}", init="init_weights"),
+             m, {"x": x}, y, loss_fn, ["prob", "logits"], lambda mod, x=x: mod(x))
+
+    # ---- (ii) UNet3D ---------------------------------------------------------------------------
+    smooth_l1 = torch.nn.SmoothL1Loss()
+    for case, kw in [("unet3d_f4", dict(in_channels=1, out_channels=1, n_filter=4, use_interpolation=False)),
+                     ("unet3d_f4_interp", dict(in_channels=1, out_channels=1, n_filter=4, use_interpolation=True))]:
+        torch.manual_seed(1)
+        m = unet3d_mod.UNet3D(**kw)
+        x = torch.rand(2, 1, 8, 16, 24)
+        y = (torch.rand(2, 1, 8, 16, 24) > 0.5).float()
+        # unet3d/train.py:140-145
+        loss_fn = lambda outs, y=y: bce_dice(outs[1], y) + smooth_l1(outs[1][1:, :, :], outs[1][:-1, :, :]) * 0.1
+        dump(case, dict(model="UNet3D", ctor=kw, seed=1, loss="unet3d/train.py:140-145 BCEDice + 0.1*SmoothL1", init="default"),
+             m, {"x": x}, y, loss_fn, ["prob", "logits"], lambda mod, x=x: mod(x))
+
+    # ---- (iii) Siam_UNet -----------------------------------------------------------------------
+    for mode in ("concat", "max", "corr", "control"):
+        torch.manual_seed(2)
+        m = siam_mod.Siam_UNet(n_filter=4, mode=mode)
+        x = torch.rand(2, 1, 32, 32)
+        px = torch.rand(2, 1, 32, 32)
+        y = (torch.rand(2, 1, 32, 32) > 0.5).float()
+        loss_fn = lambda outs, y=y: bce_dice(outs[1], y)     # criterion(y_logits, y_i), siam_unet/train.py:110
+        dump(f"siam_f4_{mode}", dict(model="Siam_UNet", ctor=dict(n_filter=4, mode=mode), seed=2,
+                                     loss="BCEDice(0.5,0.5) on logits (unet/losses.py)", init="default"),
+             m, {"x": x, "prev_x": px}, y, loss_fn, ["prob", "logits"], lambda mod, x=x, px=px: mod(x, px))
+
+    # ---- (iv) MultiOutputUnet3D ----------------------------------------------------------------
+    heads = {"seg": {"channels": 1, "activation": "sigmoid"},
+             "flow": {"channels": 2, "activation": None},
+             "dist": {"channels": 1, "activation": "tanh"}}
+    for case, interp in (("mo3d_f4_interp", True), ("mo3d_f4_convT", False)):
+        torch.manual_seed(3)
+        kw = dict(in_channels=1, output_heads=heads, n_filter=4, use_interpolation=interp)
+        m = mo3d_mod.MultiOutputUnet3D(**kw)
+        x = torch.rand(2, 1, 8, 16, 16)
+        tgt = {"seg": (torch.rand(2, 1, 8, 16, 16) > 0.5).float(), "flow": torch.randn(2, 2, 8, 16, 16),
+               "dist": torch.rand(2, 1, 8, 16, 16)}
+        # simple weighted sum of MSE on the activated outputs (the mo3d trainer's loss menu is out of the hot path)
+        loss_fn = lambda outs, tgt=tgt: sum(((outs[k] - tgt[k]) ** 2).mean() * w
+                                            for k, w in (("seg", 1.0), ("flow", 0.5), ("dist", 0.25)))
+        dump(case, dict(model="MultiOutputUnet3D", ctor=kw, seed=3, loss="sum_k w_k*MSE(out_k, tgt_k), w=(1,.5,.25)", init="default"),
+             m, {"x": x}, tgt, loss_fn, ["seg", "flow", "dist"], lambda mod, x=x: mod(x))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    main()
