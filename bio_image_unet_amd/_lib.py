@@ -1,0 +1,96 @@
+"""ctypes binding of ``libbiu_hip.so`` (the C ABI declared in ``include/biu.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` (``hipcc --offload-arch=gfx950``).  There is no
+fallback: if the shared object is missing, importing this module raises, and every op of the package fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbiu_hip.so")
+
+BIU_F32, BIU_BF16 = 0, 1
+BN_MAX_PARTIALS = 1024
+
+
+class BiuError(RuntimeError):
+    pass
+
+
+class biu_act(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("n", C.c_int32), ("d", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("c", C.c_int32), ("pitch", C.c_int32)]
+
+
+class biu_xform(C.Structure):
+    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("slope", C.c_void_p)]
+
+
+_P = C.c_void_p
+_A = C.POINTER(biu_act)
+_X = C.POINTER(biu_xform)
+_I = C.c_int
+_F = C.c_float
+_D = C.c_double
+_Z = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/biu.h one to one
+SIGNATURES = {
+    "biu_last_error": (C.c_char_p, []),
+    "biu_version": (_I, []),
+    "biu_conv_packed_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I]),
+    "biu_conv_pack": (_I, [_I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "biu_conv_fwd": (_I, [_A, _X, _P, _P, _P, _I, _I, _I, _I, _A, _I, _P]),
+    "biu_conv_bwd_data": (_I, [_A, _P, _P, _I, _I, _I, _I, _A, _I, _I, _P]),
+    "biu_conv_bwd_weight_workspace": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "biu_conv_bwd_weight": (_I, [_A, _X, _A, _I, _I, _I, _I, _P, _P, _P, _Z, _I, _P]),
+    "biu_bn_stats": (_I, [_A, _P, C.POINTER(C.c_int), _I, _P]),
+    "biu_bn_finalize": (_I, [_P, _I, _I, _D, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "biu_bn_eval_affine": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
+    "biu_xform_apply": (_I, [_A, _X, _A, _I, _P]),
+    "biu_bn_bwd_reduce": (_I, [_A, _A, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_int), _I, _P]),
+    "biu_bn_bwd_finalize": (_I, [_P, _I, _I, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "biu_bn_bwd_apply": (_I, [_A, _A, _P, _P, _P, _P, _P, _P, _A, _I, _P]),
+    "biu_maxpool_fwd": (_I, [_A, _X, _A, _I, _P]),
+    "biu_maxpool_bwd": (_I, [_A, _X, _A, _A, _I, _I, _P]),
+    "biu_nearest_down_fwd": (_I, [_A, _X, _A, _I, _P]),
+    "biu_nearest_down_bwd": (_I, [_A, _A, _I, _I, _P]),
+    "biu_nearest_up_fwd": (_I, [_A, _X, _A, _I, _P]),
+    "biu_nearest_up_bwd": (_I, [_A, _A, _I, _I, _P]),
+    "biu_convt_fwd": (_I, [_A, _X, _P, _P, _I, _A, _I, _P]),
+    "biu_convt_bwd_data": (_I, [_A, _P, _I, _A, _I, _I, _P]),
+    "biu_convt_bwd_weight": (_I, [_A, _X, _A, _I, _P, _P, _I, _P]),
+    "biu_head_fwd": (_I, [_A, _X, _P, _P, _I, _I, _P, _P, _I, _P]),
+    "biu_head_bwd_workspace": (_Z, [_I]),
+    "biu_head_bwd": (_I, [_A, _X, _P, _I, _P, _A, _P, _P, _P, _Z, _I, _P]),
+    "biu_max_join_fwd": (_I, [_A, _X, _A, _X, _A, _I, _P]),
+    "biu_max_join_bwd": (_I, [_A, _X, _A, _X, _A, _A, _A, _I, _I, _P]),
+    "biu_act_add": (_I, [_A, _A, _I, _I, _P]),
+    "biu_from_nchw": (_I, [_P, _A, _I, _P]),
+    "biu_to_nchw": (_I, [_A, _X, _P, _I, _P]),
+    "biu_adam_step": (_I, [_I, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _F, _P]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP kernels are not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` from the repository root (needs hipcc). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here == header / library out of sync
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = lib.biu_last_error()
+        raise BiuError(f"{what}: biu status {status}: {msg.decode() if msg else ''}")

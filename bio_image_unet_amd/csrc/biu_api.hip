@@ -1,0 +1,79 @@
+// Public conv / conv-transpose entry points: validation + dispatch between the MFMA implicit-GEMM kernels
+// (biu_conv_mfma.hip) and the shape-generic direct kernels (biu_direct.hip).
+#include "biu_common.h"
+#include "biu_internal.h"
+
+static bool conv_args_ok(const biu_act* x, const biu_act* y, int kd, int kh, int kw, int dil) {
+    if (!valid_act(x) || !valid_act(y) || !same_space(x, y)) return false;
+    if (!((kd == 1 || kd == 3) && kh == 3 && kw == 3) && !(kd == 1 && kh == 1 && kw == 1)) return false;
+    return dil >= 1;
+}
+
+extern "C" size_t biu_conv_packed_bytes(int kind, int cin, int cout, int kd, int kh, int kw, int dilation, int dtype) {
+    return biu_mfma_packed_bytes(kind, cin, cout, kd, kh, kw, dilation, dtype);
+}
+
+extern "C" int biu_conv_pack(int kind, const float* w, int cin, int cout, int kd, int kh, int kw, int dtype,
+                             void* packed, biu_stream stream) {
+    BIU_REQUIRE(w && packed, BIU_ERR_SHAPE, "conv_pack: null pointer");
+    BIU_REQUIRE(biu_mfma_packed_bytes(kind, cin, cout, kd, kh, kw, 1, dtype) > 0, BIU_ERR_UNSUPPORTED,
+                "conv_pack: shape (cin=%d, cout=%d, k=%dx%dx%d) is served by the direct kernels", cin, cout, kd, kh, kw);
+    return biu_mfma_pack(kind, w, cin, cout, kd, kh, kw, dtype, packed, (hipStream_t)stream);
+}
+
+extern "C" int biu_conv_fwd(const biu_act* x, const biu_xform* xf, const float* w, const void* packed,
+                            const float* bias, int kd, int kh, int kw, int dilation, const biu_act* y, int dtype,
+                            biu_stream stream) {
+    BIU_REQUIRE(conv_args_ok(x, y, kd, kh, kw, dilation), BIU_ERR_SHAPE,
+                "conv_fwd: x/y extents differ or unsupported kernel %dx%dx%d dil %d", kd, kh, kw, dilation);
+    BIU_REQUIRE(w, BIU_ERR_SHAPE, "conv_fwd: null weight");
+    if (packed && biu_mfma_conv_ok(x, y, kd, kh, kw, dilation, dtype))
+        return biu_mfma_conv(x, xf, packed, bias, kd, kh, kw, y, 0, dtype, (hipStream_t)stream);
+    return biu_conv_fwd_direct(x, xf, w, bias, kd, kh, kw, dilation, y, dtype, (hipStream_t)stream);
+}
+
+extern "C" int biu_conv_bwd_data(const biu_act* dy, const float* w, const void* packed, int kd, int kh, int kw,
+                                 int dilation, const biu_act* dx, int accumulate, int dtype, biu_stream stream) {
+    BIU_REQUIRE(conv_args_ok(dy, dx, kd, kh, kw, dilation), BIU_ERR_SHAPE, "conv_bwd_data: dy/dx extents differ");
+    BIU_REQUIRE(w, BIU_ERR_SHAPE, "conv_bwd_data: null weight");
+    if (packed && biu_mfma_conv_ok(dy, dx, kd, kh, kw, dilation, dtype))
+        return biu_mfma_conv(dy, nullptr, packed, nullptr, kd, kh, kw, dx, accumulate, dtype, (hipStream_t)stream);
+    return biu_conv_bwd_data_direct(dy, w, kd, kh, kw, dilation, dx, accumulate, dtype, (hipStream_t)stream);
+}
+
+extern "C" size_t biu_conv_bwd_weight_workspace(int cin, int cout, int kd, int kh, int kw, int dtype) {
+    return biu_mfma_wgrad_workspace(cin, cout, kd, kh, kw, dtype);
+}
+
+extern "C" int biu_conv_bwd_weight(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, int kh, int kw,
+                                   int dilation, float* dw, float* dbias, void* ws, size_t ws_bytes, int dtype,
+                                   biu_stream stream) {
+    BIU_REQUIRE(conv_args_ok(x, dy, kd, kh, kw, dilation), BIU_ERR_SHAPE, "conv_bwd_weight: x/dy extents differ");
+    BIU_REQUIRE(dw, BIU_ERR_SHAPE, "conv_bwd_weight: null dw");
+    if (biu_mfma_wgrad_ok(x, dy, kd, kh, kw, dilation, dtype)) {
+        BIU_REQUIRE(ws && ws_bytes >= biu_mfma_wgrad_workspace(x->c, dy->c, kd, kh, kw, dtype), BIU_ERR_WORKSPACE,
+                    "conv_bwd_weight: workspace too small");
+        return biu_mfma_wgrad(x, xf, dy, kd, kh, kw, dw, dbias, ws, ws_bytes, dtype, (hipStream_t)stream);
+    }
+    return biu_conv_bwd_weight_direct(x, xf, dy, kd, kh, kw, dilation, dw, dbias, dtype, (hipStream_t)stream);
+}
+
+// ---- ConvTranspose k2 s2 ---------------------------------------------------------------------------
+extern "C" int biu_convt_fwd(const biu_act* x, const biu_xform* xf, const float* w, const float* bias, int kd,
+                             const biu_act* y, int dtype, biu_stream stream) {
+    BIU_REQUIRE(valid_act(x) && valid_act(y) && w && biu_convt_shapes_ok(x, y, kd), BIU_ERR_SHAPE,
+                "convt_fwd: output must be 2x the input extent (kd=%d)", kd);
+    return biu_convt_fwd_direct(x, xf, w, bias, kd, y, dtype, (hipStream_t)stream);
+}
+extern "C" int biu_convt_bwd_data(const biu_act* dy, const float* w, int kd, const biu_act* dx, int accumulate,
+                                  int dtype, biu_stream stream) {
+    BIU_REQUIRE(valid_act(dx) && valid_act(dy) && w && biu_convt_shapes_ok(dx, dy, kd), BIU_ERR_SHAPE,
+                "convt_bwd_data: dy must be 2x the dx extent (kd=%d)", kd);
+    return biu_convt_bwd_data_direct(dy, w, kd, dx, accumulate, dtype, (hipStream_t)stream);
+}
+extern "C" int biu_convt_bwd_weight(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, float* dw,
+                                    float* dbias, int dtype, biu_stream stream) {
+    BIU_REQUIRE(valid_act(x) && valid_act(dy) && dw && biu_convt_shapes_ok(x, dy, kd), BIU_ERR_SHAPE,
+                "convt_bwd_weight: dy must be 2x the x extent (kd=%d)", kd);
+    return biu_convt_bwd_weight_direct(x, xf, dy, kd, dw, dbias, dtype, (hipStream_t)stream);
+}

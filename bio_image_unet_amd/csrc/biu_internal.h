@@ -1,0 +1,30 @@
+// Internal (non-exported) interfaces between the translation units of libbiu_hip.so.
+#pragma once
+#include "biu_common.h"
+
+// biu_direct.hip
+extern "C" int biu_conv_fwd_direct(const biu_act* x, const biu_xform* xf, const float* w, const float* bias, int kd,
+                                   int kh, int kw, int dil, const biu_act* y, int dtype, hipStream_t st);
+extern "C" int biu_conv_bwd_data_direct(const biu_act* dy, const float* w, int kd, int kh, int kw, int dil,
+                                        const biu_act* dx, int accumulate, int dtype, hipStream_t st);
+extern "C" int biu_conv_bwd_weight_direct(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, int kh,
+                                          int kw, int dil, float* dw, float* dbias, int dtype, hipStream_t st);
+extern "C" int biu_convt_fwd_direct(const biu_act* x, const biu_xform* xf, const float* w, const float* bias, int kd,
+                                    const biu_act* y, int dtype, hipStream_t st);
+extern "C" int biu_convt_bwd_data_direct(const biu_act* dy, const float* w, int kd, const biu_act* dx, int accumulate,
+                                         int dtype, hipStream_t st);
+extern "C" int biu_convt_bwd_weight_direct(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, float* dw,
+                                           float* dbias, int dtype, hipStream_t st);
+bool biu_convt_shapes_ok(const biu_act* lo, const biu_act* hi, int kd);
+
+// biu_conv_mfma.hip
+size_t biu_mfma_packed_bytes(int kind, int cin, int cout, int kd, int kh, int kw, int dilation, int dtype);
+int biu_mfma_pack(int kind, const float* w, int cin, int cout, int kd, int kh, int kw, int dtype, void* packed,
+                  hipStream_t st);
+bool biu_mfma_conv_ok(const biu_act* x, const biu_act* y, int kd, int kh, int kw, int dilation, int dtype);
+int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, int kh, int kw,
+                  const biu_act* y, int accumulate, int dtype, hipStream_t st);
+size_t biu_mfma_wgrad_workspace(int cin, int cout, int kd, int kh, int kw, int dtype);
+bool biu_mfma_wgrad_ok(const biu_act* x, const biu_act* dy, int kd, int kh, int kw, int dilation, int dtype);
+int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, int kh, int kw, float* dw,
+                   float* dbias, void* ws, size_t ws_bytes, int dtype, hipStream_t st);

@@ -1,0 +1,601 @@
+"""Host-side execution engine: a static op graph per (model, input shape) whose every node is a call into
+``libbiu_hip.so``.  PyTorch is used for device memory (caching allocator), the current HIP stream, autograd
+glue at the module boundary and nothing else -- no torch op touches an activation.
+
+Data layout in HBM:
+  * activations are channels-last ``[N, D, H, W, C]`` (2-D: ``D = 1``), bf16 or fp32;
+  * a conv block stores only its *raw* convolution output ``y``; BatchNorm-affine + LeakyReLU is a per-channel
+    transform ``T`` (scale, shift, slope) that every consumer applies while loading -- the activated tensor is
+    never written to HBM;
+  * skip-concat (reference ``unet/unet.py:62-67``) is zero-copy: the two producers write into channel slices
+    of one buffer, and the per-channel transform vectors of the buffer are the concatenation of theirs.
+Gradients mirror this: each buffer has a gradient twin; a conv block turns the incoming ``d a`` into ``d y``
+in place (BatchNorm backward), then runs the weight- and data-gradient kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import BIU_BF16, BIU_F32, BN_MAX_PARTIALS, biu_act, biu_xform, check, lib
+
+LRELU_SLOPE = 0.1      # nn.LeakyReLU(negative_slope=0.1), reference unet/unet.py:58
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Buf:
+    """One HBM buffer [N,D,H,W,C] + gradient twin + the consumer-side transform vectors of its channels."""
+
+    def __init__(self, eng: "Engine", n, d, h, w, c):
+        self.eng = eng
+        self.shape = (n, d, h, w, c)
+        self.t = torch.empty(self.shape, dtype=eng.tdtype, device=eng.device)
+        self.g: Optional[torch.Tensor] = None
+        self.scale = torch.ones(c, dtype=torch.float32, device=eng.device)
+        self.shift = torch.zeros(c, dtype=torch.float32, device=eng.device)
+        self.slope = torch.ones(c, dtype=torch.float32, device=eng.device)
+        self.leaves: Dict[Tuple[int, int], bool] = {}       # (c0, c) -> gradient written this backward?
+        self.lazy: Dict[Tuple[int, int], bool] = {}         # (c0, c) -> transform is not the identity
+
+    def slice(self, c0: int, c: int, lazy: bool) -> "Act":
+        self.leaves[(c0, c)] = False
+        self.lazy[(c0, c)] = lazy
+        return Act(self, c0, c, [(c0, c)])
+
+    def full(self) -> "Act":
+        keys = sorted(self.leaves)
+        cov = 0
+        for c0, c in keys:
+            assert c0 == cov, "concat buffer has a hole"
+            cov += c
+        assert cov == self.shape[4]
+        return Act(self, 0, cov, keys)
+
+    def grad(self) -> torch.Tensor:
+        if self.g is None:
+            self.g = torch.empty(self.shape, dtype=self.eng.tdtype, device=self.eng.device)
+        return self.g
+
+
+class Act:
+    """A channel slice of a Buf as seen by a kernel (biu_act)."""
+
+    def __init__(self, buf: Buf, c0: int, c: int, leaves):
+        self.buf, self.c0, self.c, self.leaves = buf, c0, c, leaves
+        n, d, h, w, ctot = buf.shape
+        isz = buf.t.element_size()
+        self.n, self.d, self.h, self.w = n, d, h, w
+        self._a = biu_act(buf.t.data_ptr() + c0 * isz, n, d, h, w, c, ctot)
+        self._g = None
+        self._x = None
+        self.is_input = False
+
+    @property
+    def nvox(self):
+        return self.n * self.d * self.h * self.w
+
+    @property
+    def space(self):
+        return (self.n, self.d, self.h, self.w)
+
+    def a(self):
+        return C.byref(self._a)
+
+    def g(self):
+        if self._g is None:
+            gt = self.buf.grad()
+            self._g = biu_act(gt.data_ptr() + self.c0 * gt.element_size(), self.n, self.d, self.h, self.w, self.c,
+                              self.buf.shape[4])
+        return C.byref(self._g)
+
+    def is_lazy(self):
+        return any(self.buf.lazy[k] for k in self.leaves)
+
+    def xf(self):
+        if not self.is_lazy():
+            return None
+        if self._x is None:
+            o = 4 * self.c0
+            self._x = biu_xform(self.buf.scale.data_ptr() + o, self.buf.shift.data_ptr() + o,
+                                self.buf.slope.data_ptr() + o)
+        return C.byref(self._x)
+
+    def vec(self, name):   # view of a transform vector restricted to this slice
+        return getattr(self.buf, name)[self.c0:self.c0 + self.c]
+
+    # gradient bookkeeping -------------------------------------------------------------------------
+    def g_written(self) -> bool:
+        flags = [self.buf.leaves[k] for k in self.leaves]
+        assert all(flags) or not any(flags), "partially written concat gradient"
+        return flags[0]
+
+    def mark_g(self):
+        for k in self.leaves:
+            self.buf.leaves[k] = True
+
+
+# ======================================================================================================
+# nodes
+# ======================================================================================================
+class Node:
+    params: Sequence[nn.Parameter] = ()
+
+    def fwd(self, eng: "Engine"):
+        raise NotImplementedError
+
+    def bwd(self, eng: "Engine"):
+        raise NotImplementedError
+
+
+def _ksize(w: torch.Tensor):
+    if w.dim() == 5:
+        return tuple(w.shape[2:])
+    return (1,) + tuple(w.shape[2:])
+
+
+class ConvBlockNode(Node):
+    """Conv(k=3, pad=dil, dilation=dil) -> BatchNorm -> LeakyReLU(0.1) -> Dropout(p=0)  [unet/unet.py:54-60].
+
+    forward : y = conv(T_in(x)) + b ; batch statistics of y ; (scale, shift) of the consumer transform.
+    backward: d a -> d y (BatchNorm + LeakyReLU backward, in place) ; dW, db ; d x.
+    """
+
+    def __init__(self, eng, seq: nn.Sequential, xin: Act, yout: Act):
+        conv, bn = seq[0], seq[1]
+        self.conv, self.bn, self.xin, self.y = conv, bn, xin, yout
+        self.kd, self.kh, self.kw = _ksize(conv.weight)
+        self.dil = int(conv.dilation[0])
+        drop = seq[3] if len(seq) > 3 else None
+        if drop is not None and getattr(drop, "p", 0.0) != 0.0:
+            raise NotImplementedError("Dropout p != 0 is outside the hot path (reference default dropout=0.)")
+        assert tuple(conv.weight.shape[:2]) == (yout.c, xin.c), (conv.weight.shape, yout.c, xin.c)
+        assert xin.space == yout.space
+        self.params = [conv.weight, conv.bias, bn.weight, bn.bias]
+        cout = yout.c
+        dev = eng.device
+        self.save_mean = torch.empty(cout, dtype=torch.float32, device=dev)
+        self.save_invstd = torch.empty(cout, dtype=torch.float32, device=dev)
+        yout.vec("slope").fill_(LRELU_SLOPE)
+        eng.need_partial(cout)
+        self.pk_f = eng.packed_slot(0, xin.c, cout, self.kd, self.kh, self.kw, self.dil)
+        self.pk_b = eng.packed_slot(1, xin.c, cout, self.kd, self.kh, self.kw, self.dil)
+        self.ws_bytes = lib.biu_conv_bwd_weight_workspace(xin.c, cout, self.kd, self.kh, self.kw, eng.dtype)
+        eng.need_ws(self.ws_bytes)
+
+    def fwd(self, eng):
+        st = _stream()
+        w, b = self.conv.weight.data, self.conv.bias.data if self.conv.bias is not None else None
+        packed = eng.pack(self.pk_f, 0, self.conv.weight, self.xin.c, self.y.c, self.kd, self.kh, self.kw)
+        check(lib.biu_conv_fwd(self.xin.a(), self.xin.xf(), _ptr(w), packed, _ptr(b), self.kd, self.kh, self.kw,
+                               self.dil, self.y.a(), eng.dtype, st), "conv_fwd")
+        bn = self.bn
+        scale, shift = self.y.vec("scale"), self.y.vec("shift")
+        if eng.bn_training(bn):
+            nblk = C.c_int(0)
+            check(lib.biu_bn_stats(self.y.a(), _ptr(eng.partial), C.byref(nblk), eng.dtype, st), "bn_stats")
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            track = bn.track_running_stats and bn.running_mean is not None
+            check(lib.biu_bn_finalize(_ptr(eng.partial), nblk.value, self.y.c, float(self.y.nvox), _ptr(bn.weight.data),
+                                      _ptr(bn.bias.data), _ptr(bn.running_mean) if track else None,
+                                      _ptr(bn.running_var) if track else None, mom, bn.eps, _ptr(scale), _ptr(shift),
+                                      _ptr(self.save_mean), _ptr(self.save_invstd), st), "bn_finalize")
+            if track and bn.num_batches_tracked is not None:
+                eng.nbt_bump.append(bn.num_batches_tracked)
+            self.batch_stats = True
+        else:
+            check(lib.biu_bn_eval_affine(self.y.c, _ptr(bn.weight.data), _ptr(bn.bias.data), _ptr(bn.running_mean),
+                                         _ptr(bn.running_var), bn.eps, _ptr(scale), _ptr(shift), st), "bn_eval_affine")
+            self.batch_stats = False
+
+    def bwd(self, eng):
+        if not self.y.g_written():
+            return            # no gradient reaches this block (e.g. Siam 'control' branch)
+        if not self.batch_stats:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not on the reference hot path")
+        st = _stream()
+        y, cout = self.y, self.y.c
+        scale, shift, slope = _ptr(y.vec("scale")), _ptr(y.vec("shift")), _ptr(y.vec("slope"))
+        nblk = C.c_int(0)
+        check(lib.biu_bn_bwd_reduce(y.g(), y.a(), scale, shift, slope, _ptr(self.save_mean), _ptr(self.save_invstd),
+                                    _ptr(eng.partial), C.byref(nblk), eng.dtype, st), "bn_bwd_reduce")
+        dgamma, dbeta = eng.new_grad(self.bn.weight), eng.new_grad(self.bn.bias)
+        A, B, Cc = eng.coef[0][:cout], eng.coef[1][:cout], eng.coef[2][:cout]
+        check(lib.biu_bn_bwd_finalize(_ptr(eng.partial), nblk.value, cout, float(y.nvox), scale, _ptr(self.save_mean),
+                                      _ptr(self.save_invstd), _ptr(dgamma), _ptr(dbeta), _ptr(A), _ptr(B), _ptr(Cc), st),
+              "bn_bwd_finalize")
+        check(lib.biu_bn_bwd_apply(y.g(), y.a(), scale, shift, slope, _ptr(A), _ptr(B), _ptr(Cc), y.g(), eng.dtype, st),
+              "bn_bwd_apply")
+        dw = eng.new_grad(self.conv.weight)
+        db = eng.new_grad(self.conv.bias) if self.conv.bias is not None else None
+        check(lib.biu_conv_bwd_weight(self.xin.a(), self.xin.xf(), y.g(), self.kd, self.kh, self.kw, self.dil, _ptr(dw),
+                                      _ptr(db), _ptr(eng.ws), eng.ws_bytes, eng.dtype, st), "conv_bwd_weight")
+        eng.add_grad(self.conv.weight, dw)
+        if db is not None:
+            eng.add_grad(self.conv.bias, db)
+        eng.add_grad(self.bn.weight, dgamma)
+        eng.add_grad(self.bn.bias, dbeta)
+        if eng.wants_grad(self.xin):
+            packed = eng.pack(self.pk_b, 1, self.conv.weight, self.xin.c, cout, self.kd, self.kh, self.kw)
+            check(lib.biu_conv_bwd_data(y.g(), _ptr(self.conv.weight.data), packed, self.kd, self.kh, self.kw, self.dil,
+                                        self.xin.g(), int(self.xin.g_written()), eng.dtype, st), "conv_bwd_data")
+            self.xin.mark_g()
+
+
+class ConvTNode(Node):
+    """ConvTranspose(k=2, stride=2) [unet/unet.py:38, unet3d/unet3d.py:40]; output is final (no BN)."""
+
+    def __init__(self, eng, up: nn.Module, xin: Act, yout: Act):
+        self.up, self.xin, self.y = up, xin, yout
+        w = up.weight
+        self.kd = 2 if w.dim() == 5 else 1
+        assert tuple(w.shape[:2]) == (xin.c, yout.c)
+        self.params = [up.weight, up.bias]
+
+    def fwd(self, eng):
+        check(lib.biu_convt_fwd(self.xin.a(), self.xin.xf(), _ptr(self.up.weight.data), _ptr(self.up.bias.data), self.kd,
+                                self.y.a(), eng.dtype, _stream()), "convt_fwd")
+
+    def bwd(self, eng):
+        if not self.y.g_written():
+            return
+        st = _stream()
+        dw, db = eng.new_grad(self.up.weight), eng.new_grad(self.up.bias)
+        check(lib.biu_convt_bwd_weight(self.xin.a(), self.xin.xf(), self.y.g(), self.kd, _ptr(dw), _ptr(db), eng.dtype, st),
+              "convt_bwd_weight")
+        eng.add_grad(self.up.weight, dw)
+        eng.add_grad(self.up.bias, db)
+        if eng.wants_grad(self.xin):
+            check(lib.biu_convt_bwd_data(self.y.g(), _ptr(self.up.weight.data), self.kd, self.xin.g(),
+                                         int(self.xin.g_written()), eng.dtype, st), "convt_bwd_data")
+            self.xin.mark_g()
+
+
+class ResampleNode(Node):
+    """MaxPool(2,2) / nearest x0.5 / nearest x2: output is materialised *activated* data (identity transform)."""
+
+    def __init__(self, eng, kind: str, xin: Act, yout: Act):
+        assert kind in ("maxpool", "down", "up")
+        self.kind, self.xin, self.y = kind, xin, yout
+
+    def fwd(self, eng):
+        f = {"maxpool": lib.biu_maxpool_fwd, "down": lib.biu_nearest_down_fwd, "up": lib.biu_nearest_up_fwd}[self.kind]
+        check(f(self.xin.a(), self.xin.xf(), self.y.a(), eng.dtype, _stream()), self.kind + "_fwd")
+
+    def bwd(self, eng):
+        if not self.y.g_written() or not eng.wants_grad(self.xin):
+            return
+        acc, st = int(self.xin.g_written()), _stream()
+        if self.kind == "maxpool":
+            check(lib.biu_maxpool_bwd(self.xin.a(), self.xin.xf(), self.y.g(), self.xin.g(), acc, eng.dtype, st), "maxpool_bwd")
+        elif self.kind == "down":
+            check(lib.biu_nearest_down_bwd(self.y.g(), self.xin.g(), acc, eng.dtype, st), "nearest_down_bwd")
+        else:
+            check(lib.biu_nearest_up_bwd(self.y.g(), self.xin.g(), acc, eng.dtype, st), "nearest_up_bwd")
+        self.xin.mark_g()
+
+
+class MaxJoinNode(Node):
+    """torch.maximum(m4, mm4) -- Siam 'max' join [siam_unet/siam_unet.py:117]."""
+
+    def __init__(self, eng, a: Act, b: Act, out: Act):
+        self.a_, self.b_, self.y = a, b, out
+
+    def fwd(self, eng):
+        check(lib.biu_max_join_fwd(self.a_.a(), self.a_.xf(), self.b_.a(), self.b_.xf(), self.y.a(), eng.dtype, _stream()),
+              "max_join_fwd")
+
+    def bwd(self, eng):
+        if not self.y.g_written():
+            return
+        assert self.a_.g_written() == self.b_.g_written()
+        check(lib.biu_max_join_bwd(self.a_.a(), self.a_.xf(), self.b_.a(), self.b_.xf(), self.y.g(), self.a_.g(),
+                                   self.b_.g(), int(self.a_.g_written()), eng.dtype, _stream()), "max_join_bwd")
+        self.a_.mark_g()
+        self.b_.mark_g()
+
+
+class CopyNode(Node):
+    """out = T(x) into another slice (Siam concat of the two pooled bottlenecks, 'control' join)."""
+
+    def __init__(self, eng, xin: Act, out: Act):
+        self.xin, self.y = xin, out
+
+    def fwd(self, eng):
+        check(lib.biu_xform_apply(self.xin.a(), self.xin.xf(), self.y.a(), eng.dtype, _stream()), "xform_apply")
+
+    def bwd(self, eng):
+        if not self.y.g_written() or not eng.wants_grad(self.xin):
+            return
+        assert not self.xin.is_lazy(), "CopyNode backward expects an identity transform"
+        check(lib.biu_act_add(self.y.g(), self.xin.g(), int(self.xin.g_written()), eng.dtype, _stream()), "act_add")
+        self.xin.mark_g()
+
+
+_ACT_CODE = {None: 0, "none": 0, "sigmoid": 1, "tanh": 2, "relu": 3}
+
+
+class HeadNode(Node):
+    """1x1(x1) conv head + activation; fp32 NC[D]HW outputs [unet/unet.py:51,103-104; mo3d :164-168]."""
+
+    def __init__(self, eng, conv: nn.Module, xin: Act, activation, want_logits: bool, want_act: bool):
+        self.conv, self.xin = conv, xin
+        self.cout = conv.weight.shape[0]
+        assert conv.weight.shape[1] == xin.c
+        if activation not in _ACT_CODE:
+            activation = None          # reference apply_activation: unknown strings fall through to identity
+        self.activation = activation
+        self.act = _ACT_CODE[activation]
+        self.want_logits, self.want_act = want_logits, want_act
+        self.params = [conv.weight, conv.bias]
+        eng.need_ws(lib.biu_head_bwd_workspace(xin.c))
+        self.logits = self.activated = None
+
+    def out_shape(self, eng):
+        x = self.xin
+        return (x.n, self.cout, x.d, x.h, x.w) if eng.nd == 3 else (x.n, self.cout, x.h, x.w)
+
+    def fwd(self, eng):
+        shp = self.out_shape(eng)
+        self.logits = torch.empty(shp, dtype=torch.float32, device=eng.device) if self.want_logits else None
+        self.activated = torch.empty(shp, dtype=torch.float32, device=eng.device) if self.want_act else None
+        w = self.conv.weight.data.reshape(self.cout, self.xin.c)
+        check(lib.biu_head_fwd(self.xin.a(), self.xin.xf(), _ptr(w), _ptr(self.conv.bias.data), self.cout, self.act,
+                               _ptr(self.logits), _ptr(self.activated), eng.dtype, _stream()), "head_fwd")
+
+    def dlogits(self, g_logits, g_act):
+        """Combine the caller's gradients wrt (logits, activated output) into d logits (tiny fp32 tensors)."""
+        tot = g_logits
+        if g_act is not None:
+            a = self.activated
+            if self.act == 1:
+                t = g_act * a * (1 - a)
+            elif self.act == 2:
+                t = g_act * (1 - a * a)
+            elif self.act == 3:
+                t = g_act * (a > 0).to(g_act.dtype)
+            else:
+                t = g_act
+            tot = t if tot is None else tot + t
+        return tot
+
+    def bwd_with(self, eng, dl: Optional[torch.Tensor]):
+        if dl is None:
+            return
+        dl = dl.contiguous().float()
+        st = _stream()
+        dw, db = eng.new_grad(self.conv.weight), eng.new_grad(self.conv.bias)
+        want_dx = eng.wants_grad(self.xin)
+        assert not self.xin.g_written(), "heads that share a trunk go through Engine._backward_heads"
+        check(lib.biu_head_bwd(self.xin.a(), self.xin.xf(), _ptr(self.conv.weight.data), self.cout, _ptr(dl),
+                               self.xin.g() if want_dx else None, _ptr(dw), _ptr(db), _ptr(eng.ws), eng.ws_bytes,
+                               eng.dtype, st), "head_bwd")
+        eng.add_grad(self.conv.weight, dw)
+        eng.add_grad(self.conv.bias, db)
+        if want_dx:
+            self.xin.mark_g()
+
+
+# ======================================================================================================
+# engine
+# ======================================================================================================
+class Engine:
+    """Static graph for one input shape.  ``nd`` = 2 or 3 spatial dims; ``tdtype`` = torch.float32 / bfloat16."""
+
+    def __init__(self, device, tdtype, nd: int):
+        if torch.device(device).type != "cuda":
+            raise RuntimeError("bio_image_unet_amd executes only through its HIP kernels on an MI355X; "
+                               f"got device '{device}'. There is no CPU fallback.")
+        self.device, self.tdtype, self.nd = torch.device(device), tdtype, nd
+        self.dtype = {torch.float32: BIU_F32, torch.bfloat16: BIU_BF16}[tdtype]
+        self.nodes: List[Node] = []
+        self.heads: List[HeadNode] = []
+        self.bufs: List[Buf] = []
+        self.inputs: List[Act] = []
+        self._partial_c = 0
+        self.ws_bytes = 0
+        self.partial = self.ws = None
+        self.coef = None
+        self.grads: Dict[nn.Parameter, torch.Tensor] = {}
+        self.nbt_bump: List[torch.Tensor] = []
+        self.grad_mode = False
+        self.module_training = True
+        self.input_requires_grad = False
+        self._packed: Dict[int, dict] = {}
+
+    # ---- build helpers -------------------------------------------------------------------------------
+    def new_buf(self, n, d, h, w, c) -> Buf:
+        b = Buf(self, n, d, h, w, c)
+        self.bufs.append(b)
+        return b
+
+    def new_act(self, space, c, lazy: bool) -> Act:
+        n, d, h, w = space
+        return self.new_buf(n, d, h, w, c).slice(0, c, lazy)
+
+    def add(self, node: Node):
+        self.nodes.append(node)
+        return node
+
+    def need_partial(self, c):
+        self._partial_c = max(self._partial_c, c)
+
+    def need_ws(self, nbytes):
+        self.ws_bytes = max(self.ws_bytes, int(nbytes))
+
+    def finalize(self):
+        dev = self.device
+        c = max(self._partial_c, 1)
+        self.partial = torch.empty(BN_MAX_PARTIALS * c * 2, dtype=torch.float32, device=dev)
+        self.coef = torch.empty((3, c), dtype=torch.float32, device=dev)
+        self.ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=dev)
+        self.params: List[nn.Parameter] = []
+        seen = set()
+        for nd_ in self.nodes:
+            for p in nd_.params:
+                if p is not None and id(p) not in seen:
+                    seen.add(id(p))
+                    self.params.append(p)
+
+    # ---- MFMA weight packing cache ---------------------------------------------------------------------
+    def packed_slot(self, kind, cin, cout, kd, kh, kw, dil):
+        nbytes = lib.biu_conv_packed_bytes(kind, cin, cout, kd, kh, kw, dil, self.dtype)
+        if nbytes == 0:
+            return None
+        return {"buf": torch.empty(nbytes, dtype=torch.uint8, device=self.device), "ver": None}
+
+    def pack(self, slot, kind, weight: nn.Parameter, cin, cout, kd, kh, kw):
+        if slot is None:
+            return None
+        ver = (weight.data_ptr(), weight._version)
+        if slot["ver"] != ver:
+            check(lib.biu_conv_pack(kind, _ptr(weight.data), cin, cout, kd, kh, kw, self.dtype, _ptr(slot["buf"]), _stream()),
+                  "conv_pack")
+            slot["ver"] = ver
+        return _ptr(slot["buf"])
+
+    # ---- run-time helpers --------------------------------------------------------------------------------
+    def bn_training(self, bn: nn.Module) -> bool:
+        # nn.BatchNorm semantics: batch statistics when training, or when no running stats exist
+        return bn.training or bn.running_mean is None
+
+    def wants_grad(self, act: Act) -> bool:
+        return self.input_requires_grad if act.is_input else True
+
+    def new_input(self, space, c) -> Act:
+        a = self.new_act(space, c, lazy=False)
+        a.is_input = True
+        self.inputs.append(a)
+        return a
+
+    def new_grad(self, p: nn.Parameter) -> torch.Tensor:
+        return torch.empty(p.shape, dtype=torch.float32, device=self.device)
+
+    def add_grad(self, p: nn.Parameter, g: torch.Tensor):
+        if p in self.grads:
+            self.grads[p] = self.grads[p] + g
+        else:
+            self.grads[p] = g
+
+    # ---- execution ----------------------------------------------------------------------------------------
+    def load_inputs(self, xs: Sequence[torch.Tensor]):
+        st = _stream()
+        for act, x in zip(self.inputs, xs):
+            x = x.detach()
+            if x.dtype != torch.float32:
+                x = x.float()
+            x = x.contiguous()
+            check(lib.biu_from_nchw(_ptr(x), act.a(), self.dtype, st), "from_nchw")
+
+    def forward(self):
+        self.nbt_bump = []
+        for nd_ in self.nodes:
+            nd_.fwd(self)
+        if self.nbt_bump:
+            torch._foreach_add_(self.nbt_bump, 1)
+
+    def backward(self, head_grads: Sequence[Optional[torch.Tensor]]):
+        """head_grads[i] = d loss / d logits of head i (already combined with the activation's gradient)."""
+        self.grads = {}
+        for b in self.bufs:
+            for k in b.leaves:
+                b.leaves[k] = False
+        self._backward_heads(head_grads)
+        for nd_ in reversed(self.nodes):
+            if isinstance(nd_, HeadNode):
+                continue
+            nd_.bwd(self)
+        return self.grads
+
+    def _backward_heads(self, head_grads):
+        live = [(h, g) for h, g in zip(self.heads, head_grads) if g is not None]
+        if not live:
+            return
+        if len(live) == 1:
+            live[0][0].bwd_with(self, live[0][1])
+            return
+        # several heads read the same trunk output: one fused (cout-stacked) backward keeps d x single-pass
+        x = live[0][0].xin
+        assert all(h.xin is x for h, _ in live)
+        w = torch.cat([h.conv.weight.data.reshape(h.cout, x.c) for h, _ in live], 0).contiguous()
+        dl = torch.cat([g.contiguous().float() for _, g in live], 1).contiguous()
+        cout = w.shape[0]
+        dw = torch.empty_like(w)
+        db = torch.empty(cout, dtype=torch.float32, device=self.device)
+        check(lib.biu_head_bwd(x.a(), x.xf(), _ptr(w), cout, _ptr(dl), x.g(), _ptr(dw), _ptr(db), _ptr(self.ws),
+                               self.ws_bytes, self.dtype, _stream()), "head_bwd(stacked)")
+        x.mark_g()
+        o = 0
+        for h, _ in live:
+            self.add_grad(h.conv.weight, dw[o:o + h.cout].reshape(h.conv.weight.shape).clone())
+            self.add_grad(h.conv.bias, db[o:o + h.cout].clone())
+            o += h.cout
+
+    def input_grads(self) -> List[Optional[torch.Tensor]]:
+        outs = []
+        st = _stream()
+        for act in self.inputs:
+            if not self.input_requires_grad or not act.g_written():
+                outs.append(None)
+                continue
+            shp = (act.n, act.c, act.d, act.h, act.w) if self.nd == 3 else (act.n, act.c, act.h, act.w)
+            t = torch.empty(shp, dtype=torch.float32, device=self.device)
+            ga = biu_act(act.buf.grad().data_ptr(), act.n, act.d, act.h, act.w, act.c, act.buf.shape[4])
+            check(lib.biu_to_nchw(C.byref(ga), None, _ptr(t), self.dtype, st), "to_nchw")
+            outs.append(t)
+        return outs
+
+
+# ======================================================================================================
+# autograd glue at the module boundary
+# ======================================================================================================
+class _NetFn(torch.autograd.Function):
+    """One autograd node for the whole network: forward/backward are the engine's kernel sequences."""
+
+    @staticmethod
+    def forward(ctx, eng: Engine, n_inputs: int, out_spec, *tensors):
+        xs, ctx.n_inputs = tensors[:n_inputs], n_inputs
+        eng.load_inputs(xs)
+        eng.forward()
+        ctx.eng, ctx.out_spec = eng, out_spec
+        outs = []
+        for hi, kind in out_spec:
+            h = eng.heads[hi]
+            outs.append(h.logits if kind == "logits" else h.activated)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        eng: Engine = ctx.eng
+        per_head: Dict[int, List[Optional[torch.Tensor]]] = {}
+        for (hi, kind), g in zip(ctx.out_spec, gouts):
+            slot = per_head.setdefault(hi, [None, None])
+            slot[0 if kind == "logits" else 1] = g
+        head_grads = []
+        for hi, h in enumerate(eng.heads):
+            gl, ga = per_head.get(hi, [None, None])
+            head_grads.append(h.dlogits(gl, ga) if (gl is not None or ga is not None) else None)
+        grads = eng.backward(head_grads)
+        dxs = eng.input_grads()
+        pg = []
+        for p in eng.params:
+            g = grads.get(p)
+            pg.append(g)
+        return (None, None, None, *dxs, *pg)
+
+
+def run(eng: Engine, xs: Sequence[torch.Tensor], out_spec):
+    """Execute the graph under autograd.  Parameters are passed so that autograd routes their gradients."""
+    eng.grad_mode = torch.is_grad_enabled()
+    eng.input_requires_grad = eng.grad_mode and any(x.requires_grad for x in xs)
+    return _NetFn.apply(eng, len(xs), tuple(out_spec), *xs, *eng.params)

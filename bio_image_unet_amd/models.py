@@ -1,0 +1,364 @@
+"""The four hot-path networks with the reference's constructor signatures, attribute names and state_dict keys.
+
+Every layer attribute (``encode1`` ... ``decode8``, ``up1`` ..., ``final``) is a plain ``torch.nn`` container that
+*owns parameters and buffers only* -- so ``.to()``, ``.apply(init_weights)``, ``state_dict()`` /
+``load_state_dict()`` of reference checkpoints behave exactly as in the reference -- while ``forward`` never calls
+those containers: it runs the HIP graph built by ``_build`` (``engine.py``).
+
+Reference classes mirrored here:
+  Unet ................. unet/unet.py:5-104
+  UNet3D ............... unet3d/unet3d.py:6-99
+  Siam_UNet ............ siam_unet/siam_unet.py:7-148
+  MultiOutputUnet3D .... multi_output_unet3d/multi_output_unet3d.py:7-170
+"""
+from __future__ import annotations
+
+import logging
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from . import engine as E
+
+
+def _block(nd: int, cin: int, cout: int, dilation: int = 1, dropout: float = 0.0) -> nn.Sequential:
+    """Parameter container of one conv block; same child indices (0 conv, 1 BN) as the reference's Sequential."""
+    conv = nn.Conv3d if nd == 3 else nn.Conv2d
+    bn = nn.BatchNorm3d if nd == 3 else nn.BatchNorm2d
+    drop = nn.Dropout3d if nd == 3 else nn.Dropout2d
+    return nn.Sequential(conv(cin, cout, 3, padding=dilation, dilation=dilation), bn(cout),
+                         nn.LeakyReLU(negative_slope=0.1, inplace=True), drop(dropout))
+
+
+class _HipNet(nn.Module):
+    """Shared plumbing: engine cache keyed by input shape, compute dtype switch, loud CPU refusal."""
+    nd = 2
+    _max_cached = 2
+
+    def __init__(self):
+        super().__init__()
+        self._engines: "OrderedDict[tuple, E.Engine]" = OrderedDict()
+        self.compute_dtype = torch.float32
+
+    def set_compute_dtype(self, dtype):
+        """torch.float32 (reference numerics) or torch.bfloat16 (bf16 storage, fp32 accumulate)."""
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.compute_dtype = dtype
+        self._engines.clear()
+        return self
+
+    def _engine_for(self, *xs: torch.Tensor) -> E.Engine:
+        x = xs[0]
+        if x.device.type != "cuda":
+            raise RuntimeError(f"{type(self).__name__}: input is on '{x.device}'. This package has no CPU path -- "
+                               "every layer is a HIP kernel for MI355X (gfx950).")
+        p = next(self.parameters())
+        if p.device != x.device:
+            raise RuntimeError(f"parameters are on {p.device} but the input is on {x.device}")
+        key = (tuple(x.shape), str(x.device), self.compute_dtype)
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = E.Engine(x.device, self.compute_dtype, self.nd)
+            self._build(eng, *[tuple(t.shape) for t in xs])
+            eng.finalize()
+            self._engines[key] = eng
+            while len(self._engines) > self._max_cached:
+                self._engines.popitem(last=False)
+        else:
+            self._engines.move_to_end(key)
+        return eng
+
+    def _space(self, shape):
+        if self.nd == 3:
+            n, c, d, h, w = shape
+            return (n, d, h, w), c
+        n, c, h, w = shape
+        return (n, 1, h, w), c
+
+    def _apply(self, fn, *a, **k):      # parameters moved (.to / .cuda): graphs hold stale pointers
+        self._engines.clear()
+        return super()._apply(fn, *a, **k)
+
+
+def _half(space):
+    n, d, h, w = space
+    return (n, d // 2 if d > 1 else 1, h // 2, w // 2)
+
+
+# ------------------------------------------------------------------------------------------------------
+# 2-D U-Net (+ Siamese variant)
+# ------------------------------------------------------------------------------------------------------
+class Unet(_HipNet):
+    """``Unet(in_channels=1, out_channels=1, n_filter=32, dilation=1)`` -> ``forward(x) = (sigmoid(logits), logits)``."""
+    nd = 2
+
+    def __init__(self, in_channels=1, out_channels=1, n_filter=32, dilation=1):
+        super().__init__()
+        f = n_filter
+        widths = [f, 2 * f, 4 * f, 8 * f]
+        c = in_channels
+        for lvl, wd in enumerate(widths):           # encode1..8 carry the ctor's dilation (reference :20-31)
+            setattr(self, f"encode{2 * lvl + 1}", _block(2, c, wd, dilation))
+            setattr(self, f"encode{2 * lvl + 2}", _block(2, wd, wd, dilation))
+            setattr(self, f"maxpool{lvl + 1}", nn.MaxPool2d(kernel_size=2, stride=2))
+            c = wd
+        self._make_middle(f, dilation)
+        c = 16 * f
+        for lvl in (1, 2, 3, 4):                    # decoder always dilation 1 (reference :38-49)
+            setattr(self, f"up{lvl}", nn.ConvTranspose2d(c, c // 2, kernel_size=2, stride=2))
+            setattr(self, f"decode{2 * lvl - 1}", _block(2, c, c // 2))
+            setattr(self, f"decode{2 * lvl}", _block(2, c // 2, c // 2))
+            c //= 2
+        self.final = nn.Sequential(nn.Conv2d(f, out_channels, kernel_size=1, padding=0))
+
+    def _make_middle(self, f, dilation):
+        self.middle_conv1 = _block(2, 8 * f, 16 * f, dilation)
+        self.middle_conv2 = _block(2, 16 * f, 16 * f, dilation)
+
+    # graph ---------------------------------------------------------------------------------------------
+    def _check_divisible(self, space):
+        n, d, h, w = space
+        if h % 16 or w % 16:
+            # the reference fails inside concat() when a pooled extent is odd (unet/unet.py:62-67)
+            raise ValueError("concatenation failed: wrong dimensions")
+
+    def _build_encoder(self, eng, x, spaces, cat_bufs, pool_out_slices=None):
+        t = x
+        skips = []
+        for lvl in range(4):
+            b1, b2 = getattr(self, f"encode{2 * lvl + 1}"), getattr(self, f"encode{2 * lvl + 2}")
+            wd = b1[0].out_channels
+            a = eng.new_act(spaces[lvl], wd, lazy=True)
+            eng.add(E.ConvBlockNode(eng, b1, t, a))
+            skip = cat_bufs[lvl].slice(wd, wd, lazy=True) if cat_bufs is not None else eng.new_act(spaces[lvl], wd, True)
+            eng.add(E.ConvBlockNode(eng, b2, a, skip))
+            skips.append(skip)
+            if lvl == 3 and pool_out_slices is not None:
+                pooled = pool_out_slices
+            else:
+                pooled = eng.new_act(spaces[lvl + 1], wd, lazy=False)
+            eng.add(E.ResampleNode(eng, "maxpool", skip, pooled))
+            t = pooled
+        return t, skips
+
+    def _build_decoder(self, eng, mid2, cat_bufs, spaces):
+        t = mid2
+        for lvl in (1, 2, 3, 4):
+            buf = cat_bufs[4 - lvl]
+            up = getattr(self, f"up{lvl}")
+            u = buf.slice(0, up.out_channels, lazy=False)
+            eng.add(E.ConvTNode(eng, up, t, u))
+            cat = buf.full()
+            b1, b2 = getattr(self, f"decode{2 * lvl - 1}"), getattr(self, f"decode{2 * lvl}")
+            a = eng.new_act(spaces[4 - lvl], b1[0].out_channels, lazy=True)
+            eng.add(E.ConvBlockNode(eng, b1, cat, a))
+            t = eng.new_act(spaces[4 - lvl], b2[0].out_channels, lazy=True)
+            eng.add(E.ConvBlockNode(eng, b2, a, t))
+        head = E.HeadNode(eng, self.final[0], t, "sigmoid", want_logits=True, want_act=True)
+        eng.add(head)
+        eng.heads.append(head)
+
+    def _spaces(self, space):
+        sp = [space]
+        for _ in range(4):
+            sp.append(_half(sp[-1]))
+        return sp
+
+    def _build(self, eng, xshape):
+        space, cin = self._space(xshape)
+        assert cin == self.encode1[0].in_channels, f"expected {self.encode1[0].in_channels} input channels, got {cin}"
+        self._check_divisible(space)
+        spaces = self._spaces(space)
+        cat_bufs = [eng.new_buf(*spaces[l], 2 * getattr(self, f"encode{2 * l + 2}")[0].out_channels) for l in range(4)]
+        x = eng.new_input(space, cin)
+        m4, _ = self._build_encoder(eng, x, spaces, cat_bufs)
+        mid1 = eng.new_act(spaces[4], self.middle_conv1[0].out_channels, lazy=True)
+        eng.add(E.ConvBlockNode(eng, self.middle_conv1, m4, mid1))
+        mid2 = eng.new_act(spaces[4], self.middle_conv2[0].out_channels, lazy=True)
+        eng.add(E.ConvBlockNode(eng, self.middle_conv2, mid1, mid2))
+        self._build_decoder(eng, mid2, cat_bufs, spaces)
+
+    def forward(self, x):
+        eng = self._engine_for(x)
+        logits, prob = E.run(eng, [x], [(0, "logits"), (0, "act")])
+        return prob, logits
+
+
+class Siam_UNet(Unet):
+    """``Siam_UNet(n_filter=32, mode='concat')`` -> ``forward(x, prev_x)``; encoder weights shared by both frames."""
+
+    def __init__(self, n_filter=32, mode="concat"):
+        self.mode = mode
+        super().__init__(in_channels=1, out_channels=1, n_filter=n_filter, dilation=1)
+
+    def _make_middle(self, f, dilation):
+        if self.mode == "concat":                       # reference siam_unet.py:38-39 (registered before middle_conv1)
+            self.conv_concat = _block(2, 16 * f, 8 * f)
+        super()._make_middle(f, dilation)
+
+    def _build(self, eng, xshape, pshape):
+        if self.mode not in ("concat", "max", "control", "corr"):
+            raise NotImplementedError("Unknown mode: {}".format(self.mode))
+        if self.mode == "corr":
+            raise NotImplementedError("Siam_UNet mode 'corr' (depth-wise cross-correlation join) has no HIP kernel yet")
+        if tuple(xshape) != tuple(pshape):
+            logging.critical(f"Shapes: {xshape}, {pshape}")
+            raise ValueError("concatenation failed: wrong dimensions")
+        space, cin = self._space(xshape)
+        self._check_divisible(space)
+        spaces = self._spaces(space)
+        cat_bufs = [eng.new_buf(*spaces[l], 2 * getattr(self, f"encode{2 * l + 2}")[0].out_channels) for l in range(4)]
+        x = eng.new_input(space, 1)
+        px = eng.new_input(space, 1)
+        c8 = self.encode8[0].out_channels
+        if self.mode == "concat":
+            jbuf = eng.new_buf(*spaces[4], 2 * c8)
+            m4, _ = self._build_encoder(eng, x, spaces, cat_bufs, pool_out_slices=jbuf.slice(0, c8, lazy=False))
+            mm4, _ = self._build_encoder(eng, px, spaces, None, pool_out_slices=jbuf.slice(c8, c8, lazy=False))
+            join = eng.new_act(spaces[4], self.conv_concat[0].out_channels, lazy=True)
+            eng.add(E.ConvBlockNode(eng, self.conv_concat, jbuf.full(), join))
+        else:
+            m4, _ = self._build_encoder(eng, x, spaces, cat_bufs)
+            mm4, _ = self._build_encoder(eng, px, spaces, None)     # 'control' still runs it (BN running stats!)
+            if self.mode == "max":
+                join = eng.new_act(spaces[4], c8, lazy=False)
+                eng.add(E.MaxJoinNode(eng, m4, mm4, join))
+            else:
+                join = m4
+        mid1 = eng.new_act(spaces[4], self.middle_conv1[0].out_channels, lazy=True)
+        eng.add(E.ConvBlockNode(eng, self.middle_conv1, join, mid1))
+        mid2 = eng.new_act(spaces[4], self.middle_conv2[0].out_channels, lazy=True)
+        eng.add(E.ConvBlockNode(eng, self.middle_conv2, mid1, mid2))
+        self._build_decoder(eng, mid2, cat_bufs, spaces)
+
+    def forward(self, x, prev_x):
+        eng = self._engine_for(x, prev_x)
+        logits, prob = E.run(eng, [x, prev_x], [(0, "logits"), (0, "act")])
+        return prob, logits
+
+
+# ------------------------------------------------------------------------------------------------------
+# 3-D U-Nets
+# ------------------------------------------------------------------------------------------------------
+class _Body3D(_HipNet):
+    nd = 3
+
+    def _make_body(self, in_channels, f, *, conv_t: bool, up_convs: bool, pools: bool):
+        plan = [(in_channels, f // 2), (f // 2, f), (f, f), (f, 2 * f), (2 * f, 2 * f), (2 * f, 4 * f)]
+        for i, (ci, co) in enumerate(plan):
+            setattr(self, f"encode{i + 1}", _block(3, ci, co))
+            if pools and i % 2 == 1:
+                setattr(self, f"maxpool{i // 2 + 1}", nn.MaxPool3d(kernel_size=2, stride=2))
+        self.middle_conv1 = _block(3, 4 * f, 4 * f)
+        self.middle_conv2 = _block(3, 4 * f, 8 * f)
+        if conv_t:
+            for lvl, c in ((1, 8 * f), (2, 4 * f), (3, 2 * f)):
+                setattr(self, f"up{lvl}", nn.ConvTranspose3d(c, c, kernel_size=2, stride=2))
+        if up_convs:
+            for lvl, c in ((1, 8 * f), (2, 4 * f), (3, 2 * f)):
+                setattr(self, f"up{lvl}_conv", _block(3, c, c))
+        for i, (ci, co) in enumerate([(12 * f, 4 * f), (4 * f, 4 * f), (6 * f, 2 * f), (2 * f, 2 * f), (3 * f, f),
+                                      (f, f // 2)]):
+            setattr(self, f"decode{i + 1}", _block(3, ci, co))
+
+    def _build_body(self, eng, xshape, *, down: str, up: str):
+        space, cin = self._space(xshape)
+        n, d, h, w = space
+        if d % 8 or h % 8 or w % 8:
+            # reference: bare torch.cat raises RuntimeError on the first mismatching level (unet3d.py:60-61)
+            raise RuntimeError("Sizes of tensors must match except in dimension 1 (input extents must be divisible by 8)")
+        spaces = [space]
+        for _ in range(3):
+            spaces.append(_half(spaces[-1]))
+        up_c = [self.middle_conv2[0].out_channels, self.decode2[0].out_channels, self.decode4[0].out_channels]
+        skip_c = [self.encode6[0].out_channels, self.encode4[0].out_channels, self.encode2[0].out_channels]
+        cat_bufs = [eng.new_buf(*spaces[2 - i], up_c[i] + skip_c[i]) for i in range(3)]   # level 2,1,0
+        x = eng.new_input(space, cin)
+        t = x
+        for lvl in range(3):
+            b1, b2 = getattr(self, f"encode{2 * lvl + 1}"), getattr(self, f"encode{2 * lvl + 2}")
+            a = eng.new_act(spaces[lvl], b1[0].out_channels, lazy=True)
+            eng.add(E.ConvBlockNode(eng, b1, t, a))
+            buf = cat_bufs[2 - lvl]
+            skip = buf.slice(up_c[2 - lvl], skip_c[2 - lvl], lazy=True)
+            eng.add(E.ConvBlockNode(eng, b2, a, skip))
+            pooled = eng.new_act(spaces[lvl + 1], skip.c, lazy=False)
+            eng.add(E.ResampleNode(eng, "maxpool" if down == "maxpool" else "down", skip, pooled))
+            t = pooled
+        mid1 = eng.new_act(spaces[3], self.middle_conv1[0].out_channels, lazy=True)
+        eng.add(E.ConvBlockNode(eng, self.middle_conv1, t, mid1))
+        t = eng.new_act(spaces[3], self.middle_conv2[0].out_channels, lazy=True)
+        eng.add(E.ConvBlockNode(eng, self.middle_conv2, mid1, t))
+        for i, lvl in enumerate((1, 2, 3)):
+            buf = cat_bufs[i]
+            sp = spaces[3 - lvl]
+            if up == "convT":
+                u = buf.slice(0, up_c[i], lazy=False)
+                eng.add(E.ConvTNode(eng, getattr(self, f"up{lvl}"), t, u))
+            elif up == "nearest_conv":
+                r = eng.new_act(sp, t.c, lazy=False)
+                eng.add(E.ResampleNode(eng, "up", t, r))
+                u = buf.slice(0, up_c[i], lazy=True)
+                eng.add(E.ConvBlockNode(eng, getattr(self, f"up{lvl}_conv"), r, u))
+            else:
+                raise NotImplementedError("UNet3D(use_interpolation=True): the trilinear up-sampling path (K10) has no "
+                                          "HIP kernel yet")
+            cat = buf.full()
+            b1, b2 = getattr(self, f"decode{2 * lvl - 1}"), getattr(self, f"decode{2 * lvl}")
+            a = eng.new_act(sp, b1[0].out_channels, lazy=True)
+            eng.add(E.ConvBlockNode(eng, b1, cat, a))
+            t = eng.new_act(sp, b2[0].out_channels, lazy=True)
+            eng.add(E.ConvBlockNode(eng, b2, a, t))
+        return t
+
+
+class UNet3D(_Body3D):
+    """``UNet3D(in_channels=1, out_channels=1, n_filter=16, use_interpolation=False)`` -> (sigmoid(logits), logits)."""
+
+    def __init__(self, in_channels=1, out_channels=1, n_filter=16, use_interpolation=False):
+        super().__init__()
+        self.use_interpolation = use_interpolation
+        self._make_body(in_channels, n_filter, conv_t=not use_interpolation, up_convs=False, pools=True)
+        self.final = nn.Conv3d(n_filter // 2, out_channels=out_channels, kernel_size=1, padding=0)
+
+    def _build(self, eng, xshape):
+        d6 = self._build_body(eng, xshape, down="maxpool", up="trilinear" if self.use_interpolation else "convT")
+        head = E.HeadNode(eng, self.final, d6, "sigmoid", want_logits=True, want_act=True)
+        eng.add(head)
+        eng.heads.append(head)
+
+    def forward(self, x):
+        eng = self._engine_for(x)
+        logits, prob = E.run(eng, [x], [(0, "logits"), (0, "act")])
+        return prob, logits
+
+
+class MultiOutputUnet3D(_Body3D):
+    """``MultiOutputUnet3D(in_channels=1, output_heads=None, n_filter=16, use_interpolation=True)`` -> dict of
+    activated head outputs (no logits), reference multi_output_unet3d.py:106-170."""
+
+    def __init__(self, in_channels: int = 1, output_heads: Optional[Dict[str, dict]] = None, n_filter: int = 16,
+                 use_interpolation: bool = True):
+        super().__init__()
+        self.output_heads = output_heads or {"default": {"channels": 1, "activation": "sigmoid"}}
+        self.use_interpolation = use_interpolation
+        self._make_body(in_channels, n_filter, conv_t=not use_interpolation, up_convs=use_interpolation,
+                        pools=not use_interpolation)
+        self.output_layers = nn.ModuleDict()
+        for name, cfg in self.output_heads.items():
+            self.output_layers[name] = nn.Conv3d(n_filter // 2, cfg["channels"], kernel_size=1)
+
+    def _build(self, eng, xshape):
+        d6 = self._build_body(eng, xshape, down="down" if self.use_interpolation else "maxpool",
+                              up="nearest_conv" if self.use_interpolation else "convT")
+        for name, cfg in self.output_heads.items():
+            head = E.HeadNode(eng, self.output_layers[name], d6, cfg.get("activation"), want_logits=False, want_act=True)
+            eng.add(head)
+            eng.heads.append(head)
+
+    def forward(self, x):
+        eng = self._engine_for(x)
+        outs = E.run(eng, [x], [(i, "act") for i in range(len(self.output_heads))])
+        return {name: o for name, o in zip(self.output_heads, outs)}

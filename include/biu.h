@@ -1,0 +1,203 @@
+/*
+ * biu.h -- C ABI of the MI355X-native U-Net hot path (libbiu_hip.so).
+ *
+ * The reference (danihae/bio-image-unet) has no FFI: its seam is class injection of an nn.Module whose
+ * forward/backward dispatch to torch.nn primitives.  Each entry point below replaces one of
+ * those primitive call sites with a hand-written gfx950 kernel; the citation on every declaration names the
+ * reference line whose arithmetic it takes over.  Paths are relative to /root/reference/bio_image_unet.
+ *
+ * Conventions
+ *   - Activations live in HBM channels-last: element (n,d,h,w,c) of a biu_act is at
+ *         p + (((n*D + d)*H + h)*W + w) * pitch + c          (2-D tensors use D = 1)
+ *     `pitch` >= c lets several tensors share one buffer as channel slices, which is how the
+ *     skip-concat (unet/unet.py:62-67) costs zero bytes: producers write straight into their slice.
+ *   - dtype: BIU_F32 or BIU_BF16 for activations / activation gradients.  Parameters, parameter
+ *     gradients and all BatchNorm vectors are always fp32.
+ *   - A biu_xform is the per-channel epilogue of the *producer* applied by the *consumer* while loading:
+ *         T(v) = max(t, slope[c]*t),  t = scale[c]*v + shift[c]        (0 <= slope <= 1)
+ *     i.e. BatchNorm-affine followed by LeakyReLU.  NULL members mean scale=1 / shift=0 / slope=1.
+ *     Spatial zero padding is applied AFTER T (padding pads the activated tensor).
+ *   - Every function only enqueues work on `stream`; no allocation, no host synchronisation.  Outputs and
+ *     workspaces are caller-owned (PyTorch's caching allocator in practice).
+ *   - Return value: 0 = BIU_OK, otherwise a negative biu_status; biu_last_error() gives a message.
+ *     Nothing throws across this boundary.
+ */
+#ifndef BIU_H
+#define BIU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* biu_stream;          /* hipStream_t */
+
+enum { BIU_F32 = 0, BIU_BF16 = 1 };
+
+typedef enum {
+    BIU_OK = 0,
+    BIU_ERR_SHAPE = -1,            /* operand shapes inconsistent with each other             */
+    BIU_ERR_UNSUPPORTED = -2,      /* valid request that no kernel covers                     */
+    BIU_ERR_ALIGN = -3,            /* pointer / pitch alignment requirement violated          */
+    BIU_ERR_WORKSPACE = -4,        /* workspace too small                                     */
+    BIU_ERR_LAUNCH = -5            /* hipLaunchKernel reported an error                       */
+} biu_status;
+
+typedef struct {
+    void*   p;                     /* first element of channel 0 of the slice                 */
+    int32_t n, d, h, w;            /* batch and spatial extent                                */
+    int32_t c;                     /* channels in this slice                                  */
+    int32_t pitch;                 /* elements between consecutive voxels                     */
+} biu_act;
+
+typedef struct {
+    const float* scale;
+    const float* shift;
+    const float* slope;
+} biu_xform;
+
+const char* biu_last_error(void);
+int  biu_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * 3x3 / 3x3x3 "same" convolution, stride 1, padding = dilation            [K1, K2 of SURVEY 2b]
+ * replaces nn.Conv2d / nn.Conv3d inside the conv block: unet/unet.py:56, unet3d/unet3d.py:54,
+ * siam_unet/siam_unet.py:61, multi_output_unet3d/multi_output_unet3d.py:86-87
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Weight packing for the MFMA implicit-GEMM kernels.  `kind`: 0 = forward operand, 1 = data-gradient
+ * operand (spatially flipped, Cin<->Cout swapped).  w is the PyTorch tensor (Cout,Cin,kd,kh,kw) fp32,
+ * kd = 1 for 2-D.  biu_conv_packed_bytes returns 0 when the shape is served by the direct kernels and
+ * no packing is needed. */
+size_t biu_conv_packed_bytes(int kind, int cin, int cout, int kd, int kh, int kw, int dilation, int dtype);
+int    biu_conv_pack(int kind, const float* w, int cin, int cout, int kd, int kh, int kw, int dtype,
+                     void* packed, biu_stream stream);
+
+/* y = conv(T(x), w) + bias.  w: PyTorch layout fp32; packed: result of biu_conv_pack(kind 0), or NULL
+ * when biu_conv_packed_bytes() returned 0 for this shape.                                                */
+int biu_conv_fwd(const biu_act* x, const biu_xform* xf, const float* w, const void* packed,
+                 const float* bias, int kd, int kh, int kw, int dilation,
+                 const biu_act* y, int dtype, biu_stream stream);
+
+/* dx = conv_transpose_of_the_above(dy): dx[v,ci] = sum_{tap,co} dy[v - off(tap), co] * w[co,ci,tap].
+ * packed: result of biu_conv_pack(kind 1) or NULL.  accumulate != 0 adds into dx.                       */
+int biu_conv_bwd_data(const biu_act* dy, const float* w, const void* packed,
+                      int kd, int kh, int kw, int dilation,
+                      const biu_act* dx, int accumulate, int dtype, biu_stream stream);
+
+/* dw[co,ci,tap] = sum_v T(x)[v + off(tap), ci] * dy[v, co]  (PyTorch layout fp32, overwritten);
+ * dbias[co] = sum_v dy[v,co] (may be NULL).  ws: biu_conv_bwd_weight_workspace() bytes.                 */
+size_t biu_conv_bwd_weight_workspace(int cin, int cout, int kd, int kh, int kw, int dtype);
+int biu_conv_bwd_weight(const biu_act* x, const biu_xform* xf, const biu_act* dy,
+                        int kd, int kh, int kw, int dilation,
+                        float* dw, float* dbias, void* ws, size_t ws_bytes, int dtype, biu_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm (training: batch statistics) + LeakyReLU(0.1)                          [K3, K4]
+ * replaces nn.BatchNorm2d/3d + nn.LeakyReLU: unet/unet.py:57-58, unet3d/unet3d.py:55-56
+ * ---------------------------------------------------------------------------------------------- */
+#define BIU_BN_MAX_PARTIALS 1024
+/* partial: float[nblk][c][2]; returns nblk actually written through *nblk_out (<= BIU_BN_MAX_PARTIALS). */
+int biu_bn_stats(const biu_act* y, float* partial, int* nblk_out, int dtype, biu_stream stream);
+
+/* Training-mode finalize: mean/biased var from the partials (fp64 merge), running stats updated with the
+ * unbiased variance and `momentum`, and the consumer transform (scale, shift) = (g*r, b - mean*g*r).
+ * save_mean / save_invstd are kept for the backward pass.                                                */
+int biu_bn_finalize(const float* partial, int nblk, int c, double count,
+                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    float momentum, float eps, float* scale, float* shift,
+                    float* save_mean, float* save_invstd, biu_stream stream);
+
+/* Eval-mode transform from the running statistics.                                                       */
+int biu_bn_eval_affine(int c, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, biu_stream stream);
+
+/* out = T(x) (materialises BatchNorm-affine + LeakyReLU; also plain dtype-preserving copies).            */
+int biu_xform_apply(const biu_act* x, const biu_xform* xf, const biu_act* out, int dtype, biu_stream stream);
+
+/* Backward of a = T(y), T = lrelu_slope(scale*y+shift) with scale/shift from batch statistics.
+ *   reduce:   partial[nblk][c][2] = (sum dz, sum dz*yhat),  dz = da * T'(.)
+ *   finalize: dgamma, dbeta and the three vectors of   dy = A*dz + B*y + C
+ *   apply:    dy (may alias da)                                                                           */
+int biu_bn_bwd_reduce(const biu_act* da, const biu_act* y, const float* scale, const float* shift,
+                      const float* slope, const float* save_mean, const float* save_invstd,
+                      float* partial, int* nblk_out, int dtype, biu_stream stream);
+int biu_bn_bwd_finalize(const float* partial, int nblk, int c, double count,
+                        const float* scale, const float* save_mean, const float* save_invstd,
+                        float* dgamma, float* dbeta, float* coefA, float* coefB, float* coefC,
+                        biu_stream stream);
+int biu_bn_bwd_apply(const biu_act* da, const biu_act* y, const float* scale, const float* shift,
+                     const float* slope, const float* coefA, const float* coefB, const float* coefC,
+                     const biu_act* dy, int dtype, biu_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 2x2 / 2x2x2 max-pool, stride 2                                                        [K6]
+ * replaces nn.MaxPool2d/3d: unet/unet.py:22-31, unet3d/unet3d.py:26-32
+ * bwd routes the gradient to the FIRST maximum in (d,h,w) scan order (PyTorch tie rule).
+ * nearest: F.interpolate(scale 0.5 / 2, 'nearest'), multi_output_unet3d.py:112-156     [K11]
+ * ---------------------------------------------------------------------------------------------- */
+int biu_maxpool_fwd(const biu_act* x, const biu_xform* xf, const biu_act* out, int dtype, biu_stream stream);
+int biu_maxpool_bwd(const biu_act* x, const biu_xform* xf, const biu_act* dout, const biu_act* dx,
+                    int accumulate, int dtype, biu_stream stream);
+int biu_nearest_down_fwd(const biu_act* x, const biu_xform* xf, const biu_act* out, int dtype, biu_stream stream);
+int biu_nearest_down_bwd(const biu_act* dout, const biu_act* dx, int accumulate, int dtype, biu_stream stream);
+int biu_nearest_up_fwd(const biu_act* x, const biu_xform* xf, const biu_act* out, int dtype, biu_stream stream);
+int biu_nearest_up_bwd(const biu_act* dout, const biu_act* dx, int accumulate, int dtype, biu_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ConvTranspose k=2, stride=2 (non-overlapping)                                         [K7]
+ * replaces nn.ConvTranspose2d/3d: unet/unet.py:38-47, unet3d/unet3d.py:40-42
+ * w: PyTorch layout (Cin, Cout, kd, 2, 2) fp32 with kd = 2 (3-D) or 1 (2-D).
+ * ---------------------------------------------------------------------------------------------- */
+int biu_convt_fwd(const biu_act* x, const biu_xform* xf, const float* w, const float* bias, int kd,
+                  const biu_act* y, int dtype, biu_stream stream);
+int biu_convt_bwd_data(const biu_act* dy, const float* w, int kd, const biu_act* dx, int accumulate,
+                       int dtype, biu_stream stream);
+int biu_convt_bwd_weight(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd,
+                         float* dw, float* dbias, int dtype, biu_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 1x1(x1) head + activation                                                             [K9]
+ * replaces final Conv + torch.sigmoid: unet/unet.py:51,103-104, unet3d/unet3d.py:50,98-99,
+ * multi_output_unet3d.py:80-82,164-168.  Outputs are fp32 NCDHW (what the caller's loss consumes).
+ * act: 0 none, 1 sigmoid, 2 tanh, 3 relu.  logits / activated may each be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int biu_head_fwd(const biu_act* x, const biu_xform* xf, const float* w, const float* bias, int cout,
+                 int act, float* logits, float* activated, int dtype, biu_stream stream);
+/* dlogits: fp32 NCDHW.  dx = W^T dlogits (activation-gradient layout); dw (cout,cin), dbias (cout) fp32,
+ * overwritten; each of dx / dw / dbias may be NULL.  ws: biu_head_bwd_workspace(cin) bytes (for dw).      */
+size_t biu_head_bwd_workspace(int cin);
+int biu_head_bwd(const biu_act* x, const biu_xform* xf, const float* w, int cout, const float* dlogits,
+                 const biu_act* dx, float* dw, float* dbias, void* ws, size_t ws_bytes, int dtype,
+                 biu_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Element-wise helpers on activation slices
+ * ---------------------------------------------------------------------------------------------- */
+/* out = max(T1(a), T2(b))  -- Siam 'max' join, siam_unet/siam_unet.py:117; bwd routes to a on ties.      */
+int biu_max_join_fwd(const biu_act* a, const biu_xform* xa, const biu_act* b, const biu_xform* xb,
+                     const biu_act* out, int dtype, biu_stream stream);
+int biu_max_join_bwd(const biu_act* a, const biu_xform* xa, const biu_act* b, const biu_xform* xb,
+                     const biu_act* dout, const biu_act* da, const biu_act* db, int accumulate,
+                     int dtype, biu_stream stream);
+/* dst (+)= src, both activation slices of equal shape.                                                   */
+int biu_act_add(const biu_act* src, const biu_act* dst, int accumulate, int dtype, biu_stream stream);
+/* NC[D]HW fp32 <-> channels-last activation (network input / gradient at the module boundary).           */
+int biu_from_nchw(const float* src, const biu_act* dst, int dtype, biu_stream stream);
+int biu_to_nchw(const biu_act* src, const biu_xform* xf, float* dst, int dtype, biu_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused multi-tensor Adam                                                               [K14]
+ * replaces torch.optim.Adam(lr) step: unet/train.py:102,139 (betas 0.9/0.999, eps 1e-8, no decay).
+ * One launch updates `n` parameter tensors; ptrs are device arrays of device pointers.
+ * ---------------------------------------------------------------------------------------------- */
+int biu_adam_step(int n, float* const* params, const float* const* grads, float* const* exp_avg,
+                  float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2,
+                  float eps, int step, float grad_scale, biu_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIU_H */

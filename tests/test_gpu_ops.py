@@ -1,0 +1,295 @@
+"""Per-kernel parity through the C ABI (libbiu_hip.so) against torch CPU fp32 functional ops -- the same ATen
+kernels the reference's nn.Modules dispatch to.  Shapes include odd channel counts, channel-slice (pitch > C)
+operands, 2-D (D = 1) and 3-D, dilation 2, and negative BatchNorm scales in the fused input transform."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from tests.gpu_util import DT, XF, Dev, assert_close, check, lib, ptr, stream  # noqa: E402
+
+DTYPES = ["f32", "bf16"]
+
+
+def rnd(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def conv_ref(x, w, b, dil):
+    f = F.conv3d if w.dim() == 5 else F.conv2d
+    return f(x, w, b, padding=dil, dilation=dil)
+
+
+CONV_CASES = [
+    # (nd, N, Cin, Cout, spatial, dil)
+    (2, 2, 1, 4, (12, 20), 1),
+    (2, 1, 5, 3, (9, 7), 2),
+    (2, 2, 8, 16, (16, 16), 1),
+    (3, 1, 3, 5, (4, 6, 10), 1),
+    (3, 2, 4, 8, (8, 8, 8), 1),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_bwd(case, dtype):
+    nd, n, cin, cout, sp, dil = case
+    x = rnd(n, cin, *sp, seed=1)
+    w = rnd(cout, cin, *([3] * nd), seed=2) * 0.3
+    b = rnd(cout, seed=3)
+    xf = XF(cin, seed=4)
+    dx_ = Dev(x, dtype=dtype, pitch=cin + 3, c0=2)
+    xr = dx_.ref().squeeze(2) if nd == 2 else dx_.ref()
+    xa = xf.apply(xr).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    yref = conv_ref(xa, wr, br, dil)
+    dy = rnd(*yref.shape, seed=5)
+    kd = 3 if nd == 3 else 1
+    wd, bd = w.cuda(), b.cuda()
+    yd = Dev(shape=(n, cout, 1 if nd == 2 else sp[0], sp[-2], sp[-1]), dtype=dtype, pitch=cout + 1, c0=1)
+    check(lib.biu_conv_fwd(dx_.a(), xf.x(), ptr(wd), None, ptr(bd), kd, 3, 3, dil, yd.a(), DT[dtype][1], stream()), "conv_fwd")
+    got = yd.get(squeeze2d=(nd == 2))
+    assert_close(got, yref.detach(), dtype, "conv_fwd")
+    # backward: data gradient is wrt T(x) (the activated input), weight gradient sees T(x)
+    dyd = Dev(dy, dtype=dtype)
+    dyr = dyd.ref().squeeze(2) if nd == 2 else dyd.ref()
+    yref.backward(dyr)
+    dxd = Dev(shape=(n, cin, 1 if nd == 2 else sp[0], sp[-2], sp[-1]), dtype=dtype)
+    check(lib.biu_conv_bwd_data(dyd.a(), ptr(wd), None, kd, 3, 3, dil, dxd.a(), 0, DT[dtype][1], stream()), "conv_bwd_data")
+    assert_close(dxd.get(squeeze2d=(nd == 2)), xa.grad, dtype, "conv_bwd_data")
+    dw = torch.empty_like(wd)
+    db = torch.empty_like(bd)
+    ws = torch.empty(max(lib.biu_conv_bwd_weight_workspace(cin, cout, kd, 3, 3, DT[dtype][1]), 16), dtype=torch.uint8, device="cuda")
+    check(lib.biu_conv_bwd_weight(dx_.a(), xf.x(), dyd.a(), kd, 3, 3, dil, ptr(dw), ptr(db), ptr(ws), ws.numel(), DT[dtype][1],
+                                  stream()), "conv_bwd_weight")
+    assert_close(dw.cpu(), wr.grad, dtype, "conv_bwd_weight")
+    assert_close(db.cpu(), br.grad, dtype, "conv dbias")
+    # accumulate flag
+    check(lib.biu_conv_bwd_data(dyd.a(), ptr(wd), None, kd, 3, 3, dil, dxd.a(), 1, DT[dtype][1], stream()), "conv_bwd_data acc")
+    assert_close(dxd.get(squeeze2d=(nd == 2)), 2 * xa.grad, dtype, "conv_bwd_data(accumulate)")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 5, 1, 8, 12), (2, 16, 4, 6, 10), (1, 300, 1, 4, 4)])
+def test_batchnorm_fwd_bwd(shape, dtype):
+    n, c, d, h, w = shape
+    y = rnd(*shape, seed=1) * 2 + 0.5
+    yd = Dev(y, dtype=dtype, pitch=c + 8, c0=8)
+    yr = yd.ref().requires_grad_(True)
+    gamma = (rnd(c, seed=2) * 0.3 + 1).requires_grad_(True)
+    beta = (rnd(c, seed=3) * 0.2).requires_grad_(True)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    out = F.leaky_relu(F.batch_norm(yr, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5), 0.1)
+    # device
+    partial = torch.empty(1024 * c * 2, device="cuda")
+    nblk = C.c_int(0)
+    check(lib.biu_bn_stats(yd.a(), ptr(partial), C.byref(nblk), DT[dtype][1], stream()), "bn_stats")
+    g_d, b_d = gamma.detach().cuda(), beta.detach().cuda()
+    rm_d, rv_d = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    scale, shift, mean, invstd = (torch.empty(c, device="cuda") for _ in range(4))
+    check(lib.biu_bn_finalize(ptr(partial), nblk.value, c, float(n * d * h * w), ptr(g_d), ptr(b_d), ptr(rm_d), ptr(rv_d), 0.1, 1e-5,
+                              ptr(scale), ptr(shift), ptr(mean), ptr(invstd), stream()), "bn_finalize")
+    torch.testing.assert_close(rm_d.cpu(), rm, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rv_d.cpu(), rv, rtol=1e-4, atol=1e-5)
+    slope = torch.full((c,), 0.1, device="cuda")
+    od = Dev(shape=shape, dtype=dtype)
+    from tests.gpu_util import biu_xform
+    xfs = biu_xform(scale.data_ptr(), shift.data_ptr(), slope.data_ptr())
+    check(lib.biu_xform_apply(yd.a(), C.byref(xfs), od.a(), DT[dtype][1], stream()), "xform_apply")
+    assert_close(od.get(), out.detach(), dtype, "bn+lrelu fwd")
+    # backward
+    da = rnd(*shape, seed=4)
+    dad = Dev(da, dtype=dtype)
+    out.backward(dad.ref())
+    check(lib.biu_bn_bwd_reduce(dad.a(), yd.a(), ptr(scale), ptr(shift), ptr(slope), ptr(mean), ptr(invstd), ptr(partial),
+                                C.byref(nblk), DT[dtype][1], stream()), "bn_bwd_reduce")
+    dg, dbt, A, B, Cc = (torch.empty(c, device="cuda") for _ in range(5))
+    check(lib.biu_bn_bwd_finalize(ptr(partial), nblk.value, c, float(n * d * h * w), ptr(scale), ptr(mean), ptr(invstd), ptr(dg),
+                                  ptr(dbt), ptr(A), ptr(B), ptr(Cc), stream()), "bn_bwd_finalize")
+    check(lib.biu_bn_bwd_apply(dad.a(), yd.a(), ptr(scale), ptr(shift), ptr(slope), ptr(A), ptr(B), ptr(Cc), dad.a(), DT[dtype][1],
+                               stream()), "bn_bwd_apply")
+    assert_close(dg.cpu(), gamma.grad, dtype, "dgamma")
+    assert_close(dbt.cpu(), beta.grad, dtype, "dbeta")
+    assert_close(dad.get(), yr.grad, dtype, "bn dy")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 5, 1, 8, 12), (1, 8, 4, 6, 10), (2, 16, 2, 4, 4)])
+def test_maxpool_and_nearest(shape, dtype):
+    n, c, d, h, w = shape
+    nd = 2 if d == 1 else 3
+    x = rnd(*shape, seed=1)
+    x[0, 0, 0, 0, 0] = x[0, 0, 0, 0, 1] = 5.0            # a tie: gradient must go to the first maximum
+    xf = XF(c, seed=2)
+    xd = Dev(x, dtype=dtype, pitch=c + 8, c0=0)
+    xa = xf.apply(xd.ref()).requires_grad_(True)
+    xs = xa.squeeze(2) if nd == 2 else xa
+    pool = F.max_pool2d if nd == 2 else F.max_pool3d
+    ref = pool(xs, 2, 2)
+    oshape = (n, c, max(d // 2, 1), h // 2, w // 2)
+    od = Dev(shape=oshape, dtype=dtype)
+    check(lib.biu_maxpool_fwd(xd.a(), xf.x(), od.a(), DT[dtype][1], stream()), "maxpool_fwd")
+    assert_close(od.get(squeeze2d=nd == 2), ref.detach(), dtype, "maxpool_fwd")
+    g = rnd(*ref.shape, seed=3)
+    gd = Dev(g, dtype=dtype)
+    gr = gd.ref().squeeze(2) if nd == 2 else gd.ref()
+    ref.backward(gr)
+    dxd = Dev(shape=shape, dtype=dtype, fill=0.0)
+    check(lib.biu_maxpool_bwd(xd.a(), xf.x(), gd.a(), dxd.a(), 0, DT[dtype][1], stream()), "maxpool_bwd")
+    assert_close(dxd.get(), xa.grad, dtype, "maxpool_bwd")
+    check(lib.biu_maxpool_bwd(xd.a(), xf.x(), gd.a(), dxd.a(), 1, DT[dtype][1], stream()), "maxpool_bwd acc")
+    assert_close(dxd.get(), 2 * xa.grad, dtype, "maxpool_bwd(accumulate)")
+    # nearest x0.5 and x2 (3-D only in the reference; the kernels are dimension-agnostic)
+    xa2 = xf.apply(xd.ref()).requires_grad_(True)
+    xs2 = xa2.squeeze(2) if nd == 2 else xa2
+    down = F.interpolate(xs2, scale_factor=0.5, mode="nearest")
+    check(lib.biu_nearest_down_fwd(xd.a(), xf.x(), od.a(), DT[dtype][1], stream()), "nearest_down_fwd")
+    assert_close(od.get(squeeze2d=nd == 2), down.detach(), dtype, "nearest_down_fwd")
+    down.backward(gr)
+    check(lib.biu_nearest_down_bwd(gd.a(), dxd.a(), 0, DT[dtype][1], stream()), "nearest_down_bwd")
+    assert_close(dxd.get(), xa2.grad, dtype, "nearest_down_bwd")
+    sm = rnd(*oshape, seed=5)
+    sd_ = Dev(sm, dtype=dtype)
+    sr = sd_.ref().requires_grad_(True)
+    srs = sr.squeeze(2) if nd == 2 else sr
+    up = F.interpolate(srs, scale_factor=2, mode="nearest")
+    ud = Dev(shape=shape, dtype=dtype)
+    check(lib.biu_nearest_up_fwd(sd_.a(), None, ud.a(), DT[dtype][1], stream()), "nearest_up_fwd")
+    assert_close(ud.get(squeeze2d=nd == 2), up.detach(), dtype, "nearest_up_fwd")
+    gu = Dev(rnd(*shape, seed=6), dtype=dtype)
+    up.backward(gu.ref().squeeze(2) if nd == 2 else gu.ref())
+    dsd = Dev(shape=oshape, dtype=dtype)
+    check(lib.biu_nearest_up_bwd(gu.a(), dsd.a(), 0, DT[dtype][1], stream()), "nearest_up_bwd")
+    assert_close(dsd.get(), sr.grad, dtype, "nearest_up_bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 2, 6, 3, (4, 6)), (3, 1, 4, 4, (2, 4, 6)), (3, 2, 16, 16, (2, 2, 2))])
+def test_convtranspose(case, dtype):
+    nd, n, cin, cout, sp = case
+    x = rnd(n, cin, *sp, seed=1)
+    w = rnd(cin, cout, *([2] * nd), seed=2) * 0.3
+    b = rnd(cout, seed=3)
+    xf = XF(cin, seed=4)
+    xd = Dev(x, dtype=dtype)
+    xr = xd.ref().squeeze(2) if nd == 2 else xd.ref()
+    xa = xf.apply(xr).requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    f = F.conv_transpose3d if nd == 3 else F.conv_transpose2d
+    ref = f(xa, wr, br, stride=2)
+    kd = 2 if nd == 3 else 1
+    osp = tuple(2 * s for s in sp)
+    oshape = (n, cout, 1 if nd == 2 else osp[0], osp[-2], osp[-1])
+    yd = Dev(shape=oshape, dtype=dtype, pitch=cout + 5, c0=0)
+    wd, bd = w.cuda(), b.cuda()
+    check(lib.biu_convt_fwd(xd.a(), xf.x(), ptr(wd), ptr(bd), kd, yd.a(), DT[dtype][1], stream()), "convt_fwd")
+    assert_close(yd.get(squeeze2d=nd == 2), ref.detach(), dtype, "convt_fwd")
+    gd = Dev(rnd(*ref.shape, seed=5), dtype=dtype)
+    ref.backward(gd.ref().squeeze(2) if nd == 2 else gd.ref())
+    dxd = Dev(shape=(n, cin, 1 if nd == 2 else sp[0], sp[-2], sp[-1]), dtype=dtype)
+    check(lib.biu_convt_bwd_data(gd.a(), ptr(wd), kd, dxd.a(), 0, DT[dtype][1], stream()), "convt_bwd_data")
+    assert_close(dxd.get(squeeze2d=nd == 2), xa.grad, dtype, "convt_bwd_data")
+    dw, db = torch.empty_like(wd), torch.empty_like(bd)
+    check(lib.biu_convt_bwd_weight(xd.a(), xf.x(), gd.a(), kd, ptr(dw), ptr(db), DT[dtype][1], stream()), "convt_bwd_weight")
+    assert_close(dw.cpu(), wr.grad, dtype, "convt dw")
+    assert_close(db.cpu(), br.grad, dtype, "convt db")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 2, 7, 1, (6, 10), 1), (3, 1, 8, 2, (2, 4, 6), 0), (3, 2, 16, 3, (2, 4, 4), 2)])
+def test_head(case, dtype):
+    nd, n, cin, cout, sp, act = case
+    x = rnd(n, cin, *sp, seed=1)
+    w = rnd(cout, cin, seed=2) * 0.5
+    b = rnd(cout, seed=3)
+    xf = XF(cin, seed=4)
+    xd = Dev(x, dtype=dtype)
+    xr = xd.ref().squeeze(2) if nd == 2 else xd.ref()
+    xa = xf.apply(xr).requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    f = F.conv3d if nd == 3 else F.conv2d
+    logits = f(xa, wr.view(cout, cin, *([1] * nd)), br)
+    actf = {0: lambda t: t, 1: torch.sigmoid, 2: torch.tanh, 3: F.relu}[act]
+    lo = torch.empty(logits.shape, device="cuda")
+    ac = torch.empty(logits.shape, device="cuda")
+    wd, bd = w.cuda(), b.cuda()
+    check(lib.biu_head_fwd(xd.a(), xf.x(), ptr(wd), ptr(bd), cout, act, ptr(lo), ptr(ac), DT[dtype][1], stream()), "head_fwd")
+    # outputs are fp32; the only bf16 effect is the stored input
+    torch.testing.assert_close(lo.cpu(), logits.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(ac.cpu(), actf(logits).detach(), rtol=1e-4, atol=1e-4)
+    dl = rnd(*logits.shape, seed=6)
+    logits.backward(dl)
+    dxd = Dev(shape=(n, cin, 1 if nd == 2 else sp[0], sp[-2], sp[-1]), dtype=dtype)
+    dw, db = torch.empty_like(wd), torch.empty_like(bd)
+    ws = torch.empty(lib.biu_head_bwd_workspace(cin), dtype=torch.uint8, device="cuda")
+    dld = dl.cuda()
+    check(lib.biu_head_bwd(xd.a(), xf.x(), ptr(wd), cout, ptr(dld), dxd.a(), ptr(dw), ptr(db), ptr(ws), ws.numel(), DT[dtype][1],
+                           stream()), "head_bwd")
+    assert_close(dxd.get(squeeze2d=nd == 2), xa.grad, dtype, "head dx")
+    assert_close(dw.cpu(), wr.grad, "f32", "head dw")
+    assert_close(db.cpu(), br.grad, "f32", "head db")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_elementwise_helpers(dtype):
+    shape = (2, 8, 1, 4, 6)
+    a, b = rnd(*shape, seed=1), rnd(*shape, seed=2)
+    b[0, 0, 0, 0, 0] = a[0, 0, 0, 0, 0] = 1.0
+    ad, bd = Dev(a, dtype=dtype), Dev(b, dtype=dtype)
+    ar, br = ad.ref().requires_grad_(True), bd.ref().requires_grad_(True)
+    ref = torch.maximum(ar, br)
+    od = Dev(shape=shape, dtype=dtype)
+    check(lib.biu_max_join_fwd(ad.a(), None, bd.a(), None, od.a(), DT[dtype][1], stream()), "max_join_fwd")
+    assert_close(od.get(), ref.detach(), dtype, "max_join_fwd")
+    gd = Dev(rnd(*shape, seed=3), dtype=dtype)
+    ref.backward(gd.ref())
+    dad, dbd = Dev(shape=shape, dtype=dtype), Dev(shape=shape, dtype=dtype)
+    check(lib.biu_max_join_bwd(ad.a(), None, bd.a(), None, gd.a(), dad.a(), dbd.a(), 0, DT[dtype][1], stream()), "max_join_bwd")
+    assert_close(dad.get(), ar.grad, dtype, "max_join da")
+    assert_close(dbd.get(), br.grad, dtype, "max_join db")
+    # nchw <-> channels-last
+    x = rnd(2, 3, 4, 5, 6, seed=4)
+    xd = Dev(shape=(2, 3, 4, 5, 6), dtype=dtype, pitch=7, c0=1)
+    xs = x.cuda()
+    check(lib.biu_from_nchw(ptr(xs), xd.a(), DT[dtype][1], stream()), "from_nchw")
+    assert_close(xd.get(), x, dtype, "from_nchw")
+    back = torch.empty_like(xs)
+    check(lib.biu_to_nchw(xd.a(), None, ptr(back), DT[dtype][1], stream()), "to_nchw")
+    torch.testing.assert_close(back.cpu(), xd.ref())
+
+
+def test_adam_matches_torch():
+    torch.manual_seed(0)
+    ps = [torch.randn(s) for s in [(7,), (3, 5), (64, 3, 3, 3)]]
+    gs = [torch.randn_like(p) for p in ps]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    opt = torch.optim.Adam(ref, lr=1e-3)
+    dp = [p.clone().cuda() for p in ps]
+    m = [torch.zeros_like(p) for p in dp]
+    v = [torch.zeros_like(p) for p in dp]
+    for step in (1, 2, 3):
+        for r, g in zip(ref, gs):
+            r.grad = g.clone() * step
+        opt.step()
+        dg = [(g * step).cuda() for g in gs]
+        mk = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device="cuda")
+        numel = torch.tensor([p.numel() for p in dp], dtype=torch.int64, device="cuda")
+        check(lib.biu_adam_step(len(dp), ptr(mk(dp)), ptr(mk(dg)), ptr(mk(m)), ptr(mk(v)), ptr(numel), 1e-3, 0.9, 0.999, 1e-8, step, 1.0,
+                                stream()), "adam")
+        torch.cuda.synchronize()
+    for r, p in zip(ref, dp):
+        torch.testing.assert_close(p.cpu(), r.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_shape_errors_are_reported_not_thrown():
+    x = Dev(rnd(1, 4, 1, 8, 8), dtype="f32")
+    y = Dev(shape=(1, 4, 1, 4, 8), dtype="f32")
+    w = torch.zeros(4, 4, 3, 3, device="cuda")
+    rc = lib.biu_conv_fwd(x.a(), None, ptr(w), None, None, 1, 3, 3, 1, y.a(), 0, stream())
+    assert rc == -1 and b"conv_fwd" in lib.biu_last_error()
+    rc = lib.biu_maxpool_fwd(x.a(), None, x.a(), 0, stream())
+    assert rc == -1
