@@ -501,8 +501,15 @@ class Engine:
         self.nbt_bump = []
         for nd_ in self.nodes:
             nd_.fwd(self)
-        if self.nbt_bump:
-            torch._foreach_add_(self.nbt_bump, 1)
+        if self.nbt_bump:       # a weight-shared block (Siam encoder) appears once per application
+            counts: Dict[int, list] = {}
+            for t in self.nbt_bump:
+                counts.setdefault(id(t), [t, 0])[1] += 1
+            by_k: Dict[int, list] = {}
+            for t, k in counts.values():
+                by_k.setdefault(k, []).append(t)
+            for k, ts in by_k.items():
+                torch._foreach_add_(ts, k)
 
     def backward(self, head_grads: Sequence[Optional[torch.Tensor]]):
         """head_grads[i] = d loss / d logits of head i (already combined with the activation's gradient)."""

