@@ -59,9 +59,12 @@ SIGNATURES = {
     "biu_nearest_down_bwd": (_I, [_A, _A, _I, _I, _P]),
     "biu_nearest_up_fwd": (_I, [_A, _X, _A, _I, _P]),
     "biu_nearest_up_bwd": (_I, [_A, _A, _I, _I, _P]),
-    "biu_convt_fwd": (_I, [_A, _X, _P, _P, _I, _A, _I, _P]),
-    "biu_convt_bwd_data": (_I, [_A, _P, _I, _A, _I, _I, _P]),
-    "biu_convt_bwd_weight": (_I, [_A, _X, _A, _I, _P, _P, _I, _P]),
+    "biu_convt_packed_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "biu_convt_pack": (_I, [_I, _P, _I, _I, _I, _I, _P, _P]),
+    "biu_convt_fwd": (_I, [_A, _X, _P, _P, _P, _I, _A, _I, _P]),
+    "biu_convt_bwd_data": (_I, [_A, _P, _P, _I, _A, _I, _I, _P]),
+    "biu_convt_bwd_weight_workspace": (_Z, [_I, _I, _I, _I]),
+    "biu_convt_bwd_weight": (_I, [_A, _X, _A, _I, _P, _P, _P, _Z, _I, _P]),
     "biu_head_fwd": (_I, [_A, _X, _P, _P, _I, _I, _P, _P, _I, _P]),
     "biu_head_bwd_workspace": (_Z, [_I]),
     "biu_head_bwd": (_I, [_A, _X, _P, _I, _P, _A, _P, _P, _P, _Z, _I, _P]),

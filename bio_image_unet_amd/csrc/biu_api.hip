@@ -59,21 +59,40 @@ extern "C" int biu_conv_bwd_weight(const biu_act* x, const biu_xform* xf, const 
 }
 
 // ---- ConvTranspose k2 s2 ---------------------------------------------------------------------------
-extern "C" int biu_convt_fwd(const biu_act* x, const biu_xform* xf, const float* w, const float* bias, int kd,
-                             const biu_act* y, int dtype, biu_stream stream) {
+extern "C" size_t biu_convt_packed_bytes(int kind, int cin, int cout, int kd, int dtype) {
+    return biu_mfma_convt_packed_bytes(kind, cin, cout, kd, dtype);
+}
+extern "C" int biu_convt_pack(int kind, const float* w, int cin, int cout, int kd, int dtype, void* packed, biu_stream stream) {
+    BIU_REQUIRE(w && packed, BIU_ERR_SHAPE, "convt_pack: null pointer");
+    return biu_mfma_convt_pack(kind, w, cin, cout, kd, dtype, packed, (hipStream_t)stream);
+}
+extern "C" int biu_convt_fwd(const biu_act* x, const biu_xform* xf, const float* w, const void* packed, const float* bias,
+                             int kd, const biu_act* y, int dtype, biu_stream stream) {
     BIU_REQUIRE(valid_act(x) && valid_act(y) && w && biu_convt_shapes_ok(x, y, kd), BIU_ERR_SHAPE,
                 "convt_fwd: output must be 2x the input extent (kd=%d)", kd);
+    if (packed && biu_mfma_convt_ok(0, x, y, kd, dtype))
+        return biu_mfma_convt_fwd(x, xf, packed, bias, kd, y, dtype, (hipStream_t)stream);
     return biu_convt_fwd_direct(x, xf, w, bias, kd, y, dtype, (hipStream_t)stream);
 }
-extern "C" int biu_convt_bwd_data(const biu_act* dy, const float* w, int kd, const biu_act* dx, int accumulate,
-                                  int dtype, biu_stream stream) {
+extern "C" int biu_convt_bwd_data(const biu_act* dy, const float* w, const void* packed, int kd, const biu_act* dx,
+                                  int accumulate, int dtype, biu_stream stream) {
     BIU_REQUIRE(valid_act(dx) && valid_act(dy) && w && biu_convt_shapes_ok(dx, dy, kd), BIU_ERR_SHAPE,
                 "convt_bwd_data: dy must be 2x the dx extent (kd=%d)", kd);
+    if (packed && biu_mfma_convt_ok(1, dx, dy, kd, dtype))
+        return biu_mfma_convt_dgrad(dy, packed, kd, dx, accumulate, dtype, (hipStream_t)stream);
     return biu_convt_bwd_data_direct(dy, w, kd, dx, accumulate, dtype, (hipStream_t)stream);
 }
+extern "C" size_t biu_convt_bwd_weight_workspace(int cin, int cout, int kd, int dtype) {
+    return biu_mfma_wgrad_workspace(cin, cout, kd, 2, 2, dtype);
+}
 extern "C" int biu_convt_bwd_weight(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, float* dw,
-                                    float* dbias, int dtype, biu_stream stream) {
+                                    float* dbias, void* ws, size_t ws_bytes, int dtype, biu_stream stream) {
     BIU_REQUIRE(valid_act(x) && valid_act(dy) && dw && biu_convt_shapes_ok(x, dy, kd), BIU_ERR_SHAPE,
                 "convt_bwd_weight: dy must be 2x the x extent (kd=%d)", kd);
+    if (biu_mfma_convt_wgrad_ok(x, dy, kd, dtype)) {
+        BIU_REQUIRE(ws && ws_bytes >= biu_mfma_wgrad_workspace(x->c, dy->c, kd, 2, 2, dtype), BIU_ERR_WORKSPACE,
+                    "convt_bwd_weight: workspace too small");
+        return biu_mfma_convt_wgrad(x, xf, dy, kd, dw, dbias, ws, ws_bytes, dtype, (hipStream_t)stream);
+    }
     return biu_convt_bwd_weight_direct(x, xf, dy, kd, dw, dbias, dtype, (hipStream_t)stream);
 }

@@ -66,9 +66,14 @@ struct ConvArgs {
     const float* xb;
     const float* xl;
     int xpitch, ypitch;  // elements
-    int N, D, H, W, Cin, Cout;
+    int N, Cin, Cout;
+    int GD, GH, GW;      // extent of the brick grid (= output extent / output stride)
+    int ID, IH, IW;      // input extent
+    int OD, OH, OW;      // output extent
+    int osd, osh, osw;   // output stride: output voxel = grid voxel * os + offset(blockIdx.z)   (ConvTranspose scatter)
     int nbd, nbh, nbw;
     int nKS;             // total k-steps = Cin / (2 * PE)
+    int wz_stride;       // packed-weight stride (uint4) between blockIdx.z slices
     int accumulate;
 };
 
@@ -79,18 +84,23 @@ constexpr int cpad_planes(int hv, int ckp) {     // plane stride in 16-B units: 
     return v;
 }
 
-template <typename T, int KD, int TD, int TH, int TW, int NT, int CKP>
+// KD x KHW x KHW taps; input voxel = grid voxel * S + tap - pad, pad = 1 for 3-tap axes, 0 otherwise; the D axis has
+// stride 1 when KD == 1 (2-D tensors).  (KD,KHW,S) = (3|1,3,1): 3x3(x3) conv and its data gradient;
+// (2|1,2,2): data gradient of ConvTranspose k2 s2; (1,1,1) + output scatter: ConvTranspose k2 s2 forward.
+template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP>
 __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
     using F = Frag<T>;
     constexpr int PE = F::PE;
     constexpr int PD = (KD == 3) ? 1 : 0;
-    constexpr int HD = TD + 2 * PD, HH = TH + 2, HW = TW + 2;
+    constexpr int PHW = (KHW == 3) ? 1 : 0;
+    constexpr int SD = (KD == 1) ? 1 : S;
+    constexpr int HD = (TD - 1) * SD + KD, HH = (TH - 1) * S + KHW, HW = (TW - 1) * S + KHW;
     constexpr int HV = HD * HH * HW;
     constexpr int PSV = cpad_planes(HV, CKP);
     constexpr int TILES = TD * TH * TW / 32;
     static_assert(TILES % 4 == 0, "brick must give a multiple of 4 voxel tiles");
     constexpr int MT = TILES / 4;
-    constexpr int TAPS = KD * 9;
+    constexpr int TAPS = KD * KHW * KHW;
     constexpr int SPC = CKP / 2;                     // k-steps per chunk
     constexpr int NITEMS = HV * CKP;
     constexpr int NPASS = (NITEMS + 255) / 256;
@@ -119,9 +129,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
         const int t = hv / HW;
         const int hh = t % HH;
         const int hd = t / HH;
-        const int gd = d0 - PD + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
-        const bool inb = (hv < HV) && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-        voxidx[j] = inb ? ((n * a.D + gd) * a.H + gh) * a.W + gw : (hv < HV ? -1 : -2);
+        const int gd = d0 * SD - PD + hd, gh = h0 * S - PHW + hh, gw = w0 * S - PHW + hw;
+        const bool inb = (hv < HV) && gd >= 0 && gd < a.ID && gh >= 0 && gh < a.IH && gw >= 0 && gw < a.IW;
+        voxidx[j] = inb ? ((n * a.ID + gd) * a.IH + gh) * a.IW + gw : (hv < HV ? -1 : -2);
     }
 
     // ---- per-lane LDS base of each of this wave's voxel tiles (tap (0,0,0) corner), in 16-B units ----------------
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
         const int t = q / TW;
         const int lh = t % TH;
         const int ld = t / TH;
-        hvb[mt] = hf * PSV + (ld * HH + lh) * HW + lw;
+        hvb[mt] = hf * PSV + (ld * SD * HH + lh * S) * HW + lw * S;
     }
 
     floatx16 acc[NT][MT];
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
     const bool has_xf = a.xs != nullptr;
     const int nchunks = a.Cin / CK;
     const size_t esz = sizeof(T);
-    const uint4* wbase = a.wpk + ((size_t)blockIdx.y * NT * a.nKS * TAPS) * 64 + lane;
+    const uint4* wbase = a.wpk + (size_t)blockIdx.z * a.wz_stride + ((size_t)blockIdx.y * NT * a.nKS * TAPS) * 64 + lane;
 
     for (int ch = 0; ch < nchunks; ++ch) {
         // -------- stage the halo tile of channels [ch*CK, ch*CK + CK) --------------------------------------------
@@ -194,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             constexpr int dummy = 0; (void)dummy;
-            const int ta = tap / 9, tb = (tap / 3) % 3, tc = tap % 3;
+            const int ta = tap / (KHW * KHW), tb = (tap / KHW) % KHW, tc = tap % KHW;
             const int tapoff = (ta * HH + tb) * HW + tc;
 #pragma unroll
             for (int s = 0; s < SPC; ++s) {
@@ -222,8 +232,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
         const int lh = t % TH;
         const int ld = t / TH;
         const int gd = d0 + ld, gh = h0 + lh, gw = w0 + lw;
-        if (gd >= a.D || gh >= a.H || gw >= a.W) continue;
-        const size_t vox = ((size_t)(n * a.D + gd) * a.H + gh) * a.W + gw;
+        if (gd >= a.GD || gh >= a.GH || gw >= a.GW) continue;
+        const int od = gd * a.osd + ((a.osd == 2) ? (int)(blockIdx.z >> 2) : 0);
+        const int oh = gh * a.osh + ((a.osh == 2) ? (int)((blockIdx.z >> 1) & 1) : 0);
+        const int ow = gw * a.osw + ((a.osw == 2) ? (int)(blockIdx.z & 1) : 0);
+        const size_t vox = ((size_t)(n * a.OD + od) * a.OH + oh) * a.OW + ow;
         T* yrow = (T*)a.y + vox * a.ypitch;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -313,18 +326,18 @@ bool biu_mfma_conv_ok(const biu_act* x, const biu_act* y, int kd, int kh, int kw
     return true;
 }
 
-template <typename T, int KD, int TD, int TH, int TW, int NT, int CKP>
-static int launch_cfg(const ConvArgs& a0, int ntiles, hipStream_t st) {
+template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP>
+static int launch_cfg(const ConvArgs& a0, int ntiles, int nz, hipStream_t st) {
     ConvArgs a = a0;
-    constexpr int PD = (KD == 3) ? 1 : 0;
-    constexpr int HV = (TD + 2 * PD) * (TH + 2) * (TW + 2);
+    constexpr int SD = (KD == 1) ? 1 : S;
+    constexpr int HV = ((TD - 1) * SD + KD) * ((TH - 1) * S + KHW) * ((TW - 1) * S + KHW);
     constexpr int PSV = cpad_planes(HV, CKP);
     const size_t lds_bytes = (size_t)CKP * PSV * 16;
-    a.nbd = (a.D + TD - 1) / TD;
-    a.nbh = (a.H + TH - 1) / TH;
-    a.nbw = (a.W + TW - 1) / TW;
-    dim3 grid((unsigned)((size_t)a.N * a.nbd * a.nbh * a.nbw), (unsigned)(ntiles / NT));
-    auto kern = k_conv_mfma<T, KD, TD, TH, TW, NT, CKP>;
+    a.nbd = (a.GD + TD - 1) / TD;
+    a.nbh = (a.GH + TH - 1) / TH;
+    a.nbw = (a.GW + TW - 1) / TW;
+    dim3 grid((unsigned)((size_t)a.N * a.nbd * a.nbh * a.nbw), (unsigned)(ntiles / NT), (unsigned)nz);
+    auto kern = k_conv_mfma<T, KD, KHW, S, TD, TH, TW, NT, CKP>;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -335,19 +348,30 @@ static int launch_cfg(const ConvArgs& a0, int ntiles, hipStream_t st) {
     return BIU_OK;
 }
 
+static inline int pick_nt(int ntiles) { return (ntiles % 4 == 0) ? 4 : (ntiles % 2 == 0 ? 2 : 1); }
+
 template <typename T>
 static int launch_conv(const ConvArgs& a, int kd, hipStream_t st) {
     const int ntiles = (a.Cout + 31) / 32;
-    const int nt = (ntiles % 4 == 0) ? 4 : (ntiles % 2 == 0 ? 2 : 1);
-    const bool wide = (a.W % 32 == 0);
+    const int nt = pick_nt(ntiles);
+    const bool wide = (a.GW % 32 == 0);
     if (kd == 3) {
-        if (nt == 1) return wide ? launch_cfg<T, 3, 4, 8, 32, 1, 2>(a, ntiles, st) : launch_cfg<T, 3, 4, 16, 16, 1, 2>(a, ntiles, st);
-        if (nt == 2) return launch_cfg<T, 3, 4, 8, 16, 2, 2>(a, ntiles, st);
-        return launch_cfg<T, 3, 4, 4, 16, 4, 2>(a, ntiles, st);
+        if (nt == 1) return wide ? launch_cfg<T, 3, 3, 1, 4, 8, 32, 1, 2>(a, ntiles, 1, st) : launch_cfg<T, 3, 3, 1, 4, 16, 16, 1, 2>(a, ntiles, 1, st);
+        if (nt == 2) return launch_cfg<T, 3, 3, 1, 4, 8, 16, 2, 2>(a, ntiles, 1, st);
+        return launch_cfg<T, 3, 3, 1, 4, 4, 16, 4, 2>(a, ntiles, 1, st);
     }
-    if (nt == 1) return wide ? launch_cfg<T, 1, 1, 32, 32, 1, 2>(a, ntiles, st) : launch_cfg<T, 1, 1, 64, 16, 1, 2>(a, ntiles, st);
-    if (nt == 2) return wide ? launch_cfg<T, 1, 1, 16, 32, 2, 2>(a, ntiles, st) : launch_cfg<T, 1, 1, 32, 16, 2, 2>(a, ntiles, st);
-    return launch_cfg<T, 1, 1, 16, 16, 4, 2>(a, ntiles, st);
+    if (nt == 1) return wide ? launch_cfg<T, 1, 3, 1, 1, 32, 32, 1, 2>(a, ntiles, 1, st) : launch_cfg<T, 1, 3, 1, 1, 64, 16, 1, 2>(a, ntiles, 1, st);
+    if (nt == 2) return wide ? launch_cfg<T, 1, 3, 1, 1, 16, 32, 2, 2>(a, ntiles, 1, st) : launch_cfg<T, 1, 3, 1, 1, 32, 16, 2, 2>(a, ntiles, 1, st);
+    return launch_cfg<T, 1, 3, 1, 1, 16, 16, 4, 2>(a, ntiles, 1, st);
+}
+
+static int fill_xf(ConvArgs& a, const biu_xform* xf) {
+    const bool has = xf && (xf->scale || xf->shift || xf->slope);
+    if (has) BIU_REQUIRE(xf->scale && xf->shift && xf->slope, BIU_ERR_UNSUPPORTED, "conv_mfma: partial biu_xform (need all three vectors)");
+    a.xs = has ? xf->scale : nullptr;
+    a.xb = has ? xf->shift : nullptr;
+    a.xl = has ? xf->slope : nullptr;
+    return BIU_OK;
 }
 
 int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, int kh, int kw,
@@ -357,25 +381,511 @@ int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, con
     a.y = (char*)y->p;
     a.wpk = (const uint4*)packed;
     a.bias = bias;
-    const bool has = xf && (xf->scale || xf->shift || xf->slope);
-    if (has) BIU_REQUIRE(xf->scale && xf->shift && xf->slope, BIU_ERR_UNSUPPORTED, "conv_mfma: partial biu_xform (need all three vectors)");
-    a.xs = has ? xf->scale : nullptr;
-    a.xb = has ? xf->shift : nullptr;
-    a.xl = has ? xf->slope : nullptr;
+    int rc = fill_xf(a, xf);
+    if (rc) return rc;
     a.xpitch = x->pitch;
     a.ypitch = y->pitch;
-    a.N = x->n; a.D = x->d; a.H = x->h; a.W = x->w;
+    a.N = x->n;
+    a.GD = a.ID = a.OD = x->d; a.GH = a.IH = a.OH = x->h; a.GW = a.IW = a.OW = x->w;
+    a.osd = a.osh = a.osw = 1;
     a.Cin = x->c; a.Cout = y->c;
     a.nKS = x->c / ks_of(dtype);
+    a.wz_stride = 0;
     a.accumulate = accumulate;
     a.nbd = a.nbh = a.nbw = 0;
     if (dtype == BIU_BF16) return launch_conv<bf16_t>(a, kd, st);
     return launch_conv<float>(a, kd, st);
 }
 
-// weight gradient: not covered yet -> direct kernels
-size_t biu_mfma_wgrad_workspace(int, int, int, int, int, int) { return 0; }
-bool biu_mfma_wgrad_ok(const biu_act*, const biu_act*, int, int, int, int, int) { return false; }
-int biu_mfma_wgrad(const biu_act*, const biu_xform*, const biu_act*, int, int, int, float*, float*, void*, size_t, int, hipStream_t) {
-    return biu_fail(BIU_ERR_UNSUPPORTED, "mfma wgrad: not built");
+// ---------------------------------------------------------------------------------------------------------------
+// ConvTranspose k2 s2 on the same kernel
+//   forward : 4 (8) one-tap GEMMs, one per output parity a (blockIdx.z), scattered to output voxel 2v + a
+//   dgrad   : a stride-2, 2x2(x2)-tap convolution from the fine grid to the coarse grid
+// packed weights (biu_mfma_pack_convt): kind 0 -> [a][ntile(co)][kstep(ci)][lane], kind 1 -> [ntile(ci)][kstep(co)][tap a][lane]
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_pack_convt(const float* __restrict__ w, int cin, int cout, int taps, int kind, uint4* __restrict__ out) {
+    using F = Frag<T>;
+    constexpr int PE = F::PE;
+    const int Kc = kind == 0 ? cin : cout, Nc = kind == 0 ? cout : cin;
+    const int nKS = Kc / (2 * PE), ntiles = (Nc + 31) / 32;
+    const size_t total = (size_t)taps * ntiles * nKS * 64;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx % 64);
+        size_t t = idx / 64;
+        int tap, ks, nt;
+        if (kind == 0) { ks = (int)(t % nKS); t /= nKS; nt = (int)(t % ntiles); tap = (int)(t / ntiles); }
+        else { tap = (int)(t % taps); t /= taps; ks = (int)(t % nKS); nt = (int)(t / nKS); }
+        const int i = nt * 32 + (lane & 31);
+        float f[PE];
+#pragma unroll
+        for (int e = 0; e < PE; ++e) {
+            const int k = ks * 2 * PE + (lane >> 5) * PE + e;
+            float v = 0.f;
+            if (i < Nc && k < Kc) {
+                // PyTorch ConvTranspose weight: (Cin, Cout, taps)
+                if (kind == 0) v = w[((size_t)k * cout + i) * taps + tap];       // rows i = co, reduce k = ci
+                else v = w[((size_t)i * cout + k) * taps + tap];                 // rows i = ci, reduce k = co
+            }
+            f[e] = v;
+        }
+        out[idx] = F::pack(f);
+    }
+}
+
+size_t biu_mfma_convt_packed_bytes(int kind, int cin, int cout, int kd, int dtype) {
+    if (dtype != BIU_BF16 && dtype != BIU_F32) return 0;
+    if (kd != 1 && kd != 2) return 0;
+    const int K = kind == 0 ? cin : cout, Nn = kind == 0 ? cout : cin;
+    if (!chan_ok(K, Nn, dtype)) return 0;
+    const size_t ntiles = (Nn + 31) / 32, nKS = K / ks_of(dtype);
+    return ntiles * nKS * (size_t)(kd * 4) * 1024;
+}
+
+int biu_mfma_convt_pack(int kind, const float* w, int cin, int cout, int kd, int dtype, void* packed, hipStream_t st) {
+    const size_t total = biu_mfma_convt_packed_bytes(kind, cin, cout, kd, dtype) / 16;
+    BIU_REQUIRE(total > 0, BIU_ERR_UNSUPPORTED, "convt_pack: shape is served by the direct kernels");
+    BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_convt<T>, dim3(grid_for((i64)total, 256, 4096)), dim3(256), 0, st, w, cin, cout,
+                                                 kd * 4, kind, (uint4*)packed));
+    BIU_CHECK_LAUNCH("pack_convt");
+    return BIU_OK;
+}
+
+static bool ptrs_ok(const biu_act* x, const biu_act* y, int dtype) {
+    const size_t es = dsize(dtype);
+    if ((uintptr_t)x->p % 16 || (uintptr_t)y->p % 16 || ((size_t)x->pitch * es) % 16 || ((size_t)y->pitch * es) % 16) return false;
+    if (nvox(x) * (i64)x->pitch >= (1LL << 31) || nvox(y) * (i64)y->pitch >= (1LL << 31)) return false;
+    return true;
+}
+
+bool biu_mfma_convt_ok(int kind, const biu_act* lo, const biu_act* hi, int kd, int dtype) {
+    const int K = kind == 0 ? lo->c : hi->c, Nn = kind == 0 ? hi->c : lo->c;
+    return (kd == 1 || kd == 2) && chan_ok(K, Nn, dtype) && ptrs_ok(lo, hi, dtype);
+}
+
+template <typename T>
+static int launch_convt_fwd(const ConvArgs& a, int kd, hipStream_t st) {
+    const int ntiles = (a.Cout + 31) / 32, nt = pick_nt(ntiles), nz = kd * 4;
+    if (kd == 2) {
+        if (nt == 1) return launch_cfg<T, 1, 1, 1, 4, 8, 16, 1, 2>(a, ntiles, nz, st);
+        if (nt == 2) return launch_cfg<T, 1, 1, 1, 4, 8, 16, 2, 2>(a, ntiles, nz, st);
+        return launch_cfg<T, 1, 1, 1, 2, 8, 16, 4, 2>(a, ntiles, nz, st);
+    }
+    if (nt == 1) return launch_cfg<T, 1, 1, 1, 1, 32, 16, 1, 2>(a, ntiles, nz, st);
+    if (nt == 2) return launch_cfg<T, 1, 1, 1, 1, 32, 16, 2, 2>(a, ntiles, nz, st);
+    return launch_cfg<T, 1, 1, 1, 1, 16, 16, 4, 2>(a, ntiles, nz, st);
+}
+
+template <typename T>
+static int launch_convt_dgrad(const ConvArgs& a, int kd, hipStream_t st) {
+    const int ntiles = (a.Cout + 31) / 32, nt = pick_nt(ntiles);
+    if (kd == 2) {
+        if (nt == 1) return launch_cfg<T, 2, 2, 2, 2, 8, 16, 1, 2>(a, ntiles, 1, st);
+        if (nt == 2) return launch_cfg<T, 2, 2, 2, 2, 8, 16, 2, 2>(a, ntiles, 1, st);
+        return launch_cfg<T, 2, 2, 2, 2, 8, 16, 4, 2>(a, ntiles, 1, st);
+    }
+    if (nt == 1) return launch_cfg<T, 1, 2, 2, 1, 16, 16, 1, 2>(a, ntiles, 1, st);
+    if (nt == 2) return launch_cfg<T, 1, 2, 2, 1, 16, 16, 2, 2>(a, ntiles, 1, st);
+    return launch_cfg<T, 1, 2, 2, 1, 16, 16, 4, 2>(a, ntiles, 1, st);
+}
+
+int biu_mfma_convt_fwd(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, const biu_act* y,
+                       int dtype, hipStream_t st) {
+    ConvArgs a;
+    a.x = (const char*)x->p;
+    a.y = (char*)y->p;
+    a.wpk = (const uint4*)packed;
+    a.bias = bias;
+    int rc = fill_xf(a, xf);
+    if (rc) return rc;
+    a.xpitch = x->pitch; a.ypitch = y->pitch;
+    a.N = x->n;
+    a.GD = a.ID = x->d; a.GH = a.IH = x->h; a.GW = a.IW = x->w;
+    a.OD = y->d; a.OH = y->h; a.OW = y->w;
+    a.osd = kd; a.osh = 2; a.osw = 2;
+    a.Cin = x->c; a.Cout = y->c;
+    a.nKS = x->c / ks_of(dtype);
+    a.wz_stride = ((a.Cout + 31) / 32) * a.nKS * 64;
+    a.accumulate = 0;
+    a.nbd = a.nbh = a.nbw = 0;
+    if (dtype == BIU_BF16) return launch_convt_fwd<bf16_t>(a, kd, st);
+    return launch_convt_fwd<float>(a, kd, st);
+}
+
+int biu_mfma_convt_dgrad(const biu_act* dy, const void* packed, int kd, const biu_act* dx, int accumulate, int dtype, hipStream_t st) {
+    ConvArgs a;
+    a.x = (const char*)dy->p;
+    a.y = (char*)dx->p;
+    a.wpk = (const uint4*)packed;
+    a.bias = nullptr;
+    a.xs = a.xb = a.xl = nullptr;
+    a.xpitch = dy->pitch; a.ypitch = dx->pitch;
+    a.N = dx->n;
+    a.GD = a.OD = dx->d; a.GH = a.OH = dx->h; a.GW = a.OW = dx->w;
+    a.ID = dy->d; a.IH = dy->h; a.IW = dy->w;
+    a.osd = a.osh = a.osw = 1;
+    a.Cin = dy->c; a.Cout = dx->c;
+    a.nKS = dy->c / ks_of(dtype);
+    a.wz_stride = 0;
+    a.accumulate = accumulate;
+    a.nbd = a.nbh = a.nbw = 0;
+    if (dtype == BIU_BF16) return launch_convt_dgrad<bf16_t>(a, kd, st);
+    return launch_convt_dgrad<float>(a, kd, st);
+}
+
+// ===============================================================================================================
+// weight gradient:  dW[i][j][tap] = sum_v A[v][i] * B[v*S + tap - pad][j]
+//   3x3(x3) conv    : A = dy (i = co), B = T(x) (j = ci), S = 1, pad = 1        -> dw (Cout, Cin, taps)
+//   ConvTranspose k2: A = T(x) (i = ci), B = dy on the fine grid (j = co), S = 2 -> dw (Cin, Cout, taps)
+//
+// GEMM view per tap: D[i][j] += A^T[i][k = voxel] * B[k = voxel][j]: the reduction runs over VOXELS, the slow axis
+// of a channels-last tensor, so both operands need a transpose on their way into the MFMA.
+//   bf16: tiles are staged row-major [voxel][32 ch] in LDS and read with ds_read_b64_tr_b16 (hardware transpose):
+//         one read hands each lane 4 consecutive voxels of its channel; two reads = one 32x32x16 operand.
+//   fp32: v_mfma_f32_32x32x2_f32 takes ONE element per lane (k = lane >> 5), so a plain ds_read_b32 of
+//         [voxel k][channel lane&31] is already the operand.
+// A block owns one 32 x 32 tile of dW for ALL taps and a contiguous range of voxel bricks (split-K); its 4 waves
+// split the taps, so the A fragment is read once per 16 voxels and re-used for a wave's taps.
+// Partial sums are flushed with fp32 atomics into ws[tap][i][j] (two 128-B segments per wave-instruction),
+// which a tiny kernel then transposes into the PyTorch layout [i][j][tap].
+// ===============================================================================================================
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct WgradArgs {
+    const char* pa;      // plain operand (brick grid extent)
+    const char* pb;      // tapped operand
+    float* ws;
+    const float* as_; const float* ab_; const float* al_;   // transform of A (or null)
+    const float* bs_; const float* bb_; const float* bl_;   // transform of B (or null)
+    int apitch, bpitch;
+    int N, CA, CB;
+    int GD, GH, GW;      // extent of A
+    int BD, BH, BW;      // extent of B
+    int nbd, nbh, nbw, nbricks;
+    int njt;             // number of 32-wide j tiles
+    int bricks_per_block;
+};
+
+template <typename T, int PE>
+__device__ __forceinline__ uint4 apply_xf16(uint4 v, const float* sc, const float* sh, const float* sl) {
+    using F = Frag<T>;
+    float f[PE];
+    F::unpack(v, f);
+#pragma unroll
+    for (int e = 0; e < PE; ++e) {
+        const float tt = fmaf(sc[e], f[e], sh[e]);
+        f[e] = fmaxf(tt, sl[e] * tt);
+    }
+    return F::pack(f);
+}
+
+template <typename T, int KD, int KHW, int S, int TD, int TH, int TW>
+__global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WgradArgs a) {
+    using F = Frag<T>;
+    constexpr int PE = F::PE;
+    constexpr int CT = 32;                           // channel tile
+    constexpr int PPV = CT / PE;                     // 16-B pieces per voxel row
+    constexpr int PD = (KD == 3) ? 1 : 0;
+    constexpr int PHW = (KHW == 3) ? 1 : 0;
+    constexpr int SD = (KD == 1) ? 1 : S;
+    constexpr int HD = (TD - 1) * SD + KD, HH = (TH - 1) * S + KHW, HW = (TW - 1) * S + KHW;
+    constexpr int HV = HD * HH * HW;
+    constexpr int BV = TD * TH * TW;
+    constexpr int TAPS = KD * KHW * KHW;
+    constexpr int TPW = (TAPS + 3) / 4;              // taps per wave
+    constexpr int RS = CT * (int)sizeof(T);          // LDS row stride in bytes
+    static_assert(TW % 16 == 0, "k-groups are 16 consecutive voxels along W");
+
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+    char* at = (char*)lds;                           // [BV][CT]
+    char* bt = at + BV * RS;                         // [HV][CT]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int it = blockIdx.y / a.njt, jt = blockIdx.y % a.njt;
+    const size_t esz = sizeof(T);
+
+    floatx16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    int tapoff[TPW];     // byte offsets of this wave's taps (tap = wave + 4 t) in the B tile
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tap = wave + 4 * t;
+        const int ta = tap / (KHW * KHW), tb = (tap / KHW) % KHW, tc = tap % KHW;
+        tapoff[t] = ((ta * HH + tb) * HW + tc) * RS;
+    }
+
+    // this thread's piece of a voxel row is fixed (256 % PPV == 0): load its transform constants once
+    const int piece = tid % PPV;
+    const int ac0 = it * CT + piece * PE, bc0 = jt * CT + piece * PE;
+    const bool apiece_ok = ac0 < a.CA, bpiece_ok = bc0 < a.CB;
+    const bool a_xf = a.as_ != nullptr, b_xf = a.bs_ != nullptr;
+    float sca[PE], sha[PE], sla[PE], scb[PE], shb[PE], slb[PE];
+    if (a_xf && apiece_ok) {
+#pragma unroll
+        for (int e = 0; e < PE; ++e) { sca[e] = a.as_[ac0 + e]; sha[e] = a.ab_[ac0 + e]; sla[e] = a.al_[ac0 + e]; }
+    }
+    if (b_xf && bpiece_ok) {
+#pragma unroll
+        for (int e = 0; e < PE; ++e) { scb[e] = a.bs_[bc0 + e]; shb[e] = a.bb_[bc0 + e]; slb[e] = a.bl_[bc0 + e]; }
+    }
+
+    // lane-constant parts of the operand addresses
+    int a_lane, b_lane;
+    if constexpr (sizeof(T) == 2) {
+        const int g = lane >> 4, li = lane & 15, qrow = li >> 2, p = li & 3, cg = g & 1, h = g >> 1;
+        a_lane = (8 * h + qrow) * RS + (16 * cg + 4 * p) * 2;
+        b_lane = (8 * h + qrow) * S * RS + (16 * cg + 4 * p) * 2;
+    } else {
+        a_lane = (lane >> 5) * RS + (lane & 31) * 4;
+        b_lane = (lane >> 5) * S * RS + (lane & 31) * 4;
+    }
+
+    const int b_begin = blockIdx.x * a.bricks_per_block;
+    int b_end = b_begin + a.bricks_per_block;
+    if (b_end > a.nbricks) b_end = a.nbricks;
+
+    for (int brick = b_begin; brick < b_end; ++brick) {
+        int b = brick;
+        const int bw = b % a.nbw; b /= a.nbw;
+        const int bh = b % a.nbh; b /= a.nbh;
+        const int bd = b % a.nbd;
+        const int n = b / a.nbd;
+        const int d0 = bd * TD, h0 = bh * TH, w0 = bw * TW;
+
+        // ---- stage A tile: item i -> (brick voxel q = i / PPV, piece); the LDS image is linear in i ------------------
+        constexpr int NA = (BV * PPV + 255) / 256;
+#pragma unroll 4
+        for (int j = 0; j < NA; ++j) {
+            const int i = tid + 256 * j;
+            const int q = i / PPV;
+            const int lw = q % TW;
+            const int t = q / TW;
+            const int lh = t % TH;
+            const int ld = t / TH;
+            const int gd = d0 + ld, gh = h0 + lh, gw = w0 + lw;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (i < BV * PPV && apiece_ok && gd < a.GD && gh < a.GH && gw < a.GW) {
+                const size_t vox = ((size_t)(n * a.GD + gd) * a.GH + gh) * a.GW + gw;
+                v = *(const uint4*)(a.pa + (vox * a.apitch + ac0) * esz);
+                if (a_xf) v = apply_xf16<T, PE>(v, sca, sha, sla);
+            }
+            if (i < BV * PPV) ((uint4*)at)[i] = v;
+        }
+        // ---- stage B tile (halo / fine-grid tile), zero padding after the transform -----------------------------------
+        constexpr int NB = (HV * PPV + 255) / 256;
+#pragma unroll 4
+        for (int j = 0; j < NB; ++j) {
+            const int i = tid + 256 * j;
+            const int hv = i / PPV;
+            const int hw = hv % HW;
+            const int t = hv / HW;
+            const int hh = t % HH;
+            const int hd = t / HH;
+            const int gd = d0 * SD - PD + hd, gh = h0 * S - PHW + hh, gw = w0 * S - PHW + hw;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (i < HV * PPV && bpiece_ok && gd >= 0 && gd < a.BD && gh >= 0 && gh < a.BH && gw >= 0 && gw < a.BW) {
+                const size_t vox = ((size_t)(n * a.BD + gd) * a.BH + gh) * a.BW + gw;
+                v = *(const uint4*)(a.pb + (vox * a.bpitch + bc0) * esz);
+                if (b_xf) v = apply_xf16<T, PE>(v, scb, shb, slb);
+            }
+            if (i < HV * PPV) ((uint4*)bt)[i] = v;
+        }
+        __syncthreads();
+
+        // ---- MFMA over the brick's voxels ---------------------------------------------------------------------------
+        if constexpr (sizeof(T) == 2) {
+            constexpr int NKG = BV / 16;
+#pragma unroll 4
+            for (int kg = 0; kg < NKG; ++kg) {
+                const int q0 = kg * 16;                      // 16 consecutive voxels along W
+                const int lw0 = q0 % TW;
+                const int t = q0 / TW;
+                const int lh = t % TH;
+                const int ld = t / TH;
+                const int hbase = ((ld * SD * HH + lh * S) * HW + lw0 * S) * RS;
+                typedef bf16x4 __attribute__((address_space(3))) * lp;
+                const char* ap = at + q0 * RS + a_lane;
+                bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap));
+                bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap + 4 * RS));
+                bf16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int t2 = 0; t2 < TPW; ++t2) {
+                    if (wave + 4 * t2 < TAPS) {
+                        const char* bp = bt + hbase + tapoff[t2] + b_lane;
+                        bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp));
+                        bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp + 4 * S * RS));
+                        bf16x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t2], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            constexpr int NKP = BV / 2;
+#pragma unroll 8
+            for (int kp = 0; kp < NKP; ++kp) {
+                const int q0 = kp * 2;                       // 2 consecutive voxels along W
+                const int lw0 = q0 % TW;
+                const int t = q0 / TW;
+                const int lh = t % TH;
+                const int ld = t / TH;
+                const int hbase = ((ld * SD * HH + lh * S) * HW + lw0 * S) * RS;
+                const float af = *(const float*)(at + q0 * RS + a_lane);
+#pragma unroll
+                for (int t2 = 0; t2 < TPW; ++t2) {
+                    if (wave + 4 * t2 < TAPS) {
+                        const float bf = *(const float*)(bt + hbase + tapoff[t2] + b_lane);
+                        acc[t2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[t2], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- flush: lane (j = lane & 31, h = lane >> 5), reg e -> i = (e & 3) + 8 (e >> 2) + 4 h ---------------------------
+    const int jj = jt * CT + (lane & 31);
+    const int hf = lane >> 5;
+    if (jj < a.CB) {
+#pragma unroll
+        for (int t2 = 0; t2 < TPW; ++t2) {
+            const int tap = wave + 4 * t2;
+            if (tap < TAPS) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ii = it * CT + (e & 3) + 8 * (e >> 2) + 4 * hf;
+                    if (ii < a.CA) atomicAdd(a.ws + ((size_t)tap * a.CA + ii) * a.CB + jj, acc[t2][e]);
+                }
+            }
+        }
+    }
+}
+
+// ws[tap][i][j] -> dw[i][j][tap]
+__global__ void k_wgrad_finalize(const float* __restrict__ ws, int rows, int cols, int taps, float* __restrict__ dw) {
+    const size_t total = (size_t)rows * cols * taps;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % taps);
+        const size_t r = i / taps;
+        const int c = (int)(r % cols);
+        const int rr = (int)(r / cols);
+        dw[i] = ws[((size_t)tap * rows + rr) * cols + c];
+    }
+}
+
+static bool wgrad_chan_ok(int cin, int cout) { return cin >= 16 && cin % 8 == 0 && cout >= 16 && cout % 8 == 0; }
+
+size_t biu_mfma_wgrad_workspace(int cin, int cout, int kd, int kh, int kw, int dtype) {
+    if (!wgrad_chan_ok(cin, cout)) return 0;
+    if (kh == 3 && kw == 3 && (kd == 1 || kd == 3)) return (size_t)cin * cout * kd * 9 * sizeof(float);
+    if (kh == 2 && kw == 2 && (kd == 1 || kd == 2)) return (size_t)cin * cout * kd * 4 * sizeof(float);
+    return 0;
+}
+
+static bool wgrad_ptrs_ok(const biu_act* x, const biu_act* dy, int dtype) {
+    const size_t es = dsize(dtype);
+    return !((uintptr_t)x->p % 16 || (uintptr_t)dy->p % 16 || ((size_t)x->pitch * es) % 16 || ((size_t)dy->pitch * es) % 16);
+}
+
+bool biu_mfma_wgrad_ok(const biu_act* x, const biu_act* dy, int kd, int kh, int kw, int dilation, int dtype) {
+    if (dilation != 1 || kh != 3 || kw != 3 || (kd != 1 && kd != 3)) return false;
+    if (!wgrad_chan_ok(x->c, dy->c) || !wgrad_ptrs_ok(x, dy, dtype)) return false;
+    if (kd == 1 && x->d != 1) return false;
+    return true;
+}
+
+bool biu_mfma_convt_wgrad_ok(const biu_act* x, const biu_act* dy, int kd, int dtype) {
+    return (kd == 1 || kd == 2) && wgrad_chan_ok(x->c, dy->c) && wgrad_ptrs_ok(x, dy, dtype);
+}
+
+template <typename T, int KD, int KHW, int S, int TD, int TH, int TW>
+static int launch_wgrad(WgradArgs a, hipStream_t st) {
+    constexpr int SD = (KD == 1) ? 1 : S;
+    constexpr int HV = ((TD - 1) * SD + KD) * ((TH - 1) * S + KHW) * ((TW - 1) * S + KHW);
+    constexpr int BV = TD * TH * TW;
+    const size_t lds_bytes = (size_t)(HV + BV) * 32 * sizeof(T);
+    a.nbd = (a.GD + TD - 1) / TD;
+    a.nbh = (a.GH + TH - 1) / TH;
+    a.nbw = (a.GW + TW - 1) / TW;
+    a.nbricks = a.N * a.nbd * a.nbh * a.nbw;
+    const int nit = (a.CA + 31) / 32;
+    a.njt = (a.CB + 31) / 32;
+    const int pairs = nit * a.njt;
+    int sk = (2048 + pairs - 1) / pairs;                 // aim at ~2048 blocks (2 per CU x 256 CUs x 4 rounds)
+    if (sk > a.nbricks) sk = a.nbricks;
+    if (sk < 1) sk = 1;
+    a.bricks_per_block = (a.nbricks + sk - 1) / sk;
+    sk = (a.nbricks + a.bricks_per_block - 1) / a.bricks_per_block;
+    auto kern = k_wgrad_mfma<T, KD, KHW, S, TD, TH, TW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(sk, pairs), dim3(256), lds_bytes, st, a);
+    BIU_CHECK_LAUNCH("wgrad_mfma");
+    return BIU_OK;
+}
+
+static int wgrad_xf(const biu_xform* xf, const float** s, const float** b, const float** l) {
+    const bool has = xf && (xf->scale || xf->shift || xf->slope);
+    if (has) BIU_REQUIRE(xf->scale && xf->shift && xf->slope, BIU_ERR_UNSUPPORTED, "wgrad_mfma: partial biu_xform");
+    *s = has ? xf->scale : nullptr;
+    *b = has ? xf->shift : nullptr;
+    *l = has ? xf->slope : nullptr;
+    return BIU_OK;
+}
+
+int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, int kh, int kw, float* dw, float* dbias,
+                   void* ws, size_t ws_bytes, int dtype, hipStream_t st) {
+    WgradArgs a;
+    a.pa = (const char*)dy->p;  a.apitch = dy->pitch;  a.CA = dy->c;      // plain operand: dy  (rows i = co)
+    a.pb = (const char*)x->p;   a.bpitch = x->pitch;   a.CB = x->c;       // tapped operand: x (cols j = ci)
+    a.ws = (float*)ws;
+    a.as_ = a.ab_ = a.al_ = nullptr;
+    int rc = wgrad_xf(xf, &a.bs_, &a.bb_, &a.bl_);
+    if (rc) return rc;
+    a.N = x->n;
+    a.GD = a.BD = x->d; a.GH = a.BH = x->h; a.GW = a.BW = x->w;
+    const int taps = kd * 9;
+    const size_t need = (size_t)a.CA * a.CB * taps * sizeof(float);
+    BIU_REQUIRE(ws_bytes >= need, BIU_ERR_WORKSPACE, "wgrad_mfma: workspace %zu < %zu", ws_bytes, need);
+    if (hipMemsetAsync(ws, 0, need, st) != hipSuccess) return biu_fail(BIU_ERR_LAUNCH, "wgrad_mfma: memset failed");
+    if (dtype == BIU_BF16) rc = (kd == 3) ? launch_wgrad<bf16_t, 3, 3, 1, 4, 4, 16>(a, st) : launch_wgrad<bf16_t, 1, 3, 1, 1, 16, 16>(a, st);
+    else rc = (kd == 3) ? launch_wgrad<float, 3, 3, 1, 4, 4, 16>(a, st) : launch_wgrad<float, 1, 3, 1, 1, 16, 16>(a, st);
+    if (rc != BIU_OK) return rc;
+    hipLaunchKernelGGL(k_wgrad_finalize, dim3(grid_for((i64)a.CA * a.CB * taps, 256, 2048)), dim3(256), 0, st, (const float*)ws,
+                       a.CA, a.CB, taps, dw);
+    BIU_CHECK_LAUNCH("wgrad_finalize");
+    if (dbias) return biu_chan_sum(dy, dbias, dtype, st);   // sum over voxels of dy: direct per-channel reduction
+    return BIU_OK;
+}
+
+int biu_mfma_convt_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, float* dw, float* dbias, void* ws,
+                         size_t ws_bytes, int dtype, hipStream_t st) {
+    WgradArgs a;
+    a.pa = (const char*)x->p;   a.apitch = x->pitch;   a.CA = x->c;       // plain operand: x on the coarse grid (rows i = ci)
+    a.pb = (const char*)dy->p;  a.bpitch = dy->pitch;  a.CB = dy->c;      // tapped operand: dy on the fine grid (cols j = co)
+    a.ws = (float*)ws;
+    int rc = wgrad_xf(xf, &a.as_, &a.ab_, &a.al_);
+    if (rc) return rc;
+    a.bs_ = a.bb_ = a.bl_ = nullptr;
+    a.N = x->n;
+    a.GD = x->d; a.GH = x->h; a.GW = x->w;
+    a.BD = dy->d; a.BH = dy->h; a.BW = dy->w;
+    const int taps = kd * 4;
+    const size_t need = (size_t)a.CA * a.CB * taps * sizeof(float);
+    BIU_REQUIRE(ws_bytes >= need, BIU_ERR_WORKSPACE, "convt_wgrad_mfma: workspace %zu < %zu", ws_bytes, need);
+    if (hipMemsetAsync(ws, 0, need, st) != hipSuccess) return biu_fail(BIU_ERR_LAUNCH, "convt_wgrad_mfma: memset failed");
+    if (dtype == BIU_BF16) rc = (kd == 2) ? launch_wgrad<bf16_t, 2, 2, 2, 2, 4, 16>(a, st) : launch_wgrad<bf16_t, 1, 2, 2, 1, 8, 16>(a, st);
+    else rc = (kd == 2) ? launch_wgrad<float, 2, 2, 2, 2, 4, 16>(a, st) : launch_wgrad<float, 1, 2, 2, 1, 8, 16>(a, st);
+    if (rc != BIU_OK) return rc;
+    hipLaunchKernelGGL(k_wgrad_finalize, dim3(grid_for((i64)a.CA * a.CB * taps, 256, 2048)), dim3(256), 0, st, (const float*)ws,
+                       a.CA, a.CB, taps, dw);
+    BIU_CHECK_LAUNCH("convt_wgrad_finalize");
+    if (dbias) return biu_chan_sum(dy, dbias, dtype, st);
+    return BIU_OK;
 }

@@ -805,6 +805,12 @@ extern "C" int biu_conv_bwd_weight_direct(const biu_act* x, const biu_xform* xf,
     return BIU_OK;
 }
 
+int biu_chan_sum(const biu_act* a, float* out, int dtype, hipStream_t st) {
+    BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_chan_sum<T>, dim3(a->c), dim3(TPB), 0, st, dact(a), out));
+    BIU_CHECK_LAUNCH("chan_sum");
+    return BIU_OK;
+}
+
 extern "C" int biu_bn_stats(const biu_act* y, float* partial, int* nblk_out, int dtype, biu_stream stream) {
     BIU_REQUIRE(valid_act(y) && partial && nblk_out, BIU_ERR_SHAPE, "bn_stats: bad arguments");
     hipStream_t st = (hipStream_t)stream;

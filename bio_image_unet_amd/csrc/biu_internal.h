@@ -15,6 +15,7 @@ extern "C" int biu_convt_bwd_data_direct(const biu_act* dy, const float* w, int 
                                          int dtype, hipStream_t st);
 extern "C" int biu_convt_bwd_weight_direct(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, float* dw,
                                            float* dbias, int dtype, hipStream_t st);
+int biu_chan_sum(const biu_act* a, float* out, int dtype, hipStream_t st);
 bool biu_convt_shapes_ok(const biu_act* lo, const biu_act* hi, int kd);
 
 // biu_conv_mfma.hip
@@ -28,3 +29,13 @@ size_t biu_mfma_wgrad_workspace(int cin, int cout, int kd, int kh, int kw, int d
 bool biu_mfma_wgrad_ok(const biu_act* x, const biu_act* dy, int kd, int kh, int kw, int dilation, int dtype);
 int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, int kh, int kw, float* dw,
                    float* dbias, void* ws, size_t ws_bytes, int dtype, hipStream_t st);
+
+size_t biu_mfma_convt_packed_bytes(int kind, int cin, int cout, int kd, int dtype);
+int biu_mfma_convt_pack(int kind, const float* w, int cin, int cout, int kd, int dtype, void* packed, hipStream_t st);
+bool biu_mfma_convt_ok(int kind, const biu_act* lo, const biu_act* hi, int kd, int dtype);
+int biu_mfma_convt_fwd(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, const biu_act* y,
+                       int dtype, hipStream_t st);
+int biu_mfma_convt_dgrad(const biu_act* dy, const void* packed, int kd, const biu_act* dx, int accumulate, int dtype, hipStream_t st);
+bool biu_mfma_convt_wgrad_ok(const biu_act* x, const biu_act* dy, int kd, int dtype);
+int biu_mfma_convt_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, float* dw, float* dbias, void* ws,
+                         size_t ws_bytes, int dtype, hipStream_t st);

@@ -151,12 +151,19 @@ int biu_nearest_up_bwd(const biu_act* dout, const biu_act* dx, int accumulate, i
  * replaces nn.ConvTranspose2d/3d: unet/unet.py:38-47, unet3d/unet3d.py:40-42
  * w: PyTorch layout (Cin, Cout, kd, 2, 2) fp32 with kd = 2 (3-D) or 1 (2-D).
  * ---------------------------------------------------------------------------------------------- */
-int biu_convt_fwd(const biu_act* x, const biu_xform* xf, const float* w, const float* bias, int kd,
-                  const biu_act* y, int dtype, biu_stream stream);
-int biu_convt_bwd_data(const biu_act* dy, const float* w, int kd, const biu_act* dx, int accumulate,
-                       int dtype, biu_stream stream);
-int biu_convt_bwd_weight(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd,
-                         float* dw, float* dbias, int dtype, biu_stream stream);
+/* MFMA operand packing, as for the 3x3 kernels.  kind 0 = forward operand, 1 = data-gradient operand.          */
+size_t biu_convt_packed_bytes(int kind, int cin, int cout, int kd, int dtype);
+int    biu_convt_pack(int kind, const float* w, int cin, int cout, int kd, int dtype, void* packed, biu_stream stream);
+/* y[2v + a, co] = bias[co] + sum_ci T(x)[v, ci] * w[ci, co, a]                                                 */
+int biu_convt_fwd(const biu_act* x, const biu_xform* xf, const float* w, const void* packed, const float* bias,
+                  int kd, const biu_act* y, int dtype, biu_stream stream);
+/* dx[v, ci] (+)= sum_{a, co} dy[2v + a, co] * w[ci, co, a]                                                      */
+int biu_convt_bwd_data(const biu_act* dy, const float* w, const void* packed, int kd, const biu_act* dx,
+                       int accumulate, int dtype, biu_stream stream);
+/* dw[ci, co, a] = sum_v T(x)[v, ci] * dy[2v + a, co]; dbias[co] = sum dy (may be NULL)                          */
+size_t biu_convt_bwd_weight_workspace(int cin, int cout, int kd, int dtype);
+int biu_convt_bwd_weight(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, float* dw, float* dbias,
+                         void* ws, size_t ws_bytes, int dtype, biu_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 1x1(x1) head + activation                                                             [K9]

@@ -186,15 +186,17 @@ def test_convtranspose(case, dtype):
     oshape = (n, cout, 1 if nd == 2 else osp[0], osp[-2], osp[-1])
     yd = Dev(shape=oshape, dtype=dtype, pitch=cout + 5, c0=0)
     wd, bd = w.cuda(), b.cuda()
-    check(lib.biu_convt_fwd(xd.a(), xf.x(), ptr(wd), ptr(bd), kd, yd.a(), DT[dtype][1], stream()), "convt_fwd")
+    check(lib.biu_convt_fwd(xd.a(), xf.x(), ptr(wd), None, ptr(bd), kd, yd.a(), DT[dtype][1], stream()), "convt_fwd")
     assert_close(yd.get(squeeze2d=nd == 2), ref.detach(), dtype, "convt_fwd")
     gd = Dev(rnd(*ref.shape, seed=5), dtype=dtype)
     ref.backward(gd.ref().squeeze(2) if nd == 2 else gd.ref())
     dxd = Dev(shape=(n, cin, 1 if nd == 2 else sp[0], sp[-2], sp[-1]), dtype=dtype)
-    check(lib.biu_convt_bwd_data(gd.a(), ptr(wd), kd, dxd.a(), 0, DT[dtype][1], stream()), "convt_bwd_data")
+    check(lib.biu_convt_bwd_data(gd.a(), ptr(wd), None, kd, dxd.a(), 0, DT[dtype][1], stream()), "convt_bwd_data")
     assert_close(dxd.get(squeeze2d=nd == 2), xa.grad, dtype, "convt_bwd_data")
     dw, db = torch.empty_like(wd), torch.empty_like(bd)
-    check(lib.biu_convt_bwd_weight(xd.a(), xf.x(), gd.a(), kd, ptr(dw), ptr(db), DT[dtype][1], stream()), "convt_bwd_weight")
+    ws = torch.empty(max(lib.biu_convt_bwd_weight_workspace(cin, cout, kd, DT[dtype][1]), 16), dtype=torch.uint8, device="cuda")
+    check(lib.biu_convt_bwd_weight(xd.a(), xf.x(), gd.a(), kd, ptr(dw), ptr(db), ptr(ws), ws.numel(), DT[dtype][1], stream()),
+          "convt_bwd_weight")
     assert_close(dw.cpu(), wr.grad, dtype, "convt dw")
     assert_close(db.cpu(), br.grad, dtype, "convt db")
 
@@ -359,3 +361,80 @@ def test_conv_mfma_fwd_dgrad(case, dtype):
     torch.testing.assert_close(dxd.get(squeeze2d=(nd == 2)), 2 * xa.grad, rtol=t2["rtol"] * 2, atol=t2["atol"] * 2)
     # the pad region of the output buffer (channels outside the slice) must be untouched
     assert torch.isnan(yd.buf[..., :8].float()).all()
+    # weight gradient (MFMA, split-K with fp32 atomics): reference sees the same rounded operands
+    wq2 = wq.clone().requires_grad_(True)
+    xa2 = xa.detach()
+    conv_ref(xa2, wq2, None, 1).backward(dyr)
+    wsz = lib.biu_conv_bwd_weight_workspace(cin, cout, kd, 3, 3, code)
+    assert wsz > 0
+    ws = torch.empty(wsz, dtype=torch.uint8, device="cuda")
+    dw = torch.full_like(wd, float("nan"))
+    db = torch.empty_like(bd)
+    check(lib.biu_conv_bwd_weight(xd.a(), xf.x(), dyd.a(), kd, 3, 3, 1, ptr(dw), ptr(db), ptr(ws), ws.numel(), code, stream()),
+          "conv_bwd_weight(mfma)")
+    t3 = dict(rtol=1e-3, atol=2e-4 * float(wq2.grad.abs().max())) if dtype == "f32" else dict(rtol=1e-2, atol=1e-2 * float(wq2.grad.abs().max()))
+    torch.testing.assert_close(dw.cpu(), wq2.grad, **t3)
+    torch.testing.assert_close(db.cpu(), dyr.sum(dim=[0] + list(range(2, dyr.dim()))), rtol=1e-3, atol=1e-3 * float(dyr.abs().sum() ** 0.5))
+
+
+CONVT_MFMA_CASES = [
+    # (nd, N, Cin, Cout, coarse spatial)
+    (3, 1, 64, 64, (4, 8, 16)),
+    (3, 2, 32, 32, (3, 5, 9)),
+    (3, 1, 128, 128, (2, 4, 4)),
+    (3, 1, 16, 48, (2, 2, 20)),
+    (2, 2, 64, 32, (16, 16)),
+    (2, 1, 256, 128, (8, 8)),
+    (2, 1, 32, 16, (10, 36)),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONVT_MFMA_CASES)
+def test_convtranspose_mfma(case, dtype):
+    nd, n, cin, cout, sp = case
+    kd = 2 if nd == 3 else 1
+    code = DT[dtype][1]
+    x = rnd(n, cin, *sp, seed=1)
+    w = rnd(cin, cout, *([2] * nd), seed=2) * (1.0 / cin ** 0.5)
+    b = rnd(cout, seed=3)
+    xf = XF(cin, seed=4)
+    xd = Dev(x, dtype=dtype, pitch=cin + 8, c0=8)
+    xr = xd.ref().squeeze(2) if nd == 2 else xd.ref()
+    xa = xf.apply(xr)
+    wq = w
+    if dtype == "bf16":
+        xa, wq = xa.bfloat16().float(), w.bfloat16().float()
+    xa.requires_grad_(True)
+    wq = wq.clone().requires_grad_(True)
+    f = F.conv_transpose3d if nd == 3 else F.conv_transpose2d
+    ref = f(xa, wq, b, stride=2)
+    osp = tuple(2 * s for s in sp)
+    oshape = (n, cout, 1 if nd == 2 else osp[0], osp[-2], osp[-1])
+    yd = Dev(shape=oshape, dtype=dtype, pitch=cout + 32, c0=0)
+    wd, bd = w.cuda(), b.cuda()
+    nb = lib.biu_convt_packed_bytes(0, cin, cout, kd, code)
+    assert nb > 0
+    pk = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    check(lib.biu_convt_pack(0, ptr(wd), cin, cout, kd, code, ptr(pk), stream()), "convt_pack")
+    check(lib.biu_convt_fwd(xd.a(), xf.x(), ptr(wd), ptr(pk), ptr(bd), kd, yd.a(), code, stream()), "convt_fwd(mfma)")
+    t = dict(rtol=1e-4, atol=1e-4 * float(ref.abs().max())) if dtype == "f32" else dict(rtol=1e-2, atol=1e-2 * float(ref.abs().max()))
+    torch.testing.assert_close(yd.get(squeeze2d=nd == 2), ref.detach(), **t)
+    assert torch.isnan(yd.buf[..., cout:].float()).all()
+    gd = Dev(rnd(*ref.shape, seed=5), dtype=dtype)
+    gr = gd.ref().squeeze(2) if nd == 2 else gd.ref()
+    ref.backward(gr)
+    nb1 = lib.biu_convt_packed_bytes(1, cin, cout, kd, code)
+    pk1 = torch.empty(nb1, dtype=torch.uint8, device="cuda")
+    check(lib.biu_convt_pack(1, ptr(wd), cin, cout, kd, code, ptr(pk1), stream()), "convt_pack(dgrad)")
+    dxd = Dev(shape=(n, cin, 1 if nd == 2 else sp[0], sp[-2], sp[-1]), dtype=dtype)
+    check(lib.biu_convt_bwd_data(gd.a(), ptr(wd), ptr(pk1), kd, dxd.a(), 0, code, stream()), "convt_bwd_data(mfma)")
+    t2 = dict(rtol=1e-4, atol=1e-4 * float(xa.grad.abs().max())) if dtype == "f32" else dict(rtol=1e-2, atol=1e-2 * float(xa.grad.abs().max()))
+    torch.testing.assert_close(dxd.get(squeeze2d=nd == 2), xa.grad, **t2)
+    wsz = lib.biu_convt_bwd_weight_workspace(cin, cout, kd, code)
+    assert wsz > 0
+    ws = torch.empty(wsz, dtype=torch.uint8, device="cuda")
+    dw, db = torch.full_like(wd, float("nan")), torch.empty_like(bd)
+    check(lib.biu_convt_bwd_weight(xd.a(), xf.x(), gd.a(), kd, ptr(dw), ptr(db), ptr(ws), ws.numel(), code, stream()), "convt_bwd_weight(mfma)")
+    t3 = dict(rtol=1e-3, atol=2e-4 * float(wq.grad.abs().max())) if dtype == "f32" else dict(rtol=1e-2, atol=1e-2 * float(wq.grad.abs().max()))
+    torch.testing.assert_close(dw.cpu(), wq.grad, **t3)
