@@ -1,0 +1,275 @@
+#!/usr/bin/env python
+"""Benchmark of the U-Net hot path on MI355X:  voxels/s of a full train step (forward + loss + backward + Adam).
+
+    python bench.py --gpus N --steps K --warmup W [--workload cfg4|cfg2|cfg3|cfg5|cfg1]
+
+N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+(one rank per GPU, RCCL); per-GPU work is fixed (weak scaling), `value` is the whole-job aggregate.
+
+Workloads (BASELINE.json `configs`) -- synthetic data x ~ U[0,1), y = (U > 0.5), seed 1234:
+  cfg4 (default, the north-star target): UNet3D(1,1,32), (4,1,128,128,128) per GPU, bf16 storage / fp32 accumulate
+  cfg2: Unet(1,2,64), (16,1,512,512), fp32          cfg3: Siam_UNet(32,'max'), 2 x (16,1,512,512), bf16
+  cfg5: MultiOutputUnet3D(1, 3 heads, 64, interp), (1,1,128,256,256), bf16      cfg1: Unet(1,1,32), (2,1,256,256), fp32
+One JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel launch, timed live with HIP events inside the timed region
+  cpu_baseline -- the CPU oracle (a restatement of the reference's PyTorch-CPU path) on a bounded sample, host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK = 8.0e12            # B/s   (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
+MFMA_PEAK = {"bf16": 2.5e15, "f32": 157.3e12}
+
+HEADS5 = {"seg": {"channels": 1, "activation": "sigmoid"}, "flow": {"channels": 2, "activation": None},
+          "dist": {"channels": 1, "activation": "sigmoid"}}
+
+WORKLOADS = {
+    "cfg1": dict(model="Unet", ctor=dict(in_channels=1, out_channels=1, n_filter=32), shape=(2, 1, 256, 256), dtype="f32", out=1),
+    "cfg2": dict(model="Unet", ctor=dict(in_channels=1, out_channels=2, n_filter=64), shape=(16, 1, 512, 512), dtype="f32", out=2),
+    "cfg3": dict(model="Siam_UNet", ctor=dict(n_filter=32, mode="max"), shape=(16, 1, 512, 512), dtype="bf16", out=1),
+    "cfg4": dict(model="UNet3D", ctor=dict(in_channels=1, out_channels=1, n_filter=32), shape=(4, 1, 128, 128, 128), dtype="bf16", out=1),
+    "cfg5": dict(model="MultiOutputUnet3D", ctor=dict(in_channels=1, output_heads=HEADS5, n_filter=64, use_interpolation=True),
+                 shape=(1, 1, 128, 256, 256), dtype="bf16", out=4),
+}
+
+
+def make_step(wl, device):
+    """Returns (model, step_fn, fwd_fn, voxels_per_step). The loss expressions are the reference trainers' own."""
+    import bio_image_unet_amd as B
+    from bio_image_unet_amd.losses import BCEDiceLoss
+    from bio_image_unet_amd.optim import Adam
+
+    torch.manual_seed(1234)
+    cls = getattr(B, wl["model"])
+    model = cls(**wl["ctor"]).to(device)
+    if wl["model"] == "Unet":       # Trainer applies init_weights (Kaiming normal on nn.Conv2d only), unet/train.py:70
+        model.apply(lambda m: torch.nn.init.kaiming_normal_(m.weight, nonlinearity="leaky_relu") if isinstance(m, torch.nn.Conv2d) else None)
+    if wl["dtype"] == "bf16":
+        model.set_compute_dtype(torch.bfloat16)
+    model.train()
+    shape = wl["shape"]
+    x = torch.rand(shape, device=device)
+    px = torch.rand(shape, device=device) if wl["model"] == "Siam_UNet" else None
+    crit = BCEDiceLoss(0.5, 0.5)
+    smooth_l1 = torch.nn.SmoothL1Loss()
+    opt = Adam(model.parameters(), lr=1e-3)
+    if wl["model"] == "MultiOutputUnet3D":
+        tgt = {k: (torch.rand((shape[0], v["channels"]) + tuple(shape[2:]), device=device) > 0.5).float() for k, v in HEADS5.items()}
+    else:
+        y = (torch.rand((shape[0], wl["out"]) + tuple(shape[2:]), device=device) > 0.5).float()
+
+    def loss_of(outs):
+        if wl["model"] == "Unet":            # unet/train.py:133-134 (indexes the batch axis with the channel index)
+            oc = wl["out"]
+            return sum(crit(outs[1][ch], y[ch]) for ch in range(oc)) / oc
+        if wl["model"] == "UNet3D":          # unet3d/train.py:140-145
+            return crit(outs[1], y) + smooth_l1(outs[1][1:], outs[1][:-1]) * 0.1
+        if wl["model"] == "Siam_UNet":       # siam_unet/train.py:110
+            return crit(outs[1], y)
+        return sum(torch.nn.functional.mse_loss(outs[k], tgt[k]) for k in outs)   # mo3d: weighted per-head losses
+
+    def fwd():
+        return model(x, px) if px is not None else model(x)
+
+    from bio_image_unet_amd.ddp import GradAverager
+    avg = GradAverager(model)
+
+    def step():
+        outs = fwd()
+        loss = loss_of(outs)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if wl["model"] == "MultiOutputUnet3D":     # multi_output_unet3d/train.py:201
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+        avg.average()
+        opt.step()
+        return loss
+
+    nvox = 1
+    for s in (shape[0],) + tuple(shape[2:]):
+        nvox *= s
+    return model, step, fwd, nvox
+
+
+def call_cost(eng, api, label):
+    """Algorithmic FLOPs and bytes (SURVEY.md 8d convention) of one C-ABI call, from the node's shapes."""
+    from bio_image_unet_amd import engine as E
+    esz = 2 if eng.tdtype == torch.bfloat16 else 4
+    node = next((n for n in eng.nodes if n.label == label.split(":")[0]), None)
+    if node is None:
+        return 0.0, 0.0
+    if isinstance(node, E.ConvBlockNode) and api in ("biu_conv_fwd", "biu_conv_bwd_data", "biu_conv_bwd_weight"):
+        taps = node.kd * node.kh * node.kw
+        v = node.y.nvox
+        return 2.0 * v * taps * node.xin.c * node.y.c, float(v) * (node.xin.c + node.y.c) * esz
+    if isinstance(node, E.ConvTNode) and api.startswith("biu_convt"):
+        v = node.xin.nvox
+        taps = node.kd * 4
+        return 2.0 * v * taps * node.xin.c * node.y.c, float(v) * (node.xin.c + taps * node.y.c) * esz
+    if isinstance(node, E.ConvBlockNode):      # BN / element-wise passes over y
+        return 0.0, float(node.y.nvox) * node.y.c * esz * (3 if api == "biu_bn_bwd_apply" else (2 if api == "biu_bn_bwd_reduce" else 1))
+    if isinstance(node, E.ResampleNode):
+        return 0.0, float(node.xin.nvox * node.xin.c + node.y.nvox * node.y.c) * esz
+    return 0.0, 0.0
+
+
+def cpu_baseline(wl_name, budget_s=25.0):
+    """The oracle (CPU restatement of the reference path, fp32, torch CPU threads = host cores) on a bounded sample."""
+    from oracle import unet_oracle as O
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    torch.manual_seed(1234)
+    if wl_name in ("cfg4", "cfg5"):
+        sd = O.clone_state(O.init_unet3d(1, 1, 32, seed=0), requires_grad=True)
+        shape = (1, 1, 64, 128, 128)
+        fwd = lambda x: O.unet3d_forward(sd, x, training=True)
+        name = "UNet3D(1,1,32) oracle, (1,1,64,128,128) fp32, fwd+loss+bwd+Adam"
+    else:
+        sd = O.clone_state(O.init_unet2d(1, 1, 32, seed=0), requires_grad=True)
+        shape = (2, 1, 256, 256)
+        fwd = lambda x: O.unet2d_forward(sd, x, training=True)
+        name = "Unet(1,1,32) oracle, (2,1,256,256) fp32, fwd+loss+bwd+Adam"
+    params = [v for v in sd.values() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    x = torch.rand(shape)
+    y = (torch.rand(shape) > 0.5).float()
+    nvox = x.numel()
+    times = []
+    t_start = time.time()
+    for i in range(4):
+        t0 = time.time()
+        _, logits = fwd(x)
+        loss = O.bce_dice_loss(logits, y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        dt = time.time() - t0
+        if i > 0:
+            times.append(dt)
+        if time.time() - t_start > budget_s and times:
+            break
+    best = min(times)
+    return {"value": nvox / best, "unit": "voxels/s", "cores": ncores, "kind": "port",
+            "sample": f"{name}; {len(times)} timed steps after 1 warm-up, best {best:.3f} s/step; torch {torch.__version__} CPU threads={ncores}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", default=None, help="write the per-launch time table of one profiled step to this file")
+    args = ap.parse_args()
+
+    from bio_image_unet_amd import ddp
+    from bio_image_unet_amd._lib import lib
+    rank, local, world = ddp.init_from_env("nccl")
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    wl = WORKLOADS[args.workload]
+    model, step, fwd, nvox = make_step(wl, device)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up; the last warm-up step is profiled per C-ABI call to find the dominant launch ------------------------
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+    lib.prof = []
+    step()
+    torch.cuda.synchronize()
+    prof, lib.prof = lib.prof, None
+    eng = list(model._engines.values())[-1]
+    agg = {}
+    for api, label, e0, e1 in prof:
+        agg.setdefault((api, label), []).append(e0.elapsed_time(e1))
+    rows = sorted(((sum(v), k) for k, v in agg.items()), reverse=True)
+    total_kernel_ms = sum(r[0] for r in rows)
+    dom_ms, dom_key = rows[0]
+    if args.breakdown and rank == 0:
+        with open(args.breakdown, "w") as f:
+            f.write(f"# per-launch HIP-event times of one profiled step, workload {args.workload}; sum = {total_kernel_ms:.3f} ms\n")
+            for ms, (api, label) in rows:
+                fl, by = call_cost(eng, api, label)
+                f.write(f"{ms:9.4f} ms  {api:26s} {label:22s} {fl / ms / 1e9 if ms else 0:9.1f} TFLOP/s {by / ms / 1e6 if ms else 0:9.1f} GB/s\n")
+
+    # ---- timed region --------------------------------------------------------------------------------------------------
+    lib.watch, lib.watched = dom_key, []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    watched, lib.watch = lib.watched, None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+
+    # forward-only (eval-style use, no_grad; BN in train mode exactly as the reference's validation loop)
+    with torch.no_grad():
+        fwd()
+        barrier()
+        t1 = time.perf_counter()
+        nf = max(args.steps // 2, 1)
+        for _ in range(nf):
+            fwd()
+        barrier()
+        fwd_ms = (time.perf_counter() - t1) / nf * 1e3
+
+    if rank != 0:
+        return
+    dom_launch_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in watched) / max(len(watched), 1)
+    fl, by = call_cost(eng, *dom_key)
+    dt_name = wl["dtype"]
+    ai = fl / by if by else 0.0
+    ridge = MFMA_PEAK[dt_name] / HBM_PEAK
+    if fl > 0 and ai >= ridge * 0.5:
+        roof = {"bound": "mfma", "achieved": fl / (dom_launch_ms * 1e-3) / 1e12, "peak": MFMA_PEAK[dt_name] / 1e12, "unit": "TFLOP/s"}
+    else:
+        roof = {"bound": "hbm", "achieved": by / (dom_launch_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s"}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["traffic"] = None
+    roof["kernel"] = f"{dom_key[0]} @ {dom_key[1]}"
+    roof["launch_ms"] = dom_launch_ms
+    roof["launches_timed"] = len(watched)
+    roof["share_of_step_kernel_time"] = dom_ms / total_kernel_ms if total_kernel_ms else None
+
+    # whole-step roofline numbers of SURVEY.md 8d (cfg4: 1.316 MFLOP and 2915 B per voxel, fwd+bwd)
+    per_vox = {"cfg4": (1.316e6, 2915.0), "cfg2": (3 * 1467.8e3, 3 * 5596.0), "cfg3": (3 * 469e3, 3 * 1940.0),
+               "cfg5": (3 * 3243.7e3, 3 * 2179.0), "cfg1": (3 * 367.2e3, 3 * 2800.0)}[args.workload]
+    vps_gpu = nvox / (ms_per_step * 1e-3)
+    out = {
+        "metric": "voxels/sec fwd+bwd", "value": vps_gpu * world, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": dt_name, "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {wl['model']}({', '.join(f'{k}={v}' for k, v in wl['ctor'].items() if k != 'output_heads')}) input {wl['shape']} per GPU, "
+                               "train step = forward + reference loss + backward + Adam", "parallelism": f"dp{world}"},
+        "fwd_only": {"value": nvox / (fwd_ms * 1e-3) * world, "unit": "voxels/s", "ms": fwd_ms},
+        "step_roofline": {"hbm_frac_algorithmic": vps_gpu * per_vox[1] / HBM_PEAK, "algorithmic_GBps": vps_gpu * per_vox[1] / 1e9,
+                          "algorithmic_TFLOPps": vps_gpu * per_vox[0] / 1e12, "mfma_frac": vps_gpu * per_vox[0] / MFMA_PEAK[dt_name],
+                          "kernel_time_ms_one_step": total_kernel_ms},
+        "roofline": roof,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.workload)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

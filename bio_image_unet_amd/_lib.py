@@ -90,7 +90,44 @@ def _load():
     return lib
 
 
-lib = _load()
+class _Lib:
+    """Thin proxy over the CDLL: plain attribute access in normal operation, optional per-call HIP-event timing.
+
+    ``prof``  : list -> every call appends (api name, current label, start event, end event)
+    ``watch`` : (api name, label) -> only that call is timed, into ``watched`` (used inside bench.py's timed region)
+    Events are recorded on torch's current stream, which is the stream every kernel is launched on.
+    """
+
+    def __init__(self, cdll):
+        object.__setattr__(self, "_c", cdll)
+        object.__setattr__(self, "prof", None)
+        object.__setattr__(self, "watch", None)
+        object.__setattr__(self, "watched", [])
+        object.__setattr__(self, "label", "")
+
+    def __setattr__(self, k, v):
+        object.__setattr__(self, k, v)
+
+    def __getattr__(self, name):
+        fn = getattr(self._c, name)
+        if self.prof is None and self.watch is None:
+            return fn
+        if self.prof is None and self.watch != (name, self.label):
+            return fn
+        import torch
+
+        def timed(*args):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            (self.prof if self.prof is not None else self.watched).append((name, self.label, e0, e1))
+            return rc
+
+        return timed
+
+
+lib = _Lib(_load())
 
 
 def check(status: int, what: str = ""):

@@ -3,6 +3,14 @@
 #include "biu_common.h"
 #include "biu_internal.h"
 
+// Debug switches (read once): BIU_DISABLE=conv_fwd,conv_dgrad,conv_wgrad,convt_fwd,convt_dgrad,convt_wgrad routes the named op family to the direct kernels.
+#include <stdlib.h>
+#include <string.h>
+static bool disabled(const char* what) {
+    const char* env = getenv("BIU_DISABLE");       // re-read per call: tests flip it inside one process
+    return env && strstr(env, what) != nullptr;
+}
+
 static bool conv_args_ok(const biu_act* x, const biu_act* y, int kd, int kh, int kw, int dil) {
     if (!valid_act(x) || !valid_act(y) || !same_space(x, y)) return false;
     if (!((kd == 1 || kd == 3) && kh == 3 && kw == 3) && !(kd == 1 && kh == 1 && kw == 1)) return false;
@@ -27,7 +35,7 @@ extern "C" int biu_conv_fwd(const biu_act* x, const biu_xform* xf, const float* 
     BIU_REQUIRE(conv_args_ok(x, y, kd, kh, kw, dilation), BIU_ERR_SHAPE,
                 "conv_fwd: x/y extents differ or unsupported kernel %dx%dx%d dil %d", kd, kh, kw, dilation);
     BIU_REQUIRE(w, BIU_ERR_SHAPE, "conv_fwd: null weight");
-    if (packed && biu_mfma_conv_ok(x, y, kd, kh, kw, dilation, dtype))
+    if (packed && !disabled("conv_fwd") && biu_mfma_conv_ok(x, y, kd, kh, kw, dilation, dtype))
         return biu_mfma_conv(x, xf, packed, bias, kd, kh, kw, y, 0, dtype, (hipStream_t)stream);
     return biu_conv_fwd_direct(x, xf, w, bias, kd, kh, kw, dilation, y, dtype, (hipStream_t)stream);
 }
@@ -36,7 +44,7 @@ extern "C" int biu_conv_bwd_data(const biu_act* dy, const float* w, const void* 
                                  int dilation, const biu_act* dx, int accumulate, int dtype, biu_stream stream) {
     BIU_REQUIRE(conv_args_ok(dy, dx, kd, kh, kw, dilation), BIU_ERR_SHAPE, "conv_bwd_data: dy/dx extents differ");
     BIU_REQUIRE(w, BIU_ERR_SHAPE, "conv_bwd_data: null weight");
-    if (packed && biu_mfma_conv_ok(dy, dx, kd, kh, kw, dilation, dtype))
+    if (packed && !disabled("conv_dgrad") && biu_mfma_conv_ok(dy, dx, kd, kh, kw, dilation, dtype))
         return biu_mfma_conv(dy, nullptr, packed, nullptr, kd, kh, kw, dx, accumulate, dtype, (hipStream_t)stream);
     return biu_conv_bwd_data_direct(dy, w, kd, kh, kw, dilation, dx, accumulate, dtype, (hipStream_t)stream);
 }
@@ -50,7 +58,7 @@ extern "C" int biu_conv_bwd_weight(const biu_act* x, const biu_xform* xf, const 
                                    biu_stream stream) {
     BIU_REQUIRE(conv_args_ok(x, dy, kd, kh, kw, dilation), BIU_ERR_SHAPE, "conv_bwd_weight: x/dy extents differ");
     BIU_REQUIRE(dw, BIU_ERR_SHAPE, "conv_bwd_weight: null dw");
-    if (biu_mfma_wgrad_ok(x, dy, kd, kh, kw, dilation, dtype)) {
+    if (!disabled("conv_wgrad") && biu_mfma_wgrad_ok(x, dy, kd, kh, kw, dilation, dtype)) {
         BIU_REQUIRE(ws && ws_bytes >= biu_mfma_wgrad_workspace(x->c, dy->c, kd, kh, kw, dtype), BIU_ERR_WORKSPACE,
                     "conv_bwd_weight: workspace too small");
         return biu_mfma_wgrad(x, xf, dy, kd, kh, kw, dw, dbias, ws, ws_bytes, dtype, (hipStream_t)stream);
@@ -70,7 +78,7 @@ extern "C" int biu_convt_fwd(const biu_act* x, const biu_xform* xf, const float*
                              int kd, const biu_act* y, int dtype, biu_stream stream) {
     BIU_REQUIRE(valid_act(x) && valid_act(y) && w && biu_convt_shapes_ok(x, y, kd), BIU_ERR_SHAPE,
                 "convt_fwd: output must be 2x the input extent (kd=%d)", kd);
-    if (packed && biu_mfma_convt_ok(0, x, y, kd, dtype))
+    if (packed && !disabled("convt_fwd") && biu_mfma_convt_ok(0, x, y, kd, dtype))
         return biu_mfma_convt_fwd(x, xf, packed, bias, kd, y, dtype, (hipStream_t)stream);
     return biu_convt_fwd_direct(x, xf, w, bias, kd, y, dtype, (hipStream_t)stream);
 }
@@ -78,7 +86,7 @@ extern "C" int biu_convt_bwd_data(const biu_act* dy, const float* w, const void*
                                   int accumulate, int dtype, biu_stream stream) {
     BIU_REQUIRE(valid_act(dx) && valid_act(dy) && w && biu_convt_shapes_ok(dx, dy, kd), BIU_ERR_SHAPE,
                 "convt_bwd_data: dy must be 2x the dx extent (kd=%d)", kd);
-    if (packed && biu_mfma_convt_ok(1, dx, dy, kd, dtype))
+    if (packed && !disabled("convt_dgrad") && biu_mfma_convt_ok(1, dx, dy, kd, dtype))
         return biu_mfma_convt_dgrad(dy, packed, kd, dx, accumulate, dtype, (hipStream_t)stream);
     return biu_convt_bwd_data_direct(dy, w, kd, dx, accumulate, dtype, (hipStream_t)stream);
 }
@@ -89,7 +97,7 @@ extern "C" int biu_convt_bwd_weight(const biu_act* x, const biu_xform* xf, const
                                     float* dbias, void* ws, size_t ws_bytes, int dtype, biu_stream stream) {
     BIU_REQUIRE(valid_act(x) && valid_act(dy) && dw && biu_convt_shapes_ok(x, dy, kd), BIU_ERR_SHAPE,
                 "convt_bwd_weight: dy must be 2x the x extent (kd=%d)", kd);
-    if (biu_mfma_convt_wgrad_ok(x, dy, kd, dtype)) {
+    if (!disabled("convt_wgrad") && biu_mfma_convt_wgrad_ok(x, dy, kd, dtype)) {
         BIU_REQUIRE(ws && ws_bytes >= biu_mfma_wgrad_workspace(x->c, dy->c, kd, 2, 2, dtype), BIU_ERR_WORKSPACE,
                     "convt_bwd_weight: workspace too small");
         return biu_mfma_convt_wgrad(x, xf, dy, kd, dw, dbias, ws, ws_bytes, dtype, (hipStream_t)stream);

@@ -1,0 +1,62 @@
+"""Data parallelism for the hot path: one process per GPU, gradients averaged with one RCCL all-reduce per step.
+
+The reference has no distributed code at all; its BatchNorm layers are plain per-process BatchNorm,
+so per-rank batch statistics ARE the reference semantics.  Parameters are broadcast once from rank 0; each step the
+fp32 gradients (19 MB for UNet3D F=32 ... 124 MB for Unet F=64) are packed into one flat bucket, all-reduced
+(``backend='nccl'`` is RCCL over xGMI on ROCm; 'gloo' on CPU for the tests) and averaged.  With gradients this small
+against a >= 10 ms step a single bucket after backward costs < 3 % even unoverlapped; BN running statistics are
+left rank-local (rank 0's are the ones a checkpoint saves).
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None):
+    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun contract); returns (rank, local_rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+class GradAverager:
+    """Flat-bucket gradient all-reduce (mean) + initial parameter/buffer broadcast."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.params: List[torch.nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.views, o = [], 0
+        for p in self.params:
+            self.views.append(self.flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+        if self.world > 1:
+            with torch.no_grad():
+                for t in list(module.parameters()) + list(module.buffers()):
+                    dist.broadcast(t.data, src=0)
+
+    def average(self):
+        """Call after backward(): leaves p.grad = mean over ranks (views of one flat fp32 bucket)."""
+        if self.world == 1:
+            return
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+        torch._foreach_copy_(self.views, grads)
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.flat.mul_(1.0 / self.world)
+        for p, v in zip(self.params, self.views):
+            p.grad = v

@@ -130,6 +130,7 @@ class Act:
 # ======================================================================================================
 class Node:
     params: Sequence[nn.Parameter] = ()
+    label = "node"
 
     def fwd(self, eng: "Engine"):
         raise NotImplementedError
@@ -524,6 +525,7 @@ class Engine:
     def forward(self):
         self.nbt_bump = []
         for nd_ in self.nodes:
+            lib.label = nd_.label + ":fwd"
             nd_.fwd(self)
         if self.nbt_bump:       # a weight-shared block (Siam encoder) appears once per application
             counts: Dict[int, list] = {}
@@ -541,10 +543,12 @@ class Engine:
         for b in self.bufs:
             for k in b.leaves:
                 b.leaves[k] = False
+        lib.label = "head:bwd"
         self._backward_heads(head_grads)
         for nd_ in reversed(self.nodes):
             if isinstance(nd_, HeadNode):
                 continue
+            lib.label = nd_.label + ":bwd"
             nd_.bwd(self)
         return self.grads
 

@@ -63,6 +63,11 @@ class _HipNet(nn.Module):
             eng = E.Engine(x.device, self.compute_dtype, self.nd)
             self._build(eng, *[tuple(t.shape) for t in xs])
             eng.finalize()
+            names = {id(mod): name for name, mod in self.named_modules()}
+            for nd_ in eng.nodes:       # labels for profiling: the reference attribute name of the layer
+                mod = getattr(nd_, "conv", None) or getattr(nd_, "up", None)
+                base = names.get(id(mod), type(nd_).__name__)
+                nd_.label = base[:-2] if base.endswith(".0") and not base.startswith("final") else base
             self._engines[key] = eng
             while len(self._engines) > self._max_cached:
                 self._engines.popitem(last=False)

@@ -1,0 +1,66 @@
+"""Fused multi-tensor Adam on the HIP side (``biu_adam_step``): one launch updates every parameter.
+
+Replaces ``torch.optim.Adam(model.parameters(), lr=lr)`` of the reference trainers (``unet/train.py:102``; defaults
+betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False).  ``state_dict`` / ``param_groups`` keep the torch
+layout so ``ReduceLROnPlateau`` (``unet/train.py:103``) can drive ``param_groups[0]['lr']`` unchanged.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from ._lib import check, lib
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._tables = {}
+
+    def _group_tables(self, gi, group):
+        ps = [p for p in group["params"] if p.requires_grad]
+        key = (gi, tuple(p.data_ptr() for p in ps))
+        t = self._tables.get(gi)
+        if t is None or t["key"] != key:
+            dev = ps[0].device
+            for p in ps:
+                st = self.state[p]
+                if "exp_avg" not in st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32)
+                    st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32)
+            mk = lambda ts: torch.tensor([x.data_ptr() for x in ts], dtype=torch.int64, device=dev)
+            t = {"key": key, "ps": ps, "p": mk(ps), "m": mk([self.state[p]["exp_avg"] for p in ps]),
+                 "v": mk([self.state[p]["exp_avg_sq"] for p in ps]),
+                 "n": torch.tensor([p.numel() for p in ps], dtype=torch.int64, device=dev), "g": None, "gkey": None}
+            self._tables[gi] = t
+        return t
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        loss = closure() if closure is not None else None
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for gi, group in enumerate(self.param_groups):
+            t = self._group_tables(gi, group)
+            ps = t["ps"]
+            for p in ps:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
+            gkey = tuple(p.grad.data_ptr() for p in ps)
+            if t["gkey"] != gkey:
+                t["g"] = torch.tensor(gkey, dtype=torch.int64, device=ps[0].device)
+                t["gkey"] = gkey
+            step = self.state[ps[0]]["step"] + 1
+            for p in ps:
+                self.state[p]["step"] = step
+            b1, b2 = group["betas"]
+            check(lib.biu_adam_step(len(ps), C.c_void_p(t["p"].data_ptr()), C.c_void_p(t["g"].data_ptr()),
+                                    C.c_void_p(t["m"].data_ptr()), C.c_void_p(t["v"].data_ptr()),
+                                    C.c_void_p(t["n"].data_ptr()), float(group["lr"]), b1, b2, group["eps"], step,
+                                    float(grad_scale), st), "adam_step")
+            # the kernel wrote through raw pointers: bump the version counters so autograd and the engine's
+            # packed-weight cache (keyed on Tensor._version) see the in-place update
+            torch.autograd.graph.increment_version(ps)
+        return loss

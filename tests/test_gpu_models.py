@@ -75,8 +75,13 @@ def test_golden_train_step_fp32(case):
         assert relerr(oe[k].cpu(), v) < REL, f"eval.{k}"
 
 
-def _oracle_run(kind, sd, x, y, dt, **kw):
+def _oracle_run(kind, sd, x, y, dt, perturb=0.0, **kw):
     osd = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    if perturb:
+        g = torch.Generator().manual_seed(7)
+        for k in osd:
+            if k.endswith(".0.weight"):
+                osd[k] = osd[k] * (1 + perturb * torch.randn(osd[k].shape, generator=g, dtype=dt))
     osd = O.clone_state(osd, requires_grad=True)
     fwd = O.unet2d_forward if kind == "unet2d" else O.unet3d_forward
     prob, logits = fwd(osd, x.to(dt), training=True, **kw)
@@ -100,10 +105,12 @@ def _grad_errors(grads, truth):
 def test_seeded_midsize_vs_oracle(kind, nf, shape, dtype):
     """Channel counts that are multiples of 16 -- the shapes the MFMA implicit-GEMM kernels serve.
 
-    Weight gradients of a conv that feeds a train-mode BatchNorm are sums with heavy cancellation: the reference's
-    own fp32 CPU path is only ~5e-3 from the exact (fp64) gradient at these sizes.  So the yardstick for gradients
-    is the fp64 oracle, and the bar for the fp32 HIP path is "no worse than the reference's fp32 path" (2x its
-    error + 1e-3); forward outputs keep the plain 1e-3 bound against the fp32 oracle."""
+    Forward outputs keep the plain 1e-3 bound against the fp32 oracle.  Gradients of this network are intrinsically
+    ill-conditioned (train-mode BatchNorm after every conv): in exact fp64 arithmetic a 1e-6 relative perturbation of
+    the conv weights -- the size of one fp32 convolution's rounding error -- already moves individual parameter
+    gradients by up to ~7e-3 of their scale, and the reference's own fp32 CPU path is up to ~5e-3 away from the fp64
+    gradient.  So the yardstick is the fp64 oracle and the fp32 bar is conditioning-aware:
+        err_k <= 1e-3 + 3 * max(sensitivity_k(2e-6 perturbation), reference-fp32 error_k)."""
     torch.manual_seed(0)
     x = torch.rand(*shape)
     y = (torch.rand(*shape) > 0.5).float()
@@ -115,6 +122,8 @@ def test_seeded_midsize_vs_oracle(kind, nf, shape, dtype):
         m = B.UNet3D(1, 1, nf)
     ref_logits, ref_loss, ref_grads, osd = _oracle_run(kind, sd, x, y, torch.float32)
     _, _, true_grads, _ = _oracle_run(kind, sd, x, y, torch.float64)
+    _, _, pert_grads, _ = _oracle_run(kind, sd, x, y, torch.float64, perturb=2e-6)
+    sens = _grad_errors(pert_grads, true_grads)
     m = m.cuda()
     m.load_state_dict(sd)
     if dtype == "bf16":
@@ -133,10 +142,12 @@ def test_seeded_midsize_vs_oracle(kind, nf, shape, dtype):
     top = sorted(mine.items(), key=lambda kv: -kv[1][0])[:5]
     print("worst HIP gradient errors vs fp64 (err, cos):", top)
     print("worst CPU-fp32 gradient errors vs fp64:", sorted(cpu32.items(), key=lambda kv: -kv[1][0])[:3])
-    cpu_worst = max(v[0] for v in cpu32.values())
+    print("worst fp64 sensitivity to a 2e-6 weight perturbation:", sorted(sens.items(), key=lambda kv: -kv[1][0])[:3])
     if dtype == "f32":
         for k, (err, cos) in mine.items():
-            assert err <= 2 * cpu_worst + REL, f"grad {k}: err {err} vs reference-fp32 worst {cpu_worst}"
+            bound = REL + 3 * max(sens[k][0], cpu32[k][0])
+            assert err <= bound, f"grad {k}: err {err} > {bound} (sensitivity {sens[k][0]}, reference-fp32 err {cpu32[k][0]})"
+            assert cos > 0.999, f"grad {k}: cosine {cos}"
     else:
         # bf16 storage of activations and activation gradients: direction must be right, magnitude within 35 %
         for k, (err, cos) in mine.items():
