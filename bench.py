@@ -124,7 +124,11 @@ def call_cost(eng, api, label):
 def cpu_baseline(wl_name, budget_s=25.0):
     """The oracle (CPU restatement of the reference path, fp32, torch CPU threads = host cores) on a bounded sample."""
     from oracle import unet_oracle as O
-    ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = min(ncores, 16)            # the GPU box's CPU share for one GPU is 16 cores
     torch.set_num_threads(ncores)
     torch.manual_seed(1234)
     if wl_name in ("cfg4", "cfg5"):

@@ -35,6 +35,8 @@ extern "C" int biu_conv_fwd(const biu_act* x, const biu_xform* xf, const float* 
     BIU_REQUIRE(conv_args_ok(x, y, kd, kh, kw, dilation), BIU_ERR_SHAPE,
                 "conv_fwd: x/y extents differ or unsupported kernel %dx%dx%d dil %d", kd, kh, kw, dilation);
     BIU_REQUIRE(w, BIU_ERR_SHAPE, "conv_fwd: null weight");
+    if (!disabled("c1") && biu_c1_conv_ok(x, y, kd, kh, kw, dilation, dtype))
+        return biu_c1_conv_fwd(x, xf, w, bias, kd, y, dtype, (hipStream_t)stream);
     if (packed && !disabled("conv_fwd") && biu_mfma_conv_ok(x, y, kd, kh, kw, dilation, dtype))
         return biu_mfma_conv(x, xf, packed, bias, kd, kh, kw, y, 0, dtype, (hipStream_t)stream);
     return biu_conv_fwd_direct(x, xf, w, bias, kd, kh, kw, dilation, y, dtype, (hipStream_t)stream);
@@ -50,6 +52,7 @@ extern "C" int biu_conv_bwd_data(const biu_act* dy, const float* w, const void* 
 }
 
 extern "C" size_t biu_conv_bwd_weight_workspace(int cin, int cout, int kd, int kh, int kw, int dtype) {
+    if (cin == 1 && kh == 3 && kw == 3) return biu_c1_wgrad_workspace(cout, kd);
     return biu_mfma_wgrad_workspace(cin, cout, kd, kh, kw, dtype);
 }
 
@@ -58,6 +61,11 @@ extern "C" int biu_conv_bwd_weight(const biu_act* x, const biu_xform* xf, const 
                                    biu_stream stream) {
     BIU_REQUIRE(conv_args_ok(x, dy, kd, kh, kw, dilation), BIU_ERR_SHAPE, "conv_bwd_weight: x/dy extents differ");
     BIU_REQUIRE(dw, BIU_ERR_SHAPE, "conv_bwd_weight: null dw");
+    if (!disabled("c1") && biu_c1_conv_ok(x, dy, kd, kh, kw, dilation, dtype) && ws && ws_bytes >= biu_c1_wgrad_workspace(dy->c, kd)) {
+        int rc = biu_c1_conv_wgrad(x, xf, dy, kd, dw, ws, ws_bytes, dtype, (hipStream_t)stream);
+        if (rc == BIU_OK && dbias) rc = biu_chan_sum(dy, dbias, dtype, (hipStream_t)stream);
+        return rc;
+    }
     if (!disabled("conv_wgrad") && biu_mfma_wgrad_ok(x, dy, kd, kh, kw, dilation, dtype)) {
         BIU_REQUIRE(ws && ws_bytes >= biu_mfma_wgrad_workspace(x->c, dy->c, kd, kh, kw, dtype), BIU_ERR_WORKSPACE,
                     "conv_bwd_weight: workspace too small");

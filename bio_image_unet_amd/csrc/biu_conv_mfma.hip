@@ -778,10 +778,13 @@ __global__ void k_wgrad_finalize(const float* __restrict__ ws, int rows, int col
 
 static bool wgrad_chan_ok(int cin, int cout) { return cin >= 16 && cin % 8 == 0 && cout >= 16 && cout % 8 == 0; }
 
+static size_t wgrad_acc_bytes(int cin, int cout, int taps) { return (((size_t)cin * cout * taps * sizeof(float)) + 255) & ~(size_t)255; }
+
 size_t biu_mfma_wgrad_workspace(int cin, int cout, int kd, int kh, int kw, int dtype) {
     if (!wgrad_chan_ok(cin, cout)) return 0;
-    if (kh == 3 && kw == 3 && (kd == 1 || kd == 3)) return (size_t)cin * cout * kd * 9 * sizeof(float);
-    if (kh == 2 && kw == 2 && (kd == 1 || kd == 2)) return (size_t)cin * cout * kd * 4 * sizeof(float);
+    const size_t red = biu_chan_sum_workspace(cout);           // partials of the dbias reduction
+    if (kh == 3 && kw == 3 && (kd == 1 || kd == 3)) return wgrad_acc_bytes(cin, cout, kd * 9) + red;
+    if (kh == 2 && kw == 2 && (kd == 1 || kd == 2)) return wgrad_acc_bytes(cin, cout, kd * 4) + red;
     return 0;
 }
 
@@ -851,8 +854,8 @@ int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int
     a.N = x->n;
     a.GD = a.BD = x->d; a.GH = a.BH = x->h; a.GW = a.BW = x->w;
     const int taps = kd * 9;
-    const size_t need = (size_t)a.CA * a.CB * taps * sizeof(float);
-    BIU_REQUIRE(ws_bytes >= need, BIU_ERR_WORKSPACE, "wgrad_mfma: workspace %zu < %zu", ws_bytes, need);
+    const size_t need = wgrad_acc_bytes(a.CA, a.CB, taps);
+    BIU_REQUIRE(ws_bytes >= need + (dbias ? biu_chan_sum_workspace(dy->c) : 0), BIU_ERR_WORKSPACE, "wgrad_mfma: workspace %zu too small", ws_bytes);
     if (hipMemsetAsync(ws, 0, need, st) != hipSuccess) return biu_fail(BIU_ERR_LAUNCH, "wgrad_mfma: memset failed");
     if (dtype == BIU_BF16) rc = (kd == 3) ? launch_wgrad<bf16_t, 3, 3, 1, 4, 4, 16>(a, st) : launch_wgrad<bf16_t, 1, 3, 1, 1, 16, 16>(a, st);
     else rc = (kd == 3) ? launch_wgrad<float, 3, 3, 1, 4, 4, 16>(a, st) : launch_wgrad<float, 1, 3, 1, 1, 16, 16>(a, st);
@@ -860,7 +863,7 @@ int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int
     hipLaunchKernelGGL(k_wgrad_finalize, dim3(grid_for((i64)a.CA * a.CB * taps, 256, 2048)), dim3(256), 0, st, (const float*)ws,
                        a.CA, a.CB, taps, dw);
     BIU_CHECK_LAUNCH("wgrad_finalize");
-    if (dbias) return biu_chan_sum(dy, dbias, dtype, st);   // sum over voxels of dy: direct per-channel reduction
+    if (dbias) return biu_chan_sum_vec(dy, dbias, (char*)ws + need, dtype, st);
     return BIU_OK;
 }
 
@@ -877,8 +880,8 @@ int biu_mfma_convt_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* d
     a.GD = x->d; a.GH = x->h; a.GW = x->w;
     a.BD = dy->d; a.BH = dy->h; a.BW = dy->w;
     const int taps = kd * 4;
-    const size_t need = (size_t)a.CA * a.CB * taps * sizeof(float);
-    BIU_REQUIRE(ws_bytes >= need, BIU_ERR_WORKSPACE, "convt_wgrad_mfma: workspace %zu < %zu", ws_bytes, need);
+    const size_t need = wgrad_acc_bytes(a.CA, a.CB, taps);
+    BIU_REQUIRE(ws_bytes >= need + (dbias ? biu_chan_sum_workspace(dy->c) : 0), BIU_ERR_WORKSPACE, "convt_wgrad_mfma: workspace %zu too small", ws_bytes);
     if (hipMemsetAsync(ws, 0, need, st) != hipSuccess) return biu_fail(BIU_ERR_LAUNCH, "convt_wgrad_mfma: memset failed");
     if (dtype == BIU_BF16) rc = (kd == 2) ? launch_wgrad<bf16_t, 2, 2, 2, 2, 4, 16>(a, st) : launch_wgrad<bf16_t, 1, 2, 2, 1, 8, 16>(a, st);
     else rc = (kd == 2) ? launch_wgrad<float, 2, 2, 2, 2, 4, 16>(a, st) : launch_wgrad<float, 1, 2, 2, 1, 8, 16>(a, st);
@@ -886,6 +889,6 @@ int biu_mfma_convt_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* d
     hipLaunchKernelGGL(k_wgrad_finalize, dim3(grid_for((i64)a.CA * a.CB * taps, 256, 2048)), dim3(256), 0, st, (const float*)ws,
                        a.CA, a.CB, taps, dw);
     BIU_CHECK_LAUNCH("convt_wgrad_finalize");
-    if (dbias) return biu_chan_sum(dy, dbias, dtype, st);
+    if (dbias) return biu_chan_sum_vec(dy, dbias, (char*)ws + need, dtype, st);
     return BIU_OK;
 }

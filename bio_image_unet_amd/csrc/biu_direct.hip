@@ -5,6 +5,7 @@
 // bandwidth-bound ops (BatchNorm, pooling, head, element-wise) live only here, vectorised to 16 B/lane
 // where the slice allows it.
 #include "biu_common.h"
+#include "biu_internal.h"
 
 thread_local char biu_errbuf[512] = {0};
 
@@ -814,6 +815,7 @@ int biu_chan_sum(const biu_act* a, float* out, int dtype, hipStream_t st) {
 extern "C" int biu_bn_stats(const biu_act* y, float* partial, int* nblk_out, int dtype, biu_stream stream) {
     BIU_REQUIRE(valid_act(y) && partial && nblk_out, BIU_ERR_SHAPE, "bn_stats: bad arguments");
     hipStream_t st = (hipStream_t)stream;
+    if (biu_vec_reduce_ok(y, dtype)) return biu_bn_stats_vec(y, partial, nblk_out, dtype, st);
     ReducePlan p = plan_reduce(nvox(y), y->c, BIU_BN_MAX_PARTIALS);
     BIU_DISPATCH_DTYPE(dtype, {
         StatsF<T> f{dact(y)};
@@ -873,6 +875,8 @@ extern "C" int biu_bn_bwd_reduce(const biu_act* da, const biu_act* y, const floa
                 "bn_bwd_reduce: shape mismatch");
     BIU_REQUIRE(scale && shift && save_mean && save_invstd && partial && nblk_out, BIU_ERR_SHAPE, "bn_bwd_reduce: null vector");
     hipStream_t st = (hipStream_t)stream;
+    if (biu_vec_reduce_ok(y, dtype) && biu_vec_reduce_ok(da, dtype))
+        return biu_bn_bwd_reduce_vec(da, y, scale, shift, slope, save_mean, save_invstd, partial, nblk_out, dtype, st);
     ReducePlan p = plan_reduce(nvox(y), y->c, BIU_BN_MAX_PARTIALS);
     BIU_DISPATCH_DTYPE(dtype, {
         BnBwdF<T> f{dact(da), dact(y), DXf{scale, shift, slope}, save_mean, save_invstd};
@@ -1034,14 +1038,19 @@ extern "C" int biu_head_fwd(const biu_act* x, const biu_xform* xf, const float* 
     BIU_CHECK_LAUNCH("head_fwd");
     return BIU_OK;
 }
-extern "C" size_t biu_head_bwd_workspace(int cin) { return (size_t)BIU_BN_MAX_PARTIALS * cin * 2 * sizeof(float); }
+extern "C" size_t biu_head_bwd_workspace(int cin) {
+    size_t a = (size_t)BIU_BN_MAX_PARTIALS * cin * 2 * sizeof(float), b = biu_head_bwd_fused_workspace(cin);
+    return a > b ? a : b;
+}
 extern "C" int biu_head_bwd(const biu_act* x, const biu_xform* xf, const float* w, int cout, const float* dlogits,
                             const biu_act* dx, float* dw, float* dbias, void* ws, size_t ws_bytes, int dtype,
                             biu_stream stream) {
     BIU_REQUIRE(valid_act(x) && w && dlogits && cout > 0 && cout <= HEAD_MAX_COUT, BIU_ERR_UNSUPPORTED, "head_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
+    if (dx) BIU_REQUIRE(valid_act(dx) && same_space(x, dx) && dx->c == x->c, BIU_ERR_SHAPE, "head_bwd: dx shape mismatch");
+    if (biu_head_bwd_fused_ok(x, dx, cout, dtype) && ws && ws_bytes >= biu_head_bwd_fused_workspace(x->c))
+        return biu_head_bwd_fused(x, xf, w, cout, dlogits, dx, dw, dbias, ws, ws_bytes, dtype, st);
     if (dx) {
-        BIU_REQUIRE(valid_act(dx) && same_space(x, dx) && dx->c == x->c, BIU_ERR_SHAPE, "head_bwd: dx shape mismatch");
         i64 total = nvox(dx) * dx->c;
         BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_head_bwd_data<T>, dim3(grid_for(total, TPB, 16384)), dim3(TPB), 0,
                                                      st, x->c, w, cout, dlogits, dact(dx)));

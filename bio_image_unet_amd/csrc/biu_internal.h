@@ -39,3 +39,19 @@ int biu_mfma_convt_dgrad(const biu_act* dy, const void* packed, int kd, const bi
 bool biu_mfma_convt_wgrad_ok(const biu_act* x, const biu_act* dy, int kd, int dtype);
 int biu_mfma_convt_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, float* dw, float* dbias, void* ws,
                          size_t ws_bytes, int dtype, hipStream_t st);
+
+// biu_special.hip
+bool biu_c1_conv_ok(const biu_act* x, const biu_act* y, int kd, int kh, int kw, int dil, int dtype);
+int biu_c1_conv_fwd(const biu_act* x, const biu_xform* xf, const float* w, const float* bias, int kd, const biu_act* y, int dtype, hipStream_t st);
+size_t biu_c1_wgrad_workspace(int cout, int kd);
+int biu_c1_conv_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, float* dw, void* ws, size_t ws_bytes, int dtype, hipStream_t st);
+bool biu_vec_reduce_ok(const biu_act* a, int dtype);
+int biu_bn_stats_vec(const biu_act* y, float* partial, int* nblk_out, int dtype, hipStream_t st);
+int biu_bn_bwd_reduce_vec(const biu_act* da, const biu_act* y, const float* scale, const float* shift, const float* slope,
+                          const float* mean, const float* invstd, float* partial, int* nblk_out, int dtype, hipStream_t st);
+size_t biu_chan_sum_workspace(int c);
+int biu_chan_sum_vec(const biu_act* a, float* out, void* ws, int dtype, hipStream_t st);
+bool biu_head_bwd_fused_ok(const biu_act* x, const biu_act* dx, int cout, int dtype);
+size_t biu_head_bwd_fused_workspace(int cin);
+int biu_head_bwd_fused(const biu_act* x, const biu_xform* xf, const float* w, int cout, const float* dl, const biu_act* dx, float* dw,
+                       float* db, void* ws, size_t ws_bytes, int dtype, hipStream_t st);

@@ -1,0 +1,507 @@
+// Bandwidth-bound special cases of the hot path, written for the shapes the real networks hit:
+//   * first layer (Cin = 1): 3x3(x3) conv forward and weight gradient on the vector ALUs (no MFMA: K = 27)
+//   * 1x1 head backward fused: dx, dW and dbias in ONE pass over (x, dlogits)
+//   * per-channel two-term reductions (BatchNorm statistics, BatchNorm backward sums, channel sums) with 16-byte
+//     loads and deterministic per-block partials
+#include "biu_internal.h"
+
+#define TPB 256
+
+struct Vox4 { int n, d, h, w; };
+__device__ __forceinline__ Vox4 unvox4(i64 v, int D, int H, int W) {
+    Vox4 r;
+    r.w = (int)(v % W); v /= W;
+    r.h = (int)(v % H); v /= H;
+    r.d = (int)(v % D); v /= D;
+    r.n = (int)v;
+    return r;
+}
+
+// =====================================================================================================================
+// Cin = 1 convolution forward:  y[v, co] = b[co] + sum_tap T(x)[v + off(tap)] * w[co][tap]
+// One thread per voxel, all COUT channels in registers, weights broadcast from LDS.  Writes COUT*sizeof(T) contiguous
+// bytes per lane.  VALU-bound (27*COUT FMA per voxel) at ~0.2 ms for 8.4 M voxels x 16 channels.
+// =====================================================================================================================
+template <typename T, int COUT, int KD>
+__global__ __launch_bounds__(TPB) void k_conv_c1_fwd(DAct x, DXf xf, const float* __restrict__ w, const float* __restrict__ bias,
+                                                     DAct y, int co0) {
+    constexpr int TAPS = KD * 9;
+    __shared__ float ws[TAPS * COUT + COUT];
+    for (int i = threadIdx.x; i < TAPS * COUT; i += TPB) {
+        const int tap = i / COUT, co = i % COUT;
+        ws[i] = w[(i64)(co0 + co) * TAPS + tap];                   // PyTorch (Cout, 1, taps)
+    }
+    for (int i = threadIdx.x; i < COUT; i += TPB) ws[TAPS * COUT + i] = bias ? bias[co0 + i] : 0.f;
+    __syncthreads();
+    const float s = xf.scale ? xf.scale[0] : 1.f, b = xf.shift ? xf.shift[0] : 0.f, sl = xf.slope ? xf.slope[0] : 1.f;
+    const i64 total = (i64)y.n * y.d * y.h * y.w;
+    for (i64 v = (i64)blockIdx.x * TPB + threadIdx.x; v < total; v += (i64)gridDim.x * TPB) {
+        const Vox4 p = unvox4(v, y.d, y.h, y.w);
+        float acc[COUT];
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[c] = ws[TAPS * COUT + c];
+#pragma unroll
+        for (int a = 0; a < KD; ++a) {
+            const int id = p.d + a - KD / 2;
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb) {
+                const int ih = p.h + bb - 1;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int iw = p.w + c - 1;
+                    float xv = 0.f;
+                    if (id >= 0 && id < x.d && ih >= 0 && ih < x.h && iw >= 0 && iw < x.w) {
+                        const i64 iv = (((i64)p.n * x.d + id) * x.h + ih) * x.w + iw;
+                        const float t = fmaf(s, to_f(((const T*)x.p)[iv * x.pitch]), b);
+                        xv = t > 0.f ? t : sl * t;
+                    }
+                    const float* wr = ws + ((a * 3 + bb) * 3 + c) * COUT;
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) acc[co] = fmaf(xv, wr[co], acc[co]);
+                }
+            }
+        }
+        T* dst = (T*)y.p + v * y.pitch + co0;
+        constexpr int G = 16 / sizeof(T);
+#pragma unroll
+        for (int c = 0; c < COUT; c += G) {
+            Pack<T, G> o;
+#pragma unroll
+            for (int j = 0; j < G; ++j) o.v[j] = from_f<T>(acc[c + j]);
+            *(Pack<T, G>*)(dst + c) = o;
+        }
+    }
+}
+
+// =====================================================================================================================
+// Cin = 1 weight gradient:  dw[co][tap] = sum_v T(x)[v + off(tap)] * dy[v][co]
+// Block = NW waves; wave q owns taps [q*TPW, q*TPW + TPW); a lane walks voxels and keeps TPW x COUT partial sums.
+// Per-block partials -> fp64 merge (deterministic).
+// =====================================================================================================================
+template <typename T, int COUT, int KD, int TPW>
+__global__ void k_conv_c1_wgrad(DAct x, DXf xf, DAct dy, int co0, float* __restrict__ partial /* [nblk][TAPS*COUT] */) {
+    constexpr int TAPS = KD * 9;
+    constexpr int G = 16 / sizeof(T);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tap0 = wave * TPW;
+    float acc[TPW][COUT];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[t][c] = 0.f;
+    const float s = xf.scale ? xf.scale[0] : 1.f, b = xf.shift ? xf.shift[0] : 0.f, sl = xf.slope ? xf.slope[0] : 1.f;
+    const i64 total = (i64)dy.n * dy.d * dy.h * dy.w;
+    for (i64 v = (i64)blockIdx.x * 64 + lane; v < total; v += (i64)gridDim.x * 64) {
+        const Vox4 p = unvox4(v, dy.d, dy.h, dy.w);
+        float g[COUT];
+        const T* src = (const T*)dy.p + v * dy.pitch + co0;
+#pragma unroll
+        for (int c = 0; c < COUT; c += G) {
+            Pack<T, G> in = *(const Pack<T, G>*)(src + c);
+#pragma unroll
+            for (int j = 0; j < G; ++j) g[c + j] = to_f(in.v[j]);
+        }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int tap = tap0 + t;
+            if (tap < TAPS) {
+                const int a = tap / 9, bb = (tap / 3) % 3, c = tap % 3;
+                const int id = p.d + a - KD / 2, ih = p.h + bb - 1, iw = p.w + c - 1;
+                float xv = 0.f;
+                if (id >= 0 && id < x.d && ih >= 0 && ih < x.h && iw >= 0 && iw < x.w) {
+                    const i64 iv = (((i64)p.n * x.d + id) * x.h + ih) * x.w + iw;
+                    const float tt = fmaf(s, to_f(((const T*)x.p)[iv * x.pitch]), b);
+                    xv = tt > 0.f ? tt : sl * tt;
+                }
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[t][co] = fmaf(xv, g[co], acc[t][co]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tap = tap0 + t;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const float r = wave_sum(acc[t][co]);
+            if (lane == 0 && tap < TAPS) partial[(i64)blockIdx.x * (TAPS * COUT) + tap * COUT + co] = r;
+        }
+    }
+}
+
+// out[co0 + co][tap] (+ layout cout x taps) = sum_b partial[b][tap*COUT + co]
+__global__ void k_c1_wgrad_finalize(const float* __restrict__ partial, int nblk, int taps, int cout_chunk, int co0, float* __restrict__ dw) {
+    __shared__ double red[TPB];
+    const int o = blockIdx.x;             // tap * cout_chunk + co
+    double a = 0;
+    for (int b = threadIdx.x; b < nblk; b += TPB) a += partial[(i64)b * (taps * cout_chunk) + o];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = TPB / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int tap = o / cout_chunk, co = o % cout_chunk;
+        dw[(i64)(co0 + co) * taps + tap] = (float)red[0];
+    }
+}
+
+#define C1_MAX_BLOCKS 2048
+
+static bool c1_ok(const biu_act* x, const biu_act* y, int kd, int kh, int kw, int dil, int dtype) {
+    if (x->c != 1 || dil != 1 || kh != 3 || kw != 3 || (kd != 1 && kd != 3)) return false;
+    if (y->c % 8 != 0 || y->c < 8) return false;
+    const size_t es = dsize(dtype);
+    return ((uintptr_t)y->p % 16) == 0 && ((size_t)y->pitch * es) % 16 == 0;
+}
+bool biu_c1_conv_ok(const biu_act* x, const biu_act* y, int kd, int kh, int kw, int dil, int dtype) { return c1_ok(x, y, kd, kh, kw, dil, dtype); }
+
+template <typename T, int KD>
+static int c1_fwd_t(const biu_act* x, const biu_xform* xf, const float* w, const float* bias, const biu_act* y, hipStream_t st) {
+    const int grid = grid_for(nvox(y), TPB, 16384);
+    int co0 = 0;
+    while (co0 < y->c) {
+        const int rem = y->c - co0;
+        if (rem >= 32) { hipLaunchKernelGGL((k_conv_c1_fwd<T, 32, KD>), dim3(grid), dim3(TPB), 0, st, dact(x), dxf(xf), w, bias, dact(y), co0); co0 += 32; }
+        else if (rem >= 16) { hipLaunchKernelGGL((k_conv_c1_fwd<T, 16, KD>), dim3(grid), dim3(TPB), 0, st, dact(x), dxf(xf), w, bias, dact(y), co0); co0 += 16; }
+        else { hipLaunchKernelGGL((k_conv_c1_fwd<T, 8, KD>), dim3(grid), dim3(TPB), 0, st, dact(x), dxf(xf), w, bias, dact(y), co0); co0 += 8; }
+    }
+    BIU_CHECK_LAUNCH("conv_c1_fwd");
+    return BIU_OK;
+}
+int biu_c1_conv_fwd(const biu_act* x, const biu_xform* xf, const float* w, const float* bias, int kd, const biu_act* y, int dtype, hipStream_t st) {
+    if (dtype == BIU_BF16) return kd == 3 ? c1_fwd_t<bf16_t, 3>(x, xf, w, bias, y, st) : c1_fwd_t<bf16_t, 1>(x, xf, w, bias, y, st);
+    return kd == 3 ? c1_fwd_t<float, 3>(x, xf, w, bias, y, st) : c1_fwd_t<float, 1>(x, xf, w, bias, y, st);
+}
+
+size_t biu_c1_wgrad_workspace(int cout, int kd) { return (size_t)C1_MAX_BLOCKS * kd * 9 * 32 * sizeof(float); }
+
+template <typename T, int KD>
+static int c1_wgrad_t(const biu_act* x, const biu_xform* xf, const biu_act* dy, float* dw, void* ws, hipStream_t st) {
+    constexpr int TAPS = KD * 9;
+    const i64 total = nvox(dy);
+    int nblk = (int)((total + 64 * 64 - 1) / (64 * 64));          // >= 64 voxels per lane
+    if (nblk > C1_MAX_BLOCKS) nblk = C1_MAX_BLOCKS;
+    if (nblk < 1) nblk = 1;
+    int co0 = 0;
+    while (co0 < dy->c) {
+        const int rem = dy->c - co0;
+        int chunk;
+        if (rem >= 32) {
+            constexpr int TPW = 3; chunk = 32;
+            hipLaunchKernelGGL((k_conv_c1_wgrad<T, 32, KD, TPW>), dim3(nblk), dim3(64 * ((TAPS + TPW - 1) / TPW)), 0, st, dact(x), dxf(xf), dact(dy), co0, (float*)ws);
+        } else if (rem >= 16) {
+            constexpr int TPW = 7; chunk = 16;
+            hipLaunchKernelGGL((k_conv_c1_wgrad<T, 16, KD, TPW>), dim3(nblk), dim3(64 * ((TAPS + TPW - 1) / TPW)), 0, st, dact(x), dxf(xf), dact(dy), co0, (float*)ws);
+        } else {
+            constexpr int TPW = 9; chunk = 8;
+            hipLaunchKernelGGL((k_conv_c1_wgrad<T, 8, KD, TPW>), dim3(nblk), dim3(64 * ((TAPS + TPW - 1) / TPW)), 0, st, dact(x), dxf(xf), dact(dy), co0, (float*)ws);
+        }
+        BIU_CHECK_LAUNCH("conv_c1_wgrad");
+        hipLaunchKernelGGL(k_c1_wgrad_finalize, dim3(TAPS * chunk), dim3(TPB), 0, st, (const float*)ws, nblk, TAPS, chunk, co0, dw);
+        BIU_CHECK_LAUNCH("conv_c1_wgrad_finalize");
+        co0 += chunk;
+    }
+    return BIU_OK;
+}
+int biu_c1_conv_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, float* dw, void* ws, size_t ws_bytes, int dtype, hipStream_t st) {
+    BIU_REQUIRE(ws && ws_bytes >= biu_c1_wgrad_workspace(dy->c, kd), BIU_ERR_WORKSPACE, "conv_c1_wgrad: workspace too small");
+    if (dtype == BIU_BF16) return kd == 3 ? c1_wgrad_t<bf16_t, 3>(x, xf, dy, dw, ws, st) : c1_wgrad_t<bf16_t, 1>(x, xf, dy, dw, ws, st);
+    return kd == 3 ? c1_wgrad_t<float, 3>(x, xf, dy, dw, ws, st) : c1_wgrad_t<float, 1>(x, xf, dy, dw, ws, st);
+}
+
+// =====================================================================================================================
+// vectorised per-channel two-term reductions:  partial[blk][c][2]
+// thread = (piece of PE channels) x (voxel row); 16-byte loads; LDS tree over the rows of the block
+// =====================================================================================================================
+template <typename T> struct VStats {        // (sum y, sum y^2)
+    DAct y;
+    static constexpr int PE = 16 / sizeof(T);
+    __device__ __forceinline__ void operator()(i64 v, int c0, float* a0, float* a1) const {
+        Pack<T, PE> in = *(const Pack<T, PE>*)((const T*)y.p + v * y.pitch + c0);
+#pragma unroll
+        for (int j = 0; j < PE; ++j) {
+            const float t = to_f(in.v[j]);
+            a0[j] += t;
+            a1[j] = fmaf(t, t, a1[j]);
+        }
+    }
+};
+template <typename T> struct VBnBwd {        // (sum dz, sum dz * yhat)
+    DAct da, y;
+    const float *scale, *shift, *slope, *mean, *invstd;
+    static constexpr int PE = 16 / sizeof(T);
+    __device__ __forceinline__ void operator()(i64 v, int c0, float* a0, float* a1) const {
+        Pack<T, PE> g = *(const Pack<T, PE>*)((const T*)da.p + v * da.pitch + c0);
+        Pack<T, PE> yy = *(const Pack<T, PE>*)((const T*)y.p + v * y.pitch + c0);
+#pragma unroll
+        for (int j = 0; j < PE; ++j) {
+            const int c = c0 + j;
+            const float yv = to_f(yy.v[j]);
+            const float t = fmaf(scale[c], yv, shift[c]);
+            const float dz = to_f(g.v[j]) * (t > 0.f ? 1.f : (slope ? slope[c] : 1.f));
+            a0[j] += dz;
+            a1[j] = fmaf(dz, (yv - mean[c]) * invstd[c], a1[j]);
+        }
+    }
+};
+template <typename T> struct VSum {          // (sum a, 0)
+    DAct a;
+    static constexpr int PE = 16 / sizeof(T);
+    __device__ __forceinline__ void operator()(i64 v, int c0, float* a0, float* a1) const {
+        Pack<T, PE> in = *(const Pack<T, PE>*)((const T*)a.p + v * a.pitch + c0);
+#pragma unroll
+        for (int j = 0; j < PE; ++j) a0[j] += to_f(in.v[j]);
+    }
+};
+
+template <typename F, int PE>
+__global__ __launch_bounds__(TPB) void k_chan_reduce2_vec(F f, i64 total_vox, int C, int ppv /* pieces per voxel, pow2-padded */,
+                                                          i64 vox_per_block, float* __restrict__ partial) {
+    extern __shared__ float sm[];                 // [rows][ppv*PE][2]
+    const int rows = TPB / ppv;
+    const int piece = threadIdx.x % ppv, row = threadIdx.x / ppv;
+    const int c0 = piece * PE;
+    const i64 v0 = (i64)blockIdx.x * vox_per_block;
+    i64 v1 = v0 + vox_per_block;
+    if (v1 > total_vox) v1 = total_vox;
+    float a0[PE], a1[PE];
+#pragma unroll
+    for (int j = 0; j < PE; ++j) a0[j] = a1[j] = 0.f;
+    if (c0 < C)
+        for (i64 v = v0 + row; v < v1; v += rows) f(v, c0, a0, a1);
+    const int W = ppv * PE;
+#pragma unroll
+    for (int j = 0; j < PE; ++j) {
+        sm[(row * W + c0 + j) * 2 + 0] = a0[j];
+        sm[(row * W + c0 + j) * 2 + 1] = a1[j];
+    }
+    __syncthreads();
+    for (int r = rows >> 1; r > 0; r >>= 1) {
+        if (row < r) {
+#pragma unroll
+            for (int j = 0; j < PE; ++j) {
+                sm[(row * W + c0 + j) * 2 + 0] += sm[((row + r) * W + c0 + j) * 2 + 0];
+                sm[(row * W + c0 + j) * 2 + 1] += sm[((row + r) * W + c0 + j) * 2 + 1];
+            }
+        }
+        __syncthreads();
+    }
+    if (row == 0 && c0 < C) {
+#pragma unroll
+        for (int j = 0; j < PE; ++j) {
+            partial[((i64)blockIdx.x * C + c0 + j) * 2 + 0] = sm[(c0 + j) * 2 + 0];
+            partial[((i64)blockIdx.x * C + c0 + j) * 2 + 1] = sm[(c0 + j) * 2 + 1];
+        }
+    }
+}
+
+struct VPlan { int ppv, nblk; i64 vpb; size_t smem; };
+static VPlan vplan(i64 total_vox, int C, int PE) {
+    VPlan p;
+    const int pieces = C / PE;
+    p.ppv = 1;
+    while (p.ppv < pieces) p.ppv <<= 1;
+    const int rows = TPB / p.ppv;
+    i64 want = (total_vox + (i64)rows * 16 - 1) / ((i64)rows * 16);           // >= 16 voxels per thread
+    if (want < 1) want = 1;
+    if (want > BIU_BN_MAX_PARTIALS) want = BIU_BN_MAX_PARTIALS;
+    p.vpb = (total_vox + want - 1) / want;
+    p.nblk = (int)((total_vox + p.vpb - 1) / p.vpb);
+    p.smem = (size_t)rows * p.ppv * PE * 2 * sizeof(float);
+    return p;
+}
+bool biu_vec_reduce_ok(const biu_act* a, int dtype) {
+    const int pe = 16 / (int)dsize(dtype);
+    return a->c % pe == 0 && a->c / pe <= TPB && vec_ok(a, pe, dtype);
+}
+
+int biu_bn_stats_vec(const biu_act* y, float* partial, int* nblk_out, int dtype, hipStream_t st) {
+    BIU_DISPATCH_DTYPE(dtype, {
+        constexpr int PE = 16 / sizeof(T);
+        VPlan p = vplan(nvox(y), y->c, PE);
+        VStats<T> f{dact(y)};
+        hipLaunchKernelGGL((k_chan_reduce2_vec<VStats<T>, PE>), dim3(p.nblk), dim3(TPB), p.smem, st, f, nvox(y), y->c, p.ppv, p.vpb, partial);
+        *nblk_out = p.nblk;
+    });
+    BIU_CHECK_LAUNCH("bn_stats_vec");
+    return BIU_OK;
+}
+int biu_bn_bwd_reduce_vec(const biu_act* da, const biu_act* y, const float* scale, const float* shift, const float* slope,
+                          const float* mean, const float* invstd, float* partial, int* nblk_out, int dtype, hipStream_t st) {
+    BIU_DISPATCH_DTYPE(dtype, {
+        constexpr int PE = 16 / sizeof(T);
+        VPlan p = vplan(nvox(y), y->c, PE);
+        VBnBwd<T> f{dact(da), dact(y), scale, shift, slope, mean, invstd};
+        hipLaunchKernelGGL((k_chan_reduce2_vec<VBnBwd<T>, PE>), dim3(p.nblk), dim3(TPB), p.smem, st, f, nvox(y), y->c, p.ppv, p.vpb, partial);
+        *nblk_out = p.nblk;
+    });
+    BIU_CHECK_LAUNCH("bn_bwd_reduce_vec");
+    return BIU_OK;
+}
+
+// out[c] = sum_b partial[b][c][0]  (fp64 merge)
+__global__ void k_partial_sum0(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
+    __shared__ double red[TPB];
+    const int c = blockIdx.x;
+    double a = 0;
+    for (int b = threadIdx.x; b < nblk; b += TPB) a += partial[((i64)b * C + c) * 2];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = TPB / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = (float)red[0];
+}
+size_t biu_chan_sum_workspace(int c) { return (size_t)BIU_BN_MAX_PARTIALS * c * 2 * sizeof(float); }
+// out[c] = sum_v a[v, c]; ws >= biu_chan_sum_workspace(c)
+int biu_chan_sum_vec(const biu_act* a, float* out, void* ws, int dtype, hipStream_t st) {
+    int nblk = 0;
+    BIU_DISPATCH_DTYPE(dtype, {
+        constexpr int PE = 16 / sizeof(T);
+        VPlan p = vplan(nvox(a), a->c, PE);
+        VSum<T> f{dact(a)};
+        hipLaunchKernelGGL((k_chan_reduce2_vec<VSum<T>, PE>), dim3(p.nblk), dim3(TPB), p.smem, st, f, nvox(a), a->c, p.ppv, p.vpb, (float*)ws);
+        nblk = p.nblk;
+    });
+    BIU_CHECK_LAUNCH("chan_sum_vec");
+    hipLaunchKernelGGL(k_partial_sum0, dim3(a->c), dim3(TPB), 0, st, (const float*)ws, nblk, a->c, out);
+    BIU_CHECK_LAUNCH("partial_sum0");
+    return BIU_OK;
+}
+
+// =====================================================================================================================
+// fused 1x1 head backward: one pass over (x, dlogits) produces dx, and per-block partials of dW and dbias
+//   dx[v, c] = sum_o dl[n, o, s] * w[o, c];  dW[o, c] = sum_v dl * T(x)[v, c];  db[o] = sum_v dl
+// =====================================================================================================================
+template <typename T, int C, int O>
+__global__ __launch_bounds__(TPB) void k_head_bwd_fused(DAct x, DXf xf, const float* __restrict__ w, int cout,
+                                                        const float* __restrict__ dl, DAct dx, int want_dx,
+                                                        float* __restrict__ partial /* [nblk][O*C + O] */) {
+    constexpr int G = 16 / sizeof(T);
+    __shared__ float wsm[O * C];
+    __shared__ float red[4][O * C + O];
+    for (int i = threadIdx.x; i < O * C; i += TPB) wsm[i] = (i / C) < cout ? w[i] : 0.f;
+    __syncthreads();
+    const i64 S = (i64)x.d * x.h * x.w;
+    const i64 total = (i64)x.n * S;
+    float aw[O][C], ab[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+        ab[o] = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) aw[o][c] = 0.f;
+    }
+    for (i64 v = (i64)blockIdx.x * TPB + threadIdx.x; v < total; v += (i64)gridDim.x * TPB) {
+        const i64 n = v / S, s = v % S;
+        float g[O];
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            g[o] = (o < cout) ? dl[(n * cout + o) * S + s] : 0.f;
+            ab[o] += g[o];
+        }
+        const T* src = (const T*)x.p + v * x.pitch;
+        T* dst = want_dx ? (T*)dx.p + v * dx.pitch : nullptr;
+#pragma unroll
+        for (int c0 = 0; c0 < C; c0 += G) {
+            Pack<T, G> in = *(const Pack<T, G>*)(src + c0);
+            Pack<T, G> od;
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int c = c0 + j;
+                const float t = xf_apply(xf, c, to_f(in.v[j]));
+                float d = 0.f;
+#pragma unroll
+                for (int o = 0; o < O; ++o) {
+                    aw[o][c] = fmaf(g[o], t, aw[o][c]);
+                    d = fmaf(g[o], wsm[o * C + c], d);
+                }
+                od.v[j] = from_f<T>(d);
+            }
+            if (want_dx) *(Pack<T, G>*)(dst + c0) = od;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float r = wave_sum(aw[o][c]);
+            if (lane == 0) red[wave][o * C + c] = r;
+        }
+        const float rb = wave_sum(ab[o]);
+        if (lane == 0) red[wave][O * C + o] = rb;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < O * C + O; i += TPB)
+        partial[(i64)blockIdx.x * (O * C + O) + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+
+__global__ void k_head_bwd_finalize(const float* __restrict__ partial, int nblk, int C, int O, int cout, float* dw, float* db) {
+    __shared__ double red[TPB];
+    const int i = blockIdx.x;              // 0 .. O*C + O
+    double a = 0;
+    for (int b = threadIdx.x; b < nblk; b += TPB) a += partial[(i64)b * (O * C + O) + i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = TPB / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (i < O * C) {
+            const int o = i / C, c = i % C;
+            if (o < cout && dw) dw[o * C + c] = (float)red[0];
+        } else {
+            const int o = i - O * C;
+            if (o < cout && db) db[o] = (float)red[0];
+        }
+    }
+}
+
+#define HEAD_FUSED_BLOCKS 1024
+bool biu_head_bwd_fused_ok(const biu_act* x, const biu_act* dx, int cout, int dtype) {
+    const int c = x->c;
+    if (!(c == 8 || c == 16 || c == 32 || c == 64)) return false;
+    if (cout < 1 || cout > 4 || c * (cout == 3 ? 4 : cout) > 128) return false;
+    const int g = 16 / (int)dsize(dtype);
+    if (!vec_ok(x, g, dtype)) return false;
+    if (dx && !vec_ok(dx, g, dtype)) return false;
+    return true;
+}
+size_t biu_head_bwd_fused_workspace(int cin) { return (size_t)HEAD_FUSED_BLOCKS * (4 * cin + 4) * sizeof(float); }
+
+template <typename T, int C>
+static int head_fused_t(const biu_act* x, const biu_xform* xf, const float* w, int cout, const float* dl, const biu_act* dx, float* dw,
+                        float* db, void* ws, hipStream_t st) {
+    const i64 total = nvox(x);
+    int nblk = (int)((total + TPB * 8 - 1) / (TPB * 8));
+    if (nblk > HEAD_FUSED_BLOCKS) nblk = HEAD_FUSED_BLOCKS;
+    if (nblk < 1) nblk = 1;
+    DAct dxa = dx ? dact(dx) : dact(x);
+    const int O = cout == 3 ? 4 : cout;
+    if constexpr (C <= 32) {
+        if (O == 4) hipLaunchKernelGGL((k_head_bwd_fused<T, C, 4>), dim3(nblk), dim3(TPB), 0, st, dact(x), dxf(xf), w, cout, dl, dxa, dx ? 1 : 0, (float*)ws);
+    }
+    if (O == 2) hipLaunchKernelGGL((k_head_bwd_fused<T, C, 2>), dim3(nblk), dim3(TPB), 0, st, dact(x), dxf(xf), w, cout, dl, dxa, dx ? 1 : 0, (float*)ws);
+    if (O == 1) hipLaunchKernelGGL((k_head_bwd_fused<T, C, 1>), dim3(nblk), dim3(TPB), 0, st, dact(x), dxf(xf), w, cout, dl, dxa, dx ? 1 : 0, (float*)ws);
+    BIU_CHECK_LAUNCH("head_bwd_fused");
+    hipLaunchKernelGGL(k_head_bwd_finalize, dim3(O * C + O), dim3(TPB), 0, st, (const float*)ws, nblk, C, O, cout, dw, db);
+    BIU_CHECK_LAUNCH("head_bwd_finalize");
+    return BIU_OK;
+}
+int biu_head_bwd_fused(const biu_act* x, const biu_xform* xf, const float* w, int cout, const float* dl, const biu_act* dx, float* dw,
+                       float* db, void* ws, size_t ws_bytes, int dtype, hipStream_t st) {
+    BIU_REQUIRE(ws && ws_bytes >= biu_head_bwd_fused_workspace(x->c), BIU_ERR_WORKSPACE, "head_bwd: workspace too small");
+    BIU_DISPATCH_DTYPE(dtype, {
+        switch (x->c) {
+            case 8: return head_fused_t<T, 8>(x, xf, w, cout, dl, dx, dw, db, ws, st);
+            case 16: return head_fused_t<T, 16>(x, xf, w, cout, dl, dx, dw, db, ws, st);
+            case 32: return head_fused_t<T, 32>(x, xf, w, cout, dl, dx, dw, db, ws, st);
+            default: return head_fused_t<T, 64>(x, xf, w, cout, dl, dx, dw, db, ws, st);
+        }
+    });
+    return BIU_OK;
+}

@@ -30,6 +30,13 @@ CONV_CASES = [
     (2, 2, 8, 16, (16, 16), 1),
     (3, 1, 3, 5, (4, 6, 10), 1),
     (3, 2, 4, 8, (8, 8, 8), 1),
+    # first-layer special case (Cin = 1, Cout multiple of 8): vector-ALU kernels of biu_special.hip
+    (3, 2, 1, 16, (6, 10, 12), 1),
+    (3, 1, 1, 32, (4, 6, 8), 1),
+    (3, 1, 1, 56, (3, 5, 7), 1),
+    (2, 2, 1, 32, (20, 28), 1),
+    (2, 1, 1, 64, (16, 16), 1),
+    (2, 1, 1, 8, (9, 11), 1),
 ]
 
 
