@@ -29,6 +29,32 @@ extern "C" int biu_conv_pack(int kind, const float* w, int cin, int cout, int kd
     return biu_mfma_pack(kind, w, cin, cout, kd, kh, kw, dtype, packed, (hipStream_t)stream);
 }
 
+extern "C" int biu_conv_fwd_stats(const biu_act* x, const biu_xform* xf, const float* w, const void* packed,
+                                  const float* bias, int kd, int kh, int kw, int dilation, const biu_act* y,
+                                  float* bn_partial, size_t bn_partial_floats, int* bn_nblk, int dtype, biu_stream stream) {
+    BIU_REQUIRE(conv_args_ok(x, y, kd, kh, kw, dilation), BIU_ERR_SHAPE,
+                "conv_fwd: x/y extents differ or unsupported kernel %dx%dx%d dil %d", kd, kh, kw, dilation);
+    BIU_REQUIRE(w && bn_partial && bn_nblk, BIU_ERR_SHAPE, "conv_fwd_stats: null pointer");
+    *bn_nblk = 0;
+    if (packed && !disabled("conv_fwd") && !disabled("fused_stats") && biu_mfma_conv_ok(x, y, kd, kh, kw, dilation, dtype)) {
+        const int nb = biu_mfma_conv_bricks(y, kd);
+        if ((size_t)nb * y->c * 2 <= bn_partial_floats) {
+            int rc = biu_mfma_conv(x, xf, packed, bias, kd, kh, kw, y, 0, bn_partial, dtype, (hipStream_t)stream);
+            if (rc == BIU_OK) *bn_nblk = nb;
+            return rc;
+        }
+    }
+    int rc = biu_conv_fwd(x, xf, w, packed, bias, kd, kh, kw, dilation, y, dtype, stream);
+    if (rc != BIU_OK) return rc;
+    BIU_REQUIRE(bn_partial_floats >= (size_t)BIU_BN_MAX_PARTIALS * y->c * 2, BIU_ERR_WORKSPACE, "conv_fwd_stats: partial buffer too small");
+    return biu_bn_stats(y, bn_partial, bn_nblk, dtype, stream);
+}
+
+extern "C" size_t biu_conv_fwd_stats_floats(const biu_act* y, int kd) {
+    size_t a = (size_t)BIU_BN_MAX_PARTIALS * y->c * 2, b = (size_t)biu_mfma_conv_bricks(y, kd == 3 ? 3 : 1) * y->c * 2;
+    return a > b ? a : b;
+}
+
 extern "C" int biu_conv_fwd(const biu_act* x, const biu_xform* xf, const float* w, const void* packed,
                             const float* bias, int kd, int kh, int kw, int dilation, const biu_act* y, int dtype,
                             biu_stream stream) {
@@ -38,7 +64,7 @@ extern "C" int biu_conv_fwd(const biu_act* x, const biu_xform* xf, const float* 
     if (!disabled("c1") && biu_c1_conv_ok(x, y, kd, kh, kw, dilation, dtype))
         return biu_c1_conv_fwd(x, xf, w, bias, kd, y, dtype, (hipStream_t)stream);
     if (packed && !disabled("conv_fwd") && biu_mfma_conv_ok(x, y, kd, kh, kw, dilation, dtype))
-        return biu_mfma_conv(x, xf, packed, bias, kd, kh, kw, y, 0, dtype, (hipStream_t)stream);
+        return biu_mfma_conv(x, xf, packed, bias, kd, kh, kw, y, 0, nullptr, dtype, (hipStream_t)stream);
     return biu_conv_fwd_direct(x, xf, w, bias, kd, kh, kw, dilation, y, dtype, (hipStream_t)stream);
 }
 
@@ -47,7 +73,7 @@ extern "C" int biu_conv_bwd_data(const biu_act* dy, const float* w, const void* 
     BIU_REQUIRE(conv_args_ok(dy, dx, kd, kh, kw, dilation), BIU_ERR_SHAPE, "conv_bwd_data: dy/dx extents differ");
     BIU_REQUIRE(w, BIU_ERR_SHAPE, "conv_bwd_data: null weight");
     if (packed && !disabled("conv_dgrad") && biu_mfma_conv_ok(dy, dx, kd, kh, kw, dilation, dtype))
-        return biu_mfma_conv(dy, nullptr, packed, nullptr, kd, kh, kw, dx, accumulate, dtype, (hipStream_t)stream);
+        return biu_mfma_conv(dy, nullptr, packed, nullptr, kd, kh, kw, dx, accumulate, nullptr, dtype, (hipStream_t)stream);
     return biu_conv_bwd_data_direct(dy, w, kd, kh, kw, dilation, dx, accumulate, dtype, (hipStream_t)stream);
 }
 

@@ -75,7 +75,16 @@ struct ConvArgs {
     int nKS;             // total k-steps = Cin / (2 * PE)
     int wz_stride;       // packed-weight stride (uint4) between blockIdx.z slices
     int accumulate;
+    unsigned long long* diag;   // BIU_DIAG builds only: per-phase cycle sums
+    float* bn_partial;          // optional [nbricks][Cout][2] (sum, sum of squares) of the stored output
 };
+
+#ifdef BIU_DIAG
+extern "C" unsigned long long* biu_diag_buffer = nullptr;
+#define DIAG_STAMP(k) do { if (a.diag && tid == 0) { unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(a.diag + (k), now_ - tprev_); tprev_ = now_; } } while (0)
+#else
+#define DIAG_STAMP(k) do { } while (0)
+#endif
 
 constexpr int cpad_planes(int hv, int ckp) {     // plane stride in 16-B units: == 8/ckp (mod 8) -> conflict-free staging writes
     int want = 8 / ckp;
@@ -119,10 +128,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
     const int d0 = bd * TD, h0 = bh * TH, w0 = bw * TW;
 
     // ---- staging plan: item i = tid + 256*j  ->  (halo voxel hv = i / CKP, piece p = i % CKP) --------------------
+    // (coordinates are recomputed per pass: cheaper than 16+ live registers next to 128 accumulators)
     const int p_mine = tid % CKP;
-    int voxidx[NPASS];
-#pragma unroll
-    for (int j = 0; j < NPASS; ++j) {
+    auto stage_vox = [&](int j) -> int {
         const int i = tid + 256 * j;
         const int hv = i / CKP;
         const int hw = hv % HW;
@@ -131,8 +139,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
         const int hd = t / HH;
         const int gd = d0 * SD - PD + hd, gh = h0 * S - PHW + hh, gw = w0 * S - PHW + hw;
         const bool inb = (hv < HV) && gd >= 0 && gd < a.ID && gh >= 0 && gh < a.IH && gw >= 0 && gw < a.IW;
-        voxidx[j] = inb ? ((n * a.ID + gd) * a.IH + gh) * a.IW + gw : (hv < HV ? -1 : -2);
-    }
+        return inb ? ((n * a.ID + gd) * a.IH + gh) * a.IW + gw : (hv < HV ? -1 : -2);
+    };
 
     // ---- per-lane LDS base of each of this wave's voxel tiles (tap (0,0,0) corner), in 16-B units ----------------
     int hvb[MT];
@@ -159,7 +167,27 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
     const size_t esz = sizeof(T);
     const uint4* wbase = a.wpk + (size_t)blockIdx.z * a.wz_stride + ((size_t)blockIdx.y * NT * a.nKS * TAPS) * 64 + lane;
 
+#ifdef BIU_DIAG
+    unsigned long long tprev_ = __builtin_readcyclecounter();
+#endif
+    constexpr int WPF = 3;                            // weight fragments are prefetched WPF (tap, k-step) steps ahead
+    constexpr int NSTEP = TAPS * SPC;
+    constexpr int SB = 8;                             // staging loads in flight per thread
+
     for (int ch = 0; ch < nchunks; ++ch) {
+        DIAG_STAMP(0);     // prologue / previous barrier
+        const uint4* wch = wbase + (size_t)(ch * SPC) * TAPS * 64;
+        auto wload = [&](int step, uint4* dst) {
+            const int tap = step / SPC, s = step % SPC;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) dst[nt] = wch[((size_t)nt * a.nKS * TAPS + (size_t)s * TAPS + tap) * 64];
+        };
+        // first weight fragments go out before the staging phase so that their L2 latency hides under it
+        uint4 wq[WPF][NT];
+#pragma unroll
+        for (int i = 0; i < WPF; ++i)
+            if (i < NSTEP) wload(i, wq[i]);
+
         // -------- stage the halo tile of channels [ch*CK, ch*CK + CK) --------------------------------------------
         const int c0 = ch * CK + p_mine * PE;
         float sc[PE], sh[PE], sl[PE];
@@ -169,21 +197,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
         }
         const char* xsrc = a.x + (size_t)c0 * esz;
 #pragma unroll
-        for (int j0 = 0; j0 < NPASS; j0 += 4) {
-            uint4 v[4];
+        for (int j0 = 0; j0 < NPASS; j0 += SB) {
+            uint4 v[SB];
+            int vi[SB];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
+            for (int jj = 0; jj < SB; ++jj) {
                 const int j = j0 + jj;
                 if (j < NPASS) {
+                    vi[jj] = stage_vox(j);
                     v[jj] = make_uint4(0, 0, 0, 0);
-                    if (voxidx[j] >= 0) v[jj] = *(const uint4*)(xsrc + (size_t)voxidx[j] * a.xpitch * esz);
+                    if (vi[jj] >= 0) v[jj] = *(const uint4*)(xsrc + (size_t)vi[jj] * a.xpitch * esz);
                 }
             }
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
+            for (int jj = 0; jj < SB; ++jj) {
                 const int j = j0 + jj;
                 if (j < NPASS) {
-                    if (has_xf && voxidx[j] >= 0) {
+                    if (has_xf && vi[jj] >= 0) {
                         float f[PE];
                         F::unpack(v[jj], f);
 #pragma unroll
@@ -193,34 +223,34 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
                         }
                         v[jj] = F::pack(f);
                     }
-                    if (voxidx[j] != -2) lds[p_mine * PSV + (tid + 256 * j) / CKP] = v[jj];
+                    if (vi[jj] != -2) lds[p_mine * PSV + (tid + 256 * j) / CKP] = v[jj];
                 }
             }
         }
+        DIAG_STAMP(1);     // staging (loads + transform + LDS writes) as seen by thread 0
         __syncthreads();
+        DIAG_STAMP(2);     // barrier wait
 
-        // -------- 27 (9) taps x SPC k-steps of MFMA ----------------------------------------------------------------
-        const uint4* wch = wbase + (size_t)(ch * SPC) * TAPS * 64;
+        // -------- TAPS x SPC steps of MFMA; the weight ring stays WPF steps ahead ----------------------------------
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            constexpr int dummy = 0; (void)dummy;
+        for (int step = 0; step < NSTEP; ++step) {
+            const int tap = step / SPC, s = step % SPC;
             const int ta = tap / (KHW * KHW), tb = (tap / KHW) % KHW, tc = tap % KHW;
             const int tapoff = (ta * HH + tb) * HW + tc;
+            uint4 wf[NT];
 #pragma unroll
-            for (int s = 0; s < SPC; ++s) {
-                uint4 wf[NT];
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = wq[step % WPF][nt];
+            if (step + WPF < NSTEP) wload(step + WPF, wq[step % WPF]);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    wf[nt] = wch[((size_t)nt * a.nKS * TAPS + (size_t)s * TAPS + tap) * 64];
+            for (int mt = 0; mt < MT; ++mt) {
+                const uint4 bf = lds[hvb[mt] + 2 * s * PSV + tapoff];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const uint4 bf = lds[hvb[mt] + 2 * s * PSV + tapoff];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) F::mma(wf[nt], bf, acc[nt][mt]);
-                }
+                for (int nt = 0; nt < NT; ++nt) F::mma(wf[nt], bf, acc[nt][mt]);
             }
         }
+        DIAG_STAMP(3);     // MFMA phase
         __syncthreads();
+        DIAG_STAMP(4);     // trailing barrier
     }
 
     // ---- epilogue: lane holds, per tile, channels {4*hf + 8*q + i} of voxel r ------------------------------------
@@ -259,6 +289,342 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
                 *dst = pk;
             }
         }
+    }
+    DIAG_STAMP(5);         // epilogue
+#ifdef BIU_DIAG
+    if (a.diag && tid == 0) atomicAdd(a.diag + 7, 1ull);
+#endif
+}
+
+// ===============================================================================================================
+// Pipelined persistent variant (the one the launchers use).
+//
+// 512 threads = 8 waves, one block per CU, blocks walk bricks (XCD-grouped so halo neighbours share an L2).
+// Work item = (brick, channel chunk).  While item i is being multiplied out of LDS, the global loads of item i+1
+// -- its activation halo tile AND its weight slab -- are already in flight into registers; they are committed to LDS
+// after the MFMA phase (register-staged double buffering: issue early, write late), so HBM/L2 latency hides under
+// the MFMAs and LDS holds only one copy.  Weight fragments are read from LDS (1 KiB contiguous per wave-read).
+// Epilogue per brick: bias, optional accumulate, store; optional per-channel (sum, sum^2) partials for BatchNorm.
+// ===============================================================================================================
+template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP>
+__global__ __launch_bounds__(512, 2) void k_conv_pipe(ConvArgs a) {
+    using F = Frag<T>;
+    constexpr int NTHR = 512, NWAVE = 8;
+    constexpr int PE = F::PE;
+    constexpr int PD = (KD == 3) ? 1 : 0;
+    constexpr int PHW = (KHW == 3) ? 1 : 0;
+    constexpr int SD = (KD == 1) ? 1 : S;
+    constexpr int HD = (TD - 1) * SD + KD, HH = (TH - 1) * S + KHW, HW = (TW - 1) * S + KHW;
+    constexpr int HV = HD * HH * HW;
+    constexpr int PSV = cpad_planes(HV, CKP);
+    constexpr int TILES = TD * TH * TW / 32;
+    static_assert(TILES % NWAVE == 0, "brick must give a multiple of 8 voxel tiles");
+    constexpr int MT = TILES / NWAVE;
+    constexpr int TAPS = KD * KHW * KHW;
+    constexpr int SPC = CKP / 2;
+    constexpr int NSTEP = TAPS * SPC;
+    constexpr int CK = CKP * PE;
+    constexpr int NPA = (HV * CKP + NTHR - 1) / NTHR;            // activation pieces per thread
+    constexpr int WN = NSTEP * NT * 64;                          // weight fragments (16 B) per chunk
+    constexpr int NPW = (WN + NTHR - 1) / NTHR;
+    // weight slab path: async global->LDS copies into a double buffer (no VGPRs) when two slabs fit; otherwise
+    // register-staged like the activations
+    constexpr bool WGLDS = (size_t)(CKP * PSV + 2 * WN) * 16 <= 150 * 1024;
+    constexpr int NWB = WGLDS ? 2 : 1;
+
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+    uint4* lact = lds;                       // [CKP][PSV]
+    uint4* lw = lds + CKP * PSV;             // [NWB][NSTEP][NT][64]
+    float* lxf = (float*)(lw + NWB * WN);    // [3][Cin] transform vectors (if any)
+    float* lred = lxf + 3 * a.Cin;           // [NT*32][2] BatchNorm partial sums of the current brick
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hf = lane >> 5;
+    const bool has_xf = a.xs != nullptr;
+    const size_t esz = sizeof(T);
+    const int nchunks = a.Cin / CK;
+    const int nbricks = a.N * a.nbd * a.nbh * a.nbw;
+    const int p_mine = tid % CKP;
+
+    if (has_xf) {
+        for (int i = tid; i < a.Cin; i += NTHR) {
+            lxf[i] = a.xs[i];
+            lxf[a.Cin + i] = a.xb[i];
+            lxf[2 * a.Cin + i] = a.xl[i];
+        }
+    }
+
+    // brick walk: block b of XCD group (b % 8) takes consecutive bricks of that group's contiguous range
+    const int G = gridDim.x;
+    auto brick_of = [&](int k) -> int {       // k-th brick of this block, or >= nbricks when exhausted
+        if ((G & 7) == 0) {
+            const int per = G >> 3;
+            return k * G + (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        }
+        return k * G + blockIdx.x;
+    };
+
+    int hvb[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int q = (wave * MT + mt) * 32 + r;
+        const int lw_ = q % TW;
+        const int t = q / TW;
+        const int lh = t % TH;
+        const int ld = t / TH;
+        hvb[mt] = hf * PSV + (ld * SD * HH + lh * S) * HW + lw_ * S;
+    }
+
+    floatx16 acc[NT][MT];
+    uint4 pa[NPA];
+    uint4 pw[WGLDS ? 1 : NPW];
+    int wcur = 0;                            // weight buffer the current item reads
+    const uint4* wgrp = a.wpk + (size_t)blockIdx.z * a.wz_stride + ((size_t)blockIdx.y * NT * a.nKS * TAPS) * 64;
+
+    struct Org { int n, d0, h0, w0; };
+    auto origin = [&](int brick) -> Org {
+        int b = brick;
+        Org o;
+        o.w0 = (b % a.nbw) * TW; b /= a.nbw;
+        o.h0 = (b % a.nbh) * TH; b /= a.nbh;
+        o.d0 = (b % a.nbd) * TD;
+        o.n = b / a.nbd;
+        return o;
+    };
+    auto stage_vox = [&](const Org& o, int j) -> int {
+        const int i = tid + NTHR * j;
+        const int hv = i / CKP;
+        const int hw = hv % HW;
+        const int t = hv / HW;
+        const int hh = t % HH;
+        const int hd = t / HH;
+        const int gd = o.d0 * SD - PD + hd, gh = o.h0 * S - PHW + hh, gw = o.w0 * S - PHW + hw;
+        const bool inb = (hv < HV) && gd >= 0 && gd < a.ID && gh >= 0 && gh < a.IH && gw >= 0 && gw < a.IW;
+        return inb ? ((o.n * a.ID + gd) * a.IH + gh) * a.IW + gw : -1;
+    };
+    // issue the global loads of item (brick, ch) into pa / pw
+    unsigned inb_mask = 0;
+    auto issue = [&](int brick, int ch) {
+        const Org o = origin(brick);
+        const char* xsrc = a.x + (size_t)(ch * CK + p_mine * PE) * esz;
+        inb_mask = 0;
+#pragma unroll
+        for (int j = 0; j < NPA; ++j) {
+            const int vi = stage_vox(o, j);
+            pa[j] = make_uint4(0, 0, 0, 0);
+            if (vi >= 0) {
+                pa[j] = *(const uint4*)(xsrc + (size_t)vi * a.xpitch * esz);
+                inb_mask |= 1u << j;
+            }
+        }
+        const uint4* wch = wgrp + (size_t)(ch * SPC) * TAPS * 64;
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+            const int q = tid + NTHR * j;
+            if (q < WN) {                                  // wave-uniform: WN is a multiple of 64
+                const int ln = q & 63, nt = (q >> 6) % NT, step = q / (64 * NT);
+                const int tap = step / SPC, sidx = step % SPC;
+                const uint4* src = wch + ((size_t)nt * a.nKS * TAPS + (size_t)sidx * TAPS + tap) * 64 + ln;
+                if constexpr (WGLDS) {
+                    uint4* dstw = lw + (wcur ^ 1) * WN + (q - ln);     // wave-uniform LDS base; lane l lands at +16*l
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)dstw, 16, 0, 0);
+                } else {
+                    pw[j] = *src;
+                }
+            }
+        }
+    };
+    // commit pa / pw to LDS (producer transform + zero padding applied here)
+    auto commit = [&](int ch) {
+        float sc[PE], sh[PE], sl[PE];
+        if (has_xf) {
+            const int c0 = ch * CK + p_mine * PE;
+#pragma unroll
+            for (int e = 0; e < PE; ++e) { sc[e] = lxf[c0 + e]; sh[e] = lxf[a.Cin + c0 + e]; sl[e] = lxf[2 * a.Cin + c0 + e]; }
+        }
+#pragma unroll
+        for (int j = 0; j < NPA; ++j) {
+            const int i = tid + NTHR * j;
+            if (i < HV * CKP) {
+                uint4 v = pa[j];
+                if (has_xf && ((inb_mask >> j) & 1u)) {
+                    float f[PE];
+                    F::unpack(v, f);
+#pragma unroll
+                    for (int e = 0; e < PE; ++e) {
+                        const float t = fmaf(sc[e], f[e], sh[e]);
+                        f[e] = fmaxf(t, sl[e] * t);
+                    }
+                    v = F::pack(f);
+                }
+                lact[p_mine * PSV + i / CKP] = v;
+            }
+        }
+        if constexpr (!WGLDS) {
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) {
+                const int q = tid + NTHR * j;
+                if (q < WN) lw[q] = pw[j];
+            }
+        }
+    };
+
+#ifdef BIU_DIAG
+    unsigned long long tprev_ = __builtin_readcyclecounter();
+#endif
+    int k = 0;
+    int brick = brick_of(0);
+    if (brick >= nbricks) return;            // uniform per block
+    int ch = 0;
+    issue(brick, 0);
+    __syncthreads();                         // lxf visible (also drains the async weight copy)
+    commit(0);
+    if constexpr (WGLDS) wcur ^= 1;
+    __syncthreads();
+
+    while (true) {
+        if (ch == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[nt][mt][e] = 0.f;
+        }
+        // next item
+        int nbrick = brick, nch = ch + 1, nk = k;
+        if (nch == nchunks) { nch = 0; nk = k + 1; nbrick = brick_of(nk); }
+        const bool have_next = nbrick < nbricks;
+        DIAG_STAMP(0);
+        if (have_next) issue(nbrick, nch);
+        DIAG_STAMP(1);
+
+        // ---- MFMA phase over the committed tile.  Only the innermost (kw, k-step) window is unrolled: a fully unrolled
+        //      tap loop lets the scheduler hoist dozens of LDS fragments and spill -- and every spill reload carries an
+        //      s_waitcnt vmcnt(0) that would serialise the prefetch loads issued above.
+        const uint4* lwc = lw + (WGLDS ? wcur * WN : 0) + lane;
+#pragma unroll 1
+        for (int ta = 0; ta < KD; ++ta) {
+#pragma unroll 1
+            for (int tb = 0; tb < KHW; ++tb) {
+                const uint4* lwp = lwc + ((ta * KHW + tb) * KHW) * (SPC * NT * 64);
+                const uint4* lap = lact + (ta * HH + tb) * HW;
+#pragma unroll
+                for (int st2 = 0; st2 < KHW * SPC; ++st2) {
+                    const int tc = st2 / SPC, sidx = st2 % SPC;
+                    uint4 wf[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) wf[nt] = lwp[(st2 * NT + nt) * 64];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const uint4 bf = lap[hvb[mt] + 2 * sidx * PSV + tc];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) F::mma(wf[nt], bf, acc[nt][mt]);
+                    }
+                }
+            }
+        }
+
+        DIAG_STAMP(2);
+        // ---- brick finished: epilogue ----------------------------------------------------------------------------------
+        if (ch == nchunks - 1) {
+            const Org o = origin(brick);
+            const bool want_stats = a.bn_partial != nullptr;
+            float s1[NT][16], s2[NT][16];
+            if (want_stats) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) s1[nt][e] = s2[nt][e] = 0.f;
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int q = (wave * MT + mt) * 32 + r;
+                const int lw_ = q % TW;
+                const int t = q / TW;
+                const int lh = t % TH;
+                const int ld = t / TH;
+                const int gd = o.d0 + ld, gh = o.h0 + lh, gw = o.w0 + lw_;
+                const bool valid = gd < a.GD && gh < a.GH && gw < a.GW;
+                const int od = gd * a.osd + ((a.osd == 2) ? (int)(blockIdx.z >> 2) : 0);
+                const int oh = gh * a.osh + ((a.osh == 2) ? (int)((blockIdx.z >> 1) & 1) : 0);
+                const int ow = gw * a.osw + ((a.osw == 2) ? (int)(blockIdx.z & 1) : 0);
+                const size_t vox = ((size_t)(o.n * a.OD + od) * a.OH + oh) * a.OW + ow;
+                T* yrow = (T*)a.y + vox * a.ypitch;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const int co = (blockIdx.y * NT + nt) * 32 + 8 * qq + 4 * hf;
+                        if (co >= a.Cout || !valid) continue;
+                        float ov[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ov[i] = acc[nt][mt][4 * qq + i] + (a.bias ? a.bias[co + i] : 0.f);
+                        Pack<T, 4>* dst = (Pack<T, 4>*)(yrow + co);
+                        if (a.accumulate) {
+                            Pack<T, 4> old = *dst;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) ov[i] += (float)old.v[i];
+                        }
+                        Pack<T, 4> pk;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) pk.v[i] = (T)ov[i];
+                        *dst = pk;
+                        if (want_stats) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                s1[nt][4 * qq + i] += ov[i];
+                                s2[nt][4 * qq + i] = fmaf(ov[i], ov[i], s2[nt][4 * qq + i]);
+                            }
+                        }
+                    }
+                }
+            }
+            if (want_stats) {
+                // reduce over the 32 voxel lanes of each half-wave, then over waves through LDS atomics
+                if (tid < NT * 32 * 2) lred[tid] = 0.f;
+                __syncthreads();
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float u = s1[nt][e], v = s2[nt][e];
+#pragma unroll
+                        for (int off = 16; off > 0; off >>= 1) {
+                            u += __shfl_xor(u, off, 64);
+                            v += __shfl_xor(v, off, 64);
+                        }
+                        if (r == 0) {
+                            const int cl = nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hf;
+                            atomicAdd(&lred[cl * 2 + 0], u);
+                            atomicAdd(&lred[cl * 2 + 1], v);
+                        }
+                    }
+                __syncthreads();
+                if (tid < NT * 32) {
+                    const int co = blockIdx.y * NT * 32 + tid;
+                    if (co < a.Cout) {
+                        float* dstp = a.bn_partial + ((size_t)brick * a.Cout + co) * 2;
+                        dstp[0] = lred[tid * 2 + 0];
+                        dstp[1] = lred[tid * 2 + 1];
+                    }
+                }
+            }
+        }
+        DIAG_STAMP(3);
+#ifdef BIU_DIAG
+        if (a.diag && tid == 0) atomicAdd(a.diag + 7, 1ull);
+#endif
+        if (!have_next) break;
+        __syncthreads();                     // everyone is done reading the tile
+        DIAG_STAMP(4);
+        commit(nch);
+        if constexpr (WGLDS) wcur ^= 1;
+        DIAG_STAMP(5);
+        __syncthreads();
+        DIAG_STAMP(6);
+        brick = nbrick; ch = nch; k = nk;
     }
 }
 
@@ -326,29 +692,68 @@ bool biu_mfma_conv_ok(const biu_act* x, const biu_act* y, int kd, int kh, int kw
     return true;
 }
 
+template <int KD, int KHW, int S, int TD, int TH, int TW>
+struct BrickGeo {
+    static constexpr int SD = (KD == 1) ? 1 : S;
+    static constexpr int HV = ((TD - 1) * SD + KD) * ((TH - 1) * S + KHW) * ((TW - 1) * S + KHW);
+};
+
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        hipDeviceProp_t p;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
 template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP>
 static int launch_cfg(const ConvArgs& a0, int ntiles, int nz, hipStream_t st) {
     ConvArgs a = a0;
-    constexpr int SD = (KD == 1) ? 1 : S;
-    constexpr int HV = ((TD - 1) * SD + KD) * ((TH - 1) * S + KHW) * ((TW - 1) * S + KHW);
+    constexpr int HV = BrickGeo<KD, KHW, S, TD, TH, TW>::HV;
     constexpr int PSV = cpad_planes(HV, CKP);
-    const size_t lds_bytes = (size_t)CKP * PSV * 16;
+    constexpr int WN = KD * KHW * KHW * (CKP / 2) * NT * 64;
+    constexpr int NWB = ((size_t)(CKP * PSV + 2 * WN) * 16 <= 150 * 1024) ? 2 : 1;        // must mirror k_conv_pipe::WGLDS
+    const size_t lds_bytes = (size_t)(CKP * PSV + NWB * WN) * 16 + (size_t)3 * a.Cin * sizeof(float) + (size_t)NT * 32 * 2 * sizeof(float);
+    if (lds_bytes > 160 * 1024) return biu_fail(BIU_ERR_UNSUPPORTED, "conv_pipe: %zu bytes of LDS (Cin=%d)", lds_bytes, a.Cin);
     a.nbd = (a.GD + TD - 1) / TD;
     a.nbh = (a.GH + TH - 1) / TH;
     a.nbw = (a.GW + TW - 1) / TW;
-    dim3 grid((unsigned)((size_t)a.N * a.nbd * a.nbh * a.nbw), (unsigned)(ntiles / NT), (unsigned)nz);
-    auto kern = k_conv_mfma<T, KD, KHW, S, TD, TH, TW, NT, CKP>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        attr_set = true;
+    const int nbricks = a.N * a.nbd * a.nbh * a.nbw;
+    const int gy = ntiles / NT;
+    int g = num_cus() / (gy * nz);
+    g &= ~7;
+    if (g < 8) g = 8;
+    if (g > nbricks) g = nbricks;
+    dim3 grid((unsigned)g, (unsigned)gy, (unsigned)nz);
+    auto kern = k_conv_pipe<T, KD, KHW, S, TD, TH, TW, NT, CKP>;
+    static size_t attr_set = 0;
+    if (attr_set < lds_bytes) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return biu_fail(BIU_ERR_LAUNCH, "conv_pipe: cannot reserve %zu bytes of LDS", lds_bytes);
+        attr_set = lds_bytes;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
-    BIU_CHECK_LAUNCH("conv_mfma");
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, st, a);
+    BIU_CHECK_LAUNCH("conv_pipe");
     return BIU_OK;
 }
 
 static inline int pick_nt(int ntiles) { return (ntiles % 4 == 0) ? 4 : (ntiles % 2 == 0 ? 2 : 1); }
+
+// brick shape per (kernel kind, NT, width class): must stay in sync between launch_* and conv_brick_voxels()
+struct BrickDim { int td, th, tw; };
+static BrickDim conv3_brick(int kd, int nt, bool wide) {
+    if (kd == 3) {
+        if (nt == 1) return wide ? BrickDim{4, 8, 32} : BrickDim{4, 16, 16};
+        if (nt == 2) return BrickDim{4, 8, 16};
+        return BrickDim{4, 4, 16};
+    }
+    if (nt == 1) return wide ? BrickDim{1, 32, 32} : BrickDim{1, 64, 16};
+    if (nt == 2) return wide ? BrickDim{1, 16, 32} : BrickDim{1, 32, 16};
+    return BrickDim{1, 16, 16};
+}
 
 template <typename T>
 static int launch_conv(const ConvArgs& a, int kd, hipStream_t st) {
@@ -365,6 +770,13 @@ static int launch_conv(const ConvArgs& a, int kd, hipStream_t st) {
     return launch_cfg<T, 1, 3, 1, 1, 16, 16, 4, 2>(a, ntiles, 1, st);
 }
 
+// number of bricks (= BatchNorm partial rows) the forward conv will produce for this output
+int biu_mfma_conv_bricks(const biu_act* y, int kd) {
+    const int ntiles = (y->c + 31) / 32;
+    const BrickDim b = conv3_brick(kd, pick_nt(ntiles), y->w % 32 == 0);
+    return y->n * ((y->d + b.td - 1) / b.td) * ((y->h + b.th - 1) / b.th) * ((y->w + b.tw - 1) / b.tw);
+}
+
 static int fill_xf(ConvArgs& a, const biu_xform* xf) {
     const bool has = xf && (xf->scale || xf->shift || xf->slope);
     if (has) BIU_REQUIRE(xf->scale && xf->shift && xf->slope, BIU_ERR_UNSUPPORTED, "conv_mfma: partial biu_xform (need all three vectors)");
@@ -375,8 +787,9 @@ static int fill_xf(ConvArgs& a, const biu_xform* xf) {
 }
 
 int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, int kh, int kw,
-                  const biu_act* y, int accumulate, int dtype, hipStream_t st) {
+                  const biu_act* y, int accumulate, float* bn_partial, int dtype, hipStream_t st) {
     ConvArgs a;
+    a.bn_partial = bn_partial;
     a.x = (const char*)x->p;
     a.y = (char*)y->p;
     a.wpk = (const uint4*)packed;
@@ -393,6 +806,11 @@ int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, con
     a.wz_stride = 0;
     a.accumulate = accumulate;
     a.nbd = a.nbh = a.nbw = 0;
+#ifdef BIU_DIAG
+    a.diag = biu_diag_buffer;
+#else
+    a.diag = nullptr;
+#endif
     if (dtype == BIU_BF16) return launch_conv<bf16_t>(a, kd, st);
     return launch_conv<float>(a, kd, st);
 }
@@ -492,6 +910,7 @@ static int launch_convt_dgrad(const ConvArgs& a, int kd, hipStream_t st) {
 int biu_mfma_convt_fwd(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, const biu_act* y,
                        int dtype, hipStream_t st) {
     ConvArgs a;
+    a.bn_partial = nullptr;
     a.x = (const char*)x->p;
     a.y = (char*)y->p;
     a.wpk = (const uint4*)packed;
@@ -507,6 +926,7 @@ int biu_mfma_convt_fwd(const biu_act* x, const biu_xform* xf, const void* packed
     a.nKS = x->c / ks_of(dtype);
     a.wz_stride = ((a.Cout + 31) / 32) * a.nKS * 64;
     a.accumulate = 0;
+    a.diag = nullptr;
     a.nbd = a.nbh = a.nbw = 0;
     if (dtype == BIU_BF16) return launch_convt_fwd<bf16_t>(a, kd, st);
     return launch_convt_fwd<float>(a, kd, st);
@@ -514,6 +934,7 @@ int biu_mfma_convt_fwd(const biu_act* x, const biu_xform* xf, const void* packed
 
 int biu_mfma_convt_dgrad(const biu_act* dy, const void* packed, int kd, const biu_act* dx, int accumulate, int dtype, hipStream_t st) {
     ConvArgs a;
+    a.bn_partial = nullptr;
     a.x = (const char*)dy->p;
     a.y = (char*)dx->p;
     a.wpk = (const uint4*)packed;
@@ -528,6 +949,7 @@ int biu_mfma_convt_dgrad(const biu_act* dy, const void* packed, int kd, const bi
     a.nKS = dy->c / ks_of(dtype);
     a.wz_stride = 0;
     a.accumulate = accumulate;
+    a.diag = nullptr;
     a.nbd = a.nbh = a.nbw = 0;
     if (dtype == BIU_BF16) return launch_convt_dgrad<bf16_t>(a, kd, st);
     return launch_convt_dgrad<float>(a, kd, st);

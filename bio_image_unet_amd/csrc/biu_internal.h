@@ -24,7 +24,8 @@ int biu_mfma_pack(int kind, const float* w, int cin, int cout, int kd, int kh, i
                   hipStream_t st);
 bool biu_mfma_conv_ok(const biu_act* x, const biu_act* y, int kd, int kh, int kw, int dilation, int dtype);
 int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, int kh, int kw,
-                  const biu_act* y, int accumulate, int dtype, hipStream_t st);
+                  const biu_act* y, int accumulate, float* bn_partial, int dtype, hipStream_t st);
+int biu_mfma_conv_bricks(const biu_act* y, int kd);
 size_t biu_mfma_wgrad_workspace(int cin, int cout, int kd, int kh, int kw, int dtype);
 bool biu_mfma_wgrad_ok(const biu_act* x, const biu_act* dy, int kd, int kh, int kw, int dilation, int dtype);
 int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, int kh, int kw, float* dw,

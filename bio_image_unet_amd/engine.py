@@ -169,6 +169,7 @@ class ConvBlockNode(Node):
         self.save_invstd = torch.empty(cout, dtype=torch.float32, device=dev)
         yout.vec("slope").fill_(LRELU_SLOPE)
         eng.need_partial(cout)
+        eng.need_partial_floats(lib.biu_conv_fwd_stats_floats(yout.a(), self.kd))
         self.pk_f = eng.packed_slot(0, xin.c, cout, self.kd, self.kh, self.kw, self.dil)
         self.pk_b = eng.packed_slot(1, xin.c, cout, self.kd, self.kh, self.kw, self.dil)
         self.ws_bytes = lib.biu_conv_bwd_weight_workspace(xin.c, cout, self.kd, self.kh, self.kw, eng.dtype)
@@ -178,13 +179,14 @@ class ConvBlockNode(Node):
         st = _stream()
         w, b = self.conv.weight.data, self.conv.bias.data if self.conv.bias is not None else None
         packed = eng.pack(self.pk_f, 0, self.conv.weight, self.xin.c, self.y.c, self.kd, self.kh, self.kw)
-        check(lib.biu_conv_fwd(self.xin.a(), self.xin.xf(), _ptr(w), packed, _ptr(b), self.kd, self.kh, self.kw,
-                               self.dil, self.y.a(), eng.dtype, st), "conv_fwd")
         bn = self.bn
         scale, shift = self.y.vec("scale"), self.y.vec("shift")
         if eng.bn_training(bn):
+            # convolution + BatchNorm statistics in one call (the MFMA kernel reduces them in its epilogue)
             nblk = C.c_int(0)
-            check(lib.biu_bn_stats(self.y.a(), _ptr(eng.partial), C.byref(nblk), eng.dtype, st), "bn_stats")
+            check(lib.biu_conv_fwd_stats(self.xin.a(), self.xin.xf(), _ptr(w), packed, _ptr(b), self.kd, self.kh, self.kw,
+                                         self.dil, self.y.a(), _ptr(eng.partial), eng.partial.numel(), C.byref(nblk),
+                                         eng.dtype, st), "conv_fwd_stats")
             mom = bn.momentum if bn.momentum is not None else 0.1
             track = bn.track_running_stats and bn.running_mean is not None
             check(lib.biu_bn_finalize(_ptr(eng.partial), nblk.value, self.y.c, float(self.y.nvox), _ptr(bn.weight.data),
@@ -195,6 +197,8 @@ class ConvBlockNode(Node):
                 eng.nbt_bump.append(bn.num_batches_tracked)
             self.batch_stats = True
         else:
+            check(lib.biu_conv_fwd(self.xin.a(), self.xin.xf(), _ptr(w), packed, _ptr(b), self.kd, self.kh, self.kw,
+                                   self.dil, self.y.a(), eng.dtype, st), "conv_fwd")
             check(lib.biu_bn_eval_affine(self.y.c, _ptr(bn.weight.data), _ptr(bn.bias.data), _ptr(bn.running_mean),
                                          _ptr(bn.running_var), bn.eps, _ptr(scale), _ptr(shift), st), "bn_eval_affine")
             self.batch_stats = False
@@ -439,13 +443,17 @@ class Engine:
     def need_partial(self, c):
         self._partial_c = max(self._partial_c, c)
 
+    def need_partial_floats(self, n):
+        self._partial_floats = max(getattr(self, "_partial_floats", 0), int(n))
+
     def need_ws(self, nbytes):
         self.ws_bytes = max(self.ws_bytes, int(nbytes))
 
     def finalize(self):
         dev = self.device
         c = max(self._partial_c, 1)
-        self.partial = torch.empty(BN_MAX_PARTIALS * c * 2, dtype=torch.float32, device=dev)
+        self.partial = torch.empty(max(BN_MAX_PARTIALS * c * 2, getattr(self, "_partial_floats", 0)), dtype=torch.float32,
+                                   device=dev)
         self.coef = torch.empty((3, c), dtype=torch.float32, device=dev)
         self.ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=dev)
         self.params: List[nn.Parameter] = []

@@ -81,6 +81,14 @@ int biu_conv_fwd(const biu_act* x, const biu_xform* xf, const float* w, const vo
                  const float* bias, int kd, int kh, int kw, int dilation,
                  const biu_act* y, int dtype, biu_stream stream);
 
+/* Same, and additionally emits the BatchNorm statistics partials of y: float[nblk][cout][2] = (sum, sum of squares)
+ * per block.  On the MFMA path they come out of the convolution's own epilogue (no extra pass over y); otherwise a
+ * separate reduction runs.  bn_partial must hold biu_conv_fwd_stats_floats(y, kd) floats; *bn_nblk receives nblk.      */
+size_t biu_conv_fwd_stats_floats(const biu_act* y, int kd);
+int biu_conv_fwd_stats(const biu_act* x, const biu_xform* xf, const float* w, const void* packed,
+                       const float* bias, int kd, int kh, int kw, int dilation, const biu_act* y,
+                       float* bn_partial, size_t bn_partial_floats, int* bn_nblk, int dtype, biu_stream stream);
+
 /* dx = conv_transpose_of_the_above(dy): dx[v,ci] = sum_{tap,co} dy[v - off(tap), co] * w[co,ci,tap].
  * packed: result of biu_conv_pack(kind 1) or NULL.  accumulate != 0 adds into dx.                       */
 int biu_conv_bwd_data(const biu_act* dy, const float* w, const void* packed,

@@ -147,7 +147,8 @@ def test_seeded_midsize_vs_oracle(kind, nf, shape, dtype):
         for k, (err, cos) in mine.items():
             bound = REL + 3 * max(sens[k][0], cpu32[k][0])
             assert err <= bound, f"grad {k}: err {err} > {bound} (sensitivity {sens[k][0]}, reference-fp32 err {cpu32[k][0]})"
-            assert cos > 0.999, f"grad {k}: cosine {cos}"
+            if float(true_grads[k].abs().max()) > 1e-3 * max(float(v.abs().max()) for v in true_grads.values()):
+                assert cos > 0.999, f"grad {k}: cosine {cos}"      # (conv biases before a BN have zero gradient)
     else:
         # bf16 storage of activations and activation gradients: direction must be right, magnitude within 35 %
         for k, (err, cos) in mine.items():

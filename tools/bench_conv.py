@@ -1,0 +1,78 @@
+"""Micro-benchmark of the MFMA conv kernels through the C ABI at the layer shapes of the bench workloads.
+
+    python tools/bench_conv.py [cfg4|cfg2] [bf16|f32]
+
+Prints HIP-event time and algorithmic TFLOP/s (2*vox*taps*Cin*Cout) for forward, data-gradient and weight-gradient."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from bio_image_unet_amd._lib import biu_act, biu_xform, check, lib  # noqa: E402
+
+LAYERS = {
+    "cfg4": [("encode2", 3, 4, 16, 32, (128, 128, 128)), ("encode4", 3, 4, 32, 64, (64, 64, 64)), ("decode1", 3, 4, 384, 128, (32, 32, 32)),
+             ("decode3", 3, 4, 192, 64, (64, 64, 64)), ("decode4", 3, 4, 64, 64, (64, 64, 64)), ("decode5", 3, 4, 96, 32, (128, 128, 128)),
+             ("decode6", 3, 4, 32, 16, (128, 128, 128)), ("middle2", 3, 4, 128, 256, (16, 16, 16))],
+    "cfg2": [("encode2", 2, 16, 64, 64, (512, 512)), ("decode7", 2, 16, 128, 64, (512, 512)), ("decode5", 2, 16, 256, 128, (256, 256)),
+             ("middle2", 2, 16, 1024, 1024, (32, 32))],
+}
+
+
+def main():
+    cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
+    dt = sys.argv[2] if len(sys.argv) > 2 else ("bf16" if cfg == "cfg4" else "f32")
+    only = sys.argv[3] if len(sys.argv) > 3 else None
+    tdt, code = (torch.bfloat16, 1) if dt == "bf16" else (torch.float32, 0)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    for name, nd, n, cin, cout, sp in LAYERS[cfg]:
+        if only and only != name:
+            continue
+        kd = 3 if nd == 3 else 1
+        d, h, w = (sp if nd == 3 else (1,) + tuple(sp))
+        x = torch.randn(n, d, h, w, cin, device="cuda").to(tdt)
+        y = torch.empty(n, d, h, w, cout, device="cuda", dtype=tdt)
+        dy = torch.randn(n, d, h, w, cout, device="cuda").to(tdt)
+        dx = torch.empty_like(x)
+        wt = torch.randn((cout, cin) + (3,) * nd, device="cuda") * 0.05
+        bias = torch.randn(cout, device="cuda")
+        xs, xb, xl = torch.ones(cin, device="cuda"), torch.zeros(cin, device="cuda"), torch.full((cin,), 0.1, device="cuda")
+        xf = biu_xform(xs.data_ptr(), xb.data_ptr(), xl.data_ptr())
+        ax = biu_act(x.data_ptr(), n, d, h, w, cin, cin)
+        ay = biu_act(y.data_ptr(), n, d, h, w, cout, cout)
+        ady = biu_act(dy.data_ptr(), n, d, h, w, cout, cout)
+        adx = biu_act(dx.data_ptr(), n, d, h, w, cin, cin)
+        pk0 = torch.empty(max(lib.biu_conv_packed_bytes(0, cin, cout, kd, 3, 3, 1, code), 16), dtype=torch.uint8, device="cuda")
+        pk1 = torch.empty(max(lib.biu_conv_packed_bytes(1, cin, cout, kd, 3, 3, 1, code), 16), dtype=torch.uint8, device="cuda")
+        check(lib.biu_conv_pack(0, P(wt), cin, cout, kd, 3, 3, code, P(pk0), st))
+        check(lib.biu_conv_pack(1, P(wt), cin, cout, kd, 3, 3, code, P(pk1), st))
+        ws = torch.empty(max(lib.biu_conv_bwd_weight_workspace(cin, cout, kd, 3, 3, code), 16), dtype=torch.uint8, device="cuda")
+        dw = torch.empty_like(wt)
+        fl = 2.0 * n * d * h * w * (27 if nd == 3 else 9) * cin * cout
+        calls = {
+            "fwd": lambda: lib.biu_conv_fwd(C.byref(ax), C.byref(xf), P(wt), P(pk0), P(bias), kd, 3, 3, 1, C.byref(ay), code, st),
+            "dgrad": lambda: lib.biu_conv_bwd_data(C.byref(ady), P(wt), P(pk1), kd, 3, 3, 1, C.byref(adx), 0, code, st),
+            "wgrad": lambda: lib.biu_conv_bwd_weight(C.byref(ax), C.byref(xf), C.byref(ady), kd, 3, 3, 1, P(dw), None, P(ws), ws.numel(), code, st),
+        }
+        out = []
+        for k, f in calls.items():
+            for _ in range(2):
+                check(f())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 5
+            e0.record()
+            for _ in range(reps):
+                check(f())
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            out.append(f"{k} {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF/s")
+        print(f"{name:8s} {cin:4d}->{cout:4d} @{sp}  " + " | ".join(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,28 @@
+"""Diagnostic build (BIU_DIAG): per-phase cycle shares of the MFMA conv kernel (thread 0 of every block)."""
+import ctypes as C, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bio_image_unet_amd._lib import biu_act, biu_xform, SIGNATURES
+lib = C.CDLL(os.path.join(ROOT, "tools", "libbiu_diag.so"))
+for name, (res, args) in SIGNATURES.items():
+    getattr(lib, name).restype = res; getattr(lib, name).argtypes = args
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+P = lambda t: C.c_void_p(t.data_ptr())
+diag = torch.zeros(8, dtype=torch.int64, device="cuda")
+C.c_void_p.in_dll(lib, "biu_diag_buffer").value = diag.data_ptr()
+shapes = [("encode2", 16, 32, (128,128,128)), ("decode5", 96, 32, (128,128,128)), ("decode3", 192, 64, (64,64,64)), ("decode6", 32, 16, (128,128,128))]
+n = 4
+for name, cin, cout, (d,h,w) in shapes:
+    x = torch.randn(n,d,h,w,cin, device="cuda").to(torch.bfloat16); y = torch.empty(n,d,h,w,cout, device="cuda", dtype=torch.bfloat16)
+    wt = torch.randn(cout,cin,3,3,3, device="cuda")*0.05
+    pk = torch.empty(lib.biu_conv_packed_bytes(0,cin,cout,3,3,3,1,1), dtype=torch.uint8, device="cuda")
+    lib.biu_conv_pack(0,P(wt),cin,cout,3,3,3,1,P(pk),st)
+    ax = biu_act(x.data_ptr(),n,d,h,w,cin,cin); ay = biu_act(y.data_ptr(),n,d,h,w,cout,cout)
+    lib.biu_conv_fwd(C.byref(ax),None,P(wt),P(pk),None,3,3,3,1,C.byref(ay),1,st); torch.cuda.synchronize()
+    diag.zero_()
+    e0,e1 = torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+    e0.record(); lib.biu_conv_fwd(C.byref(ax),None,P(wt),P(pk),None,3,3,3,1,C.byref(ay),1,st); e1.record(); torch.cuda.synchronize()
+    dv = diag.cpu().tolist(); nb = max(dv[7],1)
+    names = ["loop", "issue", "mfma", "epilogue", "barrier1", "commit", "barrier2"]
+    tot = sum(dv[:7])
+    print(f"{name}: {e0.elapsed_time(e1):.3f} ms, items {nb}, cycles/item {tot/nb:.0f}: " + ", ".join(f"{nm} {dv[i]/nb:.0f} ({100*dv[i]/tot:.0f}%)" for i,nm in enumerate(names)), flush=True)
