@@ -306,6 +306,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
 // the MFMAs and LDS holds only one copy.  Weight fragments are read from LDS (1 KiB contiguous per wave-read).
 // Epilogue per brick: bias, optional accumulate, store; optional per-channel (sum, sum^2) partials for BatchNorm.
 // ===============================================================================================================
+// LDS-DMA (global -> LDS, 16 B per lane, lane l lands at lds_base + 16 l) issued through inline asm: hipcc would
+// otherwise put an s_waitcnt vmcnt(0) in front of every LDS read that follows a __builtin_amdgcn_global_load_lds,
+// which serialises the whole prefetch.  The caller drains it with an explicit s_waitcnt vmcnt(0) before the barrier
+// that precedes the first read of that buffer (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_base_uniform)
+                 : "memory");
+}
+
 template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP>
 __global__ __launch_bounds__(512, 2) void k_conv_pipe(ConvArgs a) {
     using F = Frag<T>;
@@ -404,13 +416,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_pipe(ConvArgs a) {
     };
     // issue the global loads of item (brick, ch) into pa / pw
     unsigned inb_mask = 0;
-    auto issue = [&](int brick, int ch) {
+    // `live` = false issues nothing but still (re)defines pa: the prefetch registers must not be loop-carried PHIs,
+    // or the register allocator copies them -- and waits for the loads -- in front of the MFMA phase
+    auto issue = [&](int brick, int ch, bool live) {
         const Org o = origin(brick);
         const char* xsrc = a.x + (size_t)(ch * CK + p_mine * PE) * esz;
         inb_mask = 0;
 #pragma unroll
         for (int j = 0; j < NPA; ++j) {
-            const int vi = stage_vox(o, j);
+            const int vi = live ? stage_vox(o, j) : -1;
             pa[j] = make_uint4(0, 0, 0, 0);
             if (vi >= 0) {
                 pa[j] = *(const uint4*)(xsrc + (size_t)vi * a.xpitch * esz);
@@ -421,14 +435,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_pipe(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NPW; ++j) {
             const int q = tid + NTHR * j;
-            if (q < WN) {                                  // wave-uniform: WN is a multiple of 64
+            if (q < WN && live) {                          // wave-uniform: WN is a multiple of 64
                 const int ln = q & 63, nt = (q >> 6) % NT, step = q / (64 * NT);
                 const int tap = step / SPC, sidx = step % SPC;
                 const uint4* src = wch + ((size_t)nt * a.nKS * TAPS + (size_t)sidx * TAPS + tap) * 64 + ln;
                 if constexpr (WGLDS) {
                     uint4* dstw = lw + (wcur ^ 1) * WN + (q - ln);     // wave-uniform LDS base; lane l lands at +16*l
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)dstw, 16, 0, 0);
+                    const unsigned lbase = __builtin_amdgcn_readfirstlane(
+                        (unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)dstw));
+                    glds16(src, lbase);
                 } else {
                     pw[j] = *src;
                 }
@@ -477,10 +492,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_pipe(ConvArgs a) {
     int brick = brick_of(0);
     if (brick >= nbricks) return;            // uniform per block
     int ch = 0;
-    issue(brick, 0);
-    __syncthreads();                         // lxf visible (also drains the async weight copy)
+    issue(brick, 0, true);
+    __syncthreads();                         // lxf visible
     commit(0);
-    if constexpr (WGLDS) wcur ^= 1;
+    if constexpr (WGLDS) { wcur ^= 1; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     __syncthreads();
 
     while (true) {
@@ -497,7 +512,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pipe(ConvArgs a) {
         if (nch == nchunks) { nch = 0; nk = k + 1; nbrick = brick_of(nk); }
         const bool have_next = nbrick < nbricks;
         DIAG_STAMP(0);
-        if (have_next) issue(nbrick, nch);
+        issue(have_next ? nbrick : brick, nch, have_next);
         DIAG_STAMP(1);
 
         // ---- MFMA phase over the committed tile.  Only the innermost (kw, k-step) window is unrolled: a fully unrolled
@@ -620,7 +635,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pipe(ConvArgs a) {
         __syncthreads();                     // everyone is done reading the tile
         DIAG_STAMP(4);
         commit(nch);
-        if constexpr (WGLDS) wcur ^= 1;
+        if constexpr (WGLDS) { wcur ^= 1; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // weight DMA landed
         DIAG_STAMP(5);
         __syncthreads();
         DIAG_STAMP(6);
@@ -740,19 +755,18 @@ static int launch_cfg(const ConvArgs& a0, int ntiles, int nz, hipStream_t st) {
     return BIU_OK;
 }
 
-static inline int pick_nt(int ntiles) { return (ntiles % 4 == 0) ? 4 : (ntiles % 2 == 0 ? 2 : 1); }
+// (a 4-tile weight slab no longer fits the double buffer next to the activation tile: two tiles is the widest block)
+static inline int pick_nt(int ntiles) { return (ntiles % 2 == 0) ? 2 : 1; }
 
 // brick shape per (kernel kind, NT, width class): must stay in sync between launch_* and conv_brick_voxels()
 struct BrickDim { int td, th, tw; };
 static BrickDim conv3_brick(int kd, int nt, bool wide) {
     if (kd == 3) {
         if (nt == 1) return wide ? BrickDim{4, 8, 32} : BrickDim{4, 16, 16};
-        if (nt == 2) return BrickDim{4, 8, 16};
-        return BrickDim{4, 4, 16};
+        return BrickDim{4, 8, 16};
     }
     if (nt == 1) return wide ? BrickDim{1, 32, 32} : BrickDim{1, 64, 16};
-    if (nt == 2) return wide ? BrickDim{1, 16, 32} : BrickDim{1, 32, 16};
-    return BrickDim{1, 16, 16};
+    return wide ? BrickDim{1, 16, 32} : BrickDim{1, 32, 16};
 }
 
 template <typename T>
@@ -762,12 +776,10 @@ static int launch_conv(const ConvArgs& a, int kd, hipStream_t st) {
     const bool wide = (a.GW % 32 == 0);
     if (kd == 3) {
         if (nt == 1) return wide ? launch_cfg<T, 3, 3, 1, 4, 8, 32, 1, 2>(a, ntiles, 1, st) : launch_cfg<T, 3, 3, 1, 4, 16, 16, 1, 2>(a, ntiles, 1, st);
-        if (nt == 2) return launch_cfg<T, 3, 3, 1, 4, 8, 16, 2, 2>(a, ntiles, 1, st);
-        return launch_cfg<T, 3, 3, 1, 4, 4, 16, 4, 2>(a, ntiles, 1, st);
+        return launch_cfg<T, 3, 3, 1, 4, 8, 16, 2, 2>(a, ntiles, 1, st);
     }
     if (nt == 1) return wide ? launch_cfg<T, 1, 3, 1, 1, 32, 32, 1, 2>(a, ntiles, 1, st) : launch_cfg<T, 1, 3, 1, 1, 64, 16, 1, 2>(a, ntiles, 1, st);
-    if (nt == 2) return wide ? launch_cfg<T, 1, 3, 1, 1, 16, 32, 2, 2>(a, ntiles, 1, st) : launch_cfg<T, 1, 3, 1, 1, 32, 16, 2, 2>(a, ntiles, 1, st);
-    return launch_cfg<T, 1, 3, 1, 1, 16, 16, 4, 2>(a, ntiles, 1, st);
+    return wide ? launch_cfg<T, 1, 3, 1, 1, 16, 32, 2, 2>(a, ntiles, 1, st) : launch_cfg<T, 1, 3, 1, 1, 32, 16, 2, 2>(a, ntiles, 1, st);
 }
 
 // number of bricks (= BatchNorm partial rows) the forward conv will produce for this output
@@ -886,12 +898,10 @@ static int launch_convt_fwd(const ConvArgs& a, int kd, hipStream_t st) {
     const int ntiles = (a.Cout + 31) / 32, nt = pick_nt(ntiles), nz = kd * 4;
     if (kd == 2) {
         if (nt == 1) return launch_cfg<T, 1, 1, 1, 4, 8, 16, 1, 2>(a, ntiles, nz, st);
-        if (nt == 2) return launch_cfg<T, 1, 1, 1, 4, 8, 16, 2, 2>(a, ntiles, nz, st);
-        return launch_cfg<T, 1, 1, 1, 2, 8, 16, 4, 2>(a, ntiles, nz, st);
+        return launch_cfg<T, 1, 1, 1, 4, 8, 16, 2, 2>(a, ntiles, nz, st);
     }
     if (nt == 1) return launch_cfg<T, 1, 1, 1, 1, 32, 16, 1, 2>(a, ntiles, nz, st);
-    if (nt == 2) return launch_cfg<T, 1, 1, 1, 1, 32, 16, 2, 2>(a, ntiles, nz, st);
-    return launch_cfg<T, 1, 1, 1, 1, 16, 16, 4, 2>(a, ntiles, nz, st);
+    return launch_cfg<T, 1, 1, 1, 1, 32, 16, 2, 2>(a, ntiles, nz, st);
 }
 
 template <typename T>
@@ -899,12 +909,10 @@ static int launch_convt_dgrad(const ConvArgs& a, int kd, hipStream_t st) {
     const int ntiles = (a.Cout + 31) / 32, nt = pick_nt(ntiles);
     if (kd == 2) {
         if (nt == 1) return launch_cfg<T, 2, 2, 2, 2, 8, 16, 1, 2>(a, ntiles, 1, st);
-        if (nt == 2) return launch_cfg<T, 2, 2, 2, 2, 8, 16, 2, 2>(a, ntiles, 1, st);
-        return launch_cfg<T, 2, 2, 2, 2, 8, 16, 4, 2>(a, ntiles, 1, st);
+        return launch_cfg<T, 2, 2, 2, 2, 8, 16, 2, 2>(a, ntiles, 1, st);
     }
     if (nt == 1) return launch_cfg<T, 1, 2, 2, 1, 16, 16, 1, 2>(a, ntiles, 1, st);
-    if (nt == 2) return launch_cfg<T, 1, 2, 2, 1, 16, 16, 2, 2>(a, ntiles, 1, st);
-    return launch_cfg<T, 1, 2, 2, 1, 16, 16, 4, 2>(a, ntiles, 1, st);
+    return launch_cfg<T, 1, 2, 2, 1, 16, 16, 2, 2>(a, ntiles, 1, st);
 }
 
 int biu_mfma_convt_fwd(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, const biu_act* y,
