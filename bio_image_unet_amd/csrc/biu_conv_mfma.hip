@@ -1194,6 +1194,236 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Pipelined persistent weight-gradient kernel (the one the launchers use): 512 threads, one block per CU, blocks walk
+// bricks; the next brick's two tiles are prefetched into registers while the current one is multiplied, then
+// committed to LDS (same issue-early / write-late scheme as k_conv_pipe).  Work items for the 8 waves are
+// (tap, half of the brick's voxel groups): 54 items for 27 taps -> 7/7/7/7/7/7/6/6 per wave.  Each block keeps its
+// partial dW in registers across ALL its bricks and flushes once.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int KSPLIT>
+__global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
+    using F = Frag<T>;
+    constexpr int NTHR = 512, NWAVE = 8;
+    constexpr int PE = F::PE;
+    constexpr int CT = 32;
+    constexpr int PPV = CT / PE;
+    constexpr int PD = (KD == 3) ? 1 : 0;
+    constexpr int PHW = (KHW == 3) ? 1 : 0;
+    constexpr int SD = (KD == 1) ? 1 : S;
+    constexpr int HD = (TD - 1) * SD + KD, HH = (TH - 1) * S + KHW, HW = (TW - 1) * S + KHW;
+    constexpr int HV = HD * HH * HW;
+    constexpr int BV = TD * TH * TW;
+    constexpr int TAPS = KD * KHW * KHW;
+    constexpr int NITEM = TAPS * KSPLIT;
+    constexpr int IPW = (NITEM + NWAVE - 1) / NWAVE;       // items per wave
+    constexpr int RS = CT * (int)sizeof(T);
+    constexpr int NA = (BV * PPV + NTHR - 1) / NTHR;
+    constexpr int NB = (HV * PPV + NTHR - 1) / NTHR;
+    constexpr int KUNIT = (sizeof(T) == 2) ? 16 : 2;       // voxels per MFMA k-step
+    constexpr int NKG = BV / KUNIT;
+    static_assert(TW % 16 == 0 && NKG % KSPLIT == 0, "brick / split mismatch");
+
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+    char* at = (char*)lds;                           // [BV][CT]
+    char* bt = at + BV * RS;                         // [HV][CT]
+    float* lxf = (float*)(bt + HV * RS);             // [2][3][CT] transform constants of this block's A / B channel tiles
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int it = blockIdx.y / a.njt, jt = blockIdx.y % a.njt;
+    const size_t esz = sizeof(T);
+    const int piece = tid % PPV;
+    const int ac0 = it * CT + piece * PE, bc0 = jt * CT + piece * PE;
+    const bool apiece_ok = ac0 < a.CA, bpiece_ok = bc0 < a.CB;
+    const bool a_xf = a.as_ != nullptr, b_xf = a.bs_ != nullptr;
+    if (tid < CT) {
+        const int ca = it * CT + tid, cb = jt * CT + tid;
+        lxf[0 * CT + tid] = (a_xf && ca < a.CA) ? a.as_[ca] : 1.f;
+        lxf[1 * CT + tid] = (a_xf && ca < a.CA) ? a.ab_[ca] : 0.f;
+        lxf[2 * CT + tid] = (a_xf && ca < a.CA) ? a.al_[ca] : 1.f;
+        lxf[3 * CT + tid] = (b_xf && cb < a.CB) ? a.bs_[cb] : 1.f;
+        lxf[4 * CT + tid] = (b_xf && cb < a.CB) ? a.bb_[cb] : 0.f;
+        lxf[5 * CT + tid] = (b_xf && cb < a.CB) ? a.bl_[cb] : 1.f;
+    }
+
+    floatx16 acc[IPW];
+#pragma unroll
+    for (int t = 0; t < IPW; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    // this wave's items: item = wave + 8 t -> (tap, half)
+    int tapoff[IPW], ihalf[IPW];
+#pragma unroll
+    for (int t = 0; t < IPW; ++t) {
+        const int item = wave + NWAVE * t;
+        const int tap = item % TAPS;
+        ihalf[t] = (item < NITEM) ? item / TAPS : -1;
+        const int ta = tap / (KHW * KHW), tb = (tap / KHW) % KHW, tc = tap % KHW;
+        tapoff[t] = ((ta * HH + tb) * HW + tc) * RS;
+    }
+
+    int a_lane, b_lane;
+    if constexpr (sizeof(T) == 2) {
+        const int g = lane >> 4, li = lane & 15, qrow = li >> 2, p = li & 3, cg = g & 1, h = g >> 1;
+        a_lane = (8 * h + qrow) * RS + (16 * cg + 4 * p) * 2;
+        b_lane = (8 * h + qrow) * S * RS + (16 * cg + 4 * p) * 2;
+    } else {
+        a_lane = (lane >> 5) * RS + (lane & 31) * 4;
+        b_lane = (lane >> 5) * S * RS + (lane & 31) * 4;
+    }
+
+    uint4 pa[NA], pb[NB];
+    unsigned amask = 0, bmask = 0;
+    auto issue = [&](int brick, bool live) {
+        int b = brick;
+        const int bw = b % a.nbw; b /= a.nbw;
+        const int bh = b % a.nbh; b /= a.nbh;
+        const int bd = b % a.nbd;
+        const int n = b / a.nbd;
+        const int d0 = bd * TD, h0 = bh * TH, w0 = bw * TW;
+        amask = bmask = 0;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int i = tid + NTHR * j;
+            const int q = i / PPV;
+            const int lw = q % TW;
+            const int t = q / TW;
+            const int lh = t % TH;
+            const int ld = t / TH;
+            const int gd = d0 + ld, gh = h0 + lh, gw = w0 + lw;
+            pa[j] = make_uint4(0, 0, 0, 0);
+            if (live && i < BV * PPV && apiece_ok && gd < a.GD && gh < a.GH && gw < a.GW) {
+                const size_t vox = ((size_t)(n * a.GD + gd) * a.GH + gh) * a.GW + gw;
+                pa[j] = *(const uint4*)(a.pa + (vox * a.apitch + ac0) * esz);
+                amask |= 1u << j;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int i = tid + NTHR * j;
+            const int hv = i / PPV;
+            const int hw = hv % HW;
+            const int t = hv / HW;
+            const int hh = t % HH;
+            const int hd = t / HH;
+            const int gd = d0 * SD - PD + hd, gh = h0 * S - PHW + hh, gw = w0 * S - PHW + hw;
+            pb[j] = make_uint4(0, 0, 0, 0);
+            if (live && i < HV * PPV && bpiece_ok && gd >= 0 && gd < a.BD && gh >= 0 && gh < a.BH && gw >= 0 && gw < a.BW) {
+                const size_t vox = ((size_t)(n * a.BD + gd) * a.BH + gh) * a.BW + gw;
+                pb[j] = *(const uint4*)(a.pb + (vox * a.bpitch + bc0) * esz);
+                bmask |= 1u << j;
+            }
+        }
+    };
+    auto commit = [&]() {
+        float sc[PE], sh[PE], sl[PE];
+        if (a_xf) {
+#pragma unroll
+            for (int e = 0; e < PE; ++e) { sc[e] = lxf[piece * PE + e]; sh[e] = lxf[CT + piece * PE + e]; sl[e] = lxf[2 * CT + piece * PE + e]; }
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int i = tid + NTHR * j;
+            if (i < BV * PPV) {
+                uint4 v = pa[j];
+                if (a_xf && ((amask >> j) & 1u)) v = apply_xf16<T, PE>(v, sc, sh, sl);
+                ((uint4*)at)[i] = v;
+            }
+        }
+        if (b_xf) {
+#pragma unroll
+            for (int e = 0; e < PE; ++e) { sc[e] = lxf[3 * CT + piece * PE + e]; sh[e] = lxf[4 * CT + piece * PE + e]; sl[e] = lxf[5 * CT + piece * PE + e]; }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int i = tid + NTHR * j;
+            if (i < HV * PPV) {
+                uint4 v = pb[j];
+                if (b_xf && ((bmask >> j) & 1u)) v = apply_xf16<T, PE>(v, sc, sh, sl);
+                ((uint4*)bt)[i] = v;
+            }
+        }
+    };
+
+    const int G = gridDim.x;
+    int brick = blockIdx.x;
+    if (brick < a.nbricks) {
+        issue(brick, true);
+        __syncthreads();             // lxf visible
+        commit();
+        __syncthreads();
+        while (true) {
+            const int nbrick = brick + G;
+            const bool have_next = nbrick < a.nbricks;
+            issue(have_next ? nbrick : brick, have_next);
+
+#pragma unroll 1
+            for (int h = 0; h < KSPLIT; ++h) {
+#pragma unroll 2
+                for (int kk = 0; kk < NKG / KSPLIT; ++kk) {
+                    const int kg = h * (NKG / KSPLIT) + kk;
+                    const int q0 = kg * KUNIT;
+                    const int lw0 = q0 % TW;
+                    const int t = q0 / TW;
+                    const int lh = t % TH;
+                    const int ld = t / TH;
+                    const int hbase = ((ld * SD * HH + lh * S) * HW + lw0 * S) * RS;
+                    if constexpr (sizeof(T) == 2) {
+                        typedef bf16x4 __attribute__((address_space(3))) * lp;
+                        const char* ap = at + q0 * RS + a_lane;
+                        bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap));
+                        bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap + 4 * RS));
+                        bf16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                        for (int t2 = 0; t2 < IPW; ++t2) {
+                            if (ihalf[t2] == h) {
+                                const char* bp = bt + hbase + tapoff[t2] + b_lane;
+                                bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp));
+                                bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp + 4 * S * RS));
+                                bf16x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t2], 0, 0, 0);
+                            }
+                        }
+                    } else {
+                        const float af = *(const float*)(at + q0 * RS + a_lane);
+#pragma unroll
+                        for (int t2 = 0; t2 < IPW; ++t2) {
+                            if (ihalf[t2] == h) {
+                                const float bf = *(const float*)(bt + hbase + tapoff[t2] + b_lane);
+                                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[t2], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+            if (!have_next) break;
+            __syncthreads();
+            commit();
+            __syncthreads();
+            brick = nbrick;
+        }
+    }
+
+    // ---- flush once per block ------------------------------------------------------------------------------------------
+    const int jj = jt * CT + (lane & 31);
+    const int hf = lane >> 5;
+    if (jj < a.CB) {
+#pragma unroll
+        for (int t2 = 0; t2 < IPW; ++t2) {
+            const int item = wave + NWAVE * t2;
+            if (item < NITEM) {
+                const int tap = item % TAPS;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ii = it * CT + (e & 3) + 8 * (e >> 2) + 4 * hf;
+                    if (ii < a.CA) atomicAdd(a.ws + ((size_t)tap * a.CA + ii) * a.CB + jj, acc[t2][e]);
+                }
+            }
+        }
+    }
+}
+
 // ws[tap][i][j] -> dw[i][j][tap]
 __global__ void k_wgrad_finalize(const float* __restrict__ ws, int rows, int cols, int taps, float* __restrict__ dw) {
     const size_t total = (size_t)rows * cols * taps;
@@ -1234,12 +1464,12 @@ bool biu_mfma_convt_wgrad_ok(const biu_act* x, const biu_act* dy, int kd, int dt
     return (kd == 1 || kd == 2) && wgrad_chan_ok(x->c, dy->c) && wgrad_ptrs_ok(x, dy, dtype);
 }
 
-template <typename T, int KD, int KHW, int S, int TD, int TH, int TW>
+template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int KSPLIT>
 static int launch_wgrad(WgradArgs a, hipStream_t st) {
     constexpr int SD = (KD == 1) ? 1 : S;
     constexpr int HV = ((TD - 1) * SD + KD) * ((TH - 1) * S + KHW) * ((TW - 1) * S + KHW);
     constexpr int BV = TD * TH * TW;
-    const size_t lds_bytes = (size_t)(HV + BV) * 32 * sizeof(T);
+    const size_t lds_bytes = (size_t)(HV + BV) * 32 * sizeof(T) + 6 * 32 * sizeof(float);
     a.nbd = (a.GD + TD - 1) / TD;
     a.nbh = (a.GH + TH - 1) / TH;
     a.nbw = (a.GW + TW - 1) / TW;
@@ -1247,19 +1477,19 @@ static int launch_wgrad(WgradArgs a, hipStream_t st) {
     const int nit = (a.CA + 31) / 32;
     a.njt = (a.CB + 31) / 32;
     const int pairs = nit * a.njt;
-    int sk = (2048 + pairs - 1) / pairs;                 // aim at ~2048 blocks (2 per CU x 256 CUs x 4 rounds)
-    if (sk > a.nbricks) sk = a.nbricks;
-    if (sk < 1) sk = 1;
-    a.bricks_per_block = (a.nbricks + sk - 1) / sk;
-    sk = (a.nbricks + a.bricks_per_block - 1) / a.bricks_per_block;
-    auto kern = k_wgrad_mfma<T, KD, KHW, S, TD, TH, TW>;
+    int g = num_cus() / pairs;                            // persistent: about one block per CU in total
+    if (g < 1) g = 1;
+    if (g > a.nbricks) g = a.nbricks;
+    a.bricks_per_block = 0;
+    auto kern = k_wgrad_pipe<T, KD, KHW, S, TD, TH, TW, KSPLIT>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return biu_fail(BIU_ERR_LAUNCH, "wgrad_pipe: cannot reserve %zu bytes of LDS", lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(sk, pairs), dim3(256), lds_bytes, st, a);
-    BIU_CHECK_LAUNCH("wgrad_mfma");
+    hipLaunchKernelGGL(kern, dim3(g, pairs), dim3(512), lds_bytes, st, a);
+    BIU_CHECK_LAUNCH("wgrad_pipe");
     return BIU_OK;
 }
 
@@ -1287,8 +1517,8 @@ int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int
     const size_t need = wgrad_acc_bytes(a.CA, a.CB, taps);
     BIU_REQUIRE(ws_bytes >= need + (dbias ? biu_chan_sum_workspace(dy->c) : 0), BIU_ERR_WORKSPACE, "wgrad_mfma: workspace %zu too small", ws_bytes);
     if (hipMemsetAsync(ws, 0, need, st) != hipSuccess) return biu_fail(BIU_ERR_LAUNCH, "wgrad_mfma: memset failed");
-    if (dtype == BIU_BF16) rc = (kd == 3) ? launch_wgrad<bf16_t, 3, 3, 1, 4, 4, 16>(a, st) : launch_wgrad<bf16_t, 1, 3, 1, 1, 16, 16>(a, st);
-    else rc = (kd == 3) ? launch_wgrad<float, 3, 3, 1, 4, 4, 16>(a, st) : launch_wgrad<float, 1, 3, 1, 1, 16, 16>(a, st);
+    if (dtype == BIU_BF16) rc = (kd == 3) ? launch_wgrad<bf16_t, 3, 3, 1, 4, 4, 16, 2>(a, st) : launch_wgrad<bf16_t, 1, 3, 1, 1, 16, 16, 2>(a, st);
+    else rc = (kd == 3) ? launch_wgrad<float, 3, 3, 1, 4, 4, 16, 2>(a, st) : launch_wgrad<float, 1, 3, 1, 1, 16, 16, 2>(a, st);
     if (rc != BIU_OK) return rc;
     hipLaunchKernelGGL(k_wgrad_finalize, dim3(grid_for((i64)a.CA * a.CB * taps, 256, 2048)), dim3(256), 0, st, (const float*)ws,
                        a.CA, a.CB, taps, dw);
@@ -1313,8 +1543,8 @@ int biu_mfma_convt_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* d
     const size_t need = wgrad_acc_bytes(a.CA, a.CB, taps);
     BIU_REQUIRE(ws_bytes >= need + (dbias ? biu_chan_sum_workspace(dy->c) : 0), BIU_ERR_WORKSPACE, "convt_wgrad_mfma: workspace %zu too small", ws_bytes);
     if (hipMemsetAsync(ws, 0, need, st) != hipSuccess) return biu_fail(BIU_ERR_LAUNCH, "convt_wgrad_mfma: memset failed");
-    if (dtype == BIU_BF16) rc = (kd == 2) ? launch_wgrad<bf16_t, 2, 2, 2, 2, 4, 16>(a, st) : launch_wgrad<bf16_t, 1, 2, 2, 1, 8, 16>(a, st);
-    else rc = (kd == 2) ? launch_wgrad<float, 2, 2, 2, 2, 4, 16>(a, st) : launch_wgrad<float, 1, 2, 2, 1, 8, 16>(a, st);
+    if (dtype == BIU_BF16) rc = (kd == 2) ? launch_wgrad<bf16_t, 2, 2, 2, 2, 4, 16, 2>(a, st) : launch_wgrad<bf16_t, 1, 2, 2, 1, 8, 16, 4>(a, st);
+    else rc = (kd == 2) ? launch_wgrad<float, 2, 2, 2, 2, 4, 16, 2>(a, st) : launch_wgrad<float, 1, 2, 2, 1, 8, 16, 4>(a, st);
     if (rc != BIU_OK) return rc;
     hipLaunchKernelGGL(k_wgrad_finalize, dim3(grid_for((i64)a.CA * a.CB * taps, 256, 2048)), dim3(256), 0, st, (const float*)ws,
                        a.CA, a.CB, taps, dw);

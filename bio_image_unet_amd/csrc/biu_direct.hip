@@ -861,6 +861,7 @@ extern "C" int biu_xform_apply(const biu_act* x, const biu_xform* xf, const biu_
     BIU_REQUIRE(valid_act(x) && valid_act(out) && same_space(x, out) && x->c == out->c, BIU_ERR_SHAPE,
                 "xform_apply: shape mismatch");
     hipStream_t st = (hipStream_t)stream;
+    if (biu_rowvec_ok(x, dtype) && biu_rowvec_ok(out, dtype)) return biu_xform_apply_rv(x, xf, out, dtype, st);
     const int g = 16 / (int)dsize(dtype);
     bool ok = vec_ok(x, g, dtype) && vec_ok(out, g, dtype);
     EW_LAUNCH(k_xform_apply, nvox(x) * x->c, ok, dact(x), dxf(xf), dact(out));
@@ -904,6 +905,8 @@ extern "C" int biu_bn_bwd_apply(const biu_act* da, const biu_act* y, const float
     BIU_REQUIRE(valid_act(da) && valid_act(y) && valid_act(dy) && same_space(da, y) && same_space(da, dy) &&
                     da->c == y->c && dy->c == y->c, BIU_ERR_SHAPE, "bn_bwd_apply: shape mismatch");
     hipStream_t st = (hipStream_t)stream;
+    if (biu_rowvec_ok(da, dtype) && biu_rowvec_ok(y, dtype) && biu_rowvec_ok(dy, dtype))
+        return biu_bn_bwd_apply_rv(da, y, scale, shift, slope, coefA, coefB, coefC, dy, dtype, st);
     const int g = 16 / (int)dsize(dtype);
     bool ok = vec_ok(da, g, dtype) && vec_ok(y, g, dtype) && vec_ok(dy, g, dtype);
     EW_LAUNCH(k_bn_bwd_apply, nvox(y) * y->c, ok, dact(da), dact(y), DXf{scale, shift, slope}, coefA, coefB, coefC, dact(dy));
@@ -928,6 +931,7 @@ extern "C" int biu_maxpool_fwd(const biu_act* x, const biu_xform* xf, const biu_
     int pd = pool_window(x, out, "maxpool_fwd");
     if (!pd) return BIU_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    if (biu_rowvec_ok(x, dtype) && biu_rowvec_ok(out, dtype)) return biu_maxpool_fwd_rv(x, xf, out, pd, dtype, st);
     const int g = 16 / (int)dsize(dtype);
     bool ok = vec_ok(x, g, dtype) && vec_ok(out, g, dtype);
     EW_LAUNCH(k_maxpool_fwd, nvox(out) * out->c, ok, dact(x), dxf(xf), dact(out), pd);
@@ -941,6 +945,8 @@ extern "C" int biu_maxpool_bwd(const biu_act* x, const biu_xform* xf, const biu_
     int pd = pool_window(x, dout, "maxpool_bwd");
     if (!pd) return BIU_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    if (biu_rowvec_ok(x, dtype) && biu_rowvec_ok(dout, dtype) && biu_rowvec_ok(dx, dtype))
+        return biu_maxpool_bwd_rv(x, xf, dout, dx, pd, accumulate, dtype, st);
     const int g = 16 / (int)dsize(dtype);
     bool ok = vec_ok(x, g, dtype) && vec_ok(dout, g, dtype) && vec_ok(dx, g, dtype);
     EW_LAUNCH(k_maxpool_bwd, nvox(dout) * dout->c, ok, dact(x), dxf(xf), dact(dout), dact(dx), pd, accumulate);

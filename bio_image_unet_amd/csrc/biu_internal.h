@@ -56,3 +56,9 @@ bool biu_head_bwd_fused_ok(const biu_act* x, const biu_act* dx, int cout, int dt
 size_t biu_head_bwd_fused_workspace(int cin);
 int biu_head_bwd_fused(const biu_act* x, const biu_xform* xf, const float* w, int cout, const float* dl, const biu_act* dx, float* dw,
                        float* db, void* ws, size_t ws_bytes, int dtype, hipStream_t st);
+bool biu_rowvec_ok(const biu_act* a, int dtype);
+int biu_bn_bwd_apply_rv(const biu_act* da, const biu_act* y, const float* scale, const float* shift, const float* slope,
+                        const float* A, const float* B, const float* Cc, const biu_act* dy, int dtype, hipStream_t st);
+int biu_xform_apply_rv(const biu_act* x, const biu_xform* xf, const biu_act* out, int dtype, hipStream_t st);
+int biu_maxpool_fwd_rv(const biu_act* x, const biu_xform* xf, const biu_act* out, int pd, int dtype, hipStream_t st);
+int biu_maxpool_bwd_rv(const biu_act* x, const biu_xform* xf, const biu_act* dout, const biu_act* dx, int pd, int accumulate, int dtype, hipStream_t st);

@@ -40,10 +40,10 @@ __global__ __launch_bounds__(TPB) void k_conv_c1_fwd(DAct x, DXf xf, const float
         float acc[COUT];
 #pragma unroll
         for (int c = 0; c < COUT; ++c) acc[c] = ws[TAPS * COUT + c];
-#pragma unroll
+#pragma unroll 1
         for (int a = 0; a < KD; ++a) {
             const int id = p.d + a - KD / 2;
-#pragma unroll
+#pragma unroll 1
             for (int bb = 0; bb < 3; ++bb) {
                 const int ih = p.h + bb - 1;
 #pragma unroll
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(TPB) void k_conv_c1_fwd(DAct x, DXf xf, const float
 // Per-block partials -> fp64 merge (deterministic).
 // =====================================================================================================================
 template <typename T, int COUT, int KD, int TPW>
-__global__ void k_conv_c1_wgrad(DAct x, DXf xf, DAct dy, int co0, float* __restrict__ partial /* [nblk][TAPS*COUT] */) {
+__global__ __launch_bounds__(576) void k_conv_c1_wgrad(DAct x, DXf xf, DAct dy, int co0, float* __restrict__ partial /* [nblk][TAPS*COUT] */) {
     constexpr int TAPS = KD * 9;
     constexpr int G = 16 / sizeof(T);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -147,6 +147,152 @@ __global__ void k_c1_wgrad_finalize(const float* __restrict__ partial, int nblk,
     }
 }
 
+// ---- 4 voxels per thread (consecutive along W): every LDS weight read (4 channels, 16 B, broadcast) feeds 16 FMAs,
+//      and each input row of 6 values serves 3 taps x 4 voxels.  Needs W % 4 == 0.
+template <typename T, int COUT, int KD>
+__global__ __launch_bounds__(TPB) void k_conv_c1_fwd4(DAct x, DXf xf, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      DAct y, int co0) {
+    constexpr int TAPS = KD * 9;
+    __shared__ __attribute__((aligned(16))) float ws[TAPS * COUT + COUT];
+    for (int i = threadIdx.x; i < TAPS * COUT; i += TPB) {
+        const int tap = i / COUT, co = i % COUT;
+        ws[i] = w[(i64)(co0 + co) * TAPS + tap];
+    }
+    for (int i = threadIdx.x; i < COUT; i += TPB) ws[TAPS * COUT + i] = bias ? bias[co0 + i] : 0.f;
+    __syncthreads();
+    const float s = xf.scale ? xf.scale[0] : 1.f, b = xf.shift ? xf.shift[0] : 0.f, sl = xf.slope ? xf.slope[0] : 1.f;
+    const int W4 = y.w / 4;
+    const i64 total = (i64)y.n * y.d * y.h * W4;
+    for (i64 gidx = (i64)blockIdx.x * TPB + threadIdx.x; gidx < total; gidx += (i64)gridDim.x * TPB) {
+        i64 t = gidx;
+        const int w0 = (int)(t % W4) * 4; t /= W4;
+        const int ph = (int)(t % y.h); t /= y.h;
+        const int pdd = (int)(t % y.d);
+        const int pn = (int)(t / y.d);
+        float acc[4][COUT];
+#pragma unroll
+        for (int vx = 0; vx < 4; ++vx)
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) acc[vx][c] = ws[TAPS * COUT + c];
+#pragma unroll 1
+        for (int a = 0; a < KD; ++a) {        // rolled: a fully unrolled 27-tap body spills ~2 KB per lane
+            const int id = pdd + a - KD / 2;
+#pragma unroll 1
+            for (int bb = 0; bb < 3; ++bb) {
+                const int ih = ph + bb - 1;
+                const bool rowok = id >= 0 && id < x.d && ih >= 0 && ih < x.h;
+                float xr[6];
+                const i64 rowbase = (((i64)pn * x.d + id) * x.h + ih) * x.w;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int iw = w0 - 1 + k;
+                    float xv = 0.f;
+                    if (rowok && iw >= 0 && iw < x.w) {
+                        const float tt = fmaf(s, to_f(((const T*)x.p)[(rowbase + iw) * x.pitch]), b);
+                        xv = tt > 0.f ? tt : sl * tt;
+                    }
+                    xr[k] = xv;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float4* wr = (const float4*)(ws + ((a * 3 + bb) * 3 + c) * COUT);
+#pragma unroll
+                    for (int c4 = 0; c4 < COUT / 4; ++c4) {
+                        const float4 wv = wr[c4];
+#pragma unroll
+                        for (int vx = 0; vx < 4; ++vx) {
+                            const float xv = xr[vx + c];
+                            acc[vx][c4 * 4 + 0] = fmaf(xv, wv.x, acc[vx][c4 * 4 + 0]);
+                            acc[vx][c4 * 4 + 1] = fmaf(xv, wv.y, acc[vx][c4 * 4 + 1]);
+                            acc[vx][c4 * 4 + 2] = fmaf(xv, wv.z, acc[vx][c4 * 4 + 2]);
+                            acc[vx][c4 * 4 + 3] = fmaf(xv, wv.w, acc[vx][c4 * 4 + 3]);
+                        }
+                    }
+                }
+            }
+        }
+        const i64 v0 = (((i64)pn * y.d + pdd) * y.h + ph) * y.w + w0;
+        constexpr int G = 16 / sizeof(T);
+#pragma unroll
+        for (int vx = 0; vx < 4; ++vx) {
+            T* dst = (T*)y.p + (v0 + vx) * y.pitch + co0;
+#pragma unroll
+            for (int c = 0; c < COUT; c += G) {
+                Pack<T, G> o;
+#pragma unroll
+                for (int j = 0; j < G; ++j) o.v[j] = from_f<T>(acc[vx][c + j]);
+                *(Pack<T, G>*)(dst + c) = o;
+            }
+        }
+    }
+}
+
+// weight gradient, 4 voxels per lane: wave q owns taps [q*TPW, ...); acc[t][co] += sum_vx x[vx + tap] * dy[vx][co]
+template <typename T, int COUT, int KD, int TPW>
+__global__ __launch_bounds__(256) void k_conv_c1_wgrad4(DAct x, DXf xf, DAct dy, int co0, float* __restrict__ partial) {
+    constexpr int TAPS = KD * 9;
+    constexpr int G = 16 / sizeof(T);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tap0 = wave * TPW;
+    float acc[TPW][COUT];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[t][c] = 0.f;
+    const float s = xf.scale ? xf.scale[0] : 1.f, b = xf.shift ? xf.shift[0] : 0.f, sl = xf.slope ? xf.slope[0] : 1.f;
+    const int W4 = dy.w / 4;
+    const i64 total = (i64)dy.n * dy.d * dy.h * W4;
+    for (i64 gidx = (i64)blockIdx.x * 64 + lane; gidx < total; gidx += (i64)gridDim.x * 64) {
+        i64 tt_ = gidx;
+        const int w0 = (int)(tt_ % W4) * 4; tt_ /= W4;
+        const int ph = (int)(tt_ % dy.h); tt_ /= dy.h;
+        const int pdd = (int)(tt_ % dy.d);
+        const int pn = (int)(tt_ / dy.d);
+        const i64 v0 = (((i64)pn * dy.d + pdd) * dy.h + ph) * dy.w + w0;
+        float g[4][COUT];
+#pragma unroll
+        for (int vx = 0; vx < 4; ++vx) {
+            const T* src = (const T*)dy.p + (v0 + vx) * dy.pitch + co0;
+#pragma unroll
+            for (int c = 0; c < COUT; c += G) {
+                Pack<T, G> in = *(const Pack<T, G>*)(src + c);
+#pragma unroll
+                for (int j = 0; j < G; ++j) g[vx][c + j] = to_f(in.v[j]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int tap = tap0 + t;
+            if (tap < TAPS) {
+                const int a = tap / 9, bb = (tap / 3) % 3, c = tap % 3;
+                const int id = pdd + a - KD / 2, ih = ph + bb - 1;
+                const bool rowok = id >= 0 && id < x.d && ih >= 0 && ih < x.h;
+                const i64 rowbase = (((i64)pn * x.d + id) * x.h + ih) * x.w;
+#pragma unroll
+                for (int vx = 0; vx < 4; ++vx) {
+                    const int iw = w0 + vx + c - 1;
+                    float xv = 0.f;
+                    if (rowok && iw >= 0 && iw < x.w) {
+                        const float q = fmaf(s, to_f(((const T*)x.p)[(rowbase + iw) * x.pitch]), b);
+                        xv = q > 0.f ? q : sl * q;
+                    }
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) acc[t][co] = fmaf(xv, g[vx][co], acc[t][co]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tap = tap0 + t;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const float r = wave_sum(acc[t][co]);
+            if (lane == 0 && tap < TAPS) partial[(i64)blockIdx.x * (TAPS * COUT) + tap * COUT + co] = r;
+        }
+    }
+}
+
 #define C1_MAX_BLOCKS 2048
 
 static bool c1_ok(const biu_act* x, const biu_act* y, int kd, int kh, int kw, int dil, int dtype) {
@@ -163,9 +309,16 @@ static int c1_fwd_t(const biu_act* x, const biu_xform* xf, const float* w, const
     int co0 = 0;
     while (co0 < y->c) {
         const int rem = y->c - co0;
-        if (rem >= 32) { hipLaunchKernelGGL((k_conv_c1_fwd<T, 32, KD>), dim3(grid), dim3(TPB), 0, st, dact(x), dxf(xf), w, bias, dact(y), co0); co0 += 32; }
-        else if (rem >= 16) { hipLaunchKernelGGL((k_conv_c1_fwd<T, 16, KD>), dim3(grid), dim3(TPB), 0, st, dact(x), dxf(xf), w, bias, dact(y), co0); co0 += 16; }
-        else { hipLaunchKernelGGL((k_conv_c1_fwd<T, 8, KD>), dim3(grid), dim3(TPB), 0, st, dact(x), dxf(xf), w, bias, dact(y), co0); co0 += 8; }
+        if (rem >= 32 && y->w % 4 != 0) { hipLaunchKernelGGL((k_conv_c1_fwd<T, 32, KD>), dim3(grid), dim3(TPB), 0, st, dact(x), dxf(xf), w, bias, dact(y), co0); co0 += 32; }
+        else if (rem >= 16) {
+            if (y->w % 4 == 0) hipLaunchKernelGGL((k_conv_c1_fwd4<T, 16, KD>), dim3(grid_for(nvox(y) / 4, TPB, 16384)), dim3(TPB), 0, st, dact(x), dxf(xf), w, bias, dact(y), co0);
+            else hipLaunchKernelGGL((k_conv_c1_fwd<T, 16, KD>), dim3(grid), dim3(TPB), 0, st, dact(x), dxf(xf), w, bias, dact(y), co0);
+            co0 += 16;
+        } else {
+            if (y->w % 4 == 0) hipLaunchKernelGGL((k_conv_c1_fwd4<T, 8, KD>), dim3(grid_for(nvox(y) / 4, TPB, 16384)), dim3(TPB), 0, st, dact(x), dxf(xf), w, bias, dact(y), co0);
+            else hipLaunchKernelGGL((k_conv_c1_fwd<T, 8, KD>), dim3(grid), dim3(TPB), 0, st, dact(x), dxf(xf), w, bias, dact(y), co0);
+            co0 += 8;
+        }
     }
     BIU_CHECK_LAUNCH("conv_c1_fwd");
     return BIU_OK;
@@ -188,15 +341,17 @@ static int c1_wgrad_t(const biu_act* x, const biu_xform* xf, const biu_act* dy, 
     while (co0 < dy->c) {
         const int rem = dy->c - co0;
         int chunk;
-        if (rem >= 32) {
+        if (rem >= 32 && dy->w % 4 != 0) {
             constexpr int TPW = 3; chunk = 32;
             hipLaunchKernelGGL((k_conv_c1_wgrad<T, 32, KD, TPW>), dim3(nblk), dim3(64 * ((TAPS + TPW - 1) / TPW)), 0, st, dact(x), dxf(xf), dact(dy), co0, (float*)ws);
         } else if (rem >= 16) {
             constexpr int TPW = 7; chunk = 16;
-            hipLaunchKernelGGL((k_conv_c1_wgrad<T, 16, KD, TPW>), dim3(nblk), dim3(64 * ((TAPS + TPW - 1) / TPW)), 0, st, dact(x), dxf(xf), dact(dy), co0, (float*)ws);
+            if (dy->w % 4 == 0) hipLaunchKernelGGL((k_conv_c1_wgrad4<T, 16, KD, TPW>), dim3(nblk), dim3(64 * ((TAPS + TPW - 1) / TPW)), 0, st, dact(x), dxf(xf), dact(dy), co0, (float*)ws);
+            else hipLaunchKernelGGL((k_conv_c1_wgrad<T, 16, KD, TPW>), dim3(nblk), dim3(64 * ((TAPS + TPW - 1) / TPW)), 0, st, dact(x), dxf(xf), dact(dy), co0, (float*)ws);
         } else {
             constexpr int TPW = 9; chunk = 8;
-            hipLaunchKernelGGL((k_conv_c1_wgrad<T, 8, KD, TPW>), dim3(nblk), dim3(64 * ((TAPS + TPW - 1) / TPW)), 0, st, dact(x), dxf(xf), dact(dy), co0, (float*)ws);
+            if (dy->w % 4 == 0) hipLaunchKernelGGL((k_conv_c1_wgrad4<T, 8, KD, TPW>), dim3(nblk), dim3(64 * ((TAPS + TPW - 1) / TPW)), 0, st, dact(x), dxf(xf), dact(dy), co0, (float*)ws);
+            else hipLaunchKernelGGL((k_conv_c1_wgrad<T, 8, KD, TPW>), dim3(nblk), dim3(64 * ((TAPS + TPW - 1) / TPW)), 0, st, dact(x), dxf(xf), dact(dy), co0, (float*)ws);
         }
         BIU_CHECK_LAUNCH("conv_c1_wgrad");
         hipLaunchKernelGGL(k_c1_wgrad_finalize, dim3(TAPS * chunk), dim3(TPB), 0, st, (const float*)ws, nblk, TAPS, chunk, co0, dw);
@@ -504,4 +659,154 @@ int biu_head_bwd_fused(const biu_act* x, const biu_xform* xf, const float* w, in
         }
     });
     return BIU_OK;
+}
+
+// =====================================================================================================================
+// element-wise passes with a FIXED channel group per thread: the per-channel vectors (BatchNorm coefficients, producer
+// transform) are loaded once into registers instead of once per element; every access is a 16-byte vector.
+// thread t -> (channel group g = t % cg, voxel row = t / cg); rows stride over the voxels.
+// =====================================================================================================================
+struct RowPlan { int cg, rows, grid; };
+static RowPlan row_plan(i64 total_vox, int C, int PE) {
+    RowPlan p;
+    p.cg = C / PE;
+    p.rows = TPB / p.cg;
+    i64 want = (total_vox + (i64)p.rows * 8 - 1) / ((i64)p.rows * 8);        // ~8 voxels per thread
+    if (want < 1) want = 1;
+    if (want > 4096) want = 4096;
+    p.grid = (int)want;
+    return p;
+}
+bool biu_rowvec_ok(const biu_act* a, int dtype) {
+    const int pe = 16 / (int)dsize(dtype);
+    return a->c % pe == 0 && a->c / pe <= TPB && vec_ok(a, pe, dtype);
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void k_bn_bwd_apply_rv(DAct da, DAct y, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ slope, const float* __restrict__ A,
+                                                         const float* __restrict__ B, const float* __restrict__ Cc, DAct dy, int cg, int rows) {
+    constexpr int PE = 16 / sizeof(T);
+    const int g = threadIdx.x % cg, row = threadIdx.x / cg;
+    if (row >= rows) return;
+    const int c0 = g * PE;
+    float sc[PE], sh[PE], sl[PE], ka[PE], kb[PE], kc[PE];
+#pragma unroll
+    for (int j = 0; j < PE; ++j) {
+        sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; sl[j] = slope ? slope[c0 + j] : 1.f;
+        ka[j] = A[c0 + j]; kb[j] = B[c0 + j]; kc[j] = Cc[c0 + j];
+    }
+    const i64 total = (i64)y.n * y.d * y.h * y.w;
+    for (i64 v = (i64)blockIdx.x * rows + row; v < total; v += (i64)gridDim.x * rows) {
+        Pack<T, PE> gq = *(const Pack<T, PE>*)((const T*)da.p + v * da.pitch + c0);
+        Pack<T, PE> yy = *(const Pack<T, PE>*)((const T*)y.p + v * y.pitch + c0);
+        Pack<T, PE> o;
+#pragma unroll
+        for (int j = 0; j < PE; ++j) {
+            const float yv = to_f(yy.v[j]);
+            const float t = fmaf(sc[j], yv, sh[j]);
+            const float dz = to_f(gq.v[j]) * (t > 0.f ? 1.f : sl[j]);
+            o.v[j] = from_f<T>(fmaf(ka[j], dz, fmaf(kb[j], yv, kc[j])));
+        }
+        *(Pack<T, PE>*)((T*)dy.p + v * dy.pitch + c0) = o;
+    }
+}
+int biu_bn_bwd_apply_rv(const biu_act* da, const biu_act* y, const float* scale, const float* shift, const float* slope,
+                        const float* A, const float* B, const float* Cc, const biu_act* dy, int dtype, hipStream_t st) {
+    BIU_DISPATCH_DTYPE(dtype, {
+        constexpr int PE = 16 / sizeof(T);
+        RowPlan p = row_plan(nvox(y), y->c, PE);
+        hipLaunchKernelGGL(k_bn_bwd_apply_rv<T>, dim3(p.grid), dim3(TPB), 0, st, dact(da), dact(y), scale, shift, slope, A, B, Cc, dact(dy), p.cg, p.rows);
+    });
+    BIU_CHECK_LAUNCH("bn_bwd_apply_rv");
+    return BIU_OK;
+}
+
+template <typename T, int MODE>   // MODE 0: out = T(x) ; MODE 1: max-pool fwd ; MODE 2: max-pool bwd
+__global__ __launch_bounds__(TPB) void k_pool_rv(DAct x, DXf xf, DAct small, DAct dx, int pd, int accumulate, int cg, int rows) {
+    constexpr int PE = 16 / sizeof(T);
+    const int g = threadIdx.x % cg, row = threadIdx.x / cg;
+    if (row >= rows) return;
+    const int c0 = g * PE;
+    float sc[PE], sh[PE], sl[PE];
+#pragma unroll
+    for (int j = 0; j < PE; ++j) {
+        sc[j] = xf.scale ? xf.scale[c0 + j] : 1.f;
+        sh[j] = xf.shift ? xf.shift[c0 + j] : 0.f;
+        sl[j] = xf.slope ? xf.slope[c0 + j] : 1.f;
+    }
+    const i64 total = (i64)small.n * small.d * small.h * small.w;
+    for (i64 ov = (i64)blockIdx.x * rows + row; ov < total; ov += (i64)gridDim.x * rows) {
+        if (MODE == 0) {
+            Pack<T, PE> in = *(const Pack<T, PE>*)((const T*)x.p + ov * x.pitch + c0);
+            Pack<T, PE> o;
+#pragma unroll
+            for (int j = 0; j < PE; ++j) {
+                const float t = fmaf(sc[j], to_f(in.v[j]), sh[j]);
+                o.v[j] = from_f<T>(t > 0.f ? t : sl[j] * t);
+            }
+            *(Pack<T, PE>*)((T*)small.p + ov * small.pitch + c0) = o;
+            continue;
+        }
+        const Vox4 p = unvox4(ov, small.d, small.h, small.w);
+        float best[PE];
+        int arg[PE];
+#pragma unroll
+        for (int j = 0; j < PE; ++j) { best[j] = -INFINITY; arg[j] = 0; }
+        for (int a = 0; a < pd; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const i64 iv = (((i64)p.n * x.d + p.d * pd + a) * x.h + p.h * 2 + b) * x.w + p.w * 2 + c;
+                    Pack<T, PE> in = *(const Pack<T, PE>*)((const T*)x.p + iv * x.pitch + c0);
+                    const int code = (a * 2 + b) * 2 + c;
+#pragma unroll
+                    for (int j = 0; j < PE; ++j) {
+                        float t = fmaf(sc[j], to_f(in.v[j]), sh[j]);
+                        t = t > 0.f ? t : sl[j] * t;
+                        if (t > best[j] || t != t) { best[j] = t; arg[j] = code; }
+                    }
+                }
+        if (MODE == 1) {
+            Pack<T, PE> o;
+#pragma unroll
+            for (int j = 0; j < PE; ++j) o.v[j] = from_f<T>(best[j]);
+            *(Pack<T, PE>*)((T*)small.p + ov * small.pitch + c0) = o;
+        } else {
+            Pack<T, PE> gq = *(const Pack<T, PE>*)((const T*)small.p + ov * small.pitch + c0);     // small = dout here
+            for (int a = 0; a < pd; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const i64 iv = (((i64)p.n * x.d + p.d * pd + a) * x.h + p.h * 2 + b) * x.w + p.w * 2 + c;
+                        const int code = (a * 2 + b) * 2 + c;
+                        T* dst = (T*)dx.p + iv * dx.pitch + c0;
+                        Pack<T, PE> o;
+                        if (accumulate) o = *(Pack<T, PE>*)dst;
+#pragma unroll
+                        for (int j = 0; j < PE; ++j) {
+                            const float r = (arg[j] == code) ? to_f(gq.v[j]) : 0.f;
+                            o.v[j] = from_f<T>(accumulate ? to_f(o.v[j]) + r : r);
+                        }
+                        *(Pack<T, PE>*)dst = o;
+                    }
+        }
+    }
+}
+template <int MODE>
+static int pool_rv_launch(const biu_act* x, const biu_xform* xf, const biu_act* small, const biu_act* dx, int pd, int accumulate, int dtype, hipStream_t st) {
+    BIU_DISPATCH_DTYPE(dtype, {
+        constexpr int PE = 16 / sizeof(T);
+        RowPlan p = row_plan(nvox(small), x->c, PE);
+        hipLaunchKernelGGL((k_pool_rv<T, MODE>), dim3(p.grid), dim3(TPB), 0, st, dact(x), dxf(xf), dact(small), dx ? dact(dx) : dact(x), pd, accumulate, p.cg, p.rows);
+    });
+    BIU_CHECK_LAUNCH("pool_rv");
+    return BIU_OK;
+}
+int biu_xform_apply_rv(const biu_act* x, const biu_xform* xf, const biu_act* out, int dtype, hipStream_t st) { return pool_rv_launch<0>(x, xf, out, nullptr, 1, 0, dtype, st); }
+int biu_maxpool_fwd_rv(const biu_act* x, const biu_xform* xf, const biu_act* out, int pd, int dtype, hipStream_t st) { return pool_rv_launch<1>(x, xf, out, nullptr, pd, 0, dtype, st); }
+int biu_maxpool_bwd_rv(const biu_act* x, const biu_xform* xf, const biu_act* dout, const biu_act* dx, int pd, int accumulate, int dtype, hipStream_t st) {
+    return pool_rv_launch<2>(x, xf, dout, dx, pd, accumulate, dtype, st);
 }
