@@ -1,1 +1,3 @@
+from ..losses import *          # noqa: F401,F403
 from ..models import Siam_UNet  # noqa: F401
+from ..workflow import TrainerSiam as Trainer   # noqa: F401

@@ -1,1 +1,3 @@
-from ..models import UNet3D  # noqa: F401
+from ..losses import *          # noqa: F401,F403
+from ..models import UNet3D     # noqa: F401
+from ..workflow import Trainer3D as Trainer   # noqa: F401
