@@ -404,7 +404,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_pipe(ConvArgs a) {
         return o;
     };
     auto stage_vox = [&](const Org& o, int j) -> int {
-        const int i = tid + NTHR * j;
+        int tq = tid;
+        asm volatile("" : "+v"(tq));     // opaque: keeps LICM from hoisting (and spilling) the 3*NPA halo coordinates
+        const int i = tq + NTHR * j;
         const int hv = i / CKP;
         const int hw = hv % HW;
         const int t = hv / HW;
