@@ -958,6 +958,7 @@ extern "C" int biu_nearest_down_fwd(const biu_act* x, const biu_xform* xf, const
     int pd = pool_window(x, out, "nearest_down_fwd");
     if (!pd) return BIU_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    if (biu_rowvec_ok(x, dtype) && biu_rowvec_ok(out, dtype)) return biu_nearest_rv(0, x, xf, out, pd, 0, dtype, st);
     const int g = 16 / (int)dsize(dtype);
     bool ok = vec_ok(x, g, dtype) && vec_ok(out, g, dtype);
     EW_LAUNCH(k_nearest_down_fwd, nvox(out) * out->c, ok, dact(x), dxf(xf), dact(out), pd);
@@ -969,6 +970,7 @@ extern "C" int biu_nearest_down_bwd(const biu_act* dout, const biu_act* dx, int 
     int pd = pool_window(dx, dout, "nearest_down_bwd");
     if (!pd) return BIU_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    if (biu_rowvec_ok(dout, dtype) && biu_rowvec_ok(dx, dtype)) return biu_nearest_rv(3, dout, nullptr, dx, pd, accumulate, dtype, st);
     const int g = 16 / (int)dsize(dtype);
     bool ok = vec_ok(dout, g, dtype) && vec_ok(dx, g, dtype);
     EW_LAUNCH(k_nearest_down_bwd, nvox(dx) * dx->c, ok, dact(dout), dact(dx), pd, accumulate);
@@ -980,6 +982,7 @@ extern "C" int biu_nearest_up_fwd(const biu_act* x, const biu_xform* xf, const b
     int pd = pool_window(out, x, "nearest_up_fwd");
     if (!pd) return BIU_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    if (biu_rowvec_ok(x, dtype) && biu_rowvec_ok(out, dtype)) return biu_nearest_rv(1, x, xf, out, pd, 0, dtype, st);
     const int g = 16 / (int)dsize(dtype);
     bool ok = vec_ok(x, g, dtype) && vec_ok(out, g, dtype);
     EW_LAUNCH(k_nearest_up_fwd, nvox(out) * out->c, ok, dact(x), dxf(xf), dact(out), pd);
@@ -991,6 +994,7 @@ extern "C" int biu_nearest_up_bwd(const biu_act* dout, const biu_act* dx, int ac
     int pd = pool_window(dout, dx, "nearest_up_bwd");
     if (!pd) return BIU_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    if (biu_rowvec_ok(dout, dtype) && biu_rowvec_ok(dx, dtype)) return biu_nearest_rv(2, dout, nullptr, dx, pd, accumulate, dtype, st);
     const int g = 16 / (int)dsize(dtype);
     bool ok = vec_ok(dout, g, dtype) && vec_ok(dx, g, dtype);
     EW_LAUNCH(k_nearest_up_bwd, nvox(dx) * dx->c, ok, dact(dout), dact(dx), pd, accumulate);

@@ -810,3 +810,90 @@ int biu_maxpool_fwd_rv(const biu_act* x, const biu_xform* xf, const biu_act* out
 int biu_maxpool_bwd_rv(const biu_act* x, const biu_xform* xf, const biu_act* dout, const biu_act* dx, int pd, int accumulate, int dtype, hipStream_t st) {
     return pool_rv_launch<2>(x, xf, dout, dx, pd, accumulate, dtype, st);
 }
+
+// nearest-neighbour resampling with register-resident transform (MultiOutputUnet3D's interpolation path)
+// MODE 0: down fwd  out[o] = T(x[2o])        (iterates over out)
+// MODE 1: up fwd    out[o] = T(x[o/2])       (iterates over out)
+// MODE 2: up bwd    dx[i] (+)= sum of the children of i in dout (iterates over dx)
+// MODE 3: down bwd  dx[i] (+)= dout[i/2] if every coordinate of i is even else 0   (iterates over dx)
+template <typename T, int MODE>
+__global__ __launch_bounds__(TPB) void k_nearest_rv(DAct src, DXf xf, DAct dst, int pd, int accumulate, int cg, int rows) {
+    constexpr int PE = 16 / sizeof(T);
+    const int g = threadIdx.x % cg, row = threadIdx.x / cg;
+    if (row >= rows) return;
+    const int c0 = g * PE;
+    float sc[PE], sh[PE], sl[PE];
+#pragma unroll
+    for (int j = 0; j < PE; ++j) {
+        sc[j] = xf.scale ? xf.scale[c0 + j] : 1.f;
+        sh[j] = xf.shift ? xf.shift[c0 + j] : 0.f;
+        sl[j] = xf.slope ? xf.slope[c0 + j] : 1.f;
+    }
+    const i64 total = (i64)dst.n * dst.d * dst.h * dst.w;
+    for (i64 ov = (i64)blockIdx.x * rows + row; ov < total; ov += (i64)gridDim.x * rows) {
+        const Vox4 p = unvox4(ov, dst.d, dst.h, dst.w);
+        T* dp = (T*)dst.p + ov * dst.pitch + c0;
+        Pack<T, PE> o;
+        if (MODE == 0 || MODE == 1) {
+            const i64 iv = (MODE == 0) ? ((((i64)p.n * src.d + p.d * pd) * src.h + p.h * 2) * src.w + p.w * 2)
+                                       : ((((i64)p.n * src.d + p.d / pd) * src.h + p.h / 2) * src.w + p.w / 2);
+            Pack<T, PE> in = *(const Pack<T, PE>*)((const T*)src.p + iv * src.pitch + c0);
+#pragma unroll
+            for (int j = 0; j < PE; ++j) {
+                const float t = fmaf(sc[j], to_f(in.v[j]), sh[j]);
+                o.v[j] = from_f<T>(t > 0.f ? t : sl[j] * t);
+            }
+        } else {
+            float acc[PE];
+#pragma unroll
+            for (int j = 0; j < PE; ++j) acc[j] = 0.f;
+            if (MODE == 2) {
+                for (int a = 0; a < pd; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const i64 iv = (((i64)p.n * src.d + p.d * pd + a) * src.h + p.h * 2 + b) * src.w + p.w * 2 + c;
+                            Pack<T, PE> in = *(const Pack<T, PE>*)((const T*)src.p + iv * src.pitch + c0);
+#pragma unroll
+                            for (int j = 0; j < PE; ++j) acc[j] += to_f(in.v[j]);
+                        }
+            } else {
+                const bool hit = (p.d % pd == 0) && (p.h % 2 == 0) && (p.w % 2 == 0);
+                if (accumulate && !hit) continue;
+                if (hit) {
+                    const i64 iv = (((i64)p.n * src.d + p.d / pd) * src.h + p.h / 2) * src.w + p.w / 2;
+                    Pack<T, PE> in = *(const Pack<T, PE>*)((const T*)src.p + iv * src.pitch + c0);
+#pragma unroll
+                    for (int j = 0; j < PE; ++j) acc[j] = to_f(in.v[j]);
+                }
+            }
+            if (accumulate) {
+                Pack<T, PE> old = *(Pack<T, PE>*)dp;
+#pragma unroll
+                for (int j = 0; j < PE; ++j) acc[j] += to_f(old.v[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < PE; ++j) o.v[j] = from_f<T>(acc[j]);
+        }
+        *(Pack<T, PE>*)dp = o;
+    }
+}
+template <int MODE>
+static int nearest_rv_launch(const biu_act* src, const biu_xform* xf, const biu_act* dst, int pd, int accumulate, int dtype, hipStream_t st) {
+    BIU_DISPATCH_DTYPE(dtype, {
+        constexpr int PE = 16 / sizeof(T);
+        RowPlan p = row_plan(nvox(dst), dst->c, PE);
+        hipLaunchKernelGGL((k_nearest_rv<T, MODE>), dim3(p.grid), dim3(TPB), 0, st, dact(src), dxf(xf), dact(dst), pd, accumulate, p.cg, p.rows);
+    });
+    BIU_CHECK_LAUNCH("nearest_rv");
+    return BIU_OK;
+}
+int biu_nearest_rv(int mode, const biu_act* src, const biu_xform* xf, const biu_act* dst, int pd, int accumulate, int dtype, hipStream_t st) {
+    switch (mode) {
+        case 0: return nearest_rv_launch<0>(src, xf, dst, pd, accumulate, dtype, st);
+        case 1: return nearest_rv_launch<1>(src, xf, dst, pd, accumulate, dtype, st);
+        case 2: return nearest_rv_launch<2>(src, xf, dst, pd, accumulate, dtype, st);
+        default: return nearest_rv_launch<3>(src, xf, dst, pd, accumulate, dtype, st);
+    }
+}
