@@ -48,6 +48,7 @@ SIGNATURES = {
     "biu_conv_bwd_data": (_I, [_A, _P, _P, _I, _I, _I, _I, _A, _I, _I, _P]),
     "biu_conv_bwd_weight_workspace": (_Z, [_I, _I, _I, _I, _I, _I]),
     "biu_conv_bwd_weight": (_I, [_A, _X, _A, _I, _I, _I, _I, _P, _P, _P, _Z, _I, _P]),
+    "biu_conv_bwd_weight_bn": (_I, [_A, _X, _A, _A, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _Z, _I, _P]),
     "biu_bn_stats": (_I, [_A, _P, C.POINTER(C.c_int), _I, _P]),
     "biu_bn_finalize": (_I, [_P, _I, _I, _D, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "biu_bn_eval_affine": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),

@@ -100,6 +100,28 @@ extern "C" int biu_conv_bwd_weight(const biu_act* x, const biu_xform* xf, const 
     return biu_conv_bwd_weight_direct(x, xf, dy, kd, kh, kw, dilation, dw, dbias, dtype, (hipStream_t)stream);
 }
 
+// Weight gradient with the BatchNorm(+LeakyReLU) backward of the conv's own output fused in: `da` holds d loss / d a on entry
+// and d loss / d y on return (in place), exactly what biu_bn_bwd_apply would have produced.
+extern "C" int biu_conv_bwd_weight_bn(const biu_act* x, const biu_xform* xf, const biu_act* da, const biu_act* y,
+                                      const float* scale, const float* shift, const float* slope, const float* coefA,
+                                      const float* coefB, const float* coefC, int kd, int kh, int kw, int dilation,
+                                      float* dw, void* ws, size_t ws_bytes, int dtype, biu_stream stream) {
+    BIU_REQUIRE(conv_args_ok(x, da, kd, kh, kw, dilation) && valid_act(y) && same_space(y, da) && y->c == da->c, BIU_ERR_SHAPE,
+                "conv_bwd_weight_bn: extents differ");
+    BIU_REQUIRE(dw && scale && shift && coefA && coefB && coefC, BIU_ERR_SHAPE, "conv_bwd_weight_bn: null pointer");
+    const size_t es = dsize(dtype);
+    const bool yok = ((uintptr_t)y->p % 16) == 0 && ((size_t)y->pitch * es) % 16 == 0;
+    if (!disabled("conv_wgrad") && !disabled("wgrad_bn") && yok && biu_mfma_wgrad_ok(x, da, kd, kh, kw, dilation, dtype)) {
+        BIU_REQUIRE(ws && ws_bytes >= biu_mfma_wgrad_workspace(x->c, da->c, kd, kh, kw, dtype), BIU_ERR_WORKSPACE,
+                    "conv_bwd_weight_bn: workspace too small");
+        BnBwdFuse bn{y, scale, shift, slope, coefA, coefB, coefC};
+        return biu_mfma_wgrad(x, xf, da, kd, kh, kw, dw, nullptr, ws, ws_bytes, dtype, (hipStream_t)stream, &bn);
+    }
+    int rc = biu_bn_bwd_apply(da, y, scale, shift, slope, coefA, coefB, coefC, da, dtype, stream);
+    if (rc != BIU_OK) return rc;
+    return biu_conv_bwd_weight(x, xf, da, kd, kh, kw, dilation, dw, nullptr, ws, ws_bytes, dtype, stream);
+}
+
 // ---- ConvTranspose k2 s2 ---------------------------------------------------------------------------
 extern "C" size_t biu_convt_packed_bytes(int kind, int cin, int cout, int kd, int dtype) {
     return biu_mfma_convt_packed_bytes(kind, cin, cout, kd, dtype);

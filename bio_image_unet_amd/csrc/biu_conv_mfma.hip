@@ -81,7 +81,7 @@ struct ConvArgs {
 
 #ifdef BIU_DIAG
 extern "C" unsigned long long* biu_diag_buffer = nullptr;
-#define DIAG_STAMP(k) do { if (a.diag && tid == 0) { unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(a.diag + (k), now_ - tprev_); tprev_ = now_; } } while (0)
+#define DIAG_STAMP(k) do { if (a.diag && tid == 0) { unsigned long long now_ = __builtin_readcyclecounter(); dsum_[k] += now_ - tprev_; tprev_ = now_; } } while (0)
 #else
 #define DIAG_STAMP(k) do { } while (0)
 #endif
@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
 
 #ifdef BIU_DIAG
     unsigned long long tprev_ = __builtin_readcyclecounter();
+    unsigned long long dsum_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     constexpr int WPF = 3;                            // weight fragments are prefetched WPF (tap, k-step) steps ahead
     constexpr int NSTEP = TAPS * SPC;
@@ -489,6 +490,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pipe(ConvArgs a) {
 
 #ifdef BIU_DIAG
     unsigned long long tprev_ = __builtin_readcyclecounter();
+    unsigned long long dsum_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     int k = 0;
     int brick = brick_of(0);
@@ -631,7 +633,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_pipe(ConvArgs a) {
         }
         DIAG_STAMP(3);
 #ifdef BIU_DIAG
-        if (a.diag && tid == 0) atomicAdd(a.diag + 7, 1ull);
+        dsum_[7] += 1;
+        if (!have_next && a.diag && tid == 0) { for (int q_ = 0; q_ < 8; ++q_) atomicAdd(a.diag + q_, dsum_[q_]); }
 #endif
         if (!have_next) break;
         __syncthreads();                     // everyone is done reading the tile
@@ -996,6 +999,12 @@ struct WgradArgs {
     int nbd, nbh, nbw, nbricks;
     int njt;             // number of 32-wide j tiles
     int bricks_per_block;
+    // optional fused BatchNorm backward on the plain operand: A = dy is computed on the fly from (da = pa, y = py):
+    //   dz = da * T'(scale*y + shift),  dy = cA*dz + cB*y + cC ; blocks with jt == 0 also write dy back over da
+    const char* py;
+    int ypitch;
+    const float* bn_scale; const float* bn_shift; const float* bn_slope;
+    const float* bn_cA; const float* bn_cB; const float* bn_cC;
 };
 
 template <typename T, int PE>
@@ -1229,7 +1238,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     char* at = (char*)lds;                           // [BV][CT]
     char* bt = at + BV * RS;                         // [HV][CT]
-    float* lxf = (float*)(bt + HV * RS);             // [2][3][CT] transform constants of this block's A / B channel tiles
+    float* lxf = (float*)(bt + HV * RS);             // [6][CT] transform constants of the A / B channel tiles, then [6][CT] BN-bwd
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int it = blockIdx.y / a.njt, jt = blockIdx.y % a.njt;
@@ -1238,6 +1247,17 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     const int ac0 = it * CT + piece * PE, bc0 = jt * CT + piece * PE;
     const bool apiece_ok = ac0 < a.CA, bpiece_ok = bc0 < a.CB;
     const bool a_xf = a.as_ != nullptr, b_xf = a.bs_ != nullptr;
+    const bool bn_fused = a.py != nullptr;
+    if (tid < CT && bn_fused) {
+        const int ca = it * CT + tid;
+        const bool ok = ca < a.CA;
+        lxf[6 * CT + tid] = ok ? a.bn_scale[ca] : 1.f;
+        lxf[7 * CT + tid] = ok ? a.bn_shift[ca] : 0.f;
+        lxf[8 * CT + tid] = (ok && a.bn_slope) ? a.bn_slope[ca] : 1.f;
+        lxf[9 * CT + tid] = ok ? a.bn_cA[ca] : 0.f;
+        lxf[10 * CT + tid] = ok ? a.bn_cB[ca] : 0.f;
+        lxf[11 * CT + tid] = ok ? a.bn_cC[ca] : 0.f;
+    }
     if (tid < CT) {
         const int ca = it * CT + tid, cb = jt * CT + tid;
         lxf[0 * CT + tid] = (a_xf && ca < a.CA) ? a.as_[ca] : 1.f;
@@ -1275,7 +1295,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         b_lane = (lane >> 5) * S * RS + (lane & 31) * 4;
     }
 
-    uint4 pa[NA], pb[NB];
+    uint4 pa[NA], pb[NB], pyv[NA];
+    unsigned avox[NA];                               // voxel index of each A piece (for the dy write-back)
     unsigned amask = 0, bmask = 0;
     auto issue = [&](int brick, bool live) {
         int b = brick;
@@ -1285,9 +1306,11 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         const int n = b / a.nbd;
         const int d0 = bd * TD, h0 = bh * TH, w0 = bw * TW;
         amask = bmask = 0;
+        int tq = tid;
+        asm volatile("" : "+v"(tq));     // opaque: keeps LICM from hoisting (and spilling) the per-piece coordinates
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            const int i = tid + NTHR * j;
+            const int i = tq + NTHR * j;
             const int q = i / PPV;
             const int lw = q % TW;
             const int t = q / TW;
@@ -1298,12 +1321,16 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
             if (live && i < BV * PPV && apiece_ok && gd < a.GD && gh < a.GH && gw < a.GW) {
                 const size_t vox = ((size_t)(n * a.GD + gd) * a.GH + gh) * a.GW + gw;
                 pa[j] = *(const uint4*)(a.pa + (vox * a.apitch + ac0) * esz);
+                if (bn_fused) {
+                    pyv[j] = *(const uint4*)(a.py + (vox * a.ypitch + ac0) * esz);
+                    avox[j] = (unsigned)vox;
+                }
                 amask |= 1u << j;
             }
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int i = tid + NTHR * j;
+            const int i = tq + NTHR * j;
             const int hv = i / PPV;
             const int hw = hv % HW;
             const int t = hv / HW;
@@ -1323,6 +1350,43 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         if (a_xf) {
 #pragma unroll
             for (int e = 0; e < PE; ++e) { sc[e] = lxf[piece * PE + e]; sh[e] = lxf[CT + piece * PE + e]; sl[e] = lxf[2 * CT + piece * PE + e]; }
+        }
+        if (bn_fused) {
+            // BatchNorm + LeakyReLU backward of this thread's channel piece, in two sweeps so that only three of the six
+            // coefficient vectors are live at a time:  dz = da * T'(scale*y + shift) ;  dy = cA*dz + cB*y + cC
+            {
+                float ks[PE], kh[PE], kl[PE];
+#pragma unroll
+                for (int e = 0; e < PE; ++e) { ks[e] = lxf[6 * CT + piece * PE + e]; kh[e] = lxf[7 * CT + piece * PE + e]; kl[e] = lxf[8 * CT + piece * PE + e]; }
+#pragma unroll
+                for (int j = 0; j < NA; ++j) {
+                    if ((amask >> j) & 1u) {
+                        float g[PE], yy[PE];
+                        F::unpack(pa[j], g);
+                        F::unpack(pyv[j], yy);
+#pragma unroll
+                        for (int e = 0; e < PE; ++e) g[e] *= (fmaf(ks[e], yy[e], kh[e]) > 0.f ? 1.f : kl[e]);
+                        pa[j] = F::pack(g);          // dz parked in the storage type between the two sweeps (one extra bf16 rounding)
+                    }
+                }
+            }
+            {
+                float ka[PE], kb[PE], kc[PE];
+#pragma unroll
+                for (int e = 0; e < PE; ++e) { ka[e] = lxf[9 * CT + piece * PE + e]; kb[e] = lxf[10 * CT + piece * PE + e]; kc[e] = lxf[11 * CT + piece * PE + e]; }
+#pragma unroll
+                for (int j = 0; j < NA; ++j) {
+                    if ((amask >> j) & 1u) {
+                        float g[PE], yy[PE];
+                        F::unpack(pa[j], g);
+                        F::unpack(pyv[j], yy);
+#pragma unroll
+                        for (int e = 0; e < PE; ++e) g[e] = fmaf(ka[e], g[e], fmaf(kb[e], yy[e], kc[e]));
+                        pa[j] = F::pack(g);
+                        if (jt == 0) *(uint4*)(const_cast<char*>(a.pa) + ((size_t)avox[j] * a.apitch + ac0) * esz) = pa[j];    // dy replaces da
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
@@ -1472,7 +1536,7 @@ static int launch_wgrad(WgradArgs a, hipStream_t st) {
     constexpr int SD = (KD == 1) ? 1 : S;
     constexpr int HV = ((TD - 1) * SD + KD) * ((TH - 1) * S + KHW) * ((TW - 1) * S + KHW);
     constexpr int BV = TD * TH * TW;
-    const size_t lds_bytes = (size_t)(HV + BV) * 32 * sizeof(T) + 6 * 32 * sizeof(float);
+    const size_t lds_bytes = (size_t)(HV + BV) * 32 * sizeof(T) + 12 * 32 * sizeof(float);
     a.nbd = (a.GD + TD - 1) / TD;
     a.nbh = (a.GH + TH - 1) / TH;
     a.nbw = (a.GW + TW - 1) / TW;
@@ -1506,8 +1570,16 @@ static int wgrad_xf(const biu_xform* xf, const float** s, const float** b, const
 }
 
 int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, int kh, int kw, float* dw, float* dbias,
-                   void* ws, size_t ws_bytes, int dtype, hipStream_t st) {
+                   void* ws, size_t ws_bytes, int dtype, hipStream_t st, const BnBwdFuse* bn) {
     WgradArgs a;
+    if (bn) {
+        a.py = (const char*)bn->y->p; a.ypitch = bn->y->pitch;
+        a.bn_scale = bn->scale; a.bn_shift = bn->shift; a.bn_slope = bn->slope;
+        a.bn_cA = bn->cA; a.bn_cB = bn->cB; a.bn_cC = bn->cC;
+    } else {
+        a.py = nullptr; a.ypitch = 0;
+        a.bn_scale = a.bn_shift = a.bn_slope = a.bn_cA = a.bn_cB = a.bn_cC = nullptr;
+    }
     a.pa = (const char*)dy->p;  a.apitch = dy->pitch;  a.CA = dy->c;      // plain operand: dy  (rows i = co)
     a.pb = (const char*)x->p;   a.bpitch = x->pitch;   a.CB = x->c;       // tapped operand: x (cols j = ci)
     a.ws = (float*)ws;
@@ -1533,6 +1605,8 @@ int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int
 int biu_mfma_convt_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, float* dw, float* dbias, void* ws,
                          size_t ws_bytes, int dtype, hipStream_t st) {
     WgradArgs a;
+    a.py = nullptr; a.ypitch = 0;
+    a.bn_scale = a.bn_shift = a.bn_slope = a.bn_cA = a.bn_cB = a.bn_cC = nullptr;
     a.pa = (const char*)x->p;   a.apitch = x->pitch;   a.CA = x->c;       // plain operand: x on the coarse grid (rows i = ci)
     a.pb = (const char*)dy->p;  a.bpitch = dy->pitch;  a.CB = dy->c;      // tapped operand: dy on the fine grid (cols j = co)
     a.ws = (float*)ws;

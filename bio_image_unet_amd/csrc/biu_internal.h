@@ -28,8 +28,12 @@ int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, con
 int biu_mfma_conv_bricks(const biu_act* y, int kd);
 size_t biu_mfma_wgrad_workspace(int cin, int cout, int kd, int kh, int kw, int dtype);
 bool biu_mfma_wgrad_ok(const biu_act* x, const biu_act* dy, int kd, int kh, int kw, int dilation, int dtype);
+struct BnBwdFuse {            // BatchNorm(+LeakyReLU) backward fused into the weight-gradient loader
+    const biu_act* y;
+    const float *scale, *shift, *slope, *cA, *cB, *cC;
+};
 int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, int kh, int kw, float* dw,
-                   float* dbias, void* ws, size_t ws_bytes, int dtype, hipStream_t st);
+                   float* dbias, void* ws, size_t ws_bytes, int dtype, hipStream_t st, const BnBwdFuse* bn = nullptr);
 
 size_t biu_mfma_convt_packed_bytes(int kind, int cin, int cout, int kd, int dtype);
 int biu_mfma_convt_pack(int kind, const float* w, int cin, int cout, int kd, int dtype, void* packed, hipStream_t st);

@@ -219,15 +219,15 @@ class ConvBlockNode(Node):
         check(lib.biu_bn_bwd_finalize(_ptr(eng.partial), nblk.value, cout, float(y.nvox), scale, _ptr(self.save_mean),
                                       _ptr(self.save_invstd), _ptr(dgamma), _ptr(dbeta), _ptr(A), _ptr(B), _ptr(Cc), st),
               "bn_bwd_finalize")
-        check(lib.biu_bn_bwd_apply(y.g(), y.a(), scale, shift, slope, _ptr(A), _ptr(B), _ptr(Cc), y.g(), eng.dtype, st),
-              "bn_bwd_apply")
         dw = eng.new_grad(self.conv.weight)
         # d loss / d conv-bias: the bias is removed again by the batch mean, so sum_v dy == 0 identically
         # (A*S1 + B*M*mean + C*M cancels term by term); the reference's value is pure rounding noise (~1e-8).
         # Emit the exact zero instead of spending a pass over dy on it.
         db = torch.zeros_like(self.conv.bias) if self.conv.bias is not None else None
-        check(lib.biu_conv_bwd_weight(self.xin.a(), self.xin.xf(), y.g(), self.kd, self.kh, self.kw, self.dil, _ptr(dw),
-                                      None, _ptr(eng.ws), eng.ws_bytes, eng.dtype, st), "conv_bwd_weight")
+        # BatchNorm+LeakyReLU backward (da -> dy, in place) rides inside the weight-gradient kernel's tile loader
+        check(lib.biu_conv_bwd_weight_bn(self.xin.a(), self.xin.xf(), y.g(), y.a(), scale, shift, slope, _ptr(A), _ptr(B),
+                                         _ptr(Cc), self.kd, self.kh, self.kw, self.dil, _ptr(dw), _ptr(eng.ws), eng.ws_bytes,
+                                         eng.dtype, st), "conv_bwd_weight_bn")
         eng.add_grad(self.conv.weight, dw)
         if db is not None:
             eng.add_grad(self.conv.bias, db)
@@ -630,10 +630,9 @@ class _NetFn(torch.autograd.Function):
             head_grads.append(h.dlogits(gl, ga) if (gl is not None or ga is not None) else None)
         grads = eng.backward(head_grads)
         dxs = eng.input_grads()
-        pg = []
-        for p in eng.params:
-            g = grads.get(p)
-            pg.append(g)
+        pg = [grads.pop(p, None) for p in eng.params]
+        eng.grads = {}              # sole owner is now autograd: AccumulateGrad can take the tensors without copying
+        del grads
         return (None, None, None, *dxs, *pg)
 
 

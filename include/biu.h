@@ -102,6 +102,15 @@ int biu_conv_bwd_weight(const biu_act* x, const biu_xform* xf, const biu_act* dy
                         int kd, int kh, int kw, int dilation,
                         float* dw, float* dbias, void* ws, size_t ws_bytes, int dtype, biu_stream stream);
 
+/* Weight gradient with the BatchNorm+LeakyReLU backward of the conv's own output fused into its tile loader:
+ * on entry `da` = d loss / d a (a = T(y)); on return it holds d loss / d y (what biu_bn_bwd_apply would write), and
+ * dw is the weight gradient w.r.t. that dy.  coefA/B/C come from biu_bn_bwd_finalize.  (The conv bias gradient is
+ * identically zero in front of a train-mode BatchNorm and is not produced.)                                          */
+int biu_conv_bwd_weight_bn(const biu_act* x, const biu_xform* xf, const biu_act* da, const biu_act* y,
+                           const float* scale, const float* shift, const float* slope, const float* coefA,
+                           const float* coefB, const float* coefC, int kd, int kh, int kw, int dilation,
+                           float* dw, void* ws, size_t ws_bytes, int dtype, biu_stream stream);
+
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm (training: batch statistics) + LeakyReLU(0.1)                          [K3, K4]
  * replaces nn.BatchNorm2d/3d + nn.LeakyReLU: unet/unet.py:57-58, unet3d/unet3d.py:55-56

@@ -53,8 +53,9 @@ def main():
         ws = torch.empty(max(lib.biu_conv_bwd_weight_workspace(cin, cout, kd, 3, 3, code), 16), dtype=torch.uint8, device="cuda")
         dw = torch.empty_like(wt)
         fl = 2.0 * n * d * h * w * (27 if nd == 3 else 9) * cin * cout
+        noxf = os.environ.get("BENCH_NOXF") == "1"
         calls = {
-            "fwd": lambda: lib.biu_conv_fwd(C.byref(ax), C.byref(xf), P(wt), P(pk0), P(bias), kd, 3, 3, 1, C.byref(ay), code, st),
+            "fwd": lambda: lib.biu_conv_fwd(C.byref(ax), None if noxf else C.byref(xf), P(wt), P(pk0), P(bias), kd, 3, 3, 1, C.byref(ay), code, st),
             "dgrad": lambda: lib.biu_conv_bwd_data(C.byref(ady), P(wt), P(pk1), kd, 3, 3, 1, C.byref(adx), 0, code, st),
             "wgrad": lambda: lib.biu_conv_bwd_weight(C.byref(ax), C.byref(xf), C.byref(ady), kd, 3, 3, 1, P(dw), None, P(ws), ws.numel(), code, st),
         }
