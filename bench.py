@@ -106,7 +106,7 @@ def call_cost(eng, api, label):
     node = next((n for n in eng.nodes if n.label == label.split(":")[0]), None)
     if node is None:
         return 0.0, 0.0
-    if isinstance(node, E.ConvBlockNode) and api in ("biu_conv_fwd", "biu_conv_bwd_data", "biu_conv_bwd_weight"):
+    if isinstance(node, E.ConvBlockNode) and api in ("biu_conv_fwd", "biu_conv_fwd_stats", "biu_conv_bwd_data", "biu_conv_bwd_weight", "biu_conv_bwd_weight_bn"):
         taps = node.kd * node.kh * node.kw
         v = node.y.nvox
         return 2.0 * v * taps * node.xin.c * node.y.c, float(v) * (node.xin.c + node.y.c) * esz
