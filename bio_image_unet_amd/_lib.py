@@ -46,6 +46,9 @@ SIGNATURES = {
     "biu_conv_fwd_stats_floats": (_Z, [_A, _I]),
     "biu_conv_fwd_stats": (_I, [_A, _X, _P, _P, _P, _I, _I, _I, _I, _A, _P, _Z, C.POINTER(C.c_int), _I, _P]),
     "biu_conv_bwd_data": (_I, [_A, _P, _P, _I, _I, _I, _I, _A, _I, _I, _P]),
+    "biu_bwd_data_bnred_floats": (_Z, [_A, _I, _I]),
+    "biu_conv_bwd_data_bnred": (_I, [_A, _P, _P, _I, _I, _I, _I, _A, _A, _P, _P, _P, _P, _P, _P, _Z, C.POINTER(C.c_int), _I, _P]),
+    "biu_convt_bwd_data_bnred": (_I, [_A, _P, _P, _I, _A, _A, _P, _P, _P, _P, _P, _P, _Z, C.POINTER(C.c_int), _I, _P]),
     "biu_conv_bwd_weight_workspace": (_Z, [_I, _I, _I, _I, _I, _I]),
     "biu_conv_bwd_weight": (_I, [_A, _X, _A, _I, _I, _I, _I, _P, _P, _P, _Z, _I, _P]),
     "biu_conv_bwd_weight_bn": (_I, [_A, _X, _A, _A, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _Z, _I, _P]),

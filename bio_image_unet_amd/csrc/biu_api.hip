@@ -77,6 +77,61 @@ extern "C" int biu_conv_bwd_data(const biu_act* dy, const float* w, const void* 
     return biu_conv_bwd_data_direct(dy, w, kd, kh, kw, dilation, dx, accumulate, dtype, (hipStream_t)stream);
 }
 
+// Data gradient + the BatchNorm-backward sums of the block that produced the tensor whose gradient is written (dx is that
+// block's d loss / d a, y_up its raw conv output): saves the separate biu_bn_bwd_reduce pass.  Only valid when this call
+// writes the COMPLETE gradient (accumulate == 0 and no later accumulation into dx).
+extern "C" size_t biu_bwd_data_bnred_floats(const biu_act* dx, int kd, int transposed) {
+    size_t a = (size_t)BIU_BN_MAX_PARTIALS * dx->c * 2;
+    size_t b = (size_t)(transposed ? biu_mfma_convt_dgrad_bricks(dx, kd) : biu_mfma_conv_bricks(dx, kd == 3 ? 3 : 1)) * dx->c * 2;
+    return a > b ? a : b;
+}
+extern "C" int biu_conv_bwd_data_bnred(const biu_act* dy, const float* w, const void* packed, int kd, int kh, int kw, int dilation,
+                                       const biu_act* dx, const biu_act* y_up, const float* scale, const float* shift,
+                                       const float* slope, const float* mean, const float* invstd, float* partial,
+                                       size_t partial_floats, int* nblk, int dtype, biu_stream stream) {
+    BIU_REQUIRE(conv_args_ok(dy, dx, kd, kh, kw, dilation) && valid_act(y_up) && same_space(y_up, dx) && y_up->c == dx->c, BIU_ERR_SHAPE,
+                "conv_bwd_data_bnred: extents differ");
+    BIU_REQUIRE(w && scale && shift && mean && invstd && partial && nblk, BIU_ERR_SHAPE, "conv_bwd_data_bnred: null pointer");
+    const size_t es = dsize(dtype);
+    const bool yok = ((uintptr_t)y_up->p % 16) == 0 && ((size_t)y_up->pitch * es) % 16 == 0;
+    if (packed && yok && !disabled("conv_dgrad") && !disabled("dgrad_bnred") && biu_mfma_conv_ok(dy, dx, kd, kh, kw, dilation, dtype)) {
+        const int nb = biu_mfma_conv_bricks(dx, kd);
+        if ((size_t)nb * dx->c * 2 <= partial_floats) {
+            BnRedFuse red{y_up, scale, shift, slope, mean, invstd};
+            int rc = biu_mfma_conv(dy, nullptr, packed, nullptr, kd, kh, kw, dx, 0, partial, dtype, (hipStream_t)stream, &red);
+            if (rc == BIU_OK) *nblk = nb;
+            return rc;
+        }
+    }
+    int rc = biu_conv_bwd_data(dy, w, packed, kd, kh, kw, dilation, dx, 0, dtype, stream);
+    if (rc != BIU_OK) return rc;
+    BIU_REQUIRE(partial_floats >= (size_t)BIU_BN_MAX_PARTIALS * dx->c * 2, BIU_ERR_WORKSPACE, "conv_bwd_data_bnred: partial buffer too small");
+    return biu_bn_bwd_reduce(dx, y_up, scale, shift, slope, mean, invstd, partial, nblk, dtype, stream);
+}
+extern "C" int biu_convt_bwd_data_bnred(const biu_act* dy, const float* w, const void* packed, int kd, const biu_act* dx,
+                                        const biu_act* y_up, const float* scale, const float* shift, const float* slope,
+                                        const float* mean, const float* invstd, float* partial, size_t partial_floats, int* nblk,
+                                        int dtype, biu_stream stream) {
+    BIU_REQUIRE(valid_act(dx) && valid_act(dy) && w && biu_convt_shapes_ok(dx, dy, kd) && valid_act(y_up) && same_space(y_up, dx) &&
+                    y_up->c == dx->c, BIU_ERR_SHAPE, "convt_bwd_data_bnred: extents differ");
+    BIU_REQUIRE(scale && shift && mean && invstd && partial && nblk, BIU_ERR_SHAPE, "convt_bwd_data_bnred: null pointer");
+    const size_t es = dsize(dtype);
+    const bool yok = ((uintptr_t)y_up->p % 16) == 0 && ((size_t)y_up->pitch * es) % 16 == 0;
+    if (packed && yok && !disabled("convt_dgrad") && !disabled("dgrad_bnred") && biu_mfma_convt_ok(1, dx, dy, kd, dtype)) {
+        const int nb = biu_mfma_convt_dgrad_bricks(dx, kd);
+        if ((size_t)nb * dx->c * 2 <= partial_floats) {
+            BnRedFuse red{y_up, scale, shift, slope, mean, invstd};
+            int rc = biu_mfma_convt_dgrad(dy, packed, kd, dx, 0, dtype, (hipStream_t)stream, partial, &red);
+            if (rc == BIU_OK) *nblk = nb;
+            return rc;
+        }
+    }
+    int rc = biu_convt_bwd_data(dy, w, packed, kd, dx, 0, dtype, stream);
+    if (rc != BIU_OK) return rc;
+    BIU_REQUIRE(partial_floats >= (size_t)BIU_BN_MAX_PARTIALS * dx->c * 2, BIU_ERR_WORKSPACE, "convt_bwd_data_bnred: partial buffer too small");
+    return biu_bn_bwd_reduce(dx, y_up, scale, shift, slope, mean, invstd, partial, nblk, dtype, stream);
+}
+
 extern "C" size_t biu_conv_bwd_weight_workspace(int cin, int cout, int kd, int kh, int kw, int dtype) {
     if (cin == 1 && kh == 3 && kw == 3) return biu_c1_wgrad_workspace(cout, kd);
     return biu_mfma_wgrad_workspace(cin, cout, kd, kh, kw, dtype);

@@ -76,7 +76,13 @@ struct ConvArgs {
     int wz_stride;       // packed-weight stride (uint4) between blockIdx.z slices
     int accumulate;
     unsigned long long* diag;   // BIU_DIAG builds only: per-phase cycle sums
-    float* bn_partial;          // optional [nbricks][Cout][2] (sum, sum of squares) of the stored output
+    float* bn_partial;          // optional [nbricks][Cout][2] per-brick partial sums of the epilogue reduction
+    // red_mode 0: (sum y, sum y^2) of the stored output (BatchNorm statistics of a forward conv)
+    // red_mode 1: the output is d loss / d a of an upstream conv block whose raw output is red_y: emit
+    //             (sum dz, sum dz * yhat), dz = da * T'(scale*y + shift), yhat = (y - mean) * invstd  (BatchNorm backward sums)
+    int red_mode;
+    const char* red_y; int red_ypitch;
+    const float* red_scale; const float* red_shift; const float* red_slope; const float* red_mean; const float* red_invstd;
 };
 
 #ifdef BIU_DIAG
@@ -319,7 +325,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base_unifo
                  : "memory");
 }
 
-template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP>
+template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP, bool RED>
 __global__ __launch_bounds__(512, 2) void k_conv_pipe(ConvArgs a) {
     using F = Frag<T>;
     constexpr int NTHR = 512, NWAVE = 8;
@@ -504,12 +510,16 @@ __global__ __launch_bounds__(512, 2) void k_conv_pipe(ConvArgs a) {
 
     while (true) {
         if (ch == 0) {
+            // accumulators start at the bias (lane holds channels 8*qq + 4*hf + i of each 32-channel tile)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int e = 0; e < 16; ++e) {
+                    const int co = (blockIdx.y * NT + nt) * 32 + 8 * (e >> 2) + 4 * hf + (e & 3);
+                    const float b0 = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[nt][mt][e] = 0.f;
+                    for (int mt = 0; mt < MT; ++mt) acc[nt][mt][e] = b0;
+                }
         }
         // next item
         int nbrick = brick, nch = ch + 1, nk = k;
@@ -548,85 +558,136 @@ __global__ __launch_bounds__(512, 2) void k_conv_pipe(ConvArgs a) {
         DIAG_STAMP(2);
         // ---- brick finished: epilogue ----------------------------------------------------------------------------------
         if (ch == nchunks - 1) {
+            // Every wave is done with the activation tile after this barrier, so its LDS doubles as the staging area:
+            // a wave turns its MFMA result (lane = voxel, registers = channels) into rows of 64 B of channels per
+            // voxel, 16 voxels at a time, and reads them back as 16-byte pieces -- the global stores (and the loads of
+            // the accumulate / BatchNorm-backward operands) are then 64 contiguous bytes per voxel instead of 8.
+            __syncthreads();
             const Org o = origin(brick);
             const bool want_stats = a.bn_partial != nullptr;
-            float s1[NT][16], s2[NT][16];
+            constexpr int CPP = 16 / (int)sizeof(T);     // channels per 16-byte piece: 8 (bf16) / 4 (fp32)
+            constexpr int NHB = 8 / CPP;                 // 64-byte channel blocks per 32-channel tile: 1 / 2
+            constexpr int QPB = 4 / NHB;                 // accumulator quads per block
+            constexpr int ROWB = 80;                     // staged row: 64 B + 16 B pad (spreads the rows over the banks)
+            char* stg = (char*)lact + wave * (16 * ROWB);
+            const int prow = lane >> 2, pcol = lane & 3; // read-back: lane -> (voxel row, piece)
+            float s1[NT][NHB][CPP], s2[NT][NHB][CPP];
             if (want_stats) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) s1[nt][e] = s2[nt][e] = 0.f;
+                    for (int hb = 0; hb < NHB; ++hb)
+#pragma unroll
+                        for (int e = 0; e < CPP; ++e) s1[nt][hb][e] = s2[nt][hb][e] = 0.f;
             }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int q = (wave * MT + mt) * 32 + r;
-                const int lw_ = q % TW;
-                const int t = q / TW;
-                const int lh = t % TH;
-                const int ld = t / TH;
-                const int gd = o.d0 + ld, gh = o.h0 + lh, gw = o.w0 + lw_;
-                const bool valid = gd < a.GD && gh < a.GH && gw < a.GW;
-                const int od = gd * a.osd + ((a.osd == 2) ? (int)(blockIdx.z >> 2) : 0);
-                const int oh = gh * a.osh + ((a.osh == 2) ? (int)((blockIdx.z >> 1) & 1) : 0);
-                const int ow = gw * a.osw + ((a.osw == 2) ? (int)(blockIdx.z & 1) : 0);
-                const size_t vox = ((size_t)(o.n * a.OD + od) * a.OH + oh) * a.OW + ow;
-                T* yrow = (T*)a.y + vox * a.ypitch;
+            for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
+                for (int hb = 0; hb < NHB; ++hb) {
+                    const int cl = (blockIdx.y * NT + nt) * 32 + hb * (4 * CPP) + pcol * CPP;   // this lane's channels
+                    const bool c_ok = cl < a.Cout;
+                    float rsc[CPP], rsh[CPP], rsl[CPP];
+                    if constexpr (RED) {
 #pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) {
-                        const int co = (blockIdx.y * NT + nt) * 32 + 8 * qq + 4 * hf;
-                        if (co >= a.Cout || !valid) continue;
-                        float ov[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) ov[i] = acc[nt][mt][4 * qq + i] + (a.bias ? a.bias[co + i] : 0.f);
-                        Pack<T, 4>* dst = (Pack<T, 4>*)(yrow + co);
-                        if (a.accumulate) {
-                            Pack<T, 4> old = *dst;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) ov[i] += (float)old.v[i];
+                        for (int e = 0; e < CPP; ++e) {
+                            rsc[e] = c_ok ? a.red_scale[cl + e] : 0.f;
+                            rsh[e] = c_ok ? a.red_shift[cl + e] : 0.f;
+                            rsl[e] = (c_ok && a.red_slope) ? a.red_slope[cl + e] : 1.f;
                         }
-                        Pack<T, 4> pk;
+                    }
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) pk.v[i] = (T)ov[i];
-                        *dst = pk;
-                        if (want_stats) {
+                    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                s1[nt][4 * qq + i] += ov[i];
-                                s2[nt][4 * qq + i] = fmaf(ov[i], ov[i], s2[nt][4 * qq + i]);
+                        for (int vh = 0; vh < 2; ++vh) {
+                            if ((r >> 4) == vh) {
+#pragma unroll
+                                for (int j = 0; j < QPB; ++j) {
+                                    Pack<T, 4> pk;
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) pk.v[i] = (T)acc[nt][mt][4 * (hb * QPB + j) + i];
+                                    *(Pack<T, 4>*)(stg + (r & 15) * ROWB + (8 * j + 4 * hf) * (int)sizeof(T)) = pk;
+                                }
+                            }
+                            asm volatile("" ::: "memory");       // same wave: LDS executes in order, only the compiler must not reorder
+                            uint4 piece = *(const uint4*)(stg + prow * ROWB + pcol * 16);
+                            asm volatile("" ::: "memory");
+                            const int q = (wave * MT + mt) * 32 + 16 * vh + prow;
+                            const int lw_ = q % TW;
+                            const int t = q / TW;
+                            const int lh = t % TH;
+                            const int ld = t / TH;
+                            const int gd = o.d0 + ld, gh = o.h0 + lh, gw = o.w0 + lw_;
+                            if (!(c_ok && gd < a.GD && gh < a.GH && gw < a.GW)) continue;
+                            const int od = gd * a.osd + ((a.osd == 2) ? (int)(blockIdx.z >> 2) : 0);
+                            const int oh = gh * a.osh + ((a.osh == 2) ? (int)((blockIdx.z >> 1) & 1) : 0);
+                            const int ow = gw * a.osw + ((a.osw == 2) ? (int)(blockIdx.z & 1) : 0);
+                            const size_t vox = ((size_t)(o.n * a.OD + od) * a.OH + oh) * a.OW + ow;
+                            uint4* dst = (uint4*)((T*)a.y + vox * a.ypitch + cl);
+                            float f[CPP];
+                            if (a.accumulate) {
+                                float g[CPP];
+                                F::unpack(piece, f);
+                                F::unpack(*dst, g);
+#pragma unroll
+                                for (int e = 0; e < CPP; ++e) f[e] += g[e];
+                                piece = F::pack(f);
+                            }
+                            *dst = piece;
+                            if (want_stats) {
+                                F::unpack(piece, f);          // statistics of the values as stored
+                                if constexpr (!RED) {
+#pragma unroll
+                                    for (int e = 0; e < CPP; ++e) {
+                                        s1[nt][hb][e] += f[e];
+                                        s2[nt][hb][e] = fmaf(f[e], f[e], s2[nt][hb][e]);
+                                    }
+                                } else {
+                                    float yv[CPP];
+                                    F::unpack(*(const uint4*)((const T*)a.red_y + vox * a.red_ypitch + cl), yv);
+#pragma unroll
+                                    for (int e = 0; e < CPP; ++e) {
+                                        const float tt = fmaf(rsc[e], yv[e], rsh[e]);
+                                        const float dz = f[e] * (tt > 0.f ? 1.f : rsl[e]);
+                                        s1[nt][hb][e] += dz;
+                                        s2[nt][hb][e] = fmaf(dz, yv[e], s2[nt][hb][e]);     // raw; centred when the partial is written
+                                    }
+                                }
                             }
                         }
                     }
                 }
             }
             if (want_stats) {
-                // reduce over the 32 voxel lanes of each half-wave, then over waves through LDS atomics
+                // lanes with the same (lane & 3) hold the same channels: reduce over the other 16, then over waves in LDS
                 if (tid < NT * 32 * 2) lred[tid] = 0.f;
                 __syncthreads();
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        float u = s1[nt][e], v = s2[nt][e];
+                    for (int hb = 0; hb < NHB; ++hb)
 #pragma unroll
-                        for (int off = 16; off > 0; off >>= 1) {
-                            u += __shfl_xor(u, off, 64);
-                            v += __shfl_xor(v, off, 64);
+                        for (int e = 0; e < CPP; ++e) {
+                            float u = s1[nt][hb][e], v = s2[nt][hb][e];
+#pragma unroll
+                            for (int off = 4; off < 64; off <<= 1) {
+                                u += __shfl_xor(u, off, 64);
+                                v += __shfl_xor(v, off, 64);
+                            }
+                            if (lane < 4) {
+                                const int cc = nt * 32 + hb * (4 * CPP) + lane * CPP + e;
+                                atomicAdd(&lred[cc * 2 + 0], u);
+                                atomicAdd(&lred[cc * 2 + 1], v);
+                            }
                         }
-                        if (r == 0) {
-                            const int cl = nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hf;
-                            atomicAdd(&lred[cl * 2 + 0], u);
-                            atomicAdd(&lred[cl * 2 + 1], v);
-                        }
-                    }
                 __syncthreads();
                 if (tid < NT * 32) {
                     const int co = blockIdx.y * NT * 32 + tid;
                     if (co < a.Cout) {
                         float* dstp = a.bn_partial + ((size_t)brick * a.Cout + co) * 2;
-                        dstp[0] = lred[tid * 2 + 0];
-                        dstp[1] = lred[tid * 2 + 1];
+                        const float l0 = lred[tid * 2 + 0], l1 = lred[tid * 2 + 1];
+                        dstp[0] = l0;
+                        if constexpr (RED) dstp[1] = a.red_invstd[co] * (l1 - a.red_mean[co] * l0);   // sum dz * yhat
+                        else dstp[1] = l1;
                     }
                 }
             }
@@ -729,8 +790,8 @@ static int num_cus() {
     return n;
 }
 
-template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP>
-static int launch_cfg(const ConvArgs& a0, int ntiles, int nz, hipStream_t st) {
+template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP, bool RED>
+static int launch_cfg_r(const ConvArgs& a0, int ntiles, int nz, hipStream_t st) {
     ConvArgs a = a0;
     constexpr int HV = BrickGeo<KD, KHW, S, TD, TH, TW>::HV;
     constexpr int PSV = cpad_planes(HV, CKP);
@@ -748,7 +809,7 @@ static int launch_cfg(const ConvArgs& a0, int ntiles, int nz, hipStream_t st) {
     if (g < 8) g = 8;
     if (g > nbricks) g = nbricks;
     dim3 grid((unsigned)g, (unsigned)gy, (unsigned)nz);
-    auto kern = k_conv_pipe<T, KD, KHW, S, TD, TH, TW, NT, CKP>;
+    auto kern = k_conv_pipe<T, KD, KHW, S, TD, TH, TW, NT, CKP, RED>;
     static size_t attr_set = 0;
     if (attr_set < lds_bytes) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
@@ -758,6 +819,17 @@ static int launch_cfg(const ConvArgs& a0, int ntiles, int nz, hipStream_t st) {
     hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, st, a);
     BIU_CHECK_LAUNCH("conv_pipe");
     return BIU_OK;
+}
+
+template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP>
+static int launch_cfg(const ConvArgs& a, int ntiles, int nz, hipStream_t st) {
+    // the BatchNorm-backward epilogue only exists for stride-1 3x3(x3) data gradients and stride-2 ConvT data gradients
+    if constexpr ((S == 1 && KHW == 3) || S == 2) {
+        if (a.red_mode) return launch_cfg_r<T, KD, KHW, S, TD, TH, TW, NT, CKP, true>(a, ntiles, nz, st);
+    } else {
+        if (a.red_mode) return biu_fail(BIU_ERR_UNSUPPORTED, "conv_pipe: no fused BatchNorm-backward epilogue for this kernel shape");
+    }
+    return launch_cfg_r<T, KD, KHW, S, TD, TH, TW, NT, CKP, false>(a, ntiles, nz, st);
 }
 
 // (a 4-tile weight slab no longer fits the double buffer next to the activation tile: two tiles is the widest block)
@@ -787,6 +859,12 @@ static int launch_conv(const ConvArgs& a, int kd, hipStream_t st) {
     return wide ? launch_cfg<T, 1, 3, 1, 1, 16, 32, 2, 2>(a, ntiles, 1, st) : launch_cfg<T, 1, 3, 1, 1, 32, 16, 2, 2>(a, ntiles, 1, st);
 }
 
+// number of bricks of a ConvTranspose data-gradient launch on the coarse tensor dx
+int biu_mfma_convt_dgrad_bricks(const biu_act* dx, int kd) {
+    const int td = (kd == 2) ? 2 : 1, th = (kd == 2) ? 8 : 16, tw = 16;
+    return dx->n * ((dx->d + td - 1) / td) * ((dx->h + th - 1) / th) * ((dx->w + tw - 1) / tw);
+}
+
 // number of bricks (= BatchNorm partial rows) the forward conv will produce for this output
 int biu_mfma_conv_bricks(const biu_act* y, int kd) {
     const int ntiles = (y->c + 31) / 32;
@@ -804,9 +882,15 @@ static int fill_xf(ConvArgs& a, const biu_xform* xf) {
 }
 
 int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, int kh, int kw,
-                  const biu_act* y, int accumulate, float* bn_partial, int dtype, hipStream_t st) {
+                  const biu_act* y, int accumulate, float* bn_partial, int dtype, hipStream_t st, const BnRedFuse* red) {
     ConvArgs a;
     a.bn_partial = bn_partial;
+    a.red_mode = 0; a.red_y = nullptr; a.red_ypitch = 0;
+    a.red_scale = a.red_shift = a.red_slope = a.red_mean = a.red_invstd = nullptr;
+    if (red) {
+        a.red_mode = 1; a.red_y = (const char*)red->y->p; a.red_ypitch = red->y->pitch;
+        a.red_scale = red->scale; a.red_shift = red->shift; a.red_slope = red->slope; a.red_mean = red->mean; a.red_invstd = red->invstd;
+    }
     a.x = (const char*)x->p;
     a.y = (char*)y->p;
     a.wpk = (const uint4*)packed;
@@ -924,6 +1008,8 @@ int biu_mfma_convt_fwd(const biu_act* x, const biu_xform* xf, const void* packed
                        int dtype, hipStream_t st) {
     ConvArgs a;
     a.bn_partial = nullptr;
+    a.red_mode = 0; a.red_y = nullptr; a.red_ypitch = 0;
+    a.red_scale = a.red_shift = a.red_slope = a.red_mean = a.red_invstd = nullptr;
     a.x = (const char*)x->p;
     a.y = (char*)y->p;
     a.wpk = (const uint4*)packed;
@@ -945,9 +1031,16 @@ int biu_mfma_convt_fwd(const biu_act* x, const biu_xform* xf, const void* packed
     return launch_convt_fwd<float>(a, kd, st);
 }
 
-int biu_mfma_convt_dgrad(const biu_act* dy, const void* packed, int kd, const biu_act* dx, int accumulate, int dtype, hipStream_t st) {
+int biu_mfma_convt_dgrad(const biu_act* dy, const void* packed, int kd, const biu_act* dx, int accumulate, int dtype, hipStream_t st,
+                         float* bn_partial, const BnRedFuse* red) {
     ConvArgs a;
-    a.bn_partial = nullptr;
+    a.bn_partial = red ? bn_partial : nullptr;
+    a.red_mode = 0; a.red_y = nullptr; a.red_ypitch = 0;
+    a.red_scale = a.red_shift = a.red_slope = a.red_mean = a.red_invstd = nullptr;
+    if (red) {
+        a.red_mode = 1; a.red_y = (const char*)red->y->p; a.red_ypitch = red->y->pitch;
+        a.red_scale = red->scale; a.red_shift = red->shift; a.red_slope = red->slope; a.red_mean = red->mean; a.red_invstd = red->invstd;
+    }
     a.x = (const char*)dy->p;
     a.y = (char*)dx->p;
     a.wpk = (const uint4*)packed;

@@ -23,8 +23,13 @@ size_t biu_mfma_packed_bytes(int kind, int cin, int cout, int kd, int kh, int kw
 int biu_mfma_pack(int kind, const float* w, int cin, int cout, int kd, int kh, int kw, int dtype, void* packed,
                   hipStream_t st);
 bool biu_mfma_conv_ok(const biu_act* x, const biu_act* y, int kd, int kh, int kw, int dilation, int dtype);
+struct BnRedFuse {            // BatchNorm-backward sums of the layer that PRODUCED the tensor whose gradient is being written
+    const biu_act* y;
+    const float *scale, *shift, *slope, *mean, *invstd;
+};
 int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, int kh, int kw,
-                  const biu_act* y, int accumulate, float* bn_partial, int dtype, hipStream_t st);
+                  const biu_act* y, int accumulate, float* bn_partial, int dtype, hipStream_t st, const BnRedFuse* red = nullptr);
+int biu_mfma_convt_dgrad_bricks(const biu_act* dx, int kd);
 int biu_mfma_conv_bricks(const biu_act* y, int kd);
 size_t biu_mfma_wgrad_workspace(int cin, int cout, int kd, int kh, int kw, int dtype);
 bool biu_mfma_wgrad_ok(const biu_act* x, const biu_act* dy, int kd, int kh, int kw, int dilation, int dtype);
@@ -40,7 +45,8 @@ int biu_mfma_convt_pack(int kind, const float* w, int cin, int cout, int kd, int
 bool biu_mfma_convt_ok(int kind, const biu_act* lo, const biu_act* hi, int kd, int dtype);
 int biu_mfma_convt_fwd(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, const biu_act* y,
                        int dtype, hipStream_t st);
-int biu_mfma_convt_dgrad(const biu_act* dy, const void* packed, int kd, const biu_act* dx, int accumulate, int dtype, hipStream_t st);
+int biu_mfma_convt_dgrad(const biu_act* dy, const void* packed, int kd, const biu_act* dx, int accumulate, int dtype, hipStream_t st,
+                         float* bn_partial = nullptr, const BnRedFuse* red = nullptr);
 bool biu_mfma_convt_wgrad_ok(const biu_act* x, const biu_act* dy, int kd, int dtype);
 int biu_mfma_convt_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, float* dw, float* dbias, void* ws,
                          size_t ws_bytes, int dtype, hipStream_t st);

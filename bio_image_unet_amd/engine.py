@@ -47,6 +47,8 @@ class Buf:
         self.slope = torch.ones(c, dtype=torch.float32, device=eng.device)
         self.leaves: Dict[Tuple[int, int], bool] = {}       # (c0, c) -> gradient written this backward?
         self.lazy: Dict[Tuple[int, int], bool] = {}         # (c0, c) -> transform is not the identity
+        self.ncons: Dict[Tuple[int, int], int] = {}         # (c0, c) -> number of nodes that read this slice
+        self.producer: Dict[Tuple[int, int], "Node"] = {}   # (c0, c) -> ConvBlockNode that wrote it (if any)
 
     def slice(self, c0: int, c: int, lazy: bool) -> "Act":
         self.leaves[(c0, c)] = False
@@ -124,6 +126,16 @@ class Act:
         for k in self.leaves:
             self.buf.leaves[k] = True
 
+    def consumed(self):
+        for k in self.leaves:
+            self.buf.ncons[k] = self.buf.ncons.get(k, 0) + 1
+
+    def sole_conv_block_producer(self):
+        """The ConvBlockNode whose output this Act is, if this Act is one slice with exactly one reader."""
+        if len(self.leaves) != 1 or self.buf.ncons.get(self.leaves[0], 0) != 1:
+            return None
+        return self.buf.producer.get(self.leaves[0])
+
 
 # ======================================================================================================
 # nodes
@@ -155,6 +167,11 @@ class ConvBlockNode(Node):
     def __init__(self, eng, seq: nn.Sequential, xin: Act, yout: Act):
         conv, bn = seq[0], seq[1]
         self.conv, self.bn, self.xin, self.y = conv, bn, xin, yout
+        xin.consumed()
+        if len(yout.leaves) == 1:
+            yout.buf.producer[yout.leaves[0]] = self
+        self.red_partial: Optional[torch.Tensor] = None      # BatchNorm-backward sums delivered by the consumer's dgrad
+        self.red_nblk = 0
         self.kd, self.kh, self.kw = _ksize(conv.weight)
         self.dil = int(conv.dilation[0])
         drop = seq[3] if len(seq) > 3 else None
@@ -212,11 +229,16 @@ class ConvBlockNode(Node):
         y, cout = self.y, self.y.c
         scale, shift, slope = _ptr(y.vec("scale")), _ptr(y.vec("shift")), _ptr(y.vec("slope"))
         nblk = C.c_int(0)
-        check(lib.biu_bn_bwd_reduce(y.g(), y.a(), scale, shift, slope, _ptr(self.save_mean), _ptr(self.save_invstd),
-                                    _ptr(eng.partial), C.byref(nblk), eng.dtype, st), "bn_bwd_reduce")
+        if self.red_nblk:
+            # the kernel that wrote d loss / d a (the reader's data gradient) already reduced (sum dz, sum dz*yhat)
+            partial, nblk.value, self.red_nblk = self.red_partial, self.red_nblk, 0
+        else:
+            partial = eng.partial
+            check(lib.biu_bn_bwd_reduce(y.g(), y.a(), scale, shift, slope, _ptr(self.save_mean), _ptr(self.save_invstd),
+                                        _ptr(partial), C.byref(nblk), eng.dtype, st), "bn_bwd_reduce")
         dgamma, dbeta = eng.new_grad(self.bn.weight), eng.new_grad(self.bn.bias)
         A, B, Cc = eng.coef[0][:cout], eng.coef[1][:cout], eng.coef[2][:cout]
-        check(lib.biu_bn_bwd_finalize(_ptr(eng.partial), nblk.value, cout, float(y.nvox), scale, _ptr(self.save_mean),
+        check(lib.biu_bn_bwd_finalize(_ptr(partial), nblk.value, cout, float(y.nvox), scale, _ptr(self.save_mean),
                                       _ptr(self.save_invstd), _ptr(dgamma), _ptr(dbeta), _ptr(A), _ptr(B), _ptr(Cc), st),
               "bn_bwd_finalize")
         dw = eng.new_grad(self.conv.weight)
@@ -235,9 +257,42 @@ class ConvBlockNode(Node):
         eng.add_grad(self.bn.bias, dbeta)
         if eng.wants_grad(self.xin):
             packed = eng.pack(self.pk_b, 1, self.conv.weight, self.xin.c, cout, self.kd, self.kh, self.kw)
-            check(lib.biu_conv_bwd_data(y.g(), _ptr(self.conv.weight.data), packed, self.kd, self.kh, self.kw, self.dil,
-                                        self.xin.g(), int(self.xin.g_written()), eng.dtype, st), "conv_bwd_data")
+            up = _fusable_producer(self.xin)
+            if up is not None:
+                part = up.red_buffer(eng, self.kd, 0)
+                n_up = C.c_int(0)
+                check(lib.biu_conv_bwd_data_bnred(y.g(), _ptr(self.conv.weight.data), packed, self.kd, self.kh, self.kw,
+                                                  self.dil, self.xin.g(), self.xin.a(), *up.red_coeffs(), _ptr(part),
+                                                  part.numel(), C.byref(n_up), eng.dtype, st), "conv_bwd_data_bnred")
+                up.red_nblk = n_up.value
+            else:
+                check(lib.biu_conv_bwd_data(y.g(), _ptr(self.conv.weight.data), packed, self.kd, self.kh, self.kw, self.dil,
+                                            self.xin.g(), int(self.xin.g_written()), eng.dtype, st), "conv_bwd_data")
             self.xin.mark_g()
+
+    # ---- receiving side of the fused BatchNorm-backward reduction -----------------------------------
+    def red_buffer(self, eng, kd, transposed) -> torch.Tensor:
+        need = lib.biu_bwd_data_bnred_floats(self.y.a(), kd, transposed)
+        if self.red_partial is None or self.red_partial.numel() < need:
+            self.red_partial = torch.empty(need, dtype=torch.float32, device=eng.device)
+        return self.red_partial
+
+    def red_coeffs(self):
+        y = self.y
+        return (_ptr(y.vec("scale")), _ptr(y.vec("shift")), _ptr(y.vec("slope")), _ptr(self.save_mean),
+                _ptr(self.save_invstd))
+
+
+def _fusable_producer(xin: Act):
+    """ConvBlockNode whose BatchNorm-backward sums the data-gradient kernel writing xin's gradient can also produce:
+    xin is that block's output, this node is its only reader (so the gradient is complete after this one write) and the
+    block normalised with batch statistics."""
+    if xin.g_written():
+        return None
+    up = xin.sole_conv_block_producer()
+    if up is None or not getattr(up, "batch_stats", False) or up.y.c != xin.c or up.y.c0 != xin.c0:
+        return None
+    return up
 
 
 class ConvTNode(Node):
@@ -245,6 +300,7 @@ class ConvTNode(Node):
 
     def __init__(self, eng, up: nn.Module, xin: Act, yout: Act):
         self.up, self.xin, self.y = up, xin, yout
+        xin.consumed()
         w = up.weight
         self.kd = 2 if w.dim() == 5 else 1
         assert tuple(w.shape[:2]) == (xin.c, yout.c)
@@ -269,8 +325,17 @@ class ConvTNode(Node):
         eng.add_grad(self.up.bias, db)
         if eng.wants_grad(self.xin):
             packed = eng.pack_convt(self.pk_b, 1, self.up.weight, self.xin.c, self.y.c, self.kd)
-            check(lib.biu_convt_bwd_data(self.y.g(), _ptr(self.up.weight.data), packed, self.kd, self.xin.g(),
-                                         int(self.xin.g_written()), eng.dtype, st), "convt_bwd_data")
+            up = _fusable_producer(self.xin)
+            if up is not None:
+                part = up.red_buffer(eng, self.kd, 1)
+                n_up = C.c_int(0)
+                check(lib.biu_convt_bwd_data_bnred(self.y.g(), _ptr(self.up.weight.data), packed, self.kd, self.xin.g(),
+                                                   self.xin.a(), *up.red_coeffs(), _ptr(part), part.numel(), C.byref(n_up),
+                                                   eng.dtype, st), "convt_bwd_data_bnred")
+                up.red_nblk = n_up.value
+            else:
+                check(lib.biu_convt_bwd_data(self.y.g(), _ptr(self.up.weight.data), packed, self.kd, self.xin.g(),
+                                             int(self.xin.g_written()), eng.dtype, st), "convt_bwd_data")
             self.xin.mark_g()
 
 
@@ -280,6 +345,7 @@ class ResampleNode(Node):
     def __init__(self, eng, kind: str, xin: Act, yout: Act):
         assert kind in ("maxpool", "down", "up")
         self.kind, self.xin, self.y = kind, xin, yout
+        xin.consumed()
 
     def fwd(self, eng):
         f = {"maxpool": lib.biu_maxpool_fwd, "down": lib.biu_nearest_down_fwd, "up": lib.biu_nearest_up_fwd}[self.kind]
@@ -303,6 +369,8 @@ class MaxJoinNode(Node):
 
     def __init__(self, eng, a: Act, b: Act, out: Act):
         self.a_, self.b_, self.y = a, b, out
+        a.consumed()
+        b.consumed()
 
     def fwd(self, eng):
         check(lib.biu_max_join_fwd(self.a_.a(), self.a_.xf(), self.b_.a(), self.b_.xf(), self.y.a(), eng.dtype, _stream()),
@@ -323,6 +391,7 @@ class CopyNode(Node):
 
     def __init__(self, eng, xin: Act, out: Act):
         self.xin, self.y = xin, out
+        xin.consumed()
 
     def fwd(self, eng):
         check(lib.biu_xform_apply(self.xin.a(), self.xin.xf(), self.y.a(), eng.dtype, _stream()), "xform_apply")
@@ -343,6 +412,7 @@ class HeadNode(Node):
 
     def __init__(self, eng, conv: nn.Module, xin: Act, activation, want_logits: bool, want_act: bool):
         self.conv, self.xin = conv, xin
+        xin.consumed()
         self.cout = conv.weight.shape[0]
         assert conv.weight.shape[1] == xin.c
         if activation not in _ACT_CODE:

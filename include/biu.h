@@ -95,6 +95,20 @@ int biu_conv_bwd_data(const biu_act* dy, const float* w, const void* packed,
                       int kd, int kh, int kw, int dilation,
                       const biu_act* dx, int accumulate, int dtype, biu_stream stream);
 
+/* Data gradient that also emits the BatchNorm-backward partial sums (biu_bn_bwd_reduce's output) of the conv block that
+ * PRODUCED the tensor whose gradient dx is: y_up is that block's raw conv output, (scale, shift, slope, mean, invstd) its
+ * transform / saved statistics.  Use only when this call writes the complete gradient of that tensor.  `partial` holds
+ * biu_bwd_data_bnred_floats(dx, kd, transposed) floats; *nblk receives the number of partial rows.                    */
+size_t biu_bwd_data_bnred_floats(const biu_act* dx, int kd, int transposed);
+int biu_conv_bwd_data_bnred(const biu_act* dy, const float* w, const void* packed, int kd, int kh, int kw, int dilation,
+                            const biu_act* dx, const biu_act* y_up, const float* scale, const float* shift,
+                            const float* slope, const float* mean, const float* invstd, float* partial,
+                            size_t partial_floats, int* nblk, int dtype, biu_stream stream);
+int biu_convt_bwd_data_bnred(const biu_act* dy, const float* w, const void* packed, int kd, const biu_act* dx,
+                             const biu_act* y_up, const float* scale, const float* shift, const float* slope,
+                             const float* mean, const float* invstd, float* partial, size_t partial_floats, int* nblk,
+                             int dtype, biu_stream stream);
+
 /* dw[co,ci,tap] = sum_v T(x)[v + off(tap), ci] * dy[v, co]  (PyTorch layout fp32, overwritten);
  * dbias[co] = sum_v dy[v,co] (may be NULL).  ws: biu_conv_bwd_weight_workspace() bytes.                 */
 size_t biu_conv_bwd_weight_workspace(int cin, int cout, int kd, int kh, int kw, int dtype);

@@ -445,3 +445,87 @@ def test_convtranspose_mfma(case, dtype):
     check(lib.biu_convt_bwd_weight(xd.a(), xf.x(), gd.a(), kd, ptr(dw), ptr(db), ptr(ws), ws.numel(), code, stream()), "convt_bwd_weight(mfma)")
     t3 = dict(rtol=1e-3, atol=2e-4 * float(wq.grad.abs().max())) if dtype == "f32" else dict(rtol=1e-2, atol=1e-2 * float(wq.grad.abs().max()))
     torch.testing.assert_close(dw.cpu(), wq.grad, **t3)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# data gradient with the upstream block's BatchNorm-backward sums reduced in the epilogue
+# ---------------------------------------------------------------------------------------------------------------
+def _bn_bwd_sums_ref(da, y, scale, shift, slope, mean, invstd):
+    """(sum dz, sum dz*yhat) per channel, dz = da * T'(scale*y+shift)  [torch BatchNorm backward, fp64]."""
+    shp = (1, -1) + (1,) * (y.dim() - 2)
+    t = y.double() * scale.double().view(shp) + shift.double().view(shp)
+    dz = da.double() * torch.where(t > 0, torch.ones_like(t), slope.double().view(shp).expand_as(t))
+    yhat = (y.double() - mean.double().view(shp)) * invstd.double().view(shp)
+    dims = [0] + list(range(2, y.dim()))
+    return dz.sum(dims), (dz * yhat).sum(dims)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(3, 1, 32, 32, (8, 16, 32)), (3, 2, 16, 64, (6, 10, 36)), (2, 2, 64, 32, (24, 40)),
+                                  (3, 1, 6, 8, (4, 6, 10))])
+def test_conv_bwd_data_bnred(case, dtype):
+    nd, n, cin, cout, sp = case
+    kd = 3 if nd == 3 else 1
+    code = DT[dtype][1]
+    w = rnd(cout, cin, *([3] * nd), seed=2) * (1.0 / (cin * 3 ** nd) ** 0.5)
+    wd = w.cuda()
+    nb2 = lib.biu_conv_packed_bytes(1, cin, cout, kd, 3, 3, 1, code)
+    pk2 = torch.empty(max(nb2, 16), dtype=torch.uint8, device="cuda")
+    if nb2:
+        check(lib.biu_conv_pack(1, ptr(wd), cin, cout, kd, 3, 3, code, ptr(pk2), stream()), "conv_pack(dgrad)")
+    dyd = Dev(rnd(n, cout, *sp, seed=5), dtype=dtype)
+    yup = Dev(rnd(n, cin, *sp, seed=6), dtype=dtype, pitch=cin + 8, c0=0)
+    xf = XF(cin, seed=7)
+    mean, invstd = rnd(cin, seed=8) * 0.1, rnd(cin, seed=9).abs() + 0.5
+    md, isd = mean.cuda(), invstd.cuda()
+    dshape = (n, cin, 1 if nd == 2 else sp[0], sp[-2], sp[-1])
+    dx_ref, dx = Dev(shape=dshape, dtype=dtype), Dev(shape=dshape, dtype=dtype)
+    check(lib.biu_conv_bwd_data(dyd.a(), ptr(wd), ptr(pk2) if nb2 else None, kd, 3, 3, 1, dx_ref.a(), 0, code, stream()), "dgrad")
+    nfl = lib.biu_bwd_data_bnred_floats(dx.a(), kd, 0)
+    part = torch.full((nfl,), float("nan"), device="cuda")
+    nblk = C.c_int(0)
+    check(lib.biu_conv_bwd_data_bnred(dyd.a(), ptr(wd), ptr(pk2) if nb2 else None, kd, 3, 3, 1, dx.a(), yup.a(), ptr(xf.d[0]),
+                                      ptr(xf.d[1]), ptr(xf.d[2]), ptr(md), ptr(isd), ptr(part), nfl, C.byref(nblk), code,
+                                      stream()), "conv_bwd_data_bnred")
+    assert torch.equal(dx.buf, dx_ref.buf), "the fused epilogue must not change the data gradient"
+    sums = part[:nblk.value * cin * 2].view(nblk.value, cin, 2).double().sum(0).cpu()
+    s1, s2 = _bn_bwd_sums_ref(dx.ref(), yup.ref(), xf.scale, xf.shift, xf.slope, mean, invstd)
+    scale1 = float(dx.ref().abs().sum() / cin) + 1e-12
+    torch.testing.assert_close(sums[:, 0], s1, rtol=1e-4, atol=1e-5 * scale1)
+    torch.testing.assert_close(sums[:, 1], s2, rtol=1e-4, atol=1e-5 * scale1 * float(invstd.max()) * 4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(3, 1, 64, 64, (4, 8, 16)), (3, 2, 32, 32, (3, 5, 9)), (2, 2, 64, 32, (16, 16)),
+                                  (2, 1, 6, 4, (5, 7))])
+def test_convt_bwd_data_bnred(case, dtype):
+    nd, n, cin, cout, sp = case
+    kd = 2 if nd == 3 else 1
+    code = DT[dtype][1]
+    w = rnd(cin, cout, *([2] * nd), seed=2) * (1.0 / cin ** 0.5)
+    wd = w.cuda()
+    nb1 = lib.biu_convt_packed_bytes(1, cin, cout, kd, code)
+    pk1 = torch.empty(max(nb1, 16), dtype=torch.uint8, device="cuda")
+    if nb1:
+        check(lib.biu_convt_pack(1, ptr(wd), cin, cout, kd, code, ptr(pk1), stream()), "convt_pack(dgrad)")
+    osp = tuple(2 * s for s in sp)
+    gd = Dev(rnd(n, cout, *osp, seed=5), dtype=dtype)
+    yup = Dev(rnd(n, cin, *sp, seed=6), dtype=dtype, pitch=cin + 8, c0=0)
+    xf = XF(cin, seed=7)
+    mean, invstd = rnd(cin, seed=8) * 0.1, rnd(cin, seed=9).abs() + 0.5
+    md, isd = mean.cuda(), invstd.cuda()
+    dshape = (n, cin, 1 if nd == 2 else sp[0], sp[-2], sp[-1])
+    dx_ref, dx = Dev(shape=dshape, dtype=dtype), Dev(shape=dshape, dtype=dtype)
+    check(lib.biu_convt_bwd_data(gd.a(), ptr(wd), ptr(pk1) if nb1 else None, kd, dx_ref.a(), 0, code, stream()), "convt dgrad")
+    nfl = lib.biu_bwd_data_bnred_floats(dx.a(), kd, 1)
+    part = torch.full((nfl,), float("nan"), device="cuda")
+    nblk = C.c_int(0)
+    check(lib.biu_convt_bwd_data_bnred(gd.a(), ptr(wd), ptr(pk1) if nb1 else None, kd, dx.a(), yup.a(), ptr(xf.d[0]), ptr(xf.d[1]),
+                                       ptr(xf.d[2]), ptr(md), ptr(isd), ptr(part), nfl, C.byref(nblk), code, stream()),
+          "convt_bwd_data_bnred")
+    assert torch.equal(dx.buf, dx_ref.buf)
+    sums = part[:nblk.value * cin * 2].view(nblk.value, cin, 2).double().sum(0).cpu()
+    s1, s2 = _bn_bwd_sums_ref(dx.ref(), yup.ref(), xf.scale, xf.shift, xf.slope, mean, invstd)
+    scale1 = float(dx.ref().abs().sum() / cin) + 1e-12
+    torch.testing.assert_close(sums[:, 0], s1, rtol=1e-4, atol=1e-5 * scale1)
+    torch.testing.assert_close(sums[:, 1], s2, rtol=1e-4, atol=1e-5 * scale1 * float(invstd.max()) * 4)
