@@ -325,10 +325,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base_unifo
                  : "memory");
 }
 
-template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP, bool RED>
-__global__ __launch_bounds__(512, 2) void k_conv_pipe(ConvArgs a) {
+// LDS a block may use for the activation tile + weight slabs (the transform vectors, partial sums come on top)
+#ifndef BIU_CONV_ILV
+#define BIU_CONV_ILV 1
+#endif
+constexpr size_t conv_lds_budget(int nw) { return nw == 8 ? 150 * 1024 : 72 * 1024; }
+
+template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP, bool RED, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     using F = Frag<T>;
-    constexpr int NTHR = 512, NWAVE = 8;
+    constexpr int NTHR = NW * 64, NWAVE = NW;         // NW = 8: one block per CU; NW = 4: two (half the LDS each)
     constexpr int PE = F::PE;
     constexpr int PD = (KD == 3) ? 1 : 0;
     constexpr int PHW = (KHW == 3) ? 1 : 0;
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_pipe(ConvArgs a) {
     constexpr int HV = HD * HH * HW;
     constexpr int PSV = cpad_planes(HV, CKP);
     constexpr int TILES = TD * TH * TW / 32;
-    static_assert(TILES % NWAVE == 0, "brick must give a multiple of 8 voxel tiles");
+    static_assert(TILES % NWAVE == 0, "brick must give a multiple of NW voxel tiles");
     constexpr int MT = TILES / NWAVE;
     constexpr int TAPS = KD * KHW * KHW;
     constexpr int SPC = CKP / 2;
@@ -348,8 +354,11 @@ __global__ __launch_bounds__(512, 2) void k_conv_pipe(ConvArgs a) {
     constexpr int NPW = (WN + NTHR - 1) / NTHR;
     // weight slab path: async global->LDS copies into a double buffer (no VGPRs) when two slabs fit; otherwise
     // register-staged like the activations
-    constexpr bool WGLDS = (size_t)(CKP * PSV + 2 * WN) * 16 <= 150 * 1024;
-    constexpr int NWB = WGLDS ? 2 : 1;
+    constexpr size_t BUD = conv_lds_budget(NW);
+    constexpr bool W2 = (size_t)(CKP * PSV + 2 * WN) * 16 <= BUD;            // double-buffered slab, DMA issued an item ahead
+    constexpr bool W1 = !W2 && (size_t)(CKP * PSV + WN) * 16 <= BUD;         // one slab, DMA issued between the two barriers
+    constexpr bool WGLDS = W2 || W1;
+    constexpr int NWB = W2 ? 2 : 1;
 
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     uint4* lact = lds;                       // [CKP][PSV]
@@ -410,54 +419,80 @@ __global__ __launch_bounds__(512, 2) void k_conv_pipe(ConvArgs a) {
         o.n = b / a.nbd;
         return o;
     };
-    auto stage_vox = [&](const Org& o, int j) -> int {
-        int tq = tid;
-        asm volatile("" : "+v"(tq));     // opaque: keeps LICM from hoisting (and spilling) the 3*NPA halo coordinates
-        const int i = tq + NTHR * j;
+    // Per-thread constants of the activation pieces this thread stages (they do not depend on the brick): the halo
+    // coordinate of piece j packed in 10-bit fields (hd | hh << 10 | hw << 20) and its byte offset inside the input
+    // sample relative to the tile's first voxel.  Per brick only a field-wise range test (two adds, guard bits) and one
+    // add remain; out-of-volume pieces read through the buffer descriptor's range check and come back as zeros.
+    constexpr unsigned GBITS = (1u << 9) | (1u << 19) | (1u << 29);
+    const int xrowb = a.xpitch * (int)esz;
+    unsigned xs_[NPA];
+    int lofb[NPA];
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+        const int i = tid + NTHR * j;
         const int hv = i / CKP;
         const int hw = hv % HW;
         const int t = hv / HW;
         const int hh = t % HH;
         const int hd = t / HH;
-        const int gd = o.d0 * SD - PD + hd, gh = o.h0 * S - PHW + hh, gw = o.w0 * S - PHW + hw;
-        const bool inb = (hv < HV) && gd >= 0 && gd < a.ID && gh >= 0 && gh < a.IH && gw >= 0 && gw < a.IW;
-        return inb ? ((o.n * a.ID + gd) * a.IH + gh) * a.IW + gw : -1;
+        xs_[j] = (hv < HV) ? (unsigned)(hd | (hh << 10) | (hw << 20)) : 511u;
+        lofb[j] = ((hd * a.IH + hh) * a.IW + hw) * xrowb + p_mine * PE * (int)esz;
+    }
+    const size_t sample_bytes = (size_t)a.ID * a.IH * a.IW * xrowb;          // < 2^31 (checked on the host)
+    // weight slab of chunk ch: async global->LDS copy into the buffer the NEXT item reads (or into registers)
+    auto issue_wpiece = [&](int ch, bool live, int j) {
+        const uint4* wch = wgrp + (size_t)(ch * SPC) * TAPS * 64;
+        const int q = tid + NTHR * j;
+        if (q < WN && live) {                          // wave-uniform: WN is a multiple of 64
+            const int ln = q & 63, nt = (q >> 6) % NT, step = q / (64 * NT);
+            const int tap = step / SPC, sidx = step % SPC;
+            const uint4* src = wch + ((size_t)nt * a.nKS * TAPS + (size_t)sidx * TAPS + tap) * 64 + ln;
+            if constexpr (WGLDS) {
+                uint4* dstw = lw + (W2 ? (wcur ^ 1) * WN : 0) + (q - ln);     // wave-uniform LDS base; lane l lands at +16*l
+                const unsigned lbase = __builtin_amdgcn_readfirstlane(
+                    (unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)dstw));
+                glds16(src, lbase);
+            } else {
+                pw[j] = *src;
+            }
+        }
+    };
+    auto issue_w = [&](int ch, bool live) {
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) issue_wpiece(ch, live, j);
     };
     // issue the global loads of item (brick, ch) into pa / pw
     unsigned inb_mask = 0;
     // `live` = false issues nothing but still (re)defines pa: the prefetch registers must not be loop-carried PHIs,
     // or the register allocator copies them -- and waits for the loads -- in front of the MFMA phase
-    auto issue = [&](int brick, int ch, bool live) {
+    unsigned c_lo = 0, c_hi = 0;
+    int brb = 0;
+    __amdgpu_buffer_rsrc_t rs;
+    auto issue_prep = [&](int brick, int ch, bool live) {
         const Org o = origin(brick);
-        const char* xsrc = a.x + (size_t)(ch * CK + p_mine * PE) * esz;
+        const int gd0 = o.d0 * SD - PD, gh0 = o.h0 * S - PHW, gw0 = o.w0 * S - PHW;
+        const int lod = max(0, -gd0), loh = max(0, -gh0), low = max(0, -gw0);
+        const int hid = min(HD - 1, a.ID - 1 - gd0), hih = min(HH - 1, a.IH - 1 - gh0), hiw = min(HW - 1, a.IW - 1 - gw0);
+        c_lo = GBITS - (unsigned)(lod | (loh << 10) | (low << 20));     // x + c_lo keeps a guard bit iff x >= lo
+        c_hi = GBITS + (unsigned)(hid | (hih << 10) | (hiw << 20));     // c_hi - x keeps a guard bit iff x <= hi
+        brb = ((gd0 * a.IH + gh0) * a.IW + gw0) * xrowb + ch * CK * (int)esz;
+        // a dead prefetch (nothing follows) reads through an empty descriptor: every piece is zero, nothing is fetched
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)o.n * sample_bytes), 0, live ? (int)sample_bytes : 0, 0x00020000);
         inb_mask = 0;
+    };
+    auto issue_piece = [&](int j) {
+        const unsigned in_lo = xs_[j] + c_lo, in_hi = c_hi - xs_[j];
+        const bool ok = ((in_lo & in_hi) & GBITS) == GBITS;
+        const int off = ok ? lofb[j] + brb : -1;
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+        pa[j] = make_uint4(v[0], v[1], v[2], v[3]);
+        inb_mask |= ok ? (1u << j) : 0u;
+    };
+    auto issue = [&](int brick, int ch, bool live) {
+        issue_prep(brick, ch, live);
 #pragma unroll
-        for (int j = 0; j < NPA; ++j) {
-            const int vi = live ? stage_vox(o, j) : -1;
-            pa[j] = make_uint4(0, 0, 0, 0);
-            if (vi >= 0) {
-                pa[j] = *(const uint4*)(xsrc + (size_t)vi * a.xpitch * esz);
-                inb_mask |= 1u << j;
-            }
-        }
-        const uint4* wch = wgrp + (size_t)(ch * SPC) * TAPS * 64;
-#pragma unroll
-        for (int j = 0; j < NPW; ++j) {
-            const int q = tid + NTHR * j;
-            if (q < WN && live) {                          // wave-uniform: WN is a multiple of 64
-                const int ln = q & 63, nt = (q >> 6) % NT, step = q / (64 * NT);
-                const int tap = step / SPC, sidx = step % SPC;
-                const uint4* src = wch + ((size_t)nt * a.nKS * TAPS + (size_t)sidx * TAPS + tap) * 64 + ln;
-                if constexpr (WGLDS) {
-                    uint4* dstw = lw + (wcur ^ 1) * WN + (q - ln);     // wave-uniform LDS base; lane l lands at +16*l
-                    const unsigned lbase = __builtin_amdgcn_readfirstlane(
-                        (unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)dstw));
-                    glds16(src, lbase);
-                } else {
-                    pw[j] = *src;
-                }
-            }
-        }
+        for (int j = 0; j < NPA; ++j) issue_piece(j);
+        if constexpr (!W1) issue_w(ch, live);
     };
     // commit pa / pw to LDS (producer transform + zero padding applied here)
     auto commit = [&](int ch) {
@@ -497,15 +532,17 @@ __global__ __launch_bounds__(512, 2) void k_conv_pipe(ConvArgs a) {
 #ifdef BIU_DIAG
     unsigned long long tprev_ = __builtin_readcyclecounter();
     unsigned long long dsum_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t0c_ = tprev_, t0r_ = __builtin_amdgcn_s_memrealtime();
 #endif
     int k = 0;
     int brick = brick_of(0);
     if (brick >= nbricks) return;            // uniform per block
     int ch = 0;
     issue(brick, 0, true);
+    if constexpr (W1) issue_w(0, true);
     __syncthreads();                         // lxf visible
     commit(0);
-    if constexpr (WGLDS) { wcur ^= 1; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    if constexpr (WGLDS) { if constexpr (W2) wcur ^= 1; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     __syncthreads();
 
     while (true) {
@@ -526,32 +563,52 @@ __global__ __launch_bounds__(512, 2) void k_conv_pipe(ConvArgs a) {
         if (nch == nchunks) { nch = 0; nk = k + 1; nbrick = brick_of(nk); }
         const bool have_next = nbrick < nbricks;
         DIAG_STAMP(0);
-        issue(have_next ? nbrick : brick, nch, have_next);
-        DIAG_STAMP(1);
-
-        // ---- MFMA phase over the committed tile.  Only the innermost (kw, k-step) window is unrolled: a fully unrolled
-        //      tap loop lets the scheduler hoist dozens of LDS fragments and spill -- and every spill reload carries an
-        //      s_waitcnt vmcnt(0) that would serialise the prefetch loads issued above.
-        const uint4* lwc = lw + (WGLDS ? wcur * WN : 0) + lane;
-#pragma unroll 1
-        for (int ta = 0; ta < KD; ++ta) {
-#pragma unroll 1
-            for (int tb = 0; tb < KHW; ++tb) {
-                const uint4* lwp = lwc + ((ta * KHW + tb) * KHW) * (SPC * NT * 64);
-                const uint4* lap = lact + (ta * HH + tb) * HW;
+        const uint4* lwc = lw + (W2 ? wcur * WN : 0) + lane;
+        auto window = [&](int ta, int tb) {
+            const uint4* lwp = lwc + ((ta * KHW + tb) * KHW) * (SPC * NT * 64);
+            const uint4* lap = lact + (ta * HH + tb) * HW;
 #pragma unroll
-                for (int st2 = 0; st2 < KHW * SPC; ++st2) {
-                    const int tc = st2 / SPC, sidx = st2 % SPC;
-                    uint4 wf[NT];
+            for (int st2 = 0; st2 < KHW * SPC; ++st2) {
+                const int tc = st2 / SPC, sidx = st2 % SPC;
+                uint4 wf[NT];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) wf[nt] = lwp[(st2 * NT + nt) * 64];
+                for (int nt = 0; nt < NT; ++nt) wf[nt] = lwp[(st2 * NT + nt) * 64];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const uint4 bf = lap[hvb[mt] + 2 * sidx * PSV + tc];
+                for (int mt = 0; mt < MT; ++mt) {
+                    const uint4 bf = lap[hvb[mt] + 2 * sidx * PSV + tc];
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) F::mma(wf[nt], bf, acc[nt][mt]);
-                    }
+                    for (int nt = 0; nt < NT; ++nt) F::mma(wf[nt], bf, acc[nt][mt]);
                 }
+            }
+        };
+        if constexpr (BIU_CONV_ILV) {
+            // ---- MFMA phase with the next item's global loads spread over its (kd, kh) tap groups: the address
+            //      unit takes the pieces one by one while the matrix cores run, instead of in a burst in front of them.
+            //      sched_barrier keeps the groups apart (a scheduler free to hoist LDS fragments across them spills).
+            constexpr int NG = KD * KHW;
+            issue_prep(have_next ? nbrick : brick, nch, have_next);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                for (int j = (g * NPA) / NG; j < ((g + 1) * NPA) / NG; ++j) issue_piece(j);
+                if constexpr (!W1) {
+#pragma unroll
+                    for (int j = (g * NPW) / NG; j < ((g + 1) * NPW) / NG; ++j) issue_wpiece(nch, have_next, j);
+                }
+                window(g / KHW, g % KHW);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            DIAG_STAMP(1);
+        } else {
+            issue(have_next ? nbrick : brick, nch, have_next);
+            DIAG_STAMP(1);
+            // Only the innermost (kw, k-step) window is unrolled: a fully unrolled tap loop lets the scheduler hoist dozens
+            // of LDS fragments and spill -- and every spill reload carries an s_waitcnt vmcnt(0) that would serialise the
+            // prefetch loads issued above.
+#pragma unroll 1
+            for (int ta = 0; ta < KD; ++ta) {
+#pragma unroll 1
+                for (int tb = 0; tb < KHW; ++tb) window(ta, tb);
             }
         }
 
@@ -695,13 +752,18 @@ __global__ __launch_bounds__(512, 2) void k_conv_pipe(ConvArgs a) {
         DIAG_STAMP(3);
 #ifdef BIU_DIAG
         dsum_[7] += 1;
-        if (!have_next && a.diag && tid == 0) { for (int q_ = 0; q_ < 8; ++q_) atomicAdd(a.diag + q_, dsum_[q_]); }
+        if (!have_next && a.diag && tid == 0) {
+            for (int q_ = 0; q_ < 8; ++q_) atomicAdd(a.diag + q_, dsum_[q_]);
+            atomicAdd(a.diag + 8, __builtin_readcyclecounter() - t0c_);            // shader cycles ...
+            atomicAdd(a.diag + 9, __builtin_amdgcn_s_memrealtime() - t0r_);        // ... per 100 MHz tick = clock
+        }
 #endif
         if (!have_next) break;
         __syncthreads();                     // everyone is done reading the tile
         DIAG_STAMP(4);
+        if constexpr (W1) issue_w(nch, true);                // the slab is free now; the copy flies while the tile is committed
         commit(nch);
-        if constexpr (WGLDS) { wcur ^= 1; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // weight DMA landed
+        if constexpr (WGLDS) { if constexpr (W2) wcur ^= 1; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // weight DMA landed
         DIAG_STAMP(5);
         __syncthreads();
         DIAG_STAMP(6);
@@ -742,6 +804,8 @@ __global__ void k_pack_weights(const float* __restrict__ w, int cin, int cout, i
 
 static inline int ks_of(int dtype) { return dtype == BIU_BF16 ? 16 : 8; }
 
+static inline i64 sample_bytes(const biu_act* t, size_t es) { return (i64)t->d * t->h * t->w * t->pitch * (i64)es; }
+
 static bool chan_ok(int K, int Nn, int dtype) { return K >= 16 && K % ks_of(dtype) == 0 && Nn >= 16 && Nn % 8 == 0; }
 
 size_t biu_mfma_packed_bytes(int kind, int cin, int cout, int kd, int kh, int kw, int dilation, int dtype) {
@@ -769,6 +833,7 @@ bool biu_mfma_conv_ok(const biu_act* x, const biu_act* y, int kd, int kh, int kw
     const size_t es = dsize(dtype);
     if ((uintptr_t)x->p % 16 || (uintptr_t)y->p % 16 || ((size_t)x->pitch * es) % 16 || ((size_t)y->pitch * es) % 16) return false;
     if (nvox(x) * (i64)x->pitch >= (1LL << 31) || nvox(y) * (i64)y->pitch >= (1LL << 31)) return false;   // 32-bit voxel index math
+    if (sample_bytes(x, es) >= (1LL << 31) || sample_bytes(y, es) >= (1LL << 31)) return false;            // 32-bit buffer offsets per sample
     if (kd == 1 && x->d != 1) return false;
     return true;
 }
@@ -790,46 +855,53 @@ static int num_cus() {
     return n;
 }
 
-template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP, bool RED>
+template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP, bool RED, int NW>
 static int launch_cfg_r(const ConvArgs& a0, int ntiles, int nz, hipStream_t st) {
     ConvArgs a = a0;
     constexpr int HV = BrickGeo<KD, KHW, S, TD, TH, TW>::HV;
     constexpr int PSV = cpad_planes(HV, CKP);
     constexpr int WN = KD * KHW * KHW * (CKP / 2) * NT * 64;
-    constexpr int NWB = ((size_t)(CKP * PSV + 2 * WN) * 16 <= 150 * 1024) ? 2 : 1;        // must mirror k_conv_pipe::WGLDS
+    constexpr int NWB = ((size_t)(CKP * PSV + 2 * WN) * 16 <= conv_lds_budget(NW)) ? 2 : 1;        // must mirror k_conv_pipe::W2
     const size_t lds_bytes = (size_t)(CKP * PSV + NWB * WN) * 16 + (size_t)3 * a.Cin * sizeof(float) + (size_t)NT * 32 * 2 * sizeof(float);
-    if (lds_bytes > 160 * 1024) return biu_fail(BIU_ERR_UNSUPPORTED, "conv_pipe: %zu bytes of LDS (Cin=%d)", lds_bytes, a.Cin);
+    if (lds_bytes > (size_t)(NW == 8 ? 160 : 80) * 1024) return biu_fail(BIU_ERR_UNSUPPORTED, "conv_pipe: %zu bytes of LDS (Cin=%d)", lds_bytes, a.Cin);
     a.nbd = (a.GD + TD - 1) / TD;
     a.nbh = (a.GH + TH - 1) / TH;
     a.nbw = (a.GW + TW - 1) / TW;
     const int nbricks = a.N * a.nbd * a.nbh * a.nbw;
     const int gy = ntiles / NT;
-    int g = num_cus() / (gy * nz);
+    int g = (NW == 8 ? 1 : 2) * num_cus() / (gy * nz);
     g &= ~7;
     if (g < 8) g = 8;
     if (g > nbricks) g = nbricks;
     dim3 grid((unsigned)g, (unsigned)gy, (unsigned)nz);
-    auto kern = k_conv_pipe<T, KD, KHW, S, TD, TH, TW, NT, CKP, RED>;
+    auto kern = k_conv_pipe<T, KD, KHW, S, TD, TH, TW, NT, CKP, RED, NW>;
     static size_t attr_set = 0;
     if (attr_set < lds_bytes) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
             return biu_fail(BIU_ERR_LAUNCH, "conv_pipe: cannot reserve %zu bytes of LDS", lds_bytes);
         attr_set = lds_bytes;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, st, a);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds_bytes, st, a);
     BIU_CHECK_LAUNCH("conv_pipe");
     return BIU_OK;
 }
 
-template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP>
+template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP, int NW = 8>
 static int launch_cfg(const ConvArgs& a, int ntiles, int nz, hipStream_t st) {
     // the BatchNorm-backward epilogue only exists for stride-1 3x3(x3) data gradients and stride-2 ConvT data gradients
     if constexpr ((S == 1 && KHW == 3) || S == 2) {
-        if (a.red_mode) return launch_cfg_r<T, KD, KHW, S, TD, TH, TW, NT, CKP, true>(a, ntiles, nz, st);
+        if (a.red_mode) return launch_cfg_r<T, KD, KHW, S, TD, TH, TW, NT, CKP, true, NW>(a, ntiles, nz, st);
     } else {
         if (a.red_mode) return biu_fail(BIU_ERR_UNSUPPORTED, "conv_pipe: no fused BatchNorm-backward epilogue for this kernel shape");
     }
-    return launch_cfg_r<T, KD, KHW, S, TD, TH, TW, NT, CKP, false>(a, ntiles, nz, st);
+    return launch_cfg_r<T, KD, KHW, S, TD, TH, TW, NT, CKP, false, NW>(a, ntiles, nz, st);
+}
+
+// experiment switch: BIU_CONV_NW4=1 runs single-tile (NT = 1) 3x3(x3) layers as two 256-thread blocks per CU
+static bool conv_nw4() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("BIU_CONV_NW4"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
 }
 
 // (a 4-tile weight slab no longer fits the double buffer next to the activation tile: two tiles is the widest block)
@@ -839,10 +911,10 @@ static inline int pick_nt(int ntiles) { return (ntiles % 2 == 0) ? 2 : 1; }
 struct BrickDim { int td, th, tw; };
 static BrickDim conv3_brick(int kd, int nt, bool wide) {
     if (kd == 3) {
-        if (nt == 1) return wide ? BrickDim{4, 8, 32} : BrickDim{4, 16, 16};
+        if (nt == 1) return conv_nw4() ? BrickDim{4, 8, 16} : (wide ? BrickDim{4, 8, 32} : BrickDim{4, 16, 16});
         return BrickDim{4, 8, 16};
     }
-    if (nt == 1) return wide ? BrickDim{1, 32, 32} : BrickDim{1, 64, 16};
+    if (nt == 1) return conv_nw4() ? (wide ? BrickDim{1, 16, 32} : BrickDim{1, 32, 16}) : (wide ? BrickDim{1, 32, 32} : BrickDim{1, 64, 16});
     return wide ? BrickDim{1, 16, 32} : BrickDim{1, 32, 16};
 }
 
@@ -852,9 +924,11 @@ static int launch_conv(const ConvArgs& a, int kd, hipStream_t st) {
     const int nt = pick_nt(ntiles);
     const bool wide = (a.GW % 32 == 0);
     if (kd == 3) {
+        if (nt == 1 && conv_nw4()) return launch_cfg<T, 3, 3, 1, 4, 8, 16, 1, 2, 4>(a, ntiles, 1, st);
         if (nt == 1) return wide ? launch_cfg<T, 3, 3, 1, 4, 8, 32, 1, 2>(a, ntiles, 1, st) : launch_cfg<T, 3, 3, 1, 4, 16, 16, 1, 2>(a, ntiles, 1, st);
         return launch_cfg<T, 3, 3, 1, 4, 8, 16, 2, 2>(a, ntiles, 1, st);
     }
+    if (nt == 1 && conv_nw4()) return wide ? launch_cfg<T, 1, 3, 1, 1, 16, 32, 1, 2, 4>(a, ntiles, 1, st) : launch_cfg<T, 1, 3, 1, 1, 32, 16, 1, 2, 4>(a, ntiles, 1, st);
     if (nt == 1) return wide ? launch_cfg<T, 1, 3, 1, 1, 32, 32, 1, 2>(a, ntiles, 1, st) : launch_cfg<T, 1, 3, 1, 1, 64, 16, 1, 2>(a, ntiles, 1, st);
     return wide ? launch_cfg<T, 1, 3, 1, 1, 16, 32, 2, 2>(a, ntiles, 1, st) : launch_cfg<T, 1, 3, 1, 1, 32, 16, 2, 2>(a, ntiles, 1, st);
 }
@@ -974,6 +1048,7 @@ static bool ptrs_ok(const biu_act* x, const biu_act* y, int dtype) {
     const size_t es = dsize(dtype);
     if ((uintptr_t)x->p % 16 || (uintptr_t)y->p % 16 || ((size_t)x->pitch * es) % 16 || ((size_t)y->pitch * es) % 16) return false;
     if (nvox(x) * (i64)x->pitch >= (1LL << 31) || nvox(y) * (i64)y->pitch >= (1LL << 31)) return false;
+    if (sample_bytes(x, es) >= (1LL << 31) || sample_bytes(y, es) >= (1LL << 31)) return false;
     return true;
 }
 

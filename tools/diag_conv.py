@@ -8,21 +8,25 @@ for name, (res, args) in SIGNATURES.items():
     getattr(lib, name).restype = res; getattr(lib, name).argtypes = args
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: C.c_void_p(t.data_ptr())
-diag = torch.zeros(8, dtype=torch.int64, device="cuda")
+diag = torch.zeros(10, dtype=torch.int64, device="cuda")
 C.c_void_p.in_dll(lib, "biu_diag_buffer").value = diag.data_ptr()
 shapes = [("encode2", 16, 32, (128,128,128)), ("decode5", 96, 32, (128,128,128)), ("decode3", 192, 64, (64,64,64)), ("decode6", 32, 16, (128,128,128))]
 n = 4
+use_xf = os.environ.get("DIAG_XF", "0") == "1"
 for name, cin, cout, (d,h,w) in shapes:
+    xfv = [torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda") * 0.1, torch.full((cin,), 0.1, device="cuda")]
+    xfs = biu_xform(*[t.data_ptr() for t in xfv])
+    XF = C.byref(xfs) if use_xf else None
     x = torch.randn(n,d,h,w,cin, device="cuda").to(torch.bfloat16); y = torch.empty(n,d,h,w,cout, device="cuda", dtype=torch.bfloat16)
     wt = torch.randn(cout,cin,3,3,3, device="cuda")*0.05
     pk = torch.empty(lib.biu_conv_packed_bytes(0,cin,cout,3,3,3,1,1), dtype=torch.uint8, device="cuda")
     lib.biu_conv_pack(0,P(wt),cin,cout,3,3,3,1,P(pk),st)
     ax = biu_act(x.data_ptr(),n,d,h,w,cin,cin); ay = biu_act(y.data_ptr(),n,d,h,w,cout,cout)
-    lib.biu_conv_fwd(C.byref(ax),None,P(wt),P(pk),None,3,3,3,1,C.byref(ay),1,st); torch.cuda.synchronize()
+    lib.biu_conv_fwd(C.byref(ax),XF,P(wt),P(pk),None,3,3,3,1,C.byref(ay),1,st); torch.cuda.synchronize()
     diag.zero_()
     e0,e1 = torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
-    e0.record(); lib.biu_conv_fwd(C.byref(ax),None,P(wt),P(pk),None,3,3,3,1,C.byref(ay),1,st); e1.record(); torch.cuda.synchronize()
+    e0.record(); lib.biu_conv_fwd(C.byref(ax),XF,P(wt),P(pk),None,3,3,3,1,C.byref(ay),1,st); e1.record(); torch.cuda.synchronize()
     dv = diag.cpu().tolist(); nb = max(dv[7],1)
     names = ["loop", "issue", "mfma", "epilogue", "barrier1", "commit", "barrier2"]
     tot = sum(dv[:7])
-    print(f"{name}: {e0.elapsed_time(e1):.3f} ms, items {nb}, cycles/item {tot/nb:.0f}: " + ", ".join(f"{nm} {dv[i]/nb:.0f} ({100*dv[i]/tot:.0f}%)" for i,nm in enumerate(names)), flush=True)
+    print(f"{name}: {e0.elapsed_time(e1):.3f} ms, clock {dv[8]/max(dv[9],1)*0.1:.2f} GHz, items {nb}, cycles/item {tot/nb:.0f}: " + ", ".join(f"{nm} {dv[i]/nb:.0f} ({100*dv[i]/tot:.0f}%)" for i,nm in enumerate(names)), flush=True)
