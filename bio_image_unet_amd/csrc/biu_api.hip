@@ -165,7 +165,8 @@ extern "C" int biu_conv_bwd_weight_bn(const biu_act* x, const biu_xform* xf, con
                 "conv_bwd_weight_bn: extents differ");
     BIU_REQUIRE(dw && scale && shift && coefA && coefB && coefC, BIU_ERR_SHAPE, "conv_bwd_weight_bn: null pointer");
     const size_t es = dsize(dtype);
-    const bool yok = ((uintptr_t)y->p % 16) == 0 && ((size_t)y->pitch * es) % 16 == 0;
+    const bool yok = ((uintptr_t)y->p % 16) == 0 && ((size_t)y->pitch * es) % 16 == 0 &&
+                     (i64)y->d * y->h * y->w * y->pitch * (i64)es < (1LL << 31);
     if (!disabled("conv_wgrad") && !disabled("wgrad_bn") && yok && biu_mfma_wgrad_ok(x, da, kd, kh, kw, dilation, dtype)) {
         BIU_REQUIRE(ws && ws_bytes >= biu_mfma_wgrad_workspace(x->c, da->c, kd, kh, kw, dtype), BIU_ERR_WORKSPACE,
                     "conv_bwd_weight_bn: workspace too small");

@@ -102,206 +102,6 @@ constexpr int cpad_planes(int hv, int ckp) {     // plane stride in 16-B units: 
 // KD x KHW x KHW taps; input voxel = grid voxel * S + tap - pad, pad = 1 for 3-tap axes, 0 otherwise; the D axis has
 // stride 1 when KD == 1 (2-D tensors).  (KD,KHW,S) = (3|1,3,1): 3x3(x3) conv and its data gradient;
 // (2|1,2,2): data gradient of ConvTranspose k2 s2; (1,1,1) + output scatter: ConvTranspose k2 s2 forward.
-template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP>
-__global__ __launch_bounds__(256, 2) void k_conv_mfma(ConvArgs a) {
-    using F = Frag<T>;
-    constexpr int PE = F::PE;
-    constexpr int PD = (KD == 3) ? 1 : 0;
-    constexpr int PHW = (KHW == 3) ? 1 : 0;
-    constexpr int SD = (KD == 1) ? 1 : S;
-    constexpr int HD = (TD - 1) * SD + KD, HH = (TH - 1) * S + KHW, HW = (TW - 1) * S + KHW;
-    constexpr int HV = HD * HH * HW;
-    constexpr int PSV = cpad_planes(HV, CKP);
-    constexpr int TILES = TD * TH * TW / 32;
-    static_assert(TILES % 4 == 0, "brick must give a multiple of 4 voxel tiles");
-    constexpr int MT = TILES / 4;
-    constexpr int TAPS = KD * KHW * KHW;
-    constexpr int SPC = CKP / 2;                     // k-steps per chunk
-    constexpr int NITEMS = HV * CKP;
-    constexpr int NPASS = (NITEMS + 255) / 256;
-    constexpr int CK = CKP * PE;                     // channels per chunk
-
-    extern __shared__ __attribute__((aligned(16))) uint4 lds[];   // [CKP][PSV]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, hf = lane >> 5;
-
-    int b = blockIdx.x;
-    const int bw = b % a.nbw; b /= a.nbw;
-    const int bh = b % a.nbh; b /= a.nbh;
-    const int bd = b % a.nbd;
-    const int n = b / a.nbd;
-    const int d0 = bd * TD, h0 = bh * TH, w0 = bw * TW;
-
-    // ---- staging plan: item i = tid + 256*j  ->  (halo voxel hv = i / CKP, piece p = i % CKP) --------------------
-    // (coordinates are recomputed per pass: cheaper than 16+ live registers next to 128 accumulators)
-    const int p_mine = tid % CKP;
-    auto stage_vox = [&](int j) -> int {
-        const int i = tid + 256 * j;
-        const int hv = i / CKP;
-        const int hw = hv % HW;
-        const int t = hv / HW;
-        const int hh = t % HH;
-        const int hd = t / HH;
-        const int gd = d0 * SD - PD + hd, gh = h0 * S - PHW + hh, gw = w0 * S - PHW + hw;
-        const bool inb = (hv < HV) && gd >= 0 && gd < a.ID && gh >= 0 && gh < a.IH && gw >= 0 && gw < a.IW;
-        return inb ? ((n * a.ID + gd) * a.IH + gh) * a.IW + gw : (hv < HV ? -1 : -2);
-    };
-
-    // ---- per-lane LDS base of each of this wave's voxel tiles (tap (0,0,0) corner), in 16-B units ----------------
-    int hvb[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int q = (wave * MT + mt) * 32 + r;
-        const int lw = q % TW;
-        const int t = q / TW;
-        const int lh = t % TH;
-        const int ld = t / TH;
-        hvb[mt] = hf * PSV + (ld * SD * HH + lh * S) * HW + lw * S;
-    }
-
-    floatx16 acc[NT][MT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[nt][mt][e] = 0.f;
-
-    const bool has_xf = a.xs != nullptr;
-    const int nchunks = a.Cin / CK;
-    const size_t esz = sizeof(T);
-    const uint4* wbase = a.wpk + (size_t)blockIdx.z * a.wz_stride + ((size_t)blockIdx.y * NT * a.nKS * TAPS) * 64 + lane;
-
-#ifdef BIU_DIAG
-    unsigned long long tprev_ = __builtin_readcyclecounter();
-    unsigned long long dsum_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    constexpr int WPF = 3;                            // weight fragments are prefetched WPF (tap, k-step) steps ahead
-    constexpr int NSTEP = TAPS * SPC;
-    constexpr int SB = 8;                             // staging loads in flight per thread
-
-    for (int ch = 0; ch < nchunks; ++ch) {
-        DIAG_STAMP(0);     // prologue / previous barrier
-        const uint4* wch = wbase + (size_t)(ch * SPC) * TAPS * 64;
-        auto wload = [&](int step, uint4* dst) {
-            const int tap = step / SPC, s = step % SPC;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) dst[nt] = wch[((size_t)nt * a.nKS * TAPS + (size_t)s * TAPS + tap) * 64];
-        };
-        // first weight fragments go out before the staging phase so that their L2 latency hides under it
-        uint4 wq[WPF][NT];
-#pragma unroll
-        for (int i = 0; i < WPF; ++i)
-            if (i < NSTEP) wload(i, wq[i]);
-
-        // -------- stage the halo tile of channels [ch*CK, ch*CK + CK) --------------------------------------------
-        const int c0 = ch * CK + p_mine * PE;
-        float sc[PE], sh[PE], sl[PE];
-        if (has_xf) {
-#pragma unroll
-            for (int e = 0; e < PE; ++e) { sc[e] = a.xs[c0 + e]; sh[e] = a.xb[c0 + e]; sl[e] = a.xl[c0 + e]; }
-        }
-        const char* xsrc = a.x + (size_t)c0 * esz;
-#pragma unroll
-        for (int j0 = 0; j0 < NPASS; j0 += SB) {
-            uint4 v[SB];
-            int vi[SB];
-#pragma unroll
-            for (int jj = 0; jj < SB; ++jj) {
-                const int j = j0 + jj;
-                if (j < NPASS) {
-                    vi[jj] = stage_vox(j);
-                    v[jj] = make_uint4(0, 0, 0, 0);
-                    if (vi[jj] >= 0) v[jj] = *(const uint4*)(xsrc + (size_t)vi[jj] * a.xpitch * esz);
-                }
-            }
-#pragma unroll
-            for (int jj = 0; jj < SB; ++jj) {
-                const int j = j0 + jj;
-                if (j < NPASS) {
-                    if (has_xf && vi[jj] >= 0) {
-                        float f[PE];
-                        F::unpack(v[jj], f);
-#pragma unroll
-                        for (int e = 0; e < PE; ++e) {
-                            const float t = fmaf(sc[e], f[e], sh[e]);
-                            f[e] = fmaxf(t, sl[e] * t);          // LeakyReLU for 0 <= slope <= 1
-                        }
-                        v[jj] = F::pack(f);
-                    }
-                    if (vi[jj] != -2) lds[p_mine * PSV + (tid + 256 * j) / CKP] = v[jj];
-                }
-            }
-        }
-        DIAG_STAMP(1);     // staging (loads + transform + LDS writes) as seen by thread 0
-        __syncthreads();
-        DIAG_STAMP(2);     // barrier wait
-
-        // -------- TAPS x SPC steps of MFMA; the weight ring stays WPF steps ahead ----------------------------------
-#pragma unroll
-        for (int step = 0; step < NSTEP; ++step) {
-            const int tap = step / SPC, s = step % SPC;
-            const int ta = tap / (KHW * KHW), tb = (tap / KHW) % KHW, tc = tap % KHW;
-            const int tapoff = (ta * HH + tb) * HW + tc;
-            uint4 wf[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wf[nt] = wq[step % WPF][nt];
-            if (step + WPF < NSTEP) wload(step + WPF, wq[step % WPF]);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const uint4 bf = lds[hvb[mt] + 2 * s * PSV + tapoff];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) F::mma(wf[nt], bf, acc[nt][mt]);
-            }
-        }
-        DIAG_STAMP(3);     // MFMA phase
-        __syncthreads();
-        DIAG_STAMP(4);     // trailing barrier
-    }
-
-    // ---- epilogue: lane holds, per tile, channels {4*hf + 8*q + i} of voxel r ------------------------------------
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int q = (wave * MT + mt) * 32 + r;
-        const int lw = q % TW;
-        const int t = q / TW;
-        const int lh = t % TH;
-        const int ld = t / TH;
-        const int gd = d0 + ld, gh = h0 + lh, gw = w0 + lw;
-        if (gd >= a.GD || gh >= a.GH || gw >= a.GW) continue;
-        const int od = gd * a.osd + ((a.osd == 2) ? (int)(blockIdx.z >> 2) : 0);
-        const int oh = gh * a.osh + ((a.osh == 2) ? (int)((blockIdx.z >> 1) & 1) : 0);
-        const int ow = gw * a.osw + ((a.osw == 2) ? (int)(blockIdx.z & 1) : 0);
-        const size_t vox = ((size_t)(n * a.OD + od) * a.OH + oh) * a.OW + ow;
-        T* yrow = (T*)a.y + vox * a.ypitch;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const int co = (blockIdx.y * NT + nt) * 32 + 8 * qq + 4 * hf;
-                if (co >= a.Cout) continue;
-                float o[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = acc[nt][mt][4 * qq + i] + (a.bias ? a.bias[co + i] : 0.f);
-                Pack<T, 4>* dst = (Pack<T, 4>*)(yrow + co);
-                if (a.accumulate) {
-                    Pack<T, 4> old = *dst;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] += (float)old.v[i];
-                }
-                Pack<T, 4> pk;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pk.v[i] = (T)o[i];
-                *dst = pk;
-            }
-        }
-    }
-    DIAG_STAMP(5);         // epilogue
-#ifdef BIU_DIAG
-    if (a.diag && tid == 0) atomicAdd(a.diag + 7, 1ull);
-#endif
-}
 
 // ===============================================================================================================
 // Pipelined persistent variant (the one the launchers use).
@@ -1166,6 +966,8 @@ struct WgradArgs {
     int BD, BH, BW;      // extent of B
     int nbd, nbh, nbw, nbricks;
     int njt;             // number of 32-wide j tiles
+    int jt_begin, jt_count;   // j tiles this launch covers: blockIdx.y = it * jt_count + (jt - jt_begin)
+    int write_back;           // fused BatchNorm backward: this launch overwrites da with dy
     int bricks_per_block;
     // optional fused BatchNorm backward on the plain operand: A = dy is computed on the fly from (da = pa, y = py):
     //   dz = da * T'(scale*y + shift),  dy = cA*dz + cB*y + cC ; blocks with jt == 0 also write dy back over da
@@ -1188,190 +990,6 @@ __device__ __forceinline__ uint4 apply_xf16(uint4 v, const float* sc, const floa
     return F::pack(f);
 }
 
-template <typename T, int KD, int KHW, int S, int TD, int TH, int TW>
-__global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WgradArgs a) {
-    using F = Frag<T>;
-    constexpr int PE = F::PE;
-    constexpr int CT = 32;                           // channel tile
-    constexpr int PPV = CT / PE;                     // 16-B pieces per voxel row
-    constexpr int PD = (KD == 3) ? 1 : 0;
-    constexpr int PHW = (KHW == 3) ? 1 : 0;
-    constexpr int SD = (KD == 1) ? 1 : S;
-    constexpr int HD = (TD - 1) * SD + KD, HH = (TH - 1) * S + KHW, HW = (TW - 1) * S + KHW;
-    constexpr int HV = HD * HH * HW;
-    constexpr int BV = TD * TH * TW;
-    constexpr int TAPS = KD * KHW * KHW;
-    constexpr int TPW = (TAPS + 3) / 4;              // taps per wave
-    constexpr int RS = CT * (int)sizeof(T);          // LDS row stride in bytes
-    static_assert(TW % 16 == 0, "k-groups are 16 consecutive voxels along W");
-
-    extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-    char* at = (char*)lds;                           // [BV][CT]
-    char* bt = at + BV * RS;                         // [HV][CT]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int it = blockIdx.y / a.njt, jt = blockIdx.y % a.njt;
-    const size_t esz = sizeof(T);
-
-    floatx16 acc[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-
-    int tapoff[TPW];     // byte offsets of this wave's taps (tap = wave + 4 t) in the B tile
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int tap = wave + 4 * t;
-        const int ta = tap / (KHW * KHW), tb = (tap / KHW) % KHW, tc = tap % KHW;
-        tapoff[t] = ((ta * HH + tb) * HW + tc) * RS;
-    }
-
-    // this thread's piece of a voxel row is fixed (256 % PPV == 0): load its transform constants once
-    const int piece = tid % PPV;
-    const int ac0 = it * CT + piece * PE, bc0 = jt * CT + piece * PE;
-    const bool apiece_ok = ac0 < a.CA, bpiece_ok = bc0 < a.CB;
-    const bool a_xf = a.as_ != nullptr, b_xf = a.bs_ != nullptr;
-    float sca[PE], sha[PE], sla[PE], scb[PE], shb[PE], slb[PE];
-    if (a_xf && apiece_ok) {
-#pragma unroll
-        for (int e = 0; e < PE; ++e) { sca[e] = a.as_[ac0 + e]; sha[e] = a.ab_[ac0 + e]; sla[e] = a.al_[ac0 + e]; }
-    }
-    if (b_xf && bpiece_ok) {
-#pragma unroll
-        for (int e = 0; e < PE; ++e) { scb[e] = a.bs_[bc0 + e]; shb[e] = a.bb_[bc0 + e]; slb[e] = a.bl_[bc0 + e]; }
-    }
-
-    // lane-constant parts of the operand addresses
-    int a_lane, b_lane;
-    if constexpr (sizeof(T) == 2) {
-        const int g = lane >> 4, li = lane & 15, qrow = li >> 2, p = li & 3, cg = g & 1, h = g >> 1;
-        a_lane = (8 * h + qrow) * RS + (16 * cg + 4 * p) * 2;
-        b_lane = (8 * h + qrow) * S * RS + (16 * cg + 4 * p) * 2;
-    } else {
-        a_lane = (lane >> 5) * RS + (lane & 31) * 4;
-        b_lane = (lane >> 5) * S * RS + (lane & 31) * 4;
-    }
-
-    const int b_begin = blockIdx.x * a.bricks_per_block;
-    int b_end = b_begin + a.bricks_per_block;
-    if (b_end > a.nbricks) b_end = a.nbricks;
-
-    for (int brick = b_begin; brick < b_end; ++brick) {
-        int b = brick;
-        const int bw = b % a.nbw; b /= a.nbw;
-        const int bh = b % a.nbh; b /= a.nbh;
-        const int bd = b % a.nbd;
-        const int n = b / a.nbd;
-        const int d0 = bd * TD, h0 = bh * TH, w0 = bw * TW;
-
-        // ---- stage A tile: item i -> (brick voxel q = i / PPV, piece); the LDS image is linear in i ------------------
-        constexpr int NA = (BV * PPV + 255) / 256;
-#pragma unroll 4
-        for (int j = 0; j < NA; ++j) {
-            const int i = tid + 256 * j;
-            const int q = i / PPV;
-            const int lw = q % TW;
-            const int t = q / TW;
-            const int lh = t % TH;
-            const int ld = t / TH;
-            const int gd = d0 + ld, gh = h0 + lh, gw = w0 + lw;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (i < BV * PPV && apiece_ok && gd < a.GD && gh < a.GH && gw < a.GW) {
-                const size_t vox = ((size_t)(n * a.GD + gd) * a.GH + gh) * a.GW + gw;
-                v = *(const uint4*)(a.pa + (vox * a.apitch + ac0) * esz);
-                if (a_xf) v = apply_xf16<T, PE>(v, sca, sha, sla);
-            }
-            if (i < BV * PPV) ((uint4*)at)[i] = v;
-        }
-        // ---- stage B tile (halo / fine-grid tile), zero padding after the transform -----------------------------------
-        constexpr int NB = (HV * PPV + 255) / 256;
-#pragma unroll 4
-        for (int j = 0; j < NB; ++j) {
-            const int i = tid + 256 * j;
-            const int hv = i / PPV;
-            const int hw = hv % HW;
-            const int t = hv / HW;
-            const int hh = t % HH;
-            const int hd = t / HH;
-            const int gd = d0 * SD - PD + hd, gh = h0 * S - PHW + hh, gw = w0 * S - PHW + hw;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (i < HV * PPV && bpiece_ok && gd >= 0 && gd < a.BD && gh >= 0 && gh < a.BH && gw >= 0 && gw < a.BW) {
-                const size_t vox = ((size_t)(n * a.BD + gd) * a.BH + gh) * a.BW + gw;
-                v = *(const uint4*)(a.pb + (vox * a.bpitch + bc0) * esz);
-                if (b_xf) v = apply_xf16<T, PE>(v, scb, shb, slb);
-            }
-            if (i < HV * PPV) ((uint4*)bt)[i] = v;
-        }
-        __syncthreads();
-
-        // ---- MFMA over the brick's voxels ---------------------------------------------------------------------------
-        if constexpr (sizeof(T) == 2) {
-            constexpr int NKG = BV / 16;
-#pragma unroll 4
-            for (int kg = 0; kg < NKG; ++kg) {
-                const int q0 = kg * 16;                      // 16 consecutive voxels along W
-                const int lw0 = q0 % TW;
-                const int t = q0 / TW;
-                const int lh = t % TH;
-                const int ld = t / TH;
-                const int hbase = ((ld * SD * HH + lh * S) * HW + lw0 * S) * RS;
-                typedef bf16x4 __attribute__((address_space(3))) * lp;
-                const char* ap = at + q0 * RS + a_lane;
-                bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap));
-                bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap + 4 * RS));
-                bf16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                for (int t2 = 0; t2 < TPW; ++t2) {
-                    if (wave + 4 * t2 < TAPS) {
-                        const char* bp = bt + hbase + tapoff[t2] + b_lane;
-                        bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp));
-                        bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp + 4 * S * RS));
-                        bf16x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-                        acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t2], 0, 0, 0);
-                    }
-                }
-            }
-        } else {
-            constexpr int NKP = BV / 2;
-#pragma unroll 8
-            for (int kp = 0; kp < NKP; ++kp) {
-                const int q0 = kp * 2;                       // 2 consecutive voxels along W
-                const int lw0 = q0 % TW;
-                const int t = q0 / TW;
-                const int lh = t % TH;
-                const int ld = t / TH;
-                const int hbase = ((ld * SD * HH + lh * S) * HW + lw0 * S) * RS;
-                const float af = *(const float*)(at + q0 * RS + a_lane);
-#pragma unroll
-                for (int t2 = 0; t2 < TPW; ++t2) {
-                    if (wave + 4 * t2 < TAPS) {
-                        const float bf = *(const float*)(bt + hbase + tapoff[t2] + b_lane);
-                        acc[t2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[t2], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- flush: lane (j = lane & 31, h = lane >> 5), reg e -> i = (e & 3) + 8 (e >> 2) + 4 h ---------------------------
-    const int jj = jt * CT + (lane & 31);
-    const int hf = lane >> 5;
-    if (jj < a.CB) {
-#pragma unroll
-        for (int t2 = 0; t2 < TPW; ++t2) {
-            const int tap = wave + 4 * t2;
-            if (tap < TAPS) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int ii = it * CT + (e & 3) + 8 * (e >> 2) + 4 * hf;
-                    if (ii < a.CA) atomicAdd(a.ws + ((size_t)tap * a.CA + ii) * a.CB + jj, acc[t2][e]);
-                }
-            }
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Pipelined persistent weight-gradient kernel (the one the launchers use): 512 threads, one block per CU, blocks walk
@@ -1380,6 +998,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WgradArgs a) {
 // (tap, half of the brick's voxel groups): 54 items for 27 taps -> 7/7/7/7/7/7/6/6 per wave.  Each block keeps its
 // partial dW in registers across ALL its bricks and flushes once.
 // ---------------------------------------------------------------------------------------------------------------
+// the per-thread piece-coordinate table goes to LDS when tiles + table stay under 150 KB
+constexpr bool wgrad_tab_in_lds(size_t tile_bytes, int pieces) { return tile_bytes + (size_t)pieces * 512 * 4 <= 150 * 1024; }
+
 template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int KSPLIT>
 __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     using F = Frag<T>;
@@ -1407,9 +1028,15 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     char* at = (char*)lds;                           // [BV][CT]
     char* bt = at + BV * RS;                         // [HV][CT]
     float* lxf = (float*)(bt + HV * RS);             // [6][CT] transform constants of the A / B channel tiles, then [6][CT] BN-bwd
+    // packed piece coordinates of every thread (brick-invariant): in LDS [NA + NB][NTHR] when they fit next to the tiles
+    // (the big-tile kernels have no registers to spare), else in registers
+    constexpr bool TAB_LDS = wgrad_tab_in_lds((size_t)(HV + BV) * RS, NA + NB);
+    unsigned* ltab = (unsigned*)(lxf + 12 * CT);
+    unsigned xa_[TAB_LDS ? 1 : NA], xb_[TAB_LDS ? 1 : NB];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int it = blockIdx.y / a.njt, jt = blockIdx.y % a.njt;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: item tables live in SGPRs
+    const int it = blockIdx.y / a.jt_count, jt = a.jt_begin + blockIdx.y % a.jt_count;
     const size_t esz = sizeof(T);
     const int piece = tid % PPV;
     const int ac0 = it * CT + piece * PE, bc0 = jt * CT + piece * PE;
@@ -1464,54 +1091,82 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     }
 
     uint4 pa[NA], pb[NB], pyv[NA];
-    unsigned avox[NA];                               // voxel index of each A piece (for the dy write-back)
     unsigned amask = 0, bmask = 0;
-    auto issue = [&](int brick, bool live) {
+    // Per-thread piece coordinates, packed in 10-bit fields (d | h << 10 | w << 20); 511 marks a piece this thread does
+    // not have.  Per brick: a guard-bit range test, two 24-bit multiply-adds for the offset, one buffer load whose
+    // descriptor range check returns zeros for the pieces outside the volume (same scheme as k_conv_pipe).
+    constexpr unsigned GBITS = (1u << 9) | (1u << 19) | (1u << 29);
+    // (kept in LDS, one dword per piece and thread: the kernel has no registers to spare for them)
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int i = tid + NTHR * j;
+        const int q = i / PPV;
+        const int lw = q % TW;
+        const int t = q / TW;
+        const unsigned xv = (i < BV * PPV && apiece_ok) ? (unsigned)((t / TH) | ((t % TH) << 10) | (lw << 20)) : 511u;
+        if constexpr (TAB_LDS) ltab[j * NTHR + tid] = xv; else xa_[j] = xv;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int i = tid + NTHR * j;
+        const int hv = i / PPV;
+        const int hw = hv % HW;
+        const int t = hv / HW;
+        const unsigned xv = (i < HV * PPV && bpiece_ok) ? (unsigned)((t / HH) | ((t % HH) << 10) | (hw << 20)) : 511u;
+        if constexpr (TAB_LDS) ltab[(NA + j) * NTHR + tid] = xv; else xb_[j] = xv;
+    }
+    const int rowA = a.apitch * (int)esz, rowY = a.ypitch * (int)esz, rowB = a.bpitch * (int)esz;
+    const size_t sampA = (size_t)a.GD * a.GH * a.GW * rowA, sampY = (size_t)a.GD * a.GH * a.GW * rowY;
+    const size_t sampB = (size_t)a.BD * a.BH * a.BW * rowB;                  // all < 2^31 (checked on the host)
+    unsigned ca_hi = 0, cb_lo = 0, cb_hi = 0;
+    int brA = 0, brY = 0, brB = 0;
+    __amdgpu_buffer_rsrc_t rsA, rsY, rsB;
+    auto issue_prep = [&](int brick, bool live) {
         int b = brick;
         const int bw = b % a.nbw; b /= a.nbw;
         const int bh = b % a.nbh; b /= a.nbh;
         const int bd = b % a.nbd;
         const int n = b / a.nbd;
         const int d0 = bd * TD, h0 = bh * TH, w0 = bw * TW;
+        ca_hi = GBITS + (unsigned)(min(TD - 1, a.GD - 1 - d0) | (min(TH - 1, a.GH - 1 - h0) << 10) | (min(TW - 1, a.GW - 1 - w0) << 20));
+        const int va = (d0 * a.GH + h0) * a.GW + w0;
+        brA = va * rowA + ac0 * (int)esz;
+        brY = va * rowY + ac0 * (int)esz;
+        const int gd0 = d0 * SD - PD, gh0 = h0 * S - PHW, gw0 = w0 * S - PHW;
+        cb_lo = GBITS - (unsigned)(max(0, -gd0) | (max(0, -gh0) << 10) | (max(0, -gw0) << 20));
+        cb_hi = GBITS + (unsigned)(min(HD - 1, a.BD - 1 - gd0) | (min(HH - 1, a.BH - 1 - gh0) << 10) | (min(HW - 1, a.BW - 1 - gw0) << 20));
+        brB = ((gd0 * a.BH + gh0) * a.BW + gw0) * rowB + bc0 * (int)esz;
+        // a dead prefetch reads through empty descriptors: zeros, nothing fetched
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pa + (size_t)n * sampA), 0, live ? (int)sampA : 0, 0x00020000);
+        rsY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.py + (size_t)n * sampY), 0, (live && bn_fused) ? (int)sampY : 0, 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pb + (size_t)n * sampB), 0, live ? (int)sampB : 0, 0x00020000);
         amask = bmask = 0;
-        int tq = tid;
-        asm volatile("" : "+v"(tq));     // opaque: keeps LICM from hoisting (and spilling) the per-piece coordinates
+    };
+    auto ld128 = [&](const __amdgpu_buffer_rsrc_t& rs, int off) -> uint4 {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+        return make_uint4(v[0], v[1], v[2], v[3]);
+    };
+    auto issue_a = [&](int j) {
+        const unsigned x = TAB_LDS ? ltab[j * NTHR + tid] : xa_[TAB_LDS ? 0 : j];
+        const bool ok = ((ca_hi - x) & GBITS) == GBITS;
+        const int v = (int)__umul24(__umul24(x & 511u, (unsigned)a.GH) + ((x >> 10) & 511u), (unsigned)a.GW) + (int)(x >> 20);
+        pa[j] = ld128(rsA, ok ? (int)__umul24((unsigned)v, (unsigned)rowA) + brA : -1);
+        if (bn_fused) pyv[j] = ld128(rsY, ok ? (int)__umul24((unsigned)v, (unsigned)rowY) + brY : -1);
+        amask |= ok ? (1u << j) : 0u;
+    };
+    auto issue_b = [&](int j) {
+        const unsigned x = TAB_LDS ? ltab[(NA + j) * NTHR + tid] : xb_[TAB_LDS ? 0 : j];
+        const bool ok = (((x + cb_lo) & (cb_hi - x)) & GBITS) == GBITS;
+        const int v = (int)__umul24(__umul24(x & 511u, (unsigned)a.BH) + ((x >> 10) & 511u), (unsigned)a.BW) + (int)(x >> 20);
+        pb[j] = ld128(rsB, ok ? (int)__umul24((unsigned)v, (unsigned)rowB) + brB : -1);
+        bmask |= ok ? (1u << j) : 0u;
+    };
+    auto issue = [&](int brick, bool live) {
+        issue_prep(brick, live);
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int i = tq + NTHR * j;
-            const int q = i / PPV;
-            const int lw = q % TW;
-            const int t = q / TW;
-            const int lh = t % TH;
-            const int ld = t / TH;
-            const int gd = d0 + ld, gh = h0 + lh, gw = w0 + lw;
-            pa[j] = make_uint4(0, 0, 0, 0);
-            if (live && i < BV * PPV && apiece_ok && gd < a.GD && gh < a.GH && gw < a.GW) {
-                const size_t vox = ((size_t)(n * a.GD + gd) * a.GH + gh) * a.GW + gw;
-                pa[j] = *(const uint4*)(a.pa + (vox * a.apitch + ac0) * esz);
-                if (bn_fused) {
-                    pyv[j] = *(const uint4*)(a.py + (vox * a.ypitch + ac0) * esz);
-                    avox[j] = (unsigned)vox;
-                }
-                amask |= 1u << j;
-            }
-        }
+        for (int j = 0; j < NA; ++j) issue_a(j);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int i = tq + NTHR * j;
-            const int hv = i / PPV;
-            const int hw = hv % HW;
-            const int t = hv / HW;
-            const int hh = t % HH;
-            const int hd = t / HH;
-            const int gd = d0 * SD - PD + hd, gh = h0 * S - PHW + hh, gw = w0 * S - PHW + hw;
-            pb[j] = make_uint4(0, 0, 0, 0);
-            if (live && i < HV * PPV && bpiece_ok && gd >= 0 && gd < a.BD && gh >= 0 && gh < a.BH && gw >= 0 && gw < a.BW) {
-                const size_t vox = ((size_t)(n * a.BD + gd) * a.BH + gh) * a.BW + gw;
-                pb[j] = *(const uint4*)(a.pb + (vox * a.bpitch + bc0) * esz);
-                bmask |= 1u << j;
-            }
-        }
+        for (int j = 0; j < NB; ++j) issue_b(j);
     };
     auto commit = [&]() {
         float sc[PE], sh[PE], sl[PE];
@@ -1551,7 +1206,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
 #pragma unroll
                         for (int e = 0; e < PE; ++e) g[e] = fmaf(ka[e], g[e], fmaf(kb[e], yy[e], kc[e]));
                         pa[j] = F::pack(g);
-                        if (jt == 0) *(uint4*)(const_cast<char*>(a.pa) + ((size_t)avox[j] * a.apitch + ac0) * esz) = pa[j];    // dy replaces da
+                        if (a.write_back) {                                      // dy replaces da (only in the launch that owns it)
+                            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                            const unsigned x = TAB_LDS ? ltab[j * NTHR + tid] : xa_[TAB_LDS ? 0 : j];
+                            const int v = (int)__umul24(__umul24(x & 511u, (unsigned)a.GH) + ((x >> 10) & 511u), (unsigned)a.GW) + (int)(x >> 20);
+                            __builtin_amdgcn_raw_buffer_store_b128(v4u{pa[j].x, pa[j].y, pa[j].z, pa[j].w}, rsA, (int)__umul24((unsigned)v, (unsigned)rowA) + brA, 0, 0);
+                        }
                     }
                 }
             }
@@ -1590,14 +1250,22 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         while (true) {
             const int nbrick = brick + G;
             const bool have_next = nbrick < a.nbricks;
-            issue(have_next ? nbrick : brick, have_next);
-
-#pragma unroll 1
-            for (int h = 0; h < KSPLIT; ++h) {
+            // the next brick's loads go out in NG slices between the k-group slices of this brick's MFMA work
+            constexpr int NG = 8;
+            static_assert(NKG % NG == 0 && NG % KSPLIT == 0, "k-groups must split into 8 slices inside the K halves");
+            constexpr int KPG = NKG / NG;
+            issue_prep(have_next ? nbrick : brick, have_next);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                for (int j = (g * NA) / NG; j < ((g + 1) * NA) / NG; ++j) issue_a(j);
+#pragma unroll
+                for (int j = (g * NB) / NG; j < ((g + 1) * NB) / NG; ++j) issue_b(j);
+                const int h = g / (NG / KSPLIT);
                 // fp32 steps are tiny (one ds_read_b32 per 64-cycle MFMA): unroll deeper so the LDS reads run ahead
-#pragma unroll(sizeof(T) == 2 ? 2 : 8)
-                for (int kk = 0; kk < NKG / KSPLIT; ++kk) {
-                    const int kg = h * (NKG / KSPLIT) + kk;
+#pragma unroll(sizeof(T) == 2 ? 2 : 4)
+                for (int kk = 0; kk < KPG; ++kk) {
+                    const int kg = g * KPG + kk;
                     const int q0 = kg * KUNIT;
                     const int lw0 = q0 % TW;
                     const int t = q0 / TW;
@@ -1631,6 +1299,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                         }
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (!have_next) break;
             __syncthreads();
@@ -1685,7 +1354,11 @@ size_t biu_mfma_wgrad_workspace(int cin, int cout, int kd, int kh, int kw, int d
 
 static bool wgrad_ptrs_ok(const biu_act* x, const biu_act* dy, int dtype) {
     const size_t es = dsize(dtype);
-    return !((uintptr_t)x->p % 16 || (uintptr_t)dy->p % 16 || ((size_t)x->pitch * es) % 16 || ((size_t)dy->pitch * es) % 16);
+    if ((uintptr_t)x->p % 16 || (uintptr_t)dy->p % 16 || ((size_t)x->pitch * es) % 16 || ((size_t)dy->pitch * es) % 16) return false;
+    // 32-bit buffer offsets inside one sample; 24-bit multiplies on tile-local voxel offsets (a tile spans <= 10 planes)
+    if (sample_bytes(x, es) >= (1LL << 31) || sample_bytes(dy, es) >= (1LL << 31)) return false;
+    const i64 plane_x = (i64)x->h * x->w, plane_y = (i64)dy->h * dy->w;
+    return 10 * (plane_x > plane_y ? plane_x : plane_y) < (1LL << 24);
 }
 
 bool biu_mfma_wgrad_ok(const biu_act* x, const biu_act* dy, int kd, int kh, int kw, int dilation, int dtype) {
@@ -1704,17 +1377,16 @@ static int launch_wgrad(WgradArgs a, hipStream_t st) {
     constexpr int SD = (KD == 1) ? 1 : S;
     constexpr int HV = ((TD - 1) * SD + KD) * ((TH - 1) * S + KHW) * ((TW - 1) * S + KHW);
     constexpr int BV = TD * TH * TW;
-    const size_t lds_bytes = (size_t)(HV + BV) * 32 * sizeof(T) + 12 * 32 * sizeof(float);
+    constexpr int PPV_ = 32 / (16 / (int)sizeof(T));
+    constexpr int NA_ = (BV * PPV_ + 511) / 512, NB_ = (HV * PPV_ + 511) / 512;
+    const size_t tile_bytes = (size_t)(HV + BV) * 32 * sizeof(T);
+    const size_t lds_bytes = tile_bytes + 12 * 32 * sizeof(float) + (wgrad_tab_in_lds(tile_bytes, NA_ + NB_) ? (size_t)(NA_ + NB_) * 512 * sizeof(unsigned) : 0);
     a.nbd = (a.GD + TD - 1) / TD;
     a.nbh = (a.GH + TH - 1) / TH;
     a.nbw = (a.GW + TW - 1) / TW;
     a.nbricks = a.N * a.nbd * a.nbh * a.nbw;
     const int nit = (a.CA + 31) / 32;
     a.njt = (a.CB + 31) / 32;
-    const int pairs = nit * a.njt;
-    int g = num_cus() / pairs;                            // persistent: about one block per CU in total
-    if (g < 1) g = 1;
-    if (g > a.nbricks) g = a.nbricks;
     a.bricks_per_block = 0;
     auto kern = k_wgrad_pipe<T, KD, KHW, S, TD, TH, TW, KSPLIT>;
     static bool attr_set = false;
@@ -1723,7 +1395,25 @@ static int launch_wgrad(WgradArgs a, hipStream_t st) {
             return biu_fail(BIU_ERR_LAUNCH, "wgrad_pipe: cannot reserve %zu bytes of LDS", lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(g, pairs), dim3(512), lds_bytes, st, a);
+    auto launch = [&](int jt_begin, int jt_count, int write_back) {
+        WgradArgs b = a;
+        b.jt_begin = jt_begin; b.jt_count = jt_count; b.write_back = write_back;
+        const int pairs = nit * jt_count;
+        int g = num_cus() / pairs;                        // persistent: about one block per CU in total
+        if (g < 1) g = 1;
+        if (g > b.nbricks) g = b.nbricks;
+        hipLaunchKernelGGL(kern, dim3(g, pairs), dim3(512), lds_bytes, st, b);
+    };
+    if (a.py && a.njt > 1) {
+        // Fused BatchNorm backward rewrites da as dy IN PLACE while every j tile needs the original da: the tiles that
+        // only read go first, the one that also writes back runs after them (stream order is the only safe ordering
+        // between workgroups).
+        launch(1, a.njt - 1, 0);
+        BIU_CHECK_LAUNCH("wgrad_pipe");
+        launch(0, 1, 1);
+    } else {
+        launch(0, a.njt, a.py ? 1 : 0);
+    }
     BIU_CHECK_LAUNCH("wgrad_pipe");
     return BIU_OK;
 }

@@ -529,3 +529,45 @@ def test_convt_bwd_data_bnred(case, dtype):
     scale1 = float(dx.ref().abs().sum() / cin) + 1e-12
     torch.testing.assert_close(sums[:, 0], s1, rtol=1e-4, atol=1e-5 * scale1)
     torch.testing.assert_close(sums[:, 1], s2, rtol=1e-4, atol=1e-5 * scale1 * float(invstd.max()) * 4)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# weight gradient with BatchNorm+LeakyReLU backward fused into its operand loader (da -> dy in place)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(3, 2, 96, 32, (8, 16, 32)), (3, 1, 32, 64, (6, 10, 20)), (2, 2, 128, 64, (24, 40)),
+                                  (3, 1, 6, 8, (4, 6, 10))])
+def test_conv_bwd_weight_bn(case, dtype):
+    """Several 32-wide input-channel tiles (Cin = 96, 128) read the same da that one of them overwrites with dy."""
+    nd, n, cin, cout, sp = case
+    kd = 3 if nd == 3 else 1
+    code = DT[dtype][1]
+    x = Dev(rnd(n, cin, *sp, seed=1), dtype=dtype, pitch=cin + 8, c0=0)
+    xf = XF(cin, seed=2)
+    y = Dev(rnd(n, cout, *sp, seed=3), dtype=dtype)
+    da0 = rnd(n, cout, *sp, seed=4)
+    yxf = XF(cout, seed=5)
+    cA, cB, cC = (rnd(cout, seed=6) * 0.3 + 1.0), rnd(cout, seed=7) * 0.05, rnd(cout, seed=8) * 0.05
+    coef = [t.cuda() for t in (cA, cB, cC)]
+    wsz = max(lib.biu_conv_bwd_weight_workspace(cin, cout, kd, 3, 3, code), 16)
+    ws = torch.empty(wsz, dtype=torch.uint8, device="cuda")
+    wshape = (cout, cin) + (3,) * nd
+    # reference path: separate BatchNorm-backward pass, then the plain weight gradient
+    da_ref = Dev(da0, dtype=dtype)
+    check(lib.biu_bn_bwd_apply(da_ref.a(), y.a(), ptr(yxf.d[0]), ptr(yxf.d[1]), ptr(yxf.d[2]), ptr(coef[0]), ptr(coef[1]),
+                               ptr(coef[2]), da_ref.a(), code, stream()), "bn_bwd_apply")
+    dw_ref = torch.full(wshape, float("nan"), device="cuda")
+    check(lib.biu_conv_bwd_weight(x.a(), xf.x(), da_ref.a(), kd, 3, 3, 1, ptr(dw_ref), None, ptr(ws), ws.numel(), code, stream()),
+          "conv_bwd_weight")
+    for rep in range(3):                              # repeated: a read/overwrite race would show as run-to-run differences
+        da = Dev(da0, dtype=dtype)
+        dw = torch.full(wshape, float("nan"), device="cuda")
+        check(lib.biu_conv_bwd_weight_bn(x.a(), xf.x(), da.a(), y.a(), ptr(yxf.d[0]), ptr(yxf.d[1]), ptr(yxf.d[2]), ptr(coef[0]),
+                                         ptr(coef[1]), ptr(coef[2]), kd, 3, 3, 1, ptr(dw), ptr(ws), ws.numel(), code, stream()),
+              "conv_bwd_weight_bn")
+        # dy written back over da: the fused path parks dz in the storage type between its two sweeps (one more rounding)
+        t = dict(rtol=1e-5, atol=1e-5) if dtype == "f32" else dict(rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(da.get(), da_ref.get(), **t)
+        scale = float(dw_ref.abs().max())
+        t2 = dict(rtol=1e-3, atol=2e-4 * scale) if dtype == "f32" else dict(rtol=2e-2, atol=2e-2 * scale)
+        torch.testing.assert_close(dw.cpu(), dw_ref.cpu(), **t2)
