@@ -248,7 +248,13 @@ def main():
     else:
         roof = {"bound": "hbm", "achieved": by / (dom_launch_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
-    roof["traffic"] = None
+    roof["traffic"] = None          # HBM bytes per launch from PMC counters (tools/pmc_traffic.py), when measured for this call
+    tr_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"pmc_traffic_{args.workload}.json")
+    if os.path.exists(tr_file):
+        tr = json.load(open(tr_file)).get(f"{dom_key[0]} @ {dom_key[1]}")
+        if tr:
+            roof["traffic"] = tr["traffic_bytes_per_call"]
+            roof["traffic_source"] = f"profiles/pmc_traffic_{args.workload}.json (rocprofv3 PMC, separate run; algorithmic bytes {by:.4g})"
     roof["kernel"] = f"{dom_key[0]} @ {dom_key[1]}"
     roof["launch_ms"] = dom_launch_ms
     roof["launches_timed"] = len(watched)

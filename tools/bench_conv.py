@@ -54,11 +54,24 @@ def main():
         dw = torch.empty_like(wt)
         fl = 2.0 * n * d * h * w * (27 if nd == 3 else 9) * cin * cout
         noxf = os.environ.get("BENCH_NOXF") == "1"
+        kvec = [torch.rand(cout, device="cuda") * 0.1 + 0.95 for _ in range(1)] + [torch.zeros(cout, device="cuda"), torch.full((cout,), 0.1, device="cuda"),
+                torch.full((cout,), 1.0, device="cuda"), torch.zeros(cout, device="cuda"), torch.zeros(cout, device="cuda")]
+        stat = torch.empty(lib.biu_conv_fwd_stats_floats(C.byref(ay), kd), device="cuda")
+        nblk = C.c_int(0)
         calls = {
             "fwd": lambda: lib.biu_conv_fwd(C.byref(ax), None if noxf else C.byref(xf), P(wt), P(pk0), P(bias), kd, 3, 3, 1, C.byref(ay), code, st),
             "dgrad": lambda: lib.biu_conv_bwd_data(C.byref(ady), P(wt), P(pk1), kd, 3, 3, 1, C.byref(adx), 0, code, st),
             "wgrad": lambda: lib.biu_conv_bwd_weight(C.byref(ax), C.byref(xf), C.byref(ady), kd, 3, 3, 1, P(dw), None, P(ws), ws.numel(), code, st),
+            # the training step's forms: forward + BatchNorm statistics; weight gradient with BatchNorm backward in its loader
+            # (cA = 1, cB = cC = 0 keeps dy bounded over the repeats)
+            "fwd_st": lambda: lib.biu_conv_fwd_stats(C.byref(ax), None if noxf else C.byref(xf), P(wt), P(pk0), P(bias), kd, 3, 3, 1, C.byref(ay),
+                                                     P(stat), stat.numel(), C.byref(nblk), code, st),
+            "wg_bn": lambda: lib.biu_conv_bwd_weight_bn(C.byref(ax), C.byref(xf), C.byref(ady), C.byref(ay), P(kvec[0]), P(kvec[1]), P(kvec[2]),
+                                                        P(kvec[3]), P(kvec[4]), P(kvec[5]), kd, 3, 3, 1, P(dw), P(ws), ws.numel(), code, st),
         }
+        legs = os.environ.get("BENCH_LEGS")
+        if legs:
+            calls = {k: v for k, v in calls.items() if k in legs.split(",")}
         out = []
         for k, f in calls.items():
             for _ in range(2):
