@@ -65,6 +65,10 @@ SIGNATURES = {
     "biu_nearest_down_bwd": (_I, [_A, _A, _I, _I, _P]),
     "biu_nearest_up_fwd": (_I, [_A, _X, _A, _I, _P]),
     "biu_nearest_up_bwd": (_I, [_A, _A, _I, _I, _P]),
+    "biu_trilinear_up_fwd": (_I, [_A, _X, _A, _I, _P]),
+    "biu_trilinear_up_bwd": (_I, [_A, _A, _I, _I, _P]),
+    "biu_xcorr_fwd": (_I, [_A, _X, _A, _X, _A, _I, _P]),
+    "biu_xcorr_bwd": (_I, [_A, _X, _A, _X, _A, _A, _A, _I, _I, _P]),
     "biu_convt_packed_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "biu_convt_pack": (_I, [_I, _P, _I, _I, _I, _I, _P, _P]),
     "biu_convt_fwd": (_I, [_A, _X, _P, _P, _P, _I, _A, _I, _P]),

@@ -1,0 +1,208 @@
+// Two ops off the main stacks, any shape, scalar per (voxel, channel) with the channel fastest (coalesced rows):
+//   * trilinear x2 up-sampling, align_corners = False  -- UNet3D(use_interpolation=True)   [unet3d/unet3d.py:82,89,96]
+//   * depth-wise cross-correlation of two bottleneck maps -- Siam_UNet(mode='corr')        [siam_unet/siam_unet.py:75-83]
+// Both sit at coarse resolutions; they are correctness-tier kernels (HBM/L2-bound gathers), not MFMA paths.
+#include <hip/hip_runtime.h>
+
+#include "biu_common.h"
+#include "biu_internal.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+// source taps of output index o for scale 2, align_corners = False (PyTorch area_pixel_compute_source_index):
+//   src = max(0.5 * (o + 0.5) - 0.5, 0), i0 = floor(src), i1 = min(i0 + 1, n - 1), l1 = src - i0, l0 = 1 - l1
+struct Tap { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Tap tap_of(int o, int n_in, bool scaled) {
+    if (!scaled) return Tap{o, o, 1.f, 0.f};
+    float src = 0.5f * ((float)o + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    const int i0 = (int)src;
+    const int i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
+    const float l1 = src - (float)i0;
+    return Tap{i0, i1, 1.f - l1, l1};
+}
+__device__ __forceinline__ void split(i64 v, int d, int h, int w, int& n, int& z, int& y, int& x) {
+    x = (int)(v % w); v /= w;
+    y = (int)(v % h); v /= h;
+    z = (int)(v % d);
+    n = (int)(v / d);
+}
+
+template <typename T>
+__global__ void k_trilinear_up_fwd(DAct x, DXf xf, DAct out, int sd) {
+    const i64 total = (i64)out.n * out.d * out.h * out.w * out.c;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
+        const int c = (int)(i % out.c);
+        const i64 ov = i / out.c;
+        int n, z, y, xx;
+        split(ov, out.d, out.h, out.w, n, z, y, xx);
+        const Tap td = tap_of(z, x.d, sd == 2), th = tap_of(y, x.h, true), tw = tap_of(xx, x.w, true);
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float wgt = (a ? td.l1 : td.l0) * (b ? th.l1 : th.l0) * (e ? tw.l1 : tw.l0);
+                    const i64 iv = (((i64)n * x.d + (a ? td.i1 : td.i0)) * x.h + (b ? th.i1 : th.i0)) * x.w + (e ? tw.i1 : tw.i0);
+                    acc = fmaf(wgt, xf_apply(xf, c, ld_act<T>(x, iv, c)), acc);
+                }
+        st_act<T>(out, ov, c, acc);
+    }
+}
+
+// gather form of the adjoint: dx[i] = sum over the (<= 4 per axis) outputs that tap i
+template <typename T>
+__global__ void k_trilinear_up_bwd(DAct dout, DAct dx, int sd, int accumulate) {
+    const i64 total = (i64)dx.n * dx.d * dx.h * dx.w * dx.c;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
+        const int c = (int)(i % dx.c);
+        const i64 v = i / dx.c;
+        int n, z, y, xx;
+        split(v, dx.d, dx.h, dx.w, n, z, y, xx);
+        float acc = 0.f;
+        const int zlo = sd == 2 ? 2 * z - 1 : z, zhi = sd == 2 ? 2 * z + 2 : z;
+        for (int oz = zlo; oz <= zhi; ++oz) {
+            if (oz < 0 || oz >= dout.d) continue;
+            const Tap td = tap_of(oz, dx.d, sd == 2);
+            const float wz = (td.i0 == z ? td.l0 : 0.f) + (td.i1 == z ? td.l1 : 0.f);
+            if (wz == 0.f) continue;
+            for (int oy = 2 * y - 1; oy <= 2 * y + 2; ++oy) {
+                if (oy < 0 || oy >= dout.h) continue;
+                const Tap th = tap_of(oy, dx.h, true);
+                const float wy = (th.i0 == y ? th.l0 : 0.f) + (th.i1 == y ? th.l1 : 0.f);
+                if (wy == 0.f) continue;
+                for (int ox = 2 * xx - 1; ox <= 2 * xx + 2; ++ox) {
+                    if (ox < 0 || ox >= dout.w) continue;
+                    const Tap tw = tap_of(ox, dx.w, true);
+                    const float wx = (tw.i0 == xx ? tw.l0 : 0.f) + (tw.i1 == xx ? tw.l1 : 0.f);
+                    if (wx == 0.f) continue;
+                    const i64 ov = (((i64)n * dout.d + oz) * dout.h + oy) * dout.w + ox;
+                    acc = fmaf(wz * wy * wx, ld_act<T>(dout, ov, c), acc);
+                }
+            }
+        }
+        if (accumulate) acc += ld_act<T>(dx, v, c);
+        st_act<T>(dx, v, c, acc);
+    }
+}
+
+// out[n,y,x,c] = sum_{i,j} T(cur)[n, y + i - ph, x + j - pw, c] * T(prev)[n, i, j, c]   (zero outside), kernel = the whole map,
+// padding='same': ph = (H - 1) / 2, pw = (W - 1) / 2 on the low side (PyTorch pads the remainder on the high side)
+template <typename T>
+__global__ void k_xcorr_fwd(DAct cur, DXf xc, DAct prev, DXf xp, DAct out) {
+    const int H = cur.h, W = cur.w, ph = (H - 1) / 2, pw = (W - 1) / 2;
+    const i64 total = (i64)out.n * H * W * out.c;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
+        const int c = (int)(t % out.c);
+        i64 v = t / out.c;
+        const int x = (int)(v % W); v /= W;
+        const int y = (int)(v % H);
+        const int n = (int)(v / H);
+        float acc = 0.f;
+        for (int i = 0; i < H; ++i) {
+            const int yy = y + i - ph;
+            if (yy < 0 || yy >= H) continue;
+            for (int j = 0; j < W; ++j) {
+                const int xx = x + j - pw;
+                if (xx < 0 || xx >= W) continue;
+                const float a = xf_apply(xc, c, ld_act<T>(cur, ((i64)n * H + yy) * W + xx, c));
+                const float b = xf_apply(xp, c, ld_act<T>(prev, ((i64)n * H + i) * W + j, c));
+                acc = fmaf(a, b, acc);
+            }
+        }
+        st_act<T>(out, ((i64)n * H + y) * W + x, c, acc);
+    }
+}
+// which = 0: d cur[n,yy,xx,c] = sum_{i,j} dout[n, yy - i + ph, xx - j + pw, c] * prev[n,i,j,c]
+// which = 1: d prev[n,i,j,c]  = sum_{y,x} dout[n,y,x,c] * cur[n, y + i - ph, x + j - pw, c]
+template <typename T>
+__global__ void k_xcorr_bwd(DAct other, DXf xo, DAct dout, DAct dst, int which, int accumulate) {
+    const int H = dout.h, W = dout.w, ph = (H - 1) / 2, pw = (W - 1) / 2;
+    const i64 total = (i64)dst.n * H * W * dst.c;
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (i64)gridDim.x * blockDim.x) {
+        const int c = (int)(t % dst.c);
+        i64 v = t / dst.c;
+        const int q = (int)(v % W); v /= W;
+        const int p = (int)(v % H);
+        const int n = (int)(v / H);
+        float acc = 0.f;
+        for (int i = 0; i < H; ++i)
+            for (int j = 0; j < W; ++j) {
+                // which 0: (p,q) = (yy,xx), (i,j) runs over prev ; which 1: (p,q) = kernel index, (i,j) runs over outputs (y,x)
+                const int oy = which == 0 ? p - i + ph : i, ox = which == 0 ? q - j + pw : j;
+                const int sy = which == 0 ? i : i + p - ph, sx = which == 0 ? j : j + q - pw;
+                if (oy < 0 || oy >= H || ox < 0 || ox >= W || sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
+                const float g = ld_act<T>(dout, ((i64)n * H + oy) * W + ox, c);
+                const float o = xf_apply(xo, c, ld_act<T>(other, ((i64)n * H + sy) * W + sx, c));
+                acc = fmaf(g, o, acc);
+            }
+        const i64 dv = ((i64)n * H + p) * W + q;
+        if (accumulate) acc += ld_act<T>(dst, dv, c);
+        st_act<T>(dst, dv, c, acc);
+    }
+}
+
+int up_depth(const biu_act* lo, const biu_act* hi, const char* who) {
+    if (lo->n != hi->n || lo->c != hi->c || hi->h != 2 * lo->h || hi->w != 2 * lo->w) {
+        biu_fail(BIU_ERR_SHAPE, "%s: expected (h,w) = 2x of the coarse tensor and equal n,c", who);
+        return 0;
+    }
+    if (hi->d == lo->d) return 1;
+    if (hi->d == 2 * lo->d) return 2;
+    biu_fail(BIU_ERR_SHAPE, "%s: depth %d vs %d is neither 1x nor 2x", who, hi->d, lo->d);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int biu_trilinear_up_fwd(const biu_act* x, const biu_xform* xf, const biu_act* out, int dtype, biu_stream stream) {
+    BIU_REQUIRE(valid_act(x) && valid_act(out), BIU_ERR_SHAPE, "trilinear_up_fwd: bad tensor");
+    const int sd = up_depth(x, out, "trilinear_up_fwd");
+    if (!sd) return BIU_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_trilinear_up_fwd<T>, dim3(grid_for(nvox(out) * out->c, TPB, 16384)), dim3(TPB), 0, st,
+                                                 dact(x), dxf(xf), dact(out), sd));
+    BIU_CHECK_LAUNCH("trilinear_up_fwd");
+    return BIU_OK;
+}
+extern "C" int biu_trilinear_up_bwd(const biu_act* dout, const biu_act* dx, int accumulate, int dtype, biu_stream stream) {
+    BIU_REQUIRE(valid_act(dout) && valid_act(dx), BIU_ERR_SHAPE, "trilinear_up_bwd: bad tensor");
+    const int sd = up_depth(dx, dout, "trilinear_up_bwd");
+    if (!sd) return BIU_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_trilinear_up_bwd<T>, dim3(grid_for(nvox(dx) * dx->c, TPB, 16384)), dim3(TPB), 0, st,
+                                                 dact(dout), dact(dx), sd, accumulate));
+    BIU_CHECK_LAUNCH("trilinear_up_bwd");
+    return BIU_OK;
+}
+
+extern "C" int biu_xcorr_fwd(const biu_act* cur, const biu_xform* xc, const biu_act* prev, const biu_xform* xp, const biu_act* out,
+                             int dtype, biu_stream stream) {
+    BIU_REQUIRE(valid_act(cur) && valid_act(prev) && valid_act(out) && same_space(cur, prev) && same_space(cur, out) &&
+                    cur->c == prev->c && cur->c == out->c && cur->d == 1, BIU_ERR_SHAPE, "xcorr_fwd: three equal 2-D tensors expected");
+    hipStream_t st = (hipStream_t)stream;
+    BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_xcorr_fwd<T>, dim3(grid_for(nvox(out) * out->c, TPB, 16384)), dim3(TPB), 0, st,
+                                                 dact(cur), dxf(xc), dact(prev), dxf(xp), dact(out)));
+    BIU_CHECK_LAUNCH("xcorr_fwd");
+    return BIU_OK;
+}
+extern "C" int biu_xcorr_bwd(const biu_act* cur, const biu_xform* xc, const biu_act* prev, const biu_xform* xp, const biu_act* dout,
+                             const biu_act* dcur, const biu_act* dprev, int accumulate, int dtype, biu_stream stream) {
+    BIU_REQUIRE(valid_act(cur) && valid_act(prev) && valid_act(dout) && valid_act(dcur) && valid_act(dprev) && same_space(cur, prev) &&
+                    same_space(cur, dout) && same_space(cur, dcur) && same_space(cur, dprev) && cur->c == prev->c && cur->c == dout->c &&
+                    cur->c == dcur->c && cur->c == dprev->c && cur->d == 1, BIU_ERR_SHAPE, "xcorr_bwd: equal 2-D tensors expected");
+    BIU_REQUIRE(!(xc && (xc->scale || xc->shift || xc->slope)) && !(xp && (xp->scale || xp->shift || xp->slope)), BIU_ERR_UNSUPPORTED,
+                "xcorr_bwd: operands must be materialised (identity transform); the gradient is taken w.r.t. the stored values");
+    hipStream_t st = (hipStream_t)stream;
+    const i64 tot = nvox(cur) * cur->c;
+    BIU_DISPATCH_DTYPE(dtype, {
+        hipLaunchKernelGGL(k_xcorr_bwd<T>, dim3(grid_for(tot, TPB, 16384)), dim3(TPB), 0, st, dact(prev), dxf(xp), dact(dout), dact(dcur), 0, accumulate);
+        hipLaunchKernelGGL(k_xcorr_bwd<T>, dim3(grid_for(tot, TPB, 16384)), dim3(TPB), 0, st, dact(cur), dxf(xc), dact(dout), dact(dprev), 1, accumulate);
+    });
+    BIU_CHECK_LAUNCH("xcorr_bwd");
+    return BIU_OK;
+}

@@ -343,12 +343,13 @@ class ResampleNode(Node):
     """MaxPool(2,2) / nearest x0.5 / nearest x2: output is materialised *activated* data (identity transform)."""
 
     def __init__(self, eng, kind: str, xin: Act, yout: Act):
-        assert kind in ("maxpool", "down", "up")
+        assert kind in ("maxpool", "down", "up", "trilinear")
         self.kind, self.xin, self.y = kind, xin, yout
         xin.consumed()
 
     def fwd(self, eng):
-        f = {"maxpool": lib.biu_maxpool_fwd, "down": lib.biu_nearest_down_fwd, "up": lib.biu_nearest_up_fwd}[self.kind]
+        f = {"maxpool": lib.biu_maxpool_fwd, "down": lib.biu_nearest_down_fwd, "up": lib.biu_nearest_up_fwd,
+             "trilinear": lib.biu_trilinear_up_fwd}[self.kind]
         check(f(self.xin.a(), self.xin.xf(), self.y.a(), eng.dtype, _stream()), self.kind + "_fwd")
 
     def bwd(self, eng):
@@ -359,6 +360,8 @@ class ResampleNode(Node):
             check(lib.biu_maxpool_bwd(self.xin.a(), self.xin.xf(), self.y.g(), self.xin.g(), acc, eng.dtype, st), "maxpool_bwd")
         elif self.kind == "down":
             check(lib.biu_nearest_down_bwd(self.y.g(), self.xin.g(), acc, eng.dtype, st), "nearest_down_bwd")
+        elif self.kind == "trilinear":
+            check(lib.biu_trilinear_up_bwd(self.y.g(), self.xin.g(), acc, eng.dtype, st), "trilinear_up_bwd")
         else:
             check(lib.biu_nearest_up_bwd(self.y.g(), self.xin.g(), acc, eng.dtype, st), "nearest_up_bwd")
         self.xin.mark_g()
@@ -382,6 +385,27 @@ class MaxJoinNode(Node):
         assert self.a_.g_written() == self.b_.g_written()
         check(lib.biu_max_join_bwd(self.a_.a(), self.a_.xf(), self.b_.a(), self.b_.xf(), self.y.g(), self.a_.g(),
                                    self.b_.g(), int(self.a_.g_written()), eng.dtype, _stream()), "max_join_bwd")
+        self.a_.mark_g()
+        self.b_.mark_g()
+
+
+class XCorrNode(Node):
+    """Depth-wise cross-correlation of the two pooled bottlenecks -- Siam 'corr' join [siam_unet/siam_unet.py:75-83,115]."""
+
+    def __init__(self, eng, a: Act, b: Act, out: Act):
+        self.a_, self.b_, self.y = a, b, out
+        a.consumed()
+        b.consumed()
+
+    def fwd(self, eng):
+        check(lib.biu_xcorr_fwd(self.a_.a(), self.a_.xf(), self.b_.a(), self.b_.xf(), self.y.a(), eng.dtype, _stream()), "xcorr_fwd")
+
+    def bwd(self, eng):
+        if not self.y.g_written():
+            return
+        assert self.a_.g_written() == self.b_.g_written()
+        check(lib.biu_xcorr_bwd(self.a_.a(), self.a_.xf(), self.b_.a(), self.b_.xf(), self.y.g(), self.a_.g(), self.b_.g(),
+                                int(self.a_.g_written()), eng.dtype, _stream()), "xcorr_bwd")
         self.a_.mark_g()
         self.b_.mark_g()
 

@@ -206,8 +206,6 @@ class Siam_UNet(Unet):
     def _build(self, eng, xshape, pshape):
         if self.mode not in ("concat", "max", "control", "corr"):
             raise NotImplementedError("Unknown mode: {}".format(self.mode))
-        if self.mode == "corr":
-            raise NotImplementedError("Siam_UNet mode 'corr' (depth-wise cross-correlation join) has no HIP kernel yet")
         if tuple(xshape) != tuple(pshape):
             logging.critical(f"Shapes: {xshape}, {pshape}")
             raise ValueError("concatenation failed: wrong dimensions")
@@ -230,6 +228,9 @@ class Siam_UNet(Unet):
             if self.mode == "max":
                 join = eng.new_act(spaces[4], c8, lazy=False)
                 eng.add(E.MaxJoinNode(eng, m4, mm4, join))
+            elif self.mode == "corr":
+                join = eng.new_act(spaces[4], c8, lazy=False)
+                eng.add(E.XCorrNode(eng, m4, mm4, join))
             else:
                 join = m4
         mid1 = eng.new_act(spaces[4], self.middle_conv1[0].out_channels, lazy=True)
@@ -307,9 +308,12 @@ class _Body3D(_HipNet):
                 eng.add(E.ResampleNode(eng, "up", t, r))
                 u = buf.slice(0, up_c[i], lazy=True)
                 eng.add(E.ConvBlockNode(eng, getattr(self, f"up{lvl}_conv"), r, u))
+            elif up == "trilinear":                       # F.interpolate(scale_factor=2, mode='trilinear') [unet3d/unet3d.py:82]
+                u = buf.slice(0, up_c[i], lazy=False)
+                assert u.c == t.c
+                eng.add(E.ResampleNode(eng, "trilinear", t, u))
             else:
-                raise NotImplementedError("UNet3D(use_interpolation=True): the trilinear up-sampling path (K10) has no "
-                                          "HIP kernel yet")
+                raise NotImplementedError(f"unknown up-sampling '{up}'")
             cat = buf.full()
             b1, b2 = getattr(self, f"decode{2 * lvl - 1}"), getattr(self, f"decode{2 * lvl}")
             a = eng.new_act(sp, b1[0].out_channels, lazy=True)

@@ -182,6 +182,20 @@ int biu_nearest_up_bwd(const biu_act* dout, const biu_act* dx, int accumulate, i
  * replaces nn.ConvTranspose2d/3d: unet/unet.py:38-47, unet3d/unet3d.py:40-42
  * w: PyTorch layout (Cin, Cout, kd, 2, 2) fp32 with kd = 2 (3-D) or 1 (2-D).
  * ---------------------------------------------------------------------------------------------- */
+/* Trilinear x2 up-sampling, align_corners = False (F.interpolate(scale_factor=2, mode='trilinear'),
+ * unet3d/unet3d.py:82,89,96): out = interp(T(x)); depth is doubled when out->d == 2 * x->d, kept when equal.
+ * bwd: dx (+)= adjoint(dout).                                                                                        */
+int biu_trilinear_up_fwd(const biu_act* x, const biu_xform* xf, const biu_act* out, int dtype, biu_stream stream);
+int biu_trilinear_up_bwd(const biu_act* dout, const biu_act* dx, int accumulate, int dtype, biu_stream stream);
+
+/* Depth-wise cross-correlation of two equal 2-D maps, padding='same' (Siam_UNet.depthwise_xcorr,
+ * siam_unet/siam_unet.py:75-83): out[n,y,x,c] = sum_ij T(cur)[n,y+i-ph,x+j-pw,c] * T(prev)[n,i,j,c], ph=(H-1)/2, pw=(W-1)/2.
+ * bwd needs identity transforms (materialised operands): dcur, dprev (+)= gradients.                                  */
+int biu_xcorr_fwd(const biu_act* cur, const biu_xform* xc, const biu_act* prev, const biu_xform* xp, const biu_act* out,
+                  int dtype, biu_stream stream);
+int biu_xcorr_bwd(const biu_act* cur, const biu_xform* xc, const biu_act* prev, const biu_xform* xp, const biu_act* dout,
+                  const biu_act* dcur, const biu_act* dprev, int accumulate, int dtype, biu_stream stream);
+
 /* MFMA operand packing, as for the 3x3 kernels.  kind 0 = forward operand, 1 = data-gradient operand.          */
 size_t biu_convt_packed_bytes(int kind, int cin, int cout, int kd, int dtype);
 int    biu_convt_pack(int kind, const float* w, int cin, int cout, int kd, int dtype, void* packed, biu_stream stream);

@@ -31,8 +31,8 @@ def masks_agree(logits, ref_logits, band):
     return bool(((logits > 0) == (ref_logits > 0))[safe].all())
 
 
-GOLDEN_GPU = ["unet2d_f4", "unet2d_f4_o2_dil2", "unet3d_f4", "siam_f4_concat", "siam_f4_max", "siam_f4_control",
-              "mo3d_f4_interp", "mo3d_f4_convT"]
+GOLDEN_GPU = ["unet2d_f4", "unet2d_f4_o2_dil2", "unet3d_f4", "unet3d_f4_interp", "siam_f4_concat", "siam_f4_max",
+              "siam_f4_corr", "siam_f4_control", "mo3d_f4_interp", "mo3d_f4_convT"]
 
 
 @pytest.mark.parametrize("case", GOLDEN_GPU)

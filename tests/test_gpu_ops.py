@@ -571,3 +571,53 @@ def test_conv_bwd_weight_bn(case, dtype):
         scale = float(dw_ref.abs().max())
         t2 = dict(rtol=1e-3, atol=2e-4 * scale) if dtype == "f32" else dict(rtol=2e-2, atol=2e-2 * scale)
         torch.testing.assert_close(dw.cpu(), dw_ref.cpu(), **t2)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# trilinear x2 (UNet3D use_interpolation=True) and depth-wise cross-correlation (Siam 'corr')
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 5, 3, 4, 6), (1, 8, 1, 5, 7), (1, 16, 2, 2, 2)])
+def test_trilinear_up(shape, dtype):
+    n, c, d, h, w = shape
+    code = DT[dtype][1]
+    xf = XF(c, seed=3)
+    xd = Dev(rnd(*shape, seed=1), dtype=dtype, pitch=c + 3, c0=2)
+    xa = xf.apply(xd.ref()).requires_grad_(True)
+    if d > 1:
+        ref = F.interpolate(xa, scale_factor=2, mode="trilinear", align_corners=False)
+    else:                                  # a D = 1 volume keeps its depth: bilinear in (h, w)
+        ref = F.interpolate(xa.squeeze(2), scale_factor=2, mode="bilinear", align_corners=False).unsqueeze(2)
+    od = Dev(shape=tuple(ref.shape), dtype=dtype, pitch=c + 1, c0=1)
+    check(lib.biu_trilinear_up_fwd(xd.a(), xf.x(), od.a(), code, stream()), "trilinear_up_fwd")
+    assert_close(od.get(), ref.detach(), dtype, "trilinear fwd")
+    gd = Dev(rnd(*ref.shape, seed=5), dtype=dtype)
+    ref.backward(gd.ref())
+    dxd = Dev(shape=shape, dtype=dtype)
+    check(lib.biu_trilinear_up_bwd(gd.a(), dxd.a(), 0, code, stream()), "trilinear_up_bwd")
+    assert_close(dxd.get(), xa.grad, dtype, "trilinear bwd")
+    check(lib.biu_trilinear_up_bwd(gd.a(), dxd.a(), 1, code, stream()), "trilinear_up_bwd(acc)")
+    assert_close(dxd.get(), 2 * xa.grad, dtype, "trilinear bwd acc")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 6, 4, 4), (1, 8, 5, 7), (2, 3, 6, 3)])
+def test_depthwise_xcorr(shape, dtype):
+    n, c, h, w = shape
+    code = DT[dtype][1]
+    cur = Dev(rnd(*shape, seed=1), dtype=dtype, pitch=c + 2, c0=1)
+    prev = Dev(rnd(*shape, seed=2), dtype=dtype)
+    a = cur.ref().squeeze(2).requires_grad_(True)
+    b = prev.ref().squeeze(2).requires_grad_(True)
+    ref = F.conv2d(a.reshape(1, n * c, h, w), b.reshape(n * c, 1, h, w), groups=n * c, padding="same").view(n, c, h, w)
+    od = Dev(shape=(n, c, 1, h, w), dtype=dtype)
+    check(lib.biu_xcorr_fwd(cur.a(), None, prev.a(), None, od.a(), code, stream()), "xcorr_fwd")
+    t = dict(rtol=1e-4, atol=1e-4 * float(ref.abs().max())) if dtype == "f32" else dict(rtol=2e-2, atol=2e-2 * float(ref.abs().max()))
+    torch.testing.assert_close(od.get(squeeze2d=True), ref.detach(), **t)
+    gd = Dev(rnd(n, c, h, w, seed=5), dtype=dtype)
+    ref.backward(gd.ref().squeeze(2))
+    da, db = Dev(shape=(n, c, 1, h, w), dtype=dtype), Dev(shape=(n, c, 1, h, w), dtype=dtype)
+    check(lib.biu_xcorr_bwd(cur.a(), None, prev.a(), None, gd.a(), da.a(), db.a(), 0, code, stream()), "xcorr_bwd")
+    for got, want in ((da, a.grad), (db, b.grad)):
+        t = dict(rtol=1e-4, atol=1e-4 * float(want.abs().max())) if dtype == "f32" else dict(rtol=2e-2, atol=2e-2 * float(want.abs().max()))
+        torch.testing.assert_close(got.get(squeeze2d=True), want, **t)
