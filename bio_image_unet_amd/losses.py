@@ -71,3 +71,38 @@ class TverskyLoss(nn.Module):
 class logcoshTverskyLoss(TverskyLoss):
     def forward(self, inputs, targets):
         return torch.log(torch.cosh(1 - _tversky_index(inputs, targets, self.alpha, self.beta, self.smooth)))
+
+
+class weightedBCELoss(nn.Module):
+    """BCE on sigmoid(logits) with weight alpha where target >= 0.5, beta elsewhere, mean over elements
+    (``siam_unet/losses.py:109-148``)."""
+
+    def __init__(self, alpha=1, beta=0.1):
+        super().__init__()
+        self.alpha, self.beta = alpha, beta
+
+    def forward(self, logits, targets):
+        probs = torch.sigmoid(logits)
+        weights = torch.where(targets >= 0.5, torch.full_like(targets, self.alpha), torch.full_like(targets, self.beta))
+        return torch.mean(nn.functional.binary_cross_entropy(probs, targets, reduction="none") * weights)
+
+
+class TemporalConsistencyLoss(nn.Module):
+    """L1 between consecutive slices of axis 2 of a (B, C, Z, X, Y) prediction (``multi_output_unet3d/losses.py``)."""
+
+    def forward(self, predictions):
+        return nn.functional.l1_loss(predictions[:, :, 1:, :, :], predictions[:, :, :-1, :, :])
+
+
+class BCEDiceTemporalLoss(nn.Module):
+    """``w0 * BCEDice(1, 1) + w1 * TemporalConsistency`` (``multi_output_unet3d/losses.py``, default weights (1.0, 0.1))."""
+
+    def __init__(self, loss_params=(1.0, 0.1)):
+        super().__init__()
+        self.bce_dice_loss = BCEDiceLoss(1, 1)
+        self.temporal_consistency_loss = TemporalConsistencyLoss()
+        self.loss_params = loss_params
+
+    def forward(self, predictions, targets):
+        return (self.loss_params[0] * self.bce_dice_loss(predictions, targets) +
+                self.loss_params[1] * self.temporal_consistency_loss(predictions))

@@ -25,8 +25,8 @@ import torch
 from torch import nn, optim
 from torch.utils.data import DataLoader, random_split
 
-from .losses import BCEDiceLoss, TverskyLoss, logcoshTverskyLoss
-from .models import Siam_UNet, UNet3D, Unet
+from .losses import BCEDiceLoss, BCEDiceTemporalLoss, TverskyLoss, logcoshTverskyLoss, weightedBCELoss
+from .models import MultiOutputUnet3D, Siam_UNet, UNet3D, Unet
 from .optim import Adam
 from .utils import get_device, init_weights
 
@@ -220,9 +220,7 @@ class TrainerSiam(_EpochLoop):
         self.model = Siam_UNet(n_filter=n_filter, mode=mode).to(self.device)      # no init_weights here (reference :61)
         self.n_filter, self.mode = n_filter, mode
         self.loss_function, self.loss_params = loss_function, loss_params
-        if loss_function == "weightedBCELoss":
-            raise NotImplementedError("weightedBCELoss (siam_unet/losses.py:109-148) is not restated yet")
-        self.criterion = _make_criterion(loss_function, loss_params)
+        self.criterion = _make_criterion(loss_function, loss_params, extra={"weightedBCELoss": weightedBCELoss})
         self._setup(dataset, num_epochs, batch_size, lr, val_split, save_dir, save_name, save_iter)
         if load_weights is not None:
             self.state = torch.load(load_weights)
@@ -270,6 +268,119 @@ class TrainerSiam(_EpochLoop):
                 self._save(f"model_epoch_{epoch}.pt")
             if test_data_path is not None:
                 raise NotImplementedError("per-epoch prediction of TIFF test folders is outside the hot path")
+
+
+class TrainerMo3d:
+    """``bio_image_unet.multi_output_unet3d.Trainer`` counterpart (``multi_output_unet3d/train.py:17-292``).
+
+    Per-head loss ``output_heads[name]['loss']`` applied to the model's (already activated) output, summed with the heads'
+    weights; ``clip_grad_norm_(1.0)`` before the step; validation applies the head activation once more before the loss
+    (``:224``); scheduler ``ReduceLROnPlateau(patience=5, factor=0.2)``; the model stays in train mode during validation."""
+
+    def __init__(self, dataset, output_heads, num_epochs, network=MultiOutputUnet3D, use_interpolation=False, batch_size=4,
+                 lr=1e-3, in_channels=1, n_filter=64, dilation=1, val_split=0.2, save_dir="./", save_name="model.pt",
+                 save_iter=False, load_weights=False, loss_function="BCEDice", loss_params=(0.5, 0.5), time_loss_weight=0.1,
+                 device: Union[torch.device, str] = "auto"):
+        self.device = _pick_device(device)
+        self.network = network
+        self.model = network(n_filter=n_filter, in_channels=in_channels, output_heads=output_heads,
+                             use_interpolation=use_interpolation).to(self.device)
+        self.model.apply(init_weights)          # a no-op on Conv3d layers, as in the reference
+        self.data, self.output_heads, self.num_epochs, self.batch_size, self.lr = dataset, output_heads, num_epochs, batch_size, lr
+        self.best_loss = torch.tensor(float("inf"))
+        self.save_iter, self.save_dir, self.save_name = save_iter, save_dir, save_name
+        self.loss_function, self.loss_params, self.time_loss_weight = loss_function, loss_params, time_loss_weight
+        self.n_filter, self.in_channels, self.use_interpolation = n_filter, in_channels, use_interpolation
+        self.loss_functions = {name: self._get_loss_function(cfg["loss"]) for name, cfg in output_heads.items()}
+        self.activations = {name: cfg.get("activation", None) for name, cfg in output_heads.items()}
+        self.loss_weights = {name: cfg.get("weight", 1.0) for name, cfg in output_heads.items()}
+        n_val = int(len(dataset) * val_split)
+        self.dim = dataset.dim_out
+        train_data, val_data = random_split(dataset, [len(dataset) - n_val, n_val])
+        self.train_loader = DataLoader(train_data, batch_size=batch_size, pin_memory=True, drop_last=True)
+        self.val_loader = DataLoader(val_data, batch_size=batch_size, pin_memory=True, drop_last=True)
+        if loss_function == "BCEDiceTemporalLoss":
+            self.criterion = BCEDiceTemporalLoss(loss_params=loss_params)
+        else:
+            self.criterion = _make_criterion(loss_function, loss_params)       # built but unused by the loop, as upstream
+        self.criterion_time = nn.SmoothL1Loss()
+        self.optimizer = Adam(self.model.parameters(), lr=lr)
+        self.scheduler = optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode="min", patience=5, factor=0.2)
+        os.makedirs(save_dir, exist_ok=True)
+        keys = ("clip_threshold", "scale_limit", "rotate_limit", "gauss_noise_lims", "shot_noise_lims", "blur_limit",
+                "random_rotate", "brightness_contrast")
+        self.params = {"optimizer": self.optimizer.state_dict(), "lr": lr, "loss_function": loss_function,
+                       "loss_params": loss_params, "time_loss_weight": time_loss_weight, "n_filter": n_filter,
+                       "use_interpolation": use_interpolation, "dilation": dilation, "batch_size": batch_size,
+                       "augmentation": getattr(dataset, "aug_factor", None),
+                       **{k: getattr(dataset, k, None) for k in keys}, "in_channels": in_channels, "output_heads": output_heads}
+        if load_weights:
+            self.state = torch.load(os.path.join(save_dir, save_name))
+            self.model.load_state_dict(self.state["state_dict"])
+            self.epoch_start = self.state["epoch"]
+        else:
+            self.epoch_start = 0
+
+    @staticmethod
+    def _get_loss_function(loss_name):
+        table = {"BCEDiceLoss": lambda: BCEDiceLoss(1, 1), "DiceLoss": lambda: BCEDiceLoss(0, 1), "TverskyLoss": TverskyLoss,
+                 "logcoshTverskyLoss": logcoshTverskyLoss, "BCEDiceTemporalLoss": BCEDiceTemporalLoss}
+        if loss_name not in table:
+            raise ValueError(f'Loss "{loss_name}" not defined!')
+        return table[loss_name]()
+
+    @staticmethod
+    def _apply_activation(x, activation):
+        fn = {"sigmoid": torch.sigmoid, "tanh": torch.tanh, "relu": torch.relu, "softmax": lambda t: torch.softmax(t, dim=1)}
+        return fn[activation](x) if activation in fn else x
+
+    def _total_loss(self, batch, validating):
+        x = batch["volume"].to(self.device, non_blocking=True)
+        y = {key: batch[key].to(self.device, non_blocking=True) for key in self.output_heads}
+        if x.dim() == 4:
+            x = x.unsqueeze(1)
+        pred = self.model(x)
+        total = 0
+        for name in self.output_heads:
+            target = y[name]
+            if target.dim() == 4:
+                target = target.unsqueeze(1)
+            p = self._apply_activation(pred[name], self.activations.get(name)) if validating else pred[name]
+            total = total + self.loss_weights[name] * self.loss_functions[name](p, target)
+        return total
+
+    def iterate(self, epoch, mode):
+        if mode == "train":
+            for batch in tqdm(self.train_loader, total=len(self.train_loader), unit="batch"):
+                loss = self._total_loss(batch, validating=False)
+                self.optimizer.zero_grad()
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=1.0)
+                self.optimizer.step()
+            return None
+        losses = []
+        with torch.no_grad():
+            for batch in tqdm(self.val_loader, total=len(self.val_loader), unit="batch"):
+                losses.append(self._total_loss(batch, validating=True).detach())
+        return torch.stack(losses).mean()
+
+    def start(self):
+        for epoch in range(self.num_epochs):
+            self.iterate(epoch, "train")
+            self.state = {"epoch": epoch + self.epoch_start, "epoch_start": self.epoch_start, "best_loss": self.best_loss,
+                          "state_dict": self.model.state_dict()}
+            self.state.update(self.params)
+            with torch.no_grad():
+                val_loss = self.iterate(epoch, "val")
+                self.scheduler.step(val_loss)
+            if val_loss < self.best_loss:
+                print(f"\nValidation loss improved from {self.best_loss.item():.5f} to {val_loss.item():.5f} - saving model state")
+                self.state["best_loss"] = self.best_loss = val_loss
+                torch.save(self.state, os.path.join(self.save_dir, self.save_name))
+            else:
+                print(f"\nValidation loss did not improve from {self.best_loss.item():.5f}")
+            if self.save_iter:
+                torch.save(self.state, os.path.join(self.save_dir, f"model_epoch_{epoch + self.epoch_start}.pt"))
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -403,3 +514,301 @@ class Predict2D:
             tifffile.imwrite(result_name, img.astype("float16") if normalize else img)
         except ImportError:
             np.save(result_name + ".npy" if not result_name.endswith(".npy") else result_name, img)
+
+
+def _load_params(model_params, device):
+    return torch.load(model_params, map_location=device) if isinstance(model_params, str) else model_params
+
+
+def _write(result_name, arr):
+    if result_name is None:
+        return
+    try:
+        import tifffile
+        tifffile.imwrite(result_name, arr)
+    except ImportError:
+        np.save(result_name if result_name.endswith(".npy") else result_name + ".npy", arr)
+
+
+class Predict3D:
+    """``bio_image_unet.unet3d.Predict`` counterpart (``unet3d/predict.py:12-195``) for in-memory volumes.
+
+    Whole-volume percentile clip to [0, 255]; patches of ``resize_dim`` (z, x, y) at ``linspace`` origins (reflect padding
+    when the volume is smaller); one eval-mode forward per patch; uint8 re-quantisation; stitching through the
+    reference's three-layer float16 buffer (patch ``n`` goes to layer ``n % 3``, later patches overwrite earlier ones of
+    the same layer, then ``nanmean`` over the layers)."""
+
+    def __init__(self, vol, result_name, model_params, network=UNet3D, resize_dim=(64, 128, 128), invert=False,
+                 normalization_mode="single", clip_threshold=(0., 99.8), add_patch=0, normalize_result=False,
+                 progress_bar=True, device: Union[torch.device, str] = "auto", progress_notifier=None):
+        self.device = _pick_device(device)
+        if isinstance(vol, str):
+            import tifffile
+            vol = tifffile.imread(vol)
+        vol = np.asarray(vol)
+        self.resize_dim, self.add_patch = tuple(resize_dim), add_patch
+        self.vol_shape = vol.shape
+        if vol.ndim == 2:
+            vol = vol[None]
+            self.vol_shape = vol.shape
+        lo, hi = np.nanpercentile(vol, clip_threshold[0]), np.percentile(vol, clip_threshold[1])
+        vol = np.clip(vol, lo, hi)
+        vol = vol - np.min(vol)
+        vol = vol / np.max(vol) * 255
+        if invert:
+            vol = 255 - vol
+        patches = self._split(vol)
+        mp = self.model_params = _load_params(model_params, self.device)
+        self.model = network(n_filter=mp["n_filter"], in_channels=mp["in_channels"], out_channels=mp["out_channels"],
+                             use_interpolation=mp.get("use_interpolation", False)).to(self.device)
+        self.model.load_state_dict(mp["state_dict"])
+        self.model.eval()
+        result_patches = np.zeros_like(patches)
+        with torch.no_grad():
+            for i, p in enumerate(patches):
+                x = torch.from_numpy(p.astype("float32") / 255).to(self.device).view((1, 1) + self.resize_dim)
+                prob, _ = self.model(x)
+                result_patches[i] = (prob.view(self.resize_dim) * 255).to(torch.uint8).cpu().numpy()
+        self.vol_result = self._stitch(result_patches)
+        out = self.vol_result
+        if normalize_result:
+            out = out - np.nanmin(out)
+            out = np.clip(out / np.nanpercentile(out, 99.8), 0, 1).astype("float16")
+        _write(result_name, out)
+
+    def _split(self, vol):
+        vs, rd, ap = self.vol_shape, self.resize_dim, self.add_patch
+        self.N_z = int(np.ceil(vs[0] / rd[0])) + ap
+        self.N_x = int(np.ceil(vs[1] / rd[1])) + ap
+        self.N_y = int(np.ceil(vs[2] / rd[2])) + ap
+        self.N_x += ap if self.N_z > 1 else 0          # (sic) the reference bumps N_x twice (unet3d/predict.py:124-126)
+        self.N_x += ap if self.N_x > 1 else 0
+        self.N_y += ap if self.N_y > 1 else 0
+        self.N = self.N_x * self.N_y * self.N_z
+        vol = np.pad(vol, [(0, max(0, rd[a] - vs[a])) for a in range(3)], "reflect")
+        self.Z_start = tile_starts(vs[0], rd[0], self.N_z)
+        self.X_start = tile_starts(vs[1], rd[1], self.N_x)
+        self.Y_start = tile_starts(vs[2], rd[2], self.N_y)
+        patches = np.zeros((self.N,) + rd, dtype="uint8")
+        n = 0
+        for z in self.Z_start:
+            for x in self.X_start:
+                for y in self.Y_start:
+                    patches[n] = vol[z:z + rd[0], x:x + rd[1], y:y + rd[2]]
+                    n += 1
+        return patches
+
+    def _stitch(self, result_patches):
+        vs, rd = self.vol_shape, self.resize_dim
+        buf = np.full((3,) + tuple(max(vs[a], rd[a]) for a in range(3)), np.nan, dtype="float16")
+        n = 0
+        for z in self.Z_start:
+            for x in self.X_start:
+                for y in self.Y_start:
+                    buf[n % 3, z:z + rd[0], x:x + rd[1], y:y + rd[2]] = result_patches[n]
+                    n += 1
+        with np.errstate(all="ignore"):
+            out = np.nanmean(buf, axis=0).astype("uint8")
+        return np.squeeze(out[:vs[0], :vs[1], :vs[2]])
+
+
+class PredictSiam:
+    """``bio_image_unet.siam_unet.Predict`` counterpart (``siam_unet/predict.py:16-250``) for an in-memory movie (T, H, W).
+
+    Frame i is predicted together with its predecessor (frame 0 with frame 1, or with itself in a one-frame movie); every
+    pair is normalised on its own (``normalization_mode`` over the two-frame stack), zero-padded (``'constant'``) up to
+    ``resize_dim``, tiled, predicted and stitched by the nan-mean of overlapping uint8 tiles."""
+
+    def __init__(self, movie, result_name, model_params, resize_dim=None, invert=False, normalization_mode="single",
+                 clip_threshold=(0., 99.8), add_tile=0, normalize_result=False, show_progress=True,
+                 device: Union[torch.device, str] = "auto", progress_notifier=None, batch_size=8):
+        self.device = _pick_device(device)
+        if isinstance(movie, str):
+            import tifffile
+            movie = tifffile.imread(movie)
+        movie = np.asarray(movie)
+        if movie.ndim == 2:
+            movie = movie[None]
+        mp = self.model_params = _load_params(model_params, self.device)
+        self.model = Siam_UNet(n_filter=mp["n_filter"], mode=mp["mode"]).to(self.device)
+        self.model.load_state_dict(mp["state_dict"])
+        self.model.eval()
+        self.tif_len = movie.shape[0]
+        self.imgs_shape = [self.tif_len, movie.shape[1], movie.shape[2]]
+        self.resize_dim = tuple(resize_dim) if resize_dim is not None else (movie.shape[1], movie.shape[2])
+        th, tw = self.resize_dim
+        self.N_x = int(np.ceil(self.imgs_shape[1] / th)) + add_tile
+        self.N_y = int(np.ceil(self.imgs_shape[2] / tw)) + add_tile
+        self.N_per_img = self.N = self.N_x * self.N_y
+        self.X_start = tile_starts(self.imgs_shape[1], th, self.N_x)
+        self.Y_start = tile_starts(self.imgs_shape[2], tw, self.N_y)
+        frames = []
+        cur = None
+        for i in range(self.tif_len):
+            prev = (movie[0] if self.tif_len == 1 else movie[1]) if i == 0 else cur
+            cur = movie[i]
+            pair = normalise_stack(np.array([prev, cur], dtype=np.float64), normalization_mode, clip_threshold, invert).astype("uint8")
+            patches = self._split(pair)
+            out = np.zeros((self.N, th, tw), dtype="uint8")
+            with torch.no_grad():
+                for b in range(0, self.N, batch_size):
+                    x = torch.from_numpy(patches[b:b + batch_size, 0:1].astype("float32") / 255).to(self.device)
+                    px = torch.from_numpy(patches[b:b + batch_size, 1:2].astype("float32") / 255).to(self.device)
+                    out[b:b + batch_size] = (self.model(x, px)[0][:, 0] * 255).to(torch.uint8).cpu().numpy()
+            frames.append(self._stitch(out))
+        self.imgs_result = np.stack(frames)
+        _write(result_name, self.imgs_result)
+
+    def _split(self, pair):
+        th, tw = self.resize_dim
+        h, w = self.imgs_shape[1], self.imgs_shape[2]
+        pair = np.pad(pair, ((0, 0), (0, max(0, th - h)), (0, max(0, tw - w))), "constant")
+        patches = np.zeros((self.N, 2, th, tw), dtype="uint8")
+        n = 0
+        for xs in self.X_start:
+            for ys in self.Y_start:
+                patches[n, 0] = pair[1][xs:xs + th, ys:ys + tw]          # current frame
+                patches[n, 1] = pair[0][xs:xs + th, ys:ys + tw]          # previous frame
+                n += 1
+        return patches
+
+    def _stitch(self, tiles):
+        th, tw = self.resize_dim
+        h, w = self.imgs_shape[1], self.imgs_shape[2]
+        H, W = max(th, h), max(tw, w)
+        acc, cnt = np.zeros((H, W), dtype=np.int64), np.zeros((H, W), dtype=np.int64)
+        n = 0
+        for xs in self.X_start:
+            for ys in self.Y_start:
+                acc[xs:xs + th, ys:ys + tw] += tiles[n]
+                cnt[xs:xs + th, ys:ys + tw] += 1
+                n += 1
+        return (acc // np.maximum(cnt, 1)).astype("uint8")[:h, :w]      # nan-mean of uint8 tiles, truncated like astype
+
+
+class PredictMo3d:
+    """``bio_image_unet.multi_output_unet3d.Predict`` counterpart (``multi_output_unet3d/predict.py:13-307``).
+
+    Float normalisation to [0, 1] (no uint8 step), patches of ``min(volume, max_patch_size)`` on a stride of
+    ``patch * (1 - overlap_factor)`` plus a last patch flush with the border, batches of ``batch_size``, outputs kept as
+    float32 per head, weighted blending with the reference's linear ramps over ``blend_margin`` voxels at interior patch
+    faces (built exactly as upstream assigns them: plane by plane, later axes overwriting earlier ones)."""
+
+    def __init__(self, imgs, model_params, result_path=None, network=MultiOutputUnet3D, max_patch_size=(64, 256, 256),
+                 overlap_factor=0.1, batch_size=1, normalization_mode="single", clip_threshold=(0., 99.98), add_tile=0,
+                 compress_tif=False, show_progress=True, device: Union[torch.device, str] = "auto", progress_notifier=None):
+        self.device = _pick_device(device)
+        if isinstance(imgs, str):
+            import tifffile
+            imgs = tifffile.imread(imgs)
+        self.max_patch_size, self.overlap_factor, self.batch_size = max_patch_size, overlap_factor, batch_size
+        imgs = np.array(imgs, dtype="float32")
+        if imgs.ndim == 3:
+            imgs = imgs[None]
+        elif imgs.ndim != 4:
+            raise ValueError(f"Unsupported input shape: {imgs.shape}")
+        self.imgs_shape = imgs.shape
+        imgs = self._preprocess(imgs, normalization_mode, clip_threshold)
+        patches = self._split(imgs)
+        mp = self.model_params = _load_params(model_params, self.device)
+        self.model = network(in_channels=mp["in_channels"], n_filter=mp["n_filter"], output_heads=mp["output_heads"],
+                             use_interpolation=mp.get("use_interpolation", True)).to(self.device)
+        self.model.load_state_dict(mp["state_dict"])
+        self.model.eval()
+        self.target_keys = list(mp["output_heads"].keys())
+        results = {k: [] for k in self.target_keys}
+        with torch.no_grad():
+            for b in range(0, len(patches), batch_size):
+                preds = self.model(torch.tensor(patches[b:b + batch_size], dtype=torch.float32).to(self.device))
+                for k in results:
+                    results[k].append(preds[k].float().cpu().numpy())
+        result = self._stitch({k: np.concatenate(v) for k, v in results.items()})
+        if result_path is not None:
+            for k in self.target_keys:
+                _write((result_path + k + ".tif") if os.path.exists(result_path) else (result_path + "_" + k + ".tif"), result[k])
+            self.result = None
+        else:
+            self.result = result
+
+    @staticmethod
+    def _preprocess(imgs, mode, clip):
+        if mode == "single":
+            for i in range(len(imgs)):
+                c = np.clip(imgs[i], np.percentile(imgs[i], clip[0]), np.percentile(imgs[i], clip[1]))
+                imgs[i] = (c - c.min()) / (np.ptp(c) + 1e-8)
+            return imgs
+        if mode in ("first", "all"):
+            lo, hi = np.percentile(imgs[0] if mode == "first" else imgs, [clip[0], clip[1]])
+            imgs[:] = (np.clip(imgs, lo, hi) - lo) / (hi - lo + 1e-8)
+            return imgs
+        raise ValueError(f"Invalid normalization mode: {mode}")
+
+    def _split(self, imgs):
+        nvol, D, H, W = imgs.shape
+        self.patch_size = ps = tuple(min(a, b) for a, b in zip((D, H, W), self.max_patch_size))
+        stride = [max(1, int(s * (1 - self.overlap_factor))) for s in ps]
+
+        def starts(extent, patch, st):
+            v = list(range(0, max(extent - patch + 1, 1), st))
+            if v[-1] + patch < extent:
+                v.append(extent - patch)
+            return v
+        self.Z_start, self.Y_start, self.X_start = starts(D, ps[0], stride[0]), starts(H, ps[1], stride[1]), starts(W, ps[2], stride[2])
+        self.N_z, self.N_y, self.N_x = len(self.Z_start), len(self.Y_start), len(self.X_start)
+        self.N_per_vol = self.N_z * self.N_y * self.N_x
+        out = [imgs[v, z:z + ps[0], y:y + ps[1], x:x + ps[2]] for v in range(nvol) for z in self.Z_start for y in self.Y_start
+               for x in self.X_start]
+        return np.stack(out)[:, None]
+
+    def _weights(self, flags, shape, blend_margin):
+        """Blend mask of one patch; ``flags`` = (front, back, top, bottom, left, right) interior faces.  Restates the
+        assignment order of ``predict.py:246-268`` including its index arithmetic: the 'far' ramps all land on plane 0
+        (``max(-(i+1), 0) == 0``) and the depth ramps run over ``min(blend_margin, N_z)`` planes."""
+        w = np.ones(shape, dtype="float32")
+        nz = min(blend_margin, self.N_z)
+        if flags[0]:
+            for i in range(nz):
+                w[:, i, :, :] = i / blend_margin
+        if flags[1]:
+            for i in range(nz):
+                w[:, 0, :, :] = i / blend_margin
+        if flags[2]:
+            for i in range(blend_margin):
+                w[:, :, i, :] = i / blend_margin
+        if flags[3]:
+            for i in range(blend_margin):
+                w[:, :, 0, :] = i / blend_margin
+        if flags[4]:
+            for i in range(blend_margin):
+                w[:, :, :, i] = i / blend_margin
+        if flags[5]:
+            for i in range(blend_margin):
+                w[:, :, :, 0] = i / blend_margin
+        return w
+
+    def _stitch(self, result_patches, blend_margin=16):
+        nvol, D, H, W = self.imgs_shape
+        ps = self.patch_size
+        result, cache = {}, {}
+        for key in self.target_keys:
+            nch = self.model_params["output_heads"][key]["channels"]
+            vol = np.zeros((nvol, nch, D, H, W), dtype="float32")
+            wsum = np.zeros_like(vol)
+            for v in range(nvol):
+                pv = result_patches[key][v * self.N_per_vol:(v + 1) * self.N_per_vol].reshape(self.N_z, self.N_y, self.N_x, nch, *ps)
+                for zi, z0 in enumerate(self.Z_start):
+                    for yi, y0 in enumerate(self.Y_start):
+                        for xi, x0 in enumerate(self.X_start):
+                            flags = (zi > 0, zi < self.N_z - 1, yi > 0, yi < self.N_y - 1, xi > 0, xi < self.N_x - 1)
+                            if (flags, nch) not in cache:
+                                cache[(flags, nch)] = self._weights(flags, (nch,) + ps, blend_margin)
+                            pw = cache[(flags, nch)]
+                            zs, ys, xs = slice(z0, min(z0 + ps[0], D)), slice(y0, min(y0 + ps[1], H)), slice(x0, min(x0 + ps[2], W))
+                            pz, py, px = slice(0, zs.stop - zs.start), slice(0, ys.stop - ys.start), slice(0, xs.stop - xs.start)
+                            vol[v, :, zs, ys, xs] += pv[zi, yi, xi][:, pz, py, px] * pw[:, pz, py, px]
+                            wsum[v, :, zs, ys, xs] += pw[:, pz, py, px]
+            mask = wsum > 0
+            vol[mask] = vol[mask] / wsum[mask]
+            vol[~mask] = 0
+            result[key] = np.squeeze(vol)
+        return result

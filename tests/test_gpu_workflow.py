@@ -122,3 +122,123 @@ def test_predict2d_matches_oracle_tiling(tmp_path):
         want[i] = np.nanmean(stack, axis=0)
     diff = np.abs(got.astype(int) - want.astype(int))
     assert diff.max() <= 1 and (diff > 0).mean() < 0.02      # uint8 truncation may flip at exact .0 boundaries
+
+
+def _randomise_bn(sd):
+    for k in sd:
+        if k.endswith("running_mean"):
+            sd[k] = torch.randn_like(sd[k]) * 0.1
+        if k.endswith("running_var"):
+            sd[k] = torch.rand_like(sd[k]) + 0.5
+    return sd
+
+
+def test_predict3d_matches_oracle_tiling(tmp_path):
+    """unet3d.Predict: whole-volume normalisation, linspace patches, three-layer float16 stitch buffer (n % 3)."""
+    torch.manual_seed(3)
+    sd = _randomise_bn(O.init_unet3d(1, 1, 4, seed=6))
+    ck = {"n_filter": 4, "in_channels": 1, "out_channels": 1, "state_dict": sd}
+    vol = (np.random.RandomState(1).rand(20, 40, 36) * 500).astype("float32")
+    rd = (8, 16, 16)
+    p = unet3d.Predict(vol.copy(), None, ck, resize_dim=rd, add_patch=0, progress_bar=False, device="cuda")
+    got = p.vol_result
+    assert got.shape == vol.shape and got.dtype == np.uint8
+    v = np.clip(vol, np.nanpercentile(vol, 0.), np.percentile(vol, 99.8))
+    v = v - v.min()
+    v = v / v.max() * 255
+    from bio_image_unet_amd.workflow import tile_starts
+    zs, xs, ys = tile_starts(20, 8, 3), tile_starts(40, 16, 3), tile_starts(36, 16, 3)
+    buf = np.full((3, 20, 40, 36), np.nan, dtype="float16")
+    n = 0
+    for z in zs:
+        for x in xs:
+            for y in ys:
+                patch = v[z:z + 8, x:x + 16, y:y + 16].astype("uint8").astype("float32") / 255
+                with torch.no_grad():
+                    prob, _ = O.unet3d_forward(sd, torch.from_numpy(patch)[None, None], training=False)
+                buf[n % 3, z:z + 8, x:x + 16, y:y + 16] = (prob[0, 0].numpy() * 255).astype("uint8")
+                n += 1
+    want = np.nanmean(buf, axis=0).astype("uint8")
+    diff = np.abs(got.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.02
+
+
+def test_predict_siam_matches_oracle(tmp_path):
+    torch.manual_seed(4)
+    sd = _randomise_bn(O.init_unet2d(1, 1, 4, seed=7, siam_mode="max"))
+    ck = {"n_filter": 4, "mode": "max", "state_dict": sd}
+    movie = (np.random.RandomState(2).rand(3, 40, 48) * 300).astype("float32")
+    p = siam.Predict(movie.copy(), None, ck, resize_dim=(32, 32), add_tile=0, show_progress=False, device="cuda")
+    got = p.imgs_result
+    assert got.shape == movie.shape and got.dtype == np.uint8
+    from bio_image_unet_amd.workflow import normalise_stack, tile_starts
+    xs, ys = tile_starts(40, 32, 2), tile_starts(48, 32, 2)
+    for i in range(3):
+        prev = movie[1] if i == 0 else movie[i - 1]
+        pair = normalise_stack(np.array([prev, movie[i]], dtype=np.float64), "single", (0., 99.8), False).astype("uint8")
+        stack = np.full((4, 40, 48), np.nan)
+        k = 0
+        for a in xs:
+            for b in ys:
+                cur_t = torch.from_numpy(pair[1][a:a + 32, b:b + 32].astype("float32") / 255)[None, None]
+                prv_t = torch.from_numpy(pair[0][a:a + 32, b:b + 32].astype("float32") / 255)[None, None]
+                with torch.no_grad():
+                    prob, _ = O.siam_forward(sd, cur_t, prv_t, mode="max", training=False)
+                stack[k, a:a + 32, b:b + 32] = (prob[0, 0].numpy() * 255).astype("uint8")
+                k += 1
+        want = np.nanmean(stack, axis=0).astype("uint8")
+        diff = np.abs(got[i].astype(int) - want.astype(int))
+        assert diff.max() <= 1 and (diff > 0).mean() < 0.02
+
+
+HEADS = {"mask": {"channels": 1, "activation": "sigmoid", "loss": "BCEDiceLoss", "weight": 1.0},
+         "flow": {"channels": 2, "activation": "tanh", "loss": "DiceLoss", "weight": 0.5}}
+
+
+def test_mo3d_trainer_and_predict(tmp_path):
+    import bio_image_unet_amd.multi_output_unet3d as mo
+    torch.manual_seed(5)
+
+    class Vols(torch.utils.data.Dataset):
+        aug_factor = 1
+        dim_out = (8, 16, 16)
+
+        def __init__(self):
+            g = torch.Generator().manual_seed(0)
+            self.items = [{"volume": torch.rand(8, 16, 16, generator=g), "mask": (torch.rand(1, 8, 16, 16, generator=g) > 0.5).float(),
+                           "flow": (torch.rand(2, 8, 16, 16, generator=g) > 0.5).float()} for _ in range(12)]
+
+        def __len__(self):
+            return len(self.items)
+
+        def __getitem__(self, i):
+            return self.items[i]
+
+    tr = mo.Trainer(Vols(), HEADS, 1, use_interpolation=True, batch_size=2, n_filter=4, save_dir=str(tmp_path / "m"), device="cuda")
+    # one optimisation step against the oracle: same loss expression, gradients clipped to norm 1, Adam
+    sd0 = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
+    batch = next(iter(tr.train_loader))
+    loss = tr._total_loss(batch, validating=False)
+    osd = O.clone_state(sd0, requires_grad=True)
+    pred = O.mo3d_forward(osd, batch["volume"].unsqueeze(1), HEADS, use_interpolation=True, training=True)
+    want = 1.0 * O.bce_dice_loss(pred["mask"], batch["mask"], 1, 1) + 0.5 * O.bce_dice_loss(pred["flow"], batch["flow"], 0, 1)
+    assert abs(float(loss) - float(want)) < 1e-3 * max(1.0, abs(float(want)))
+    tr.start()
+    ck = torch.load(str(tmp_path / "m" / "model.pt"), weights_only=False)
+    assert ck["output_heads"] == HEADS and ck["use_interpolation"] is True and len(ck["state_dict"]) > 100
+    # prediction: overlapping patches, float outputs, weighted blend
+    vol = np.random.RandomState(3).rand(12, 40, 24).astype("float32") * 100
+    ck["state_dict"] = _randomise_bn({k: v.cpu() for k, v in ck["state_dict"].items()})
+    p = mo.Predict(vol.copy(), ck, result_path=None, max_patch_size=(8, 16, 16), overlap_factor=0.25, batch_size=3,
+                   show_progress=False, device="cuda")
+    assert set(p.result) == {"mask", "flow"} and p.result["mask"].shape == (12, 40, 24) and p.result["flow"].shape == (2, 12, 40, 24)
+    # where a single patch with weight 1 covers a voxel the blend returns that patch's value: check one interior patch centre
+    c = np.clip(vol, np.percentile(vol, 0.), np.percentile(vol, 99.98))
+    c = (c - c.min()) / (np.ptp(c) + 1e-8)
+    z0, y0, x0 = p.Z_start[0], p.Y_start[0], p.X_start[0]
+    with torch.no_grad():
+        out = O.mo3d_forward(ck["state_dict"], torch.from_numpy(c[z0:z0 + 8, y0:y0 + 16, x0:x0 + 16])[None, None], HEADS,
+                             use_interpolation=True, training=False)
+    # voxel (2, 3, 3) lies only in the first patch along every axis (strides 6, 12, 12)
+    assert abs(float(out["mask"][0, 0, 2, 3, 3]) - float(p.result["mask"][2, 3, 3])) < 2e-3
+    assert np.isfinite(p.result["flow"]).all() and float(np.abs(p.result["flow"]).max()) <= 1.0 + 1e-5
