@@ -968,6 +968,7 @@ struct WgradArgs {
     int njt;             // number of 32-wide j tiles
     int jt_begin, jt_count;   // j tiles this launch covers: blockIdx.y = it * jt_count + (jt - jt_begin)
     int write_back;           // fused BatchNorm backward: this launch overwrites da with dy
+    unsigned long long* diag; // BIU_DIAG builds only
     int bricks_per_block;
     // optional fused BatchNorm backward on the plain operand: A = dy is computed on the fly from (da = pa, y = py):
     //   dz = da * T'(scale*y + shift),  dy = cA*dz + cB*y + cC ; blocks with jt == 0 also write dy back over da
@@ -1240,6 +1241,15 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         }
     };
 
+#ifdef BIU_DIAG
+    unsigned long long* wdiag = a.diag;
+    unsigned long long tprev_ = __builtin_readcyclecounter();
+    unsigned long long dsum_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t0c_ = tprev_, t0r_ = __builtin_amdgcn_s_memrealtime();
+#define WSTAMP(k_) do { if (wdiag && tid == 0) { unsigned long long now_ = __builtin_readcyclecounter(); dsum_[k_] += now_ - tprev_; tprev_ = now_; } } while (0)
+#else
+#define WSTAMP(k_) do { } while (0)
+#endif
     const int G = gridDim.x;
     int brick = blockIdx.x;
     if (brick < a.nbricks) {
@@ -1254,6 +1264,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
             constexpr int NG = 8;
             static_assert(NKG % NG == 0 && NG % KSPLIT == 0, "k-groups must split into 8 slices inside the K halves");
             constexpr int KPG = NKG / NG;
+            WSTAMP(0);
             issue_prep(have_next ? nbrick : brick, have_next);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -1280,7 +1291,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                         bf16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                         for (int t2 = 0; t2 < IPW; ++t2) {
-                            if (ihalf[t2] == h) {
+                            if (KSPLIT == 1 || ihalf[t2] == h) {      // KSPLIT == 1: branch-free; a wave's missing last item multiplies into an accumulator nobody flushes
                                 const char* bp = bt + hbase + tapoff[t2] + b_lane;
                                 bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp));
                                 bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp + 4 * S * RS));
@@ -1292,7 +1303,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                         const float af = *(const float*)(at + q0 * RS + a_lane);
 #pragma unroll
                         for (int t2 = 0; t2 < IPW; ++t2) {
-                            if (ihalf[t2] == h) {
+                            if (KSPLIT == 1 || ihalf[t2] == h) {      // KSPLIT == 1: branch-free; a wave's missing last item multiplies into an accumulator nobody flushes
                                 const float bf = *(const float*)(bt + hbase + tapoff[t2] + b_lane);
                                 acc[t2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[t2], 0, 0, 0);
                             }
@@ -1301,10 +1312,22 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            WSTAMP(1);
+#ifdef BIU_DIAG
+            dsum_[7] += 1;
+            if (!have_next && wdiag && tid == 0) {
+                for (int q_ = 0; q_ < 8; ++q_) atomicAdd(wdiag + q_, dsum_[q_]);
+                atomicAdd(wdiag + 8, __builtin_readcyclecounter() - t0c_);
+                atomicAdd(wdiag + 9, __builtin_amdgcn_s_memrealtime() - t0r_);
+            }
+#endif
             if (!have_next) break;
             __syncthreads();
+            WSTAMP(2);
             commit();
+            WSTAMP(3);
             __syncthreads();
+            WSTAMP(4);
             brick = nbrick;
         }
     }
@@ -1397,6 +1420,11 @@ static int launch_wgrad(WgradArgs a, hipStream_t st) {
     }
     auto launch = [&](int jt_begin, int jt_count, int write_back) {
         WgradArgs b = a;
+#ifdef BIU_DIAG
+        b.diag = biu_diag_buffer;
+#else
+        b.diag = nullptr;
+#endif
         b.jt_begin = jt_begin; b.jt_count = jt_count; b.write_back = write_back;
         const int pairs = nit * jt_count;
         int g = num_cus() / pairs;                        // persistent: about one block per CU in total

@@ -30,3 +30,23 @@ for name, cin, cout, (d,h,w) in shapes:
     names = ["loop", "issue", "mfma", "epilogue", "barrier1", "commit", "barrier2"]
     tot = sum(dv[:7])
     print(f"{name}: {e0.elapsed_time(e1):.3f} ms, clock {dv[8]/max(dv[9],1)*0.1:.2f} GHz, items {nb}, cycles/item {tot/nb:.0f}: " + ", ".join(f"{nm} {dv[i]/nb:.0f} ({100*dv[i]/tot:.0f}%)" for i,nm in enumerate(names)), flush=True)
+
+# ---- weight gradient (plain and with the fused BatchNorm backward) ------------------------------------------------------
+names = ["loop", "mfma+loads", "barrier1", "commit", "barrier2"]
+for name, cin, cout, (d,h,w) in shapes:
+    x = torch.randn(n,d,h,w,cin, device="cuda").to(torch.bfloat16); y = torch.randn(n,d,h,w,cout, device="cuda").to(torch.bfloat16)
+    dy = torch.randn(n,d,h,w,cout, device="cuda").to(torch.bfloat16)
+    xfv = [torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda") * 0.1, torch.full((cin,), 0.1, device="cuda")]
+    xfs = biu_xform(*[t.data_ptr() for t in xfv])
+    kv = [torch.ones(cout, device="cuda"), torch.zeros(cout, device="cuda"), torch.full((cout,), 0.1, device="cuda"), torch.ones(cout, device="cuda"),
+          torch.zeros(cout, device="cuda"), torch.zeros(cout, device="cuda")]
+    ax = biu_act(x.data_ptr(),n,d,h,w,cin,cin); ay = biu_act(y.data_ptr(),n,d,h,w,cout,cout); ady = biu_act(dy.data_ptr(),n,d,h,w,cout,cout)
+    ws = torch.empty(lib.biu_conv_bwd_weight_workspace(cin,cout,3,3,3,1), dtype=torch.uint8, device="cuda")
+    dw = torch.empty(cout,cin,3,3,3, device="cuda")
+    for tag, call in (("wgrad", lambda: lib.biu_conv_bwd_weight(C.byref(ax),C.byref(xfs),C.byref(ady),3,3,3,1,P(dw),None,P(ws),ws.numel(),1,st)),
+                      ("wgrad_bn", lambda: lib.biu_conv_bwd_weight_bn(C.byref(ax),C.byref(xfs),C.byref(ady),C.byref(ay),P(kv[0]),P(kv[1]),P(kv[2]),P(kv[3]),P(kv[4]),P(kv[5]),3,3,3,1,P(dw),P(ws),ws.numel(),1,st))):
+        call(); torch.cuda.synchronize(); diag.zero_()
+        e0,e1 = torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+        e0.record(); call(); e1.record(); torch.cuda.synchronize()
+        dv = diag.cpu().tolist(); nb = max(dv[7],1); tot = sum(dv[:5])
+        print(f"{name} {tag}: {e0.elapsed_time(e1):.3f} ms, clock {dv[8]/max(dv[9],1)*0.1:.2f} GHz, bricks/block-sum {nb}, cycles/brick {tot/nb:.0f}: " + ", ".join(f"{nm} {dv[i]/nb:.0f} ({100*dv[i]/tot:.0f}%)" for i,nm in enumerate(names)), flush=True)
