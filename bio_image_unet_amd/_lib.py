@@ -65,6 +65,9 @@ SIGNATURES = {
     "biu_nearest_down_bwd": (_I, [_A, _A, _I, _I, _P]),
     "biu_nearest_up_fwd": (_I, [_A, _X, _A, _I, _P]),
     "biu_nearest_up_bwd": (_I, [_A, _A, _I, _I, _P]),
+    "biu_bce_dice_blocks": (_I, [C.c_longlong]),
+    "biu_bce_dice_fwd": (_I, [_P, _P, _I, C.c_longlong, _P, _P]),
+    "biu_bce_dice_bwd": (_I, [_P, _P, _I, C.c_longlong, _P, _P, _I, _P]),
     "biu_trilinear_up_fwd": (_I, [_A, _X, _A, _I, _P]),
     "biu_trilinear_up_bwd": (_I, [_A, _A, _I, _I, _P]),
     "biu_xcorr_fwd": (_I, [_A, _X, _A, _X, _A, _I, _P]),

@@ -31,12 +31,54 @@ class SoftDiceLoss(nn.Module):
         return 1 - score.mean()
 
 
+class _FusedBCEDice(torch.autograd.Function):
+    """alpha * BCEWithLogits(mean) + beta * (1 - mean_n[2 (I_n + s) / (P_n + T_n + s)]) through ``biu_bce_dice_fwd/bwd``:
+    one pass over (logits, targets) each way instead of the eager graph's full-tensor reductions with ``n`` output rows."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, alpha, beta, smooth):
+        import ctypes as C
+        from ._lib import check, lib
+        n = targets.size(0)
+        per = logits.numel() // n
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        nb = lib.biu_bce_dice_blocks(per)
+        partial = torch.empty((n, nb, 4), dtype=torch.float32, device=logits.device)
+        check(lib.biu_bce_dice_fwd(C.c_void_p(logits.data_ptr()), C.c_void_p(targets.data_ptr()), n, per,
+                                   C.c_void_p(partial.data_ptr()), st), "bce_dice_fwd")
+        sums = partial.sum(1)                                    # [n, 4]: bce, p, t, p*t
+        den = sums[:, 1] + sums[:, 2] + smooth
+        score = 2.0 * (sums[:, 3] + smooth) / den
+        ctx.save_for_backward(logits, targets, sums, den)
+        ctx.cfg = (alpha, beta, smooth, n, per)
+        return alpha * sums[:, 0].sum() / (n * per) + beta * (1 - score.mean())
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes as C
+        from ._lib import check, lib
+        logits, targets, sums, den = ctx.saved_tensors
+        alpha, beta, smooth, n, per = ctx.cfg
+        coef = torch.empty((n, 3), dtype=torch.float32, device=logits.device)
+        coef[:, 0] = g * (alpha / (n * per))
+        coef[:, 1] = g * (beta / n) * 2.0 * (sums[:, 3] + smooth) / (den * den)
+        coef[:, 2] = -g * (beta / n) * 2.0 / den
+        dl = torch.empty_like(logits)
+        check(lib.biu_bce_dice_bwd(C.c_void_p(logits.data_ptr()), C.c_void_p(targets.data_ptr()), n, per,
+                                   C.c_void_p(coef.data_ptr()), C.c_void_p(dl.data_ptr()), 0,
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "bce_dice_bwd")
+        return dl, None, None, None, None
+
+
 class BCEDiceLoss(nn.Module):
     def __init__(self, alpha, beta):
         super().__init__()
         self.bce, self.dice, self.alpha, self.beta = BCELoss2d(), SoftDiceLoss(), alpha, beta
 
     def forward(self, logits, targets):
+        if (logits.is_cuda and logits.dtype == torch.float32 and targets.dtype == torch.float32 and logits.shape == targets.shape
+                and logits.is_contiguous() and targets.is_contiguous() and logits.numel() > 0):
+            return _FusedBCEDice.apply(logits, targets, float(self.alpha), float(self.beta), float(self.dice.smooth))
         return self.alpha * self.bce(logits, targets) + self.beta * self.dice(logits, targets)
 
 

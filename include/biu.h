@@ -182,6 +182,14 @@ int biu_nearest_up_bwd(const biu_act* dout, const biu_act* dx, int accumulate, i
  * replaces nn.ConvTranspose2d/3d: unet/unet.py:38-47, unet3d/unet3d.py:40-42
  * w: PyTorch layout (Cin, Cout, kd, 2, 2) fp32 with kd = 2 (3-D) or 1 (2-D).
  * ---------------------------------------------------------------------------------------------- */
+/* BCEDiceLoss (unet/losses.py:78-112) over fp32 NC[D]HW logits / targets as the heads emit them, one pass each way.
+ * fwd: partial[n][biu_bce_dice_blocks(per_sample)][4] = per-block sums of (bce(l,t), p, t, p*t), p = sigmoid(l).
+ * bwd: dlogits_i (+)= coef[n][0]*(p_i - t_i) + (coef[n][1] + coef[n][2]*t_i) * p_i*(1 - p_i).                        */
+int biu_bce_dice_blocks(long long per_sample);
+int biu_bce_dice_fwd(const float* logits, const float* target, int n, long long per_sample, float* partial, biu_stream stream);
+int biu_bce_dice_bwd(const float* logits, const float* target, int n, long long per_sample, const float* coef, float* dlogits,
+                     int accumulate, biu_stream stream);
+
 /* Trilinear x2 up-sampling, align_corners = False (F.interpolate(scale_factor=2, mode='trilinear'),
  * unet3d/unet3d.py:82,89,96): out = interp(T(x)); depth is doubled when out->d == 2 * x->d, kept when equal.
  * bwd: dx (+)= adjoint(dout).                                                                                        */

@@ -621,3 +621,21 @@ def test_depthwise_xcorr(shape, dtype):
     for got, want in ((da, a.grad), (db, b.grad)):
         t = dict(rtol=1e-4, atol=1e-4 * float(want.abs().max())) if dtype == "f32" else dict(rtol=2e-2, atol=2e-2 * float(want.abs().max()))
         torch.testing.assert_close(got.get(squeeze2d=True), want, **t)
+
+
+@pytest.mark.parametrize("shape", [(4, 1, 8, 16, 16), (2, 3, 33, 17), (1, 40, 40)])
+def test_fused_bce_dice_loss(shape):
+    """BCEDiceLoss through biu_bce_dice_fwd/bwd against the eager expression of unet/losses.py:78-112 (value and gradient)."""
+    from bio_image_unet_amd.losses import BCEDiceLoss, BCELoss2d, SoftDiceLoss
+    torch.manual_seed(0)
+    lg = (torch.randn(shape) * 3).cuda().requires_grad_(True)
+    tg = (torch.rand(shape) > 0.5).float().cuda()
+    crit = BCEDiceLoss(0.3, 0.7)
+    loss = crit(lg, tg) * 1.7
+    loss.backward()
+    lr = lg.detach().cpu().double().requires_grad_(True)
+    tr = tg.cpu().double()
+    ref = (0.3 * BCELoss2d()(lr, tr) + 0.7 * SoftDiceLoss()(lr, tr)) * 1.7
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    torch.testing.assert_close(lg.grad.cpu().double(), lr.grad, rtol=1e-4, atol=1e-6 * float(lr.grad.abs().max()) + 1e-12)
