@@ -1418,13 +1418,14 @@ static int launch_wgrad(WgradArgs a, hipStream_t st) {
             return biu_fail(BIU_ERR_LAUNCH, "wgrad_pipe: cannot reserve %zu bytes of LDS", lds_bytes);
         attr_set = true;
     }
-    auto launch = [&](int jt_begin, int jt_count, int write_back) {
+    auto launch = [&](int jt_begin, int jt_count, int write_back, bool with_bn) {
         WgradArgs b = a;
 #ifdef BIU_DIAG
         b.diag = biu_diag_buffer;
 #else
         b.diag = nullptr;
 #endif
+        if (!with_bn) b.py = nullptr;
         b.jt_begin = jt_begin; b.jt_count = jt_count; b.write_back = write_back;
         const int pairs = nit * jt_count;
         int g = num_cus() / pairs;                        // persistent: about one block per CU in total
@@ -1433,14 +1434,14 @@ static int launch_wgrad(WgradArgs a, hipStream_t st) {
         hipLaunchKernelGGL(kern, dim3(g, pairs), dim3(512), lds_bytes, st, b);
     };
     if (a.py && a.njt > 1) {
-        // Fused BatchNorm backward rewrites da as dy IN PLACE while every j tile needs the original da: the tiles that
-        // only read go first, the one that also writes back runs after them (stream order is the only safe ordering
-        // between workgroups).
-        launch(1, a.njt - 1, 0);
+        // Fused BatchNorm backward rewrites da as dy IN PLACE.  The first input-channel tile does that (BatchNorm math in
+        // its loader, dy written back); the remaining tiles are launched after it and read the finished dy as a plain
+        // operand -- no y loads, no BatchNorm math, and stream order is the only ordering between workgroups relied on.
+        launch(0, 1, 1, true);
         BIU_CHECK_LAUNCH("wgrad_pipe");
-        launch(0, 1, 1);
+        launch(1, a.njt - 1, 0, false);
     } else {
-        launch(0, a.njt, a.py ? 1 : 0);
+        launch(0, a.njt, a.py ? 1 : 0, a.py != nullptr);
     }
     BIU_CHECK_LAUNCH("wgrad_pipe");
     return BIU_OK;

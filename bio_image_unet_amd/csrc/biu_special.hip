@@ -49,12 +49,10 @@ __global__ __launch_bounds__(TPB) void k_conv_c1_fwd(DAct x, DXf xf, const float
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const int iw = p.w + c - 1;
-                    float xv = 0.f;
-                    if (id >= 0 && id < x.d && ih >= 0 && ih < x.h && iw >= 0 && iw < x.w) {
-                        const i64 iv = (((i64)p.n * x.d + id) * x.h + ih) * x.w + iw;
-                        const float t = fmaf(s, to_f(((const T*)x.p)[iv * x.pitch]), b);
-                        xv = t > 0.f ? t : sl * t;
-                    }
+                    const bool ok = id >= 0 && id < x.d && ih >= 0 && ih < x.h && iw >= 0 && iw < x.w;
+                    const i64 iv = ok ? (((i64)p.n * x.d + id) * x.h + ih) * x.w + iw : 0;
+                    const float t = fmaf(s, to_f(((const T*)x.p)[iv * x.pitch]), b);
+                    const float xv = ok ? (t > 0.f ? t : sl * t) : 0.f;
                     const float* wr = ws + ((a * 3 + bb) * 3 + c) * COUT;
 #pragma unroll
                     for (int co = 0; co < COUT; ++co) acc[co] = fmaf(xv, wr[co], acc[co]);
@@ -107,12 +105,10 @@ __global__ __launch_bounds__(576) void k_conv_c1_wgrad(DAct x, DXf xf, DAct dy, 
             if (tap < TAPS) {
                 const int a = tap / 9, bb = (tap / 3) % 3, c = tap % 3;
                 const int id = p.d + a - KD / 2, ih = p.h + bb - 1, iw = p.w + c - 1;
-                float xv = 0.f;
-                if (id >= 0 && id < x.d && ih >= 0 && ih < x.h && iw >= 0 && iw < x.w) {
-                    const i64 iv = (((i64)p.n * x.d + id) * x.h + ih) * x.w + iw;
-                    const float tt = fmaf(s, to_f(((const T*)x.p)[iv * x.pitch]), b);
-                    xv = tt > 0.f ? tt : sl * tt;
-                }
+                const bool ok = id >= 0 && id < x.d && ih >= 0 && ih < x.h && iw >= 0 && iw < x.w;
+                const i64 iv = ok ? (((i64)p.n * x.d + id) * x.h + ih) * x.w + iw : 0;
+                const float tt = fmaf(s, to_f(((const T*)x.p)[iv * x.pitch]), b);
+                const float xv = ok ? (tt > 0.f ? tt : sl * tt) : 0.f;
 #pragma unroll
                 for (int co = 0; co < COUT; ++co) acc[t][co] = fmaf(xv, g[co], acc[t][co]);
             }
@@ -186,12 +182,10 @@ __global__ __launch_bounds__(TPB) void k_conv_c1_fwd4(DAct x, DXf xf, const floa
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
                     const int iw = w0 - 1 + k;
-                    float xv = 0.f;
-                    if (rowok && iw >= 0 && iw < x.w) {
-                        const float tt = fmaf(s, to_f(((const T*)x.p)[(rowbase + iw) * x.pitch]), b);
-                        xv = tt > 0.f ? tt : sl * tt;
-                    }
-                    xr[k] = xv;
+                    // branch-free: a clamped address and a select keep the six loads of a row in flight together
+                    const bool ok = rowok && iw >= 0 && iw < x.w;
+                    const float tt = fmaf(s, to_f(((const T*)x.p)[ok ? (rowbase + iw) * x.pitch : 0]), b);
+                    xr[k] = ok ? (tt > 0.f ? tt : sl * tt) : 0.f;
                 }
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -271,11 +265,9 @@ __global__ __launch_bounds__(256) void k_conv_c1_wgrad4(DAct x, DXf xf, DAct dy,
 #pragma unroll
                 for (int vx = 0; vx < 4; ++vx) {
                     const int iw = w0 + vx + c - 1;
-                    float xv = 0.f;
-                    if (rowok && iw >= 0 && iw < x.w) {
-                        const float q = fmaf(s, to_f(((const T*)x.p)[(rowbase + iw) * x.pitch]), b);
-                        xv = q > 0.f ? q : sl * q;
-                    }
+                    const bool ok = rowok && iw >= 0 && iw < x.w;          // branch-free (loads stay in flight together)
+                    const float q = fmaf(s, to_f(((const T*)x.p)[ok ? (rowbase + iw) * x.pitch : 0]), b);
+                    const float xv = ok ? (q > 0.f ? q : sl * q) : 0.f;
 #pragma unroll
                     for (int co = 0; co < COUT; ++co) acc[t][co] = fmaf(xv, g[vx][co], acc[t][co]);
                 }
