@@ -61,6 +61,7 @@ SIGNATURES = {
     "biu_bn_bwd_apply": (_I, [_A, _A, _P, _P, _P, _P, _P, _P, _A, _I, _P]),
     "biu_maxpool_fwd": (_I, [_A, _X, _A, _I, _P]),
     "biu_maxpool_bwd": (_I, [_A, _X, _A, _A, _I, _I, _P]),
+    "biu_maxpool_bwd_bnred": (_I, [_A, _X, _A, _A, _I, _P, _P, _P, _Z, C.POINTER(C.c_int), _I, _P]),
     "biu_nearest_down_fwd": (_I, [_A, _X, _A, _I, _P]),
     "biu_nearest_down_bwd": (_I, [_A, _A, _I, _I, _P]),
     "biu_nearest_up_fwd": (_I, [_A, _X, _A, _I, _P]),

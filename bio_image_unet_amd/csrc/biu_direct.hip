@@ -953,6 +953,24 @@ extern "C" int biu_maxpool_bwd(const biu_act* x, const biu_xform* xf, const biu_
     BIU_CHECK_LAUNCH("maxpool_bwd");
     return BIU_OK;
 }
+// max-pool backward + the BatchNorm-backward sums of the block that produced x (valid when this call completes x's gradient)
+extern "C" int biu_maxpool_bwd_bnred(const biu_act* x, const biu_xform* xf, const biu_act* dout, const biu_act* dx, int accumulate,
+                                     const float* mean, const float* invstd, float* partial, size_t partial_floats, int* nblk,
+                                     int dtype, biu_stream stream) {
+    BIU_REQUIRE(valid_act(x) && valid_act(dout) && valid_act(dx) && same_space(x, dx) && x->c == dx->c, BIU_ERR_SHAPE,
+                "maxpool_bwd_bnred: bad tensor");
+    BIU_REQUIRE(xf && xf->scale && xf->shift && mean && invstd && partial && nblk, BIU_ERR_SHAPE, "maxpool_bwd_bnred: null vector");
+    BIU_REQUIRE(partial_floats >= (size_t)BIU_BN_MAX_PARTIALS * x->c * 2, BIU_ERR_WORKSPACE, "maxpool_bwd_bnred: partial buffer too small");
+    int pd = pool_window(x, dout, "maxpool_bwd_bnred");
+    if (!pd) return BIU_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (!getenv("BIU_NO_POOL_BNRED") && biu_rowvec_ok(x, dtype) && biu_rowvec_ok(dout, dtype) && biu_rowvec_ok(dx, dtype) &&
+        x->c / 4 <= 256 && (size_t)(256 / (x->c / 4)) * x->c * 2 * sizeof(float) <= 64 * 1024)
+        return biu_maxpool_bwd_bnred_rv(x, xf, dout, dx, pd, accumulate, mean, invstd, partial, partial_floats, nblk, dtype, st);
+    int rc = biu_maxpool_bwd(x, xf, dout, dx, accumulate, dtype, stream);
+    if (rc != BIU_OK) return rc;
+    return biu_bn_bwd_reduce(dx, x, xf->scale, xf->shift, xf->slope, mean, invstd, partial, nblk, dtype, stream);
+}
 extern "C" int biu_nearest_down_fwd(const biu_act* x, const biu_xform* xf, const biu_act* out, int dtype, biu_stream stream) {
     BIU_REQUIRE(valid_act(x) && valid_act(out), BIU_ERR_SHAPE, "nearest_down_fwd: bad tensor");
     int pd = pool_window(x, out, "nearest_down_fwd");

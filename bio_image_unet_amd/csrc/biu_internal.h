@@ -72,4 +72,7 @@ int biu_bn_bwd_apply_rv(const biu_act* da, const biu_act* y, const float* scale,
 int biu_xform_apply_rv(const biu_act* x, const biu_xform* xf, const biu_act* out, int dtype, hipStream_t st);
 int biu_maxpool_fwd_rv(const biu_act* x, const biu_xform* xf, const biu_act* out, int pd, int dtype, hipStream_t st);
 int biu_maxpool_bwd_rv(const biu_act* x, const biu_xform* xf, const biu_act* dout, const biu_act* dx, int pd, int accumulate, int dtype, hipStream_t st);
+int biu_maxpool_bwd_bnred_rv(const biu_act* x, const biu_xform* xf, const biu_act* dout, const biu_act* dx, int pd, int accumulate,
+                             const float* mean, const float* invstd, float* partial, size_t partial_floats, int* nblk, int dtype,
+                             hipStream_t st);
 int biu_nearest_rv(int mode, const biu_act* src, const biu_xform* xf, const biu_act* dst, int pd, int accumulate, int dtype, hipStream_t st);

@@ -787,6 +787,94 @@ __global__ __launch_bounds__(TPB) void k_pool_rv(DAct x, DXf xf, DAct small, DAc
         }
     }
 }
+// Max-pool backward with every load of a window in flight together (x, and dx when accumulating), and -- optionally -- the
+// BatchNorm-backward sums of the layer that produced x reduced from the finished gradient in the same pass:
+//   (sum dz, sum dz * yhat),  dz = dx_final * T'(scale*x + shift),  yhat = (x - mean) * invstd      -> partial[block][C][2]
+template <typename T, bool RED, int PE>       // PE channels per thread: 4 keeps the fully unrolled window inside 128 registers
+__global__ __launch_bounds__(TPB, 4) void k_maxpool_bwd_rv(DAct x, DXf xf, DAct dout, DAct dx, int pd, int accumulate, int cg, int rows,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           float* __restrict__ partial) {
+    extern __shared__ float sm[];                 // RED: [rows][cg*PE][2]
+    const int g = threadIdx.x % cg, row = threadIdx.x / cg;
+    const int c0 = g * PE;
+    const bool live = row < rows;
+    float sc[PE], sh[PE], sl[PE], s1[PE], s2[PE];  // s2 accumulates sum dz * x raw; centred with (mean, invstd) at the end
+#pragma unroll
+    for (int j = 0; j < PE; ++j) {
+        sc[j] = xf.scale ? xf.scale[c0 + j] : 1.f;
+        sh[j] = xf.shift ? xf.shift[c0 + j] : 0.f;
+        sl[j] = xf.slope ? xf.slope[c0 + j] : 1.f;
+        s1[j] = s2[j] = 0.f;
+    }
+    const i64 total = (i64)dout.n * dout.d * dout.h * dout.w;
+    const i64 step_b = x.w, step_a = (i64)x.h * x.w;     // voxel strides of the window's h / d offsets (x and dx share extents)
+    if (live)
+        for (i64 ov = (i64)blockIdx.x * rows + row; ov < total; ov += (i64)gridDim.x * rows) {
+            const Vox4 p = unvox4(ov, dout.d, dout.h, dout.w);
+            const i64 base = (((i64)p.n * x.d + p.d * pd) * x.h + p.h * 2) * x.w + p.w * 2;
+            const T* xp = (const T*)x.p + base * x.pitch + c0;
+            T* dp = (T*)dx.p + base * dx.pitch + c0;
+            Pack<T, PE> in[8], old[8];
+            const Pack<T, PE> gq = *(const Pack<T, PE>*)((const T*)dout.p + ov * dout.pitch + c0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if ((k >> 2) < pd) in[k] = *(const Pack<T, PE>*)(xp + ((k >> 2) * step_a + ((k >> 1) & 1) * step_b + (k & 1)) * x.pitch);
+            if (accumulate) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if ((k >> 2) < pd) old[k] = *(const Pack<T, PE>*)(dp + ((k >> 2) * step_a + ((k >> 1) & 1) * step_b + (k & 1)) * dx.pitch);
+            }
+            unsigned argp = 0;                     // 3-bit argmax per channel
+#pragma unroll
+            for (int j = 0; j < PE; ++j) {
+                float best = -INFINITY;
+                unsigned arg = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if ((k >> 2) >= pd) continue;
+                    float t = fmaf(sc[j], to_f(in[k].v[j]), sh[j]);
+                    t = t > 0.f ? t : sl[j] * t;
+                    if (t > best || t != t) { best = t; arg = k; }
+                }
+                argp |= arg << (3 * j);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if ((k >> 2) >= pd) continue;
+                Pack<T, PE> o;
+#pragma unroll
+                for (int j = 0; j < PE; ++j) {
+                    const float r = (((argp >> (3 * j)) & 7u) == (unsigned)k) ? to_f(gq.v[j]) : 0.f;
+                    o.v[j] = from_f<T>(accumulate ? to_f(old[k].v[j]) + r : r);
+                    if (RED) {
+                        const float yv = to_f(in[k].v[j]);
+                        const float dz = to_f(o.v[j]) * (fmaf(sc[j], yv, sh[j]) > 0.f ? 1.f : sl[j]);
+                        s1[j] += dz;
+                        s2[j] = fmaf(dz, yv, s2[j]);
+                    }
+                }
+                *(Pack<T, PE>*)(dp + ((k >> 2) * step_a + ((k >> 1) & 1) * step_b + (k & 1)) * dx.pitch) = o;
+            }
+        }
+    if (RED) {
+        const int C = cg * PE;
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < PE; ++j) {
+                sm[(row * C + c0 + j) * 2 + 0] = s1[j];
+                sm[(row * C + c0 + j) * 2 + 1] = s2[j];
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += TPB) {
+            float a0 = 0.f, a1 = 0.f;
+            for (int r = 0; r < rows; ++r) { a0 += sm[(r * C + c) * 2]; a1 += sm[(r * C + c) * 2 + 1]; }
+            partial[((i64)blockIdx.x * C + c) * 2 + 0] = a0;
+            partial[((i64)blockIdx.x * C + c) * 2 + 1] = invstd[c] * (a1 - mean[c] * a0);        // sum dz * yhat
+        }
+    }
+}
+
 template <int MODE>
 static int pool_rv_launch(const biu_act* x, const biu_xform* xf, const biu_act* small, const biu_act* dx, int pd, int accumulate, int dtype, hipStream_t st) {
     BIU_DISPATCH_DTYPE(dtype, {
@@ -799,8 +887,38 @@ static int pool_rv_launch(const biu_act* x, const biu_xform* xf, const biu_act* 
 }
 int biu_xform_apply_rv(const biu_act* x, const biu_xform* xf, const biu_act* out, int dtype, hipStream_t st) { return pool_rv_launch<0>(x, xf, out, nullptr, 1, 0, dtype, st); }
 int biu_maxpool_fwd_rv(const biu_act* x, const biu_xform* xf, const biu_act* out, int pd, int dtype, hipStream_t st) { return pool_rv_launch<1>(x, xf, out, nullptr, pd, 0, dtype, st); }
+static RowPlan pool_bwd_plan(const biu_act* x, const biu_act* dout, int PE, i64 max_blocks) {
+    RowPlan p = row_plan(nvox(dout), x->c, PE);
+    i64 want = (nvox(dout) + (i64)p.rows * 4 - 1) / ((i64)p.rows * 4);          // ~4 pooled voxels (32 full-res) per thread
+    p.grid = (int)(want < 1 ? 1 : (want > max_blocks ? max_blocks : want));
+    return p;
+}
 int biu_maxpool_bwd_rv(const biu_act* x, const biu_xform* xf, const biu_act* dout, const biu_act* dx, int pd, int accumulate, int dtype, hipStream_t st) {
-    return pool_rv_launch<2>(x, xf, dout, dx, pd, accumulate, dtype, st);
+    BIU_DISPATCH_DTYPE(dtype, {
+        constexpr int PE = 4;
+        RowPlan p = pool_bwd_plan(x, dout, PE, 16384);
+        hipLaunchKernelGGL((k_maxpool_bwd_rv<T, false, PE>), dim3(p.grid), dim3(TPB), 0, st, dact(x), dxf(xf), dact(dout), dact(dx), pd, accumulate,
+                           p.cg, p.rows, nullptr, nullptr, nullptr);
+    });
+    BIU_CHECK_LAUNCH("maxpool_bwd_rv");
+    return BIU_OK;
+}
+// same pass + BatchNorm-backward sums of x's producer; *nblk rows of [C][2] in partial (<= BIU_BN_MAX_PARTIALS)
+int biu_maxpool_bwd_bnred_rv(const biu_act* x, const biu_xform* xf, const biu_act* dout, const biu_act* dx, int pd, int accumulate,
+                             const float* mean, const float* invstd, float* partial, size_t partial_floats, int* nblk, int dtype,
+                             hipStream_t st) {
+    i64 cap = (i64)(partial_floats / ((size_t)x->c * 2));
+    if (cap > 8192) cap = 8192;
+    BIU_DISPATCH_DTYPE(dtype, {
+        constexpr int PE = 4;
+        RowPlan p = pool_bwd_plan(x, dout, PE, cap);
+        const size_t shm = (size_t)p.rows * x->c * 2 * sizeof(float);
+        hipLaunchKernelGGL((k_maxpool_bwd_rv<T, true, PE>), dim3(p.grid), dim3(TPB), shm, st, dact(x), dxf(xf), dact(dout), dact(dx), pd, accumulate,
+                           p.cg, p.rows, mean, invstd, partial);
+        *nblk = p.grid;
+    });
+    BIU_CHECK_LAUNCH("maxpool_bwd_bnred_rv");
+    return BIU_OK;
 }
 
 // nearest-neighbour resampling with register-resident transform (MultiOutputUnet3D's interpolation path)

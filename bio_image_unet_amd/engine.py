@@ -48,6 +48,7 @@ class Buf:
         self.leaves: Dict[Tuple[int, int], bool] = {}       # (c0, c) -> gradient written this backward?
         self.lazy: Dict[Tuple[int, int], bool] = {}         # (c0, c) -> transform is not the identity
         self.ncons: Dict[Tuple[int, int], int] = {}         # (c0, c) -> number of nodes that read this slice
+        self.nwr: Dict[Tuple[int, int], int] = {}           # (c0, c) -> gradient contributions received this backward
         self.producer: Dict[Tuple[int, int], "Node"] = {}   # (c0, c) -> ConvBlockNode that wrote it (if any)
 
     def slice(self, c0: int, c: int, lazy: bool) -> "Act":
@@ -125,6 +126,19 @@ class Act:
     def mark_g(self):
         for k in self.leaves:
             self.buf.leaves[k] = True
+            self.buf.nwr[k] = self.buf.nwr.get(k, 0) + 1
+
+    def last_writer_producer(self):
+        """ConvBlockNode that produced this slice if the caller is the last reader still to contribute its gradient."""
+        if len(self.leaves) != 1:
+            return None
+        k = self.leaves[0]
+        if self.buf.ncons.get(k, 0) - self.buf.nwr.get(k, 0) != 1:
+            return None
+        up = self.buf.producer.get(k)
+        if up is None or not getattr(up, "batch_stats", False) or up.y.c != self.c or up.y.c0 != self.c0:
+            return None
+        return up
 
     def consumed(self):
         for k in self.leaves:
@@ -357,7 +371,17 @@ class ResampleNode(Node):
             return
         acc, st = int(self.xin.g_written()), _stream()
         if self.kind == "maxpool":
-            check(lib.biu_maxpool_bwd(self.xin.a(), self.xin.xf(), self.y.g(), self.xin.g(), acc, eng.dtype, st), "maxpool_bwd")
+            up = self.xin.last_writer_producer() if self.xin.xf() is not None else None
+            if up is not None:
+                # the pool is the last reader of its input: the finished gradient is reduced for the producer's BatchNorm here
+                part = up.red_buffer(eng, up.kd, 0)
+                n_up = C.c_int(0)
+                check(lib.biu_maxpool_bwd_bnred(self.xin.a(), self.xin.xf(), self.y.g(), self.xin.g(), acc, _ptr(up.save_mean),
+                                                _ptr(up.save_invstd), _ptr(part), part.numel(), C.byref(n_up), eng.dtype, st),
+                      "maxpool_bwd_bnred")
+                up.red_nblk = n_up.value
+            else:
+                check(lib.biu_maxpool_bwd(self.xin.a(), self.xin.xf(), self.y.g(), self.xin.g(), acc, eng.dtype, st), "maxpool_bwd")
         elif self.kind == "down":
             check(lib.biu_nearest_down_bwd(self.y.g(), self.xin.g(), acc, eng.dtype, st), "nearest_down_bwd")
         elif self.kind == "trilinear":
@@ -645,6 +669,7 @@ class Engine:
         for b in self.bufs:
             for k in b.leaves:
                 b.leaves[k] = False
+                b.nwr[k] = 0
         lib.label = "head:bwd"
         self._backward_heads(head_grads)
         for nd_ in reversed(self.nodes):

@@ -172,6 +172,12 @@ int biu_bn_bwd_apply(const biu_act* da, const biu_act* y, const float* scale, co
 int biu_maxpool_fwd(const biu_act* x, const biu_xform* xf, const biu_act* out, int dtype, biu_stream stream);
 int biu_maxpool_bwd(const biu_act* x, const biu_xform* xf, const biu_act* dout, const biu_act* dx,
                     int accumulate, int dtype, biu_stream stream);
+/* biu_maxpool_bwd that also emits biu_bn_bwd_reduce's partial sums for the conv block that produced x (xf = that block's
+ * BatchNorm transform, mean / invstd its saved statistics).  Use when this call completes the gradient of x.
+ * partial holds >= BIU_BN_MAX_PARTIALS * C * 2 floats (more lets the kernel use more workgroups); *nblk = rows written. */
+int biu_maxpool_bwd_bnred(const biu_act* x, const biu_xform* xf, const biu_act* dout, const biu_act* dx, int accumulate,
+                          const float* mean, const float* invstd, float* partial, size_t partial_floats, int* nblk,
+                          int dtype, biu_stream stream);
 int biu_nearest_down_fwd(const biu_act* x, const biu_xform* xf, const biu_act* out, int dtype, biu_stream stream);
 int biu_nearest_down_bwd(const biu_act* dout, const biu_act* dx, int accumulate, int dtype, biu_stream stream);
 int biu_nearest_up_fwd(const biu_act* x, const biu_xform* xf, const biu_act* out, int dtype, biu_stream stream);

@@ -639,3 +639,31 @@ def test_fused_bce_dice_loss(shape):
     ref.backward()
     assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
     torch.testing.assert_close(lg.grad.cpu().double(), lr.grad, rtol=1e-4, atol=1e-6 * float(lr.grad.abs().max()) + 1e-12)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 32, 4, 8, 12), (1, 16, 1, 10, 6), (2, 8, 2, 4, 4)])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_maxpool_bwd_bnred(shape, dtype, accumulate):
+    """Max-pool backward with the producer's BatchNorm-backward sums in the same pass == the two separate passes."""
+    n, c, d, h, w = shape
+    code = DT[dtype][1]
+    xf = XF(c, seed=3)
+    xd = Dev(rnd(*shape, seed=1), dtype=dtype)
+    pd_ = 2 if d > 1 else 1
+    gd = Dev(rnd(n, c, d // pd_, h // 2, w // 2, seed=2), dtype=dtype)
+    mean, invstd = (rnd(c, seed=8) * 0.1).cuda(), (rnd(c, seed=9).abs() + 0.5).cuda()
+    base = rnd(*shape, seed=4)
+    dx_a, dx_b = Dev(base, dtype=dtype), Dev(base, dtype=dtype)
+    nfl = 1024 * c * 2
+    pa, pb = torch.zeros(nfl, device="cuda"), torch.zeros(nfl, device="cuda")
+    na, nb = C.c_int(0), C.c_int(0)
+    check(lib.biu_maxpool_bwd(xd.a(), xf.x(), gd.a(), dx_a.a(), accumulate, code, stream()), "maxpool_bwd")
+    check(lib.biu_bn_bwd_reduce(dx_a.a(), xd.a(), ptr(xf.d[0]), ptr(xf.d[1]), ptr(xf.d[2]), ptr(mean), ptr(invstd), ptr(pa), C.byref(na),
+                                code, stream()), "bn_bwd_reduce")
+    check(lib.biu_maxpool_bwd_bnred(xd.a(), xf.x(), gd.a(), dx_b.a(), accumulate, ptr(mean), ptr(invstd), ptr(pb), nfl, C.byref(nb),
+                                    code, stream()), "maxpool_bwd_bnred")
+    assert torch.equal(dx_a.buf, dx_b.buf)
+    sa = pa[:na.value * c * 2].view(na.value, c, 2).double().sum(0).cpu()
+    sb = pb[:nb.value * c * 2].view(nb.value, c, 2).double().sum(0).cpu()
+    torch.testing.assert_close(sb, sa, rtol=1e-4, atol=1e-4 * float(sa.abs().max()) + 1e-9)
