@@ -37,7 +37,7 @@ extern "C" int biu_conv_fwd_stats(const biu_act* x, const biu_xform* xf, const f
     BIU_REQUIRE(w && bn_partial && bn_nblk, BIU_ERR_SHAPE, "conv_fwd_stats: null pointer");
     *bn_nblk = 0;
     if (packed && !disabled("conv_fwd") && !disabled("fused_stats") && biu_mfma_conv_ok(x, y, kd, kh, kw, dilation, dtype)) {
-        const int nb = biu_mfma_conv_bricks(y, kd);
+        const int nb = biu_mfma_conv_stat_rows(y, kd);           // one partial row per workgroup column
         if ((size_t)nb * y->c * 2 <= bn_partial_floats) {
             int rc = biu_mfma_conv(x, xf, packed, bias, kd, kh, kw, y, 0, bn_partial, dtype, (hipStream_t)stream);
             if (rc == BIU_OK) *bn_nblk = nb;

@@ -334,6 +334,55 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     unsigned long long dsum_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t0c_ = tprev_, t0r_ = __builtin_amdgcn_s_memrealtime();
 #endif
+    // Epilogue partial sums.  BatchNorm statistics (forward kernels) stay in registers across ALL bricks of this block and
+    // are reduced once after the loop -- one partial row per block; the cross-lane reduction costs ~7 k cycles, too much to
+    // pay per brick.  The data-gradient kernels (RED) have no registers for that and reduce per brick.
+    constexpr int CPP = 16 / (int)sizeof(T);     // channels per 16-byte piece: 8 (bf16) / 4 (fp32)
+    constexpr int NHB = 8 / CPP;                 // 64-byte channel blocks per 32-channel tile: 1 / 2
+    constexpr bool ACCB = !RED;
+    const bool want_stats = a.bn_partial != nullptr;
+    float s1[NT][NHB][CPP], s2[NT][NHB][CPP];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int hb = 0; hb < NHB; ++hb)
+#pragma unroll
+            for (int e = 0; e < CPP; ++e) s1[nt][hb][e] = s2[nt][hb][e] = 0.f;
+    auto reduce_stats = [&](int row) {
+        // lanes with the same (lane & 3) hold the same channels: reduce over the other 16, then over waves in LDS
+        if (tid < NT * 32 * 2) lred[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int hb = 0; hb < NHB; ++hb)
+#pragma unroll
+                for (int e = 0; e < CPP; ++e) {
+                    float u = s1[nt][hb][e], v = s2[nt][hb][e];
+#pragma unroll
+                    for (int off = 4; off < 64; off <<= 1) {
+                        u += __shfl_xor(u, off, 64);
+                        v += __shfl_xor(v, off, 64);
+                    }
+                    if (lane < 4) {
+                        const int cc = nt * 32 + hb * (4 * CPP) + lane * CPP + e;
+                        atomicAdd(&lred[cc * 2 + 0], u);
+                        atomicAdd(&lred[cc * 2 + 1], v);
+                    }
+                    s1[nt][hb][e] = s2[nt][hb][e] = 0.f;
+                }
+        __syncthreads();
+        if (tid < NT * 32) {
+            const int co = blockIdx.y * NT * 32 + tid;
+            if (co < a.Cout) {
+                float* dstp = a.bn_partial + ((size_t)row * a.Cout + co) * 2;
+                const float l0 = lred[tid * 2 + 0], l1 = lred[tid * 2 + 1];
+                dstp[0] = l0;
+                if constexpr (RED) dstp[1] = a.red_invstd[co] * (l1 - a.red_mean[co] * l0);   // sum dz * yhat
+                else dstp[1] = l1;
+            }
+        }
+    };
     int k = 0;
     int brick = brick_of(0);
     if (brick >= nbricks) return;            // uniform per block
@@ -421,22 +470,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
             // the accumulate / BatchNorm-backward operands) are then 64 contiguous bytes per voxel instead of 8.
             __syncthreads();
             const Org o = origin(brick);
-            const bool want_stats = a.bn_partial != nullptr;
-            constexpr int CPP = 16 / (int)sizeof(T);     // channels per 16-byte piece: 8 (bf16) / 4 (fp32)
-            constexpr int NHB = 8 / CPP;                 // 64-byte channel blocks per 32-channel tile: 1 / 2
             constexpr int QPB = 4 / NHB;                 // accumulator quads per block
             constexpr int ROWB = 80;                     // staged row: 64 B + 16 B pad (spreads the rows over the banks)
             char* stg = (char*)lact + wave * (16 * ROWB);
             const int prow = lane >> 2, pcol = lane & 3; // read-back: lane -> (voxel row, piece)
-            float s1[NT][NHB][CPP], s2[NT][NHB][CPP];
-            if (want_stats) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int hb = 0; hb < NHB; ++hb)
-#pragma unroll
-                        for (int e = 0; e < CPP; ++e) s1[nt][hb][e] = s2[nt][hb][e] = 0.f;
-            }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -514,40 +551,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
                     }
                 }
             }
-            if (want_stats) {
-                // lanes with the same (lane & 3) hold the same channels: reduce over the other 16, then over waves in LDS
-                if (tid < NT * 32 * 2) lred[tid] = 0.f;
-                __syncthreads();
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int hb = 0; hb < NHB; ++hb)
-#pragma unroll
-                        for (int e = 0; e < CPP; ++e) {
-                            float u = s1[nt][hb][e], v = s2[nt][hb][e];
-#pragma unroll
-                            for (int off = 4; off < 64; off <<= 1) {
-                                u += __shfl_xor(u, off, 64);
-                                v += __shfl_xor(v, off, 64);
-                            }
-                            if (lane < 4) {
-                                const int cc = nt * 32 + hb * (4 * CPP) + lane * CPP + e;
-                                atomicAdd(&lred[cc * 2 + 0], u);
-                                atomicAdd(&lred[cc * 2 + 1], v);
-                            }
-                        }
-                __syncthreads();
-                if (tid < NT * 32) {
-                    const int co = blockIdx.y * NT * 32 + tid;
-                    if (co < a.Cout) {
-                        float* dstp = a.bn_partial + ((size_t)brick * a.Cout + co) * 2;
-                        const float l0 = lred[tid * 2 + 0], l1 = lred[tid * 2 + 1];
-                        dstp[0] = l0;
-                        if constexpr (RED) dstp[1] = a.red_invstd[co] * (l1 - a.red_mean[co] * l0);   // sum dz * yhat
-                        else dstp[1] = l1;
-                    }
-                }
-            }
+            if (want_stats && !ACCB) reduce_stats(brick);
         }
         DIAG_STAMP(3);
 #ifdef BIU_DIAG
@@ -569,6 +573,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
         DIAG_STAMP(6);
         brick = nbrick; ch = nch; k = nk;
     }
+    if (want_stats && ACCB) reduce_stats((int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -739,11 +744,23 @@ int biu_mfma_convt_dgrad_bricks(const biu_act* dx, int kd) {
     return dx->n * ((dx->d + td - 1) / td) * ((dx->h + th - 1) / th) * ((dx->w + tw - 1) / tw);
 }
 
-// number of bricks (= BatchNorm partial rows) the forward conv will produce for this output
+// number of bricks of a 3x3(x3) launch writing y (= BatchNorm-backward partial rows of the data-gradient kernels)
 int biu_mfma_conv_bricks(const biu_act* y, int kd) {
     const int ntiles = (y->c + 31) / 32;
     const BrickDim b = conv3_brick(kd, pick_nt(ntiles), y->w % 32 == 0);
     return y->n * ((y->d + b.td - 1) / b.td) * ((y->h + b.th - 1) / b.th) * ((y->w + b.tw - 1) / b.tw);
+}
+// number of workgroup columns of that launch (= BatchNorm statistics partial rows of the forward kernels: one per block);
+// must mirror launch_cfg_r's grid computation
+int biu_mfma_conv_stat_rows(const biu_act* y, int kd) {
+    const int ntiles = (y->c + 31) / 32;
+    const int nt = pick_nt(ntiles);
+    const bool nw4 = conv_nw4() && nt == 1;
+    int g = (nw4 ? 2 : 1) * num_cus() / (ntiles / nt);
+    g &= ~7;
+    if (g < 8) g = 8;
+    const int nbricks = biu_mfma_conv_bricks(y, kd);
+    return g > nbricks ? nbricks : g;
 }
 
 static int fill_xf(ConvArgs& a, const biu_xform* xf) {
