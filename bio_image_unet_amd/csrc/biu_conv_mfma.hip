@@ -174,6 +174,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     const int nbricks = a.N * a.nbd * a.nbh * a.nbw;
     const int p_mine = tid % CKP;
 
+    if (tid < NT * 32 * 2) lred[tid] = 0.f;
     if (has_xf) {
         for (int i = tid; i < a.Cin; i += NTHR) {
             lxf[i] = a.xs[i];
@@ -349,9 +350,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < CPP; ++e) s1[nt][hb][e] = s2[nt][hb][e] = 0.f;
     auto reduce_stats = [&](int row) {
-        // lanes with the same (lane & 3) hold the same channels: reduce over the other 16, then over waves in LDS
-        if (tid < NT * 32 * 2) lred[tid] = 0.f;
-        __syncthreads();
+        // lanes with the same (lane & 3) hold the same channels.  Inside a row of 16 lanes two DPP rotate-adds (VALU, no LDS
+        // traffic) give every lane its class sum; lanes 0-3 of the four rows then add into LDS (4-way same-address), which
+        // also merges the 8 waves.  lred is zero on entry: zeroed at kernel start and by the readers below.
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -359,13 +360,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < CPP; ++e) {
                     float u = s1[nt][hb][e], v = s2[nt][hb][e];
-#pragma unroll
-                    for (int off = 4; off < 64; off <<= 1) {
-                        u += __shfl_xor(u, off, 64);
-                        v += __shfl_xor(v, off, 64);
-                    }
-                    if (lane < 4) {
-                        const int cc = nt * 32 + hb * (4 * CPP) + lane * CPP + e;
+                    u += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x124, 0xf, 0xf, false));   // row_ror:4
+                    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));
+                    u += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x128, 0xf, 0xf, false));   // row_ror:8
+                    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+                    if ((lane & 12) == 0) {
+                        const int cc = nt * 32 + hb * (4 * CPP) + (lane & 3) * CPP + e;
                         atomicAdd(&lred[cc * 2 + 0], u);
                         atomicAdd(&lred[cc * 2 + 1], v);
                     }
@@ -374,9 +374,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
         __syncthreads();
         if (tid < NT * 32) {
             const int co = blockIdx.y * NT * 32 + tid;
+            const float l0 = lred[tid * 2 + 0], l1 = lred[tid * 2 + 1];
+            lred[tid * 2 + 0] = 0.f;          // ready for the next brick: the item loop's barriers order this before its adds
+            lred[tid * 2 + 1] = 0.f;
             if (co < a.Cout) {
                 float* dstp = a.bn_partial + ((size_t)row * a.Cout + co) * 2;
-                const float l0 = lred[tid * 2 + 0], l1 = lred[tid * 2 + 1];
                 dstp[0] = l0;
                 if constexpr (RED) dstp[1] = a.red_invstd[co] * (l1 - a.red_mean[co] * l0);   // sum dz * yhat
                 else dstp[1] = l1;
