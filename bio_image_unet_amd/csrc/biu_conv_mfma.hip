@@ -880,8 +880,20 @@ template <typename T>
 static int launch_convt_fwd(const ConvArgs& a, int kd, hipStream_t st) {
     const int ntiles = (a.Cout + 31) / 32, nt = pick_nt(ntiles), nz = kd * 4;
     if (kd == 2) {
+        // one-tap GEMMs are all staging and no reuse: take the widest channel chunk the input allows (64, 32, 16 channels),
+        // i.e. the fewest (brick, chunk) items and whole 128-byte rows per piece group
+        const int e = 16 / (int)sizeof(T);        // channels per 16-byte piece
+        {
+            if (a.Cin % (8 * e) == 0) return nt == 1 ? launch_cfg<T, 1, 1, 1, 4, 8, 16, 1, 8>(a, ntiles, nz, st) : launch_cfg<T, 1, 1, 1, 4, 8, 16, 2, 8>(a, ntiles, nz, st);
+            if (a.Cin % (4 * e) == 0) return nt == 1 ? launch_cfg<T, 1, 1, 1, 4, 8, 16, 1, 4>(a, ntiles, nz, st) : launch_cfg<T, 1, 1, 1, 4, 8, 16, 2, 4>(a, ntiles, nz, st);
+        }
         if (nt == 1) return launch_cfg<T, 1, 1, 1, 4, 8, 16, 1, 2>(a, ntiles, nz, st);
         return launch_cfg<T, 1, 1, 1, 4, 8, 16, 2, 2>(a, ntiles, nz, st);
+    }
+    {
+        const int e = 16 / (int)sizeof(T);
+        if (a.Cin % (8 * e) == 0) return nt == 1 ? launch_cfg<T, 1, 1, 1, 1, 32, 16, 1, 8>(a, ntiles, nz, st) : launch_cfg<T, 1, 1, 1, 1, 32, 16, 2, 8>(a, ntiles, nz, st);
+        if (a.Cin % (4 * e) == 0) return nt == 1 ? launch_cfg<T, 1, 1, 1, 1, 32, 16, 1, 4>(a, ntiles, nz, st) : launch_cfg<T, 1, 1, 1, 1, 32, 16, 2, 4>(a, ntiles, nz, st);
     }
     if (nt == 1) return launch_cfg<T, 1, 1, 1, 1, 32, 16, 1, 2>(a, ntiles, nz, st);
     return launch_cfg<T, 1, 1, 1, 1, 32, 16, 2, 2>(a, ntiles, nz, st);
