@@ -6,6 +6,18 @@
 // Debug switches (read once): BIU_DISABLE=conv_fwd,conv_dgrad,conv_wgrad,convt_fwd,convt_dgrad,convt_wgrad routes the named op family to the direct kernels.
 #include <stdlib.h>
 #include <string.h>
+// The any-shape kernels are a correctness tier: a large layer landing on them (odd channel counts, dilation != 1, a sample
+// beyond the 4 GB descriptor range, an unaligned slice) runs orders of magnitude below the MFMA path.  Say so, once per op.
+static void warn_slow_path(const char* op, const biu_act* x, const biu_act* y, int taps) {
+    const double macs = (double)nvox(y) * x->c * y->c * taps;
+    if (macs < 4e9) return;
+    static int shown = 0;
+    if (shown++ < 8)
+        fprintf(stderr, "[biu] %s: %d->%d channels on %lld voxels takes the any-shape kernel (%.1f GMAC): expect it to be slow; "
+                        "the MFMA path needs channel counts that are multiples of 8 (>= 16), dilation 1, 16-byte aligned slices "
+                        "and samples under 4 GB\n", op, x->c, y->c, (long long)nvox(y), macs * 1e-9);
+}
+
 static bool disabled(const char* what) {
     const char* env = getenv("BIU_DISABLE");       // re-read per call: tests flip it inside one process
     return env && strstr(env, what) != nullptr;
@@ -65,6 +77,7 @@ extern "C" int biu_conv_fwd(const biu_act* x, const biu_xform* xf, const float* 
         return biu_c1_conv_fwd(x, xf, w, bias, kd, y, dtype, (hipStream_t)stream);
     if (packed && !disabled("conv_fwd") && biu_mfma_conv_ok(x, y, kd, kh, kw, dilation, dtype))
         return biu_mfma_conv(x, xf, packed, bias, kd, kh, kw, y, 0, nullptr, dtype, (hipStream_t)stream);
+    warn_slow_path("conv_fwd", x, y, kd * kh * kw);
     return biu_conv_fwd_direct(x, xf, w, bias, kd, kh, kw, dilation, y, dtype, (hipStream_t)stream);
 }
 
@@ -74,6 +87,7 @@ extern "C" int biu_conv_bwd_data(const biu_act* dy, const float* w, const void* 
     BIU_REQUIRE(w, BIU_ERR_SHAPE, "conv_bwd_data: null weight");
     if (packed && !disabled("conv_dgrad") && biu_mfma_conv_ok(dy, dx, kd, kh, kw, dilation, dtype))
         return biu_mfma_conv(dy, nullptr, packed, nullptr, kd, kh, kw, dx, accumulate, nullptr, dtype, (hipStream_t)stream);
+    warn_slow_path("conv_bwd_data", dx, dy, kd * kh * kw);
     return biu_conv_bwd_data_direct(dy, w, kd, kh, kw, dilation, dx, accumulate, dtype, (hipStream_t)stream);
 }
 
@@ -152,6 +166,7 @@ extern "C" int biu_conv_bwd_weight(const biu_act* x, const biu_xform* xf, const 
                     "conv_bwd_weight: workspace too small");
         return biu_mfma_wgrad(x, xf, dy, kd, kh, kw, dw, dbias, ws, ws_bytes, dtype, (hipStream_t)stream);
     }
+    warn_slow_path("conv_bwd_weight", x, dy, kd * kh * kw);
     return biu_conv_bwd_weight_direct(x, xf, dy, kd, kh, kw, dilation, dw, dbias, dtype, (hipStream_t)stream);
 }
 
@@ -166,7 +181,7 @@ extern "C" int biu_conv_bwd_weight_bn(const biu_act* x, const biu_xform* xf, con
     BIU_REQUIRE(dw && scale && shift && coefA && coefB && coefC, BIU_ERR_SHAPE, "conv_bwd_weight_bn: null pointer");
     const size_t es = dsize(dtype);
     const bool yok = ((uintptr_t)y->p % 16) == 0 && ((size_t)y->pitch * es) % 16 == 0 &&
-                     (i64)y->d * y->h * y->w * y->pitch * (i64)es < (1LL << 31);
+                     (i64)y->d * y->h * y->w * y->pitch * (i64)es < (1LL << 32) - 65536;
     if (!disabled("conv_wgrad") && !disabled("wgrad_bn") && yok && biu_mfma_wgrad_ok(x, da, kd, kh, kw, dilation, dtype)) {
         BIU_REQUIRE(ws && ws_bytes >= biu_mfma_wgrad_workspace(x->c, da->c, kd, kh, kw, dtype), BIU_ERR_WORKSPACE,
                     "conv_bwd_weight_bn: workspace too small");

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
         xs_[j] = (hv < HV) ? (unsigned)(hd | (hh << 10) | (hw << 20)) : 511u;
         lofb[j] = ((hd * a.IH + hh) * a.IW + hw) * xrowb + p_mine * PE * (int)esz;
     }
-    const size_t sample_bytes = (size_t)a.ID * a.IH * a.IW * xrowb;          // < 2^31 (checked on the host)
+    const size_t sample_bytes = (size_t)a.ID * a.IH * a.IW * xrowb;          // < 2^32 - 64 Ki (checked on the host)
     // weight slab of chunk ch: async global->LDS copy into the buffer the NEXT item reads (or into registers)
     auto issue_wpiece = [&](int ch, bool live, int j) {
         const uint4* wch = wgrp + (size_t)(ch * SPC) * TAPS * 64;
@@ -276,15 +276,17 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
         const int hid = min(HD - 1, a.ID - 1 - gd0), hih = min(HH - 1, a.IH - 1 - gh0), hiw = min(HW - 1, a.IW - 1 - gw0);
         c_lo = GBITS - (unsigned)(lod | (loh << 10) | (low << 20));     // x + c_lo keeps a guard bit iff x >= lo
         c_hi = GBITS + (unsigned)(hid | (hih << 10) | (hiw << 20));     // c_hi - x keeps a guard bit iff x <= hi
-        brb = ((gd0 * a.IH + gh0) * a.IW + gw0) * xrowb + ch * CK * (int)esz;
+        // byte offsets inside a sample are taken mod 2^32 (samples up to 4 GB): the base may be negative (halo above the
+        // volume) or beyond 2^31, the sum for an in-volume piece is the true offset
+        brb = (int)(unsigned)((long long)((gd0 * a.IH + gh0) * a.IW + gw0) * xrowb + (long long)ch * CK * (int)esz);
         // a dead prefetch (nothing follows) reads through an empty descriptor: every piece is zero, nothing is fetched
-        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)o.n * sample_bytes), 0, live ? (int)sample_bytes : 0, 0x00020000);
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)o.n * sample_bytes), 0, live ? (int)(unsigned)sample_bytes : 0, 0x00020000);
         inb_mask = 0;
     };
     auto issue_piece = [&](int j) {
         const unsigned in_lo = xs_[j] + c_lo, in_hi = c_hi - xs_[j];
         const bool ok = ((in_lo & in_hi) & GBITS) == GBITS;
-        const int off = ok ? lofb[j] + brb : -1;
+        const int off = ok ? (int)((unsigned)lofb[j] + (unsigned)brb) : -1;
         const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
         pa[j] = make_uint4(v[0], v[1], v[2], v[3]);
         inb_mask |= ok ? (1u << j) : 0u;
@@ -611,6 +613,8 @@ __global__ void k_pack_weights(const float* __restrict__ w, int cin, int cout, i
 
 static inline int ks_of(int dtype) { return dtype == BIU_BF16 ? 16 : 8; }
 
+// buffer descriptors address one sample with 32-bit byte offsets (0xFFFFFFFF marks a padding piece)
+constexpr i64 BIU_MAX_SAMPLE_BYTES = (1LL << 32) - 65536;
 static inline i64 sample_bytes(const biu_act* t, size_t es) { return (i64)t->d * t->h * t->w * t->pitch * (i64)es; }
 
 static bool chan_ok(int K, int Nn, int dtype) { return K >= 16 && K % ks_of(dtype) == 0 && Nn >= 16 && Nn % 8 == 0; }
@@ -640,7 +644,7 @@ bool biu_mfma_conv_ok(const biu_act* x, const biu_act* y, int kd, int kh, int kw
     const size_t es = dsize(dtype);
     if ((uintptr_t)x->p % 16 || (uintptr_t)y->p % 16 || ((size_t)x->pitch * es) % 16 || ((size_t)y->pitch * es) % 16) return false;
     if (nvox(x) * (i64)x->pitch >= (1LL << 31) || nvox(y) * (i64)y->pitch >= (1LL << 31)) return false;   // 32-bit voxel index math
-    if (sample_bytes(x, es) >= (1LL << 31) || sample_bytes(y, es) >= (1LL << 31)) return false;            // 32-bit buffer offsets per sample
+    if (sample_bytes(x, es) >= BIU_MAX_SAMPLE_BYTES || sample_bytes(y, es) >= BIU_MAX_SAMPLE_BYTES) return false;            // 32-bit buffer offsets per sample
     if (kd == 1 && x->d != 1) return false;
     return true;
 }
@@ -867,7 +871,7 @@ static bool ptrs_ok(const biu_act* x, const biu_act* y, int dtype) {
     const size_t es = dsize(dtype);
     if ((uintptr_t)x->p % 16 || (uintptr_t)y->p % 16 || ((size_t)x->pitch * es) % 16 || ((size_t)y->pitch * es) % 16) return false;
     if (nvox(x) * (i64)x->pitch >= (1LL << 31) || nvox(y) * (i64)y->pitch >= (1LL << 31)) return false;
-    if (sample_bytes(x, es) >= (1LL << 31) || sample_bytes(y, es) >= (1LL << 31)) return false;
+    if (sample_bytes(x, es) >= BIU_MAX_SAMPLE_BYTES || sample_bytes(y, es) >= BIU_MAX_SAMPLE_BYTES) return false;
     return true;
 }
 
@@ -1162,16 +1166,16 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         const int d0 = bd * TD, h0 = bh * TH, w0 = bw * TW;
         ca_hi = GBITS + (unsigned)(min(TD - 1, a.GD - 1 - d0) | (min(TH - 1, a.GH - 1 - h0) << 10) | (min(TW - 1, a.GW - 1 - w0) << 20));
         const int va = (d0 * a.GH + h0) * a.GW + w0;
-        brA = va * rowA + ac0 * (int)esz;
-        brY = va * rowY + ac0 * (int)esz;
+        brA = (int)(unsigned)((long long)va * rowA + ac0 * (int)esz);          // mod 2^32, see k_conv_pipe
+        brY = (int)(unsigned)((long long)va * rowY + ac0 * (int)esz);
         const int gd0 = d0 * SD - PD, gh0 = h0 * S - PHW, gw0 = w0 * S - PHW;
         cb_lo = GBITS - (unsigned)(max(0, -gd0) | (max(0, -gh0) << 10) | (max(0, -gw0) << 20));
         cb_hi = GBITS + (unsigned)(min(HD - 1, a.BD - 1 - gd0) | (min(HH - 1, a.BH - 1 - gh0) << 10) | (min(HW - 1, a.BW - 1 - gw0) << 20));
-        brB = ((gd0 * a.BH + gh0) * a.BW + gw0) * rowB + bc0 * (int)esz;
+        brB = (int)(unsigned)((long long)((gd0 * a.BH + gh0) * a.BW + gw0) * rowB + bc0 * (int)esz);
         // a dead prefetch reads through empty descriptors: zeros, nothing fetched
-        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pa + (size_t)n * sampA), 0, live ? (int)sampA : 0, 0x00020000);
-        rsY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.py + (size_t)n * sampY), 0, (live && bn_fused) ? (int)sampY : 0, 0x00020000);
-        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pb + (size_t)n * sampB), 0, live ? (int)sampB : 0, 0x00020000);
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pa + (size_t)n * sampA), 0, live ? (int)(unsigned)sampA : 0, 0x00020000);
+        rsY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.py + (size_t)n * sampY), 0, (live && bn_fused) ? (int)(unsigned)sampY : 0, 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pb + (size_t)n * sampB), 0, live ? (int)(unsigned)sampB : 0, 0x00020000);
         amask = bmask = 0;
     };
     auto ld128 = [&](const __amdgpu_buffer_rsrc_t& rs, int off) -> uint4 {
@@ -1182,15 +1186,15 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         const unsigned x = TAB_LDS ? ltab[j * NTHR + tid] : xa_[TAB_LDS ? 0 : j];
         const bool ok = ((ca_hi - x) & GBITS) == GBITS;
         const int v = (int)__umul24(__umul24(x & 511u, (unsigned)a.GH) + ((x >> 10) & 511u), (unsigned)a.GW) + (int)(x >> 20);
-        pa[j] = ld128(rsA, ok ? (int)__umul24((unsigned)v, (unsigned)rowA) + brA : -1);
-        if (bn_fused) pyv[j] = ld128(rsY, ok ? (int)__umul24((unsigned)v, (unsigned)rowY) + brY : -1);
+        pa[j] = ld128(rsA, ok ? (int)(__umul24((unsigned)v, (unsigned)rowA) + (unsigned)brA) : -1);
+        if (bn_fused) pyv[j] = ld128(rsY, ok ? (int)(__umul24((unsigned)v, (unsigned)rowY) + (unsigned)brY) : -1);
         amask |= ok ? (1u << j) : 0u;
     };
     auto issue_b = [&](int j) {
         const unsigned x = TAB_LDS ? ltab[(NA + j) * NTHR + tid] : xb_[TAB_LDS ? 0 : j];
         const bool ok = (((x + cb_lo) & (cb_hi - x)) & GBITS) == GBITS;
         const int v = (int)__umul24(__umul24(x & 511u, (unsigned)a.BH) + ((x >> 10) & 511u), (unsigned)a.BW) + (int)(x >> 20);
-        pb[j] = ld128(rsB, ok ? (int)__umul24((unsigned)v, (unsigned)rowB) + brB : -1);
+        pb[j] = ld128(rsB, ok ? (int)(__umul24((unsigned)v, (unsigned)rowB) + (unsigned)brB) : -1);
         bmask |= ok ? (1u << j) : 0u;
     };
     auto issue = [&](int brick, bool live) {
@@ -1242,7 +1246,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                             typedef unsigned v4u __attribute__((ext_vector_type(4)));
                             const unsigned x = TAB_LDS ? ltab[j * NTHR + tid] : xa_[TAB_LDS ? 0 : j];
                             const int v = (int)__umul24(__umul24(x & 511u, (unsigned)a.GH) + ((x >> 10) & 511u), (unsigned)a.GW) + (int)(x >> 20);
-                            __builtin_amdgcn_raw_buffer_store_b128(v4u{pa[j].x, pa[j].y, pa[j].z, pa[j].w}, rsA, (int)__umul24((unsigned)v, (unsigned)rowA) + brA, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(v4u{pa[j].x, pa[j].y, pa[j].z, pa[j].w}, rsA, (int)(__umul24((unsigned)v, (unsigned)rowA) + (unsigned)brA), 0, 0);
                         }
                     }
                 }
@@ -1410,7 +1414,7 @@ static bool wgrad_ptrs_ok(const biu_act* x, const biu_act* dy, int dtype) {
     const size_t es = dsize(dtype);
     if ((uintptr_t)x->p % 16 || (uintptr_t)dy->p % 16 || ((size_t)x->pitch * es) % 16 || ((size_t)dy->pitch * es) % 16) return false;
     // 32-bit buffer offsets inside one sample; 24-bit multiplies on tile-local voxel offsets (a tile spans <= 10 planes)
-    if (sample_bytes(x, es) >= (1LL << 31) || sample_bytes(dy, es) >= (1LL << 31)) return false;
+    if (sample_bytes(x, es) >= BIU_MAX_SAMPLE_BYTES || sample_bytes(dy, es) >= BIU_MAX_SAMPLE_BYTES) return false;
     const i64 plane_x = (i64)x->h * x->w, plane_y = (i64)dy->h * dy->w;
     return 10 * (plane_x > plane_y ? plane_x : plane_y) < (1LL << 24);
 }

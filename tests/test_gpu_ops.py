@@ -667,3 +667,34 @@ def test_maxpool_bwd_bnred(shape, dtype, accumulate):
     sa = pa[:na.value * c * 2].view(na.value, c, 2).double().sum(0).cpu()
     sb = pb[:nb.value * c * 2].view(nb.value, c, 2).double().sum(0).cpu()
     torch.testing.assert_close(sb, sa, rtol=1e-4, atol=1e-4 * float(sa.abs().max()) + 1e-9)
+
+
+def test_conv_mfma_sample_beyond_2gb():
+    """Byte offsets inside a sample are 32-bit modular (buffer descriptors): a 2.6 GB sample must address correctly."""
+    dtype, code = "bf16", DT["bf16"][1]
+    n, cin, cout, sp = 1, 16, 16, (8, 400, 400)                  # 1.28 M voxels x pitch 1024 x 2 B = 2.6 GB
+    x = rnd(n, cin, *sp, seed=1)
+    w = rnd(cout, cin, 3, 3, 3, seed=2) * 0.05
+    xd = Dev(x, dtype=dtype, pitch=1024, c0=1000)
+    assert xd.buf.numel() * 2 > 2 ** 31
+    wd = w.cuda()
+    xr = xd.ref()
+    wq = w.bfloat16().float().requires_grad_(True)
+    xq = xr.clone().requires_grad_(True)
+    ref = conv_ref(xq, wq, None, 1)
+    pk = torch.empty(lib.biu_conv_packed_bytes(0, cin, cout, 3, 3, 3, 1, code), dtype=torch.uint8, device="cuda")
+    check(lib.biu_conv_pack(0, ptr(wd), cin, cout, 3, 3, 3, code, ptr(pk), stream()), "pack")
+    yd = Dev(shape=(n, cout) + sp, dtype=dtype)
+    check(lib.biu_conv_fwd(xd.a(), None, ptr(wd), ptr(pk), None, 3, 3, 3, 1, yd.a(), code, stream()), "conv_fwd")
+    torch.testing.assert_close(yd.get(), ref.detach(), rtol=1e-2, atol=1e-2 * float(ref.abs().max()))
+    gd = Dev(rnd(n, cout, *sp, seed=3), dtype=dtype, pitch=1024, c0=8)
+    ref.backward(gd.ref())
+    pk1 = torch.empty(lib.biu_conv_packed_bytes(1, cin, cout, 3, 3, 3, 1, code), dtype=torch.uint8, device="cuda")
+    check(lib.biu_conv_pack(1, ptr(wd), cin, cout, 3, 3, 3, code, ptr(pk1), stream()), "pack1")
+    dxd = Dev(shape=(n, cin) + sp, dtype=dtype)
+    check(lib.biu_conv_bwd_data(gd.a(), ptr(wd), ptr(pk1), 3, 3, 3, 1, dxd.a(), 0, code, stream()), "conv_bwd_data")
+    torch.testing.assert_close(dxd.get(), xq.grad, rtol=1e-2, atol=1e-2 * float(xq.grad.abs().max()))
+    ws = torch.empty(lib.biu_conv_bwd_weight_workspace(cin, cout, 3, 3, 3, code), dtype=torch.uint8, device="cuda")
+    dw = torch.full_like(wd, float("nan"))
+    check(lib.biu_conv_bwd_weight(xd.a(), None, gd.a(), 3, 3, 3, 1, ptr(dw), None, ptr(ws), ws.numel(), code, stream()), "conv_bwd_weight")
+    torch.testing.assert_close(dw.cpu(), wq.grad, rtol=1e-2, atol=1e-2 * float(wq.grad.abs().max()))
