@@ -1051,8 +1051,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     constexpr int HV = HD * HH * HW;
     constexpr int BV = TD * TH * TW;
     constexpr int TAPS = KD * KHW * KHW;
-    constexpr int NITEM = TAPS * KSPLIT;
-    constexpr int IPW = (NITEM + NWAVE - 1) / NWAVE;       // items per wave
+    constexpr int WPQ = NWAVE / KSPLIT;                    // waves per K split
+    constexpr int IPW = (TAPS + WPQ - 1) / WPQ;            // taps per wave
+    static_assert(NWAVE % KSPLIT == 0, "K split must divide the wave count");
     constexpr int RS = CT * (int)sizeof(T);
     constexpr int NA = (BV * PPV + NTHR - 1) / NTHR;
     constexpr int NB = (HV * PPV + NTHR - 1) / NTHR;
@@ -1105,13 +1106,14 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
-    // this wave's items: item = wave + 8 t -> (tap, half)
-    int tapoff[IPW], ihalf[IPW];
+    // Work split: wave w owns K split q = w % KSPLIT (a contiguous run of this brick's k-groups) and the taps
+    // w / KSPLIT + WPQ * t, t < IPW -- every wave runs the same branch-free loop over ITS k-groups with IPW MFMAs per A
+    // fragment; a tap index past the last one multiplies into an accumulator nobody flushes.
+    const int wq = wave % KSPLIT, wtap0 = wave / KSPLIT;
+    int tapoff[IPW];
 #pragma unroll
     for (int t = 0; t < IPW; ++t) {
-        const int item = wave + NWAVE * t;
-        const int tap = item % TAPS;
-        ihalf[t] = (item < NITEM) ? item / TAPS : -1;
+        const int tap = (wtap0 + WPQ * t) % TAPS;
         const int ta = tap / (KHW * KHW), tb = (tap / KHW) % KHW, tc = tap % KHW;
         tapoff[t] = ((ta * HH + tb) * HW + tc) * RS;
     }
@@ -1296,9 +1298,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
             const int nbrick = brick + G;
             const bool have_next = nbrick < a.nbricks;
             // the next brick's loads go out in NG slices between the k-group slices of this brick's MFMA work
-            constexpr int NG = 8;
-            static_assert(NKG % NG == 0 && NG % KSPLIT == 0, "k-groups must split into 8 slices inside the K halves");
-            constexpr int KPG = NKG / NG;
+            constexpr int KPW = NKG / KSPLIT;                  // k-groups a wave walks per brick
+            constexpr int NG = KPW < 8 ? KPW : 8;
+            static_assert(NKG % KSPLIT == 0 && KPW % NG == 0, "k-groups must split evenly into slices");
+            constexpr int KPG = KPW / NG;
             WSTAMP(0);
             issue_prep(have_next ? nbrick : brick, have_next);
 #pragma unroll
@@ -1307,11 +1310,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                 for (int j = (g * NA) / NG; j < ((g + 1) * NA) / NG; ++j) issue_a(j);
 #pragma unroll
                 for (int j = (g * NB) / NG; j < ((g + 1) * NB) / NG; ++j) issue_b(j);
-                const int h = g / (NG / KSPLIT);
                 // fp32 steps are tiny (one ds_read_b32 per 64-cycle MFMA): unroll deeper so the LDS reads run ahead
-#pragma unroll(sizeof(T) == 2 ? 2 : 4)
+#pragma unroll(sizeof(T) == 2 ? 2 : (IPW > 5 ? 2 : 4))
                 for (int kk = 0; kk < KPG; ++kk) {
-                    const int kg = g * KPG + kk;
+                    const int kg = wq * KPW + g * KPG + kk;
                     const int q0 = kg * KUNIT;
                     const int lw0 = q0 % TW;
                     const int t = q0 / TW;
@@ -1326,7 +1328,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                         bf16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                         for (int t2 = 0; t2 < IPW; ++t2) {
-                            if (KSPLIT == 1 || ihalf[t2] == h) {      // KSPLIT == 1: branch-free; a wave's missing last item multiplies into an accumulator nobody flushes
+                            {
                                 const char* bp = bt + hbase + tapoff[t2] + b_lane;
                                 bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp));
                                 bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp + 4 * S * RS));
@@ -1338,7 +1340,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                         const float af = *(const float*)(at + q0 * RS + a_lane);
 #pragma unroll
                         for (int t2 = 0; t2 < IPW; ++t2) {
-                            if (KSPLIT == 1 || ihalf[t2] == h) {      // KSPLIT == 1: branch-free; a wave's missing last item multiplies into an accumulator nobody flushes
+                            {
                                 const float bf = *(const float*)(bt + hbase + tapoff[t2] + b_lane);
                                 acc[t2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[t2], 0, 0, 0);
                             }
@@ -1373,9 +1375,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     if (jj < a.CB) {
 #pragma unroll
         for (int t2 = 0; t2 < IPW; ++t2) {
-            const int item = wave + NWAVE * t2;
-            if (item < NITEM) {
-                const int tap = item % TAPS;
+            const int tap = wtap0 + WPQ * t2;
+            if (tap < TAPS) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int ii = it * CT + (e & 3) + 8 * (e >> 2) + 4 * hf;
@@ -1515,7 +1516,7 @@ int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int
     BIU_REQUIRE(ws_bytes >= need + (dbias ? biu_chan_sum_workspace(dy->c) : 0), BIU_ERR_WORKSPACE, "wgrad_mfma: workspace %zu too small", ws_bytes);
     if (hipMemsetAsync(ws, 0, need, st) != hipSuccess) return biu_fail(BIU_ERR_LAUNCH, "wgrad_mfma: memset failed");
     if (dtype == BIU_BF16) rc = (kd == 3) ? launch_wgrad<bf16_t, 3, 3, 1, 4, 8, 16, 1>(a, st) : launch_wgrad<bf16_t, 1, 3, 1, 1, 16, 32, 4>(a, st);
-    else rc = (kd == 3) ? launch_wgrad<float, 3, 3, 1, 4, 4, 16, 2>(a, st) : launch_wgrad<float, 1, 3, 1, 1, 16, 16, 4>(a, st);
+    else rc = (kd == 3) ? launch_wgrad<float, 3, 3, 1, 4, 4, 16, 1>(a, st) : launch_wgrad<float, 1, 3, 1, 1, 16, 16, 4>(a, st);
     if (rc != BIU_OK) return rc;
     hipLaunchKernelGGL(k_wgrad_finalize, dim3(grid_for((i64)a.CA * a.CB * taps, 256, 2048)), dim3(256), 0, st, (const float*)ws,
                        a.CA, a.CB, taps, dw);
