@@ -1037,13 +1037,16 @@ __device__ __forceinline__ uint4 apply_xf16(uint4 v, const float* sc, const floa
 // the per-thread piece-coordinate table goes to LDS when tiles + table stay under 150 KB
 constexpr bool wgrad_tab_in_lds(size_t tile_bytes, int pieces) { return tile_bytes + (size_t)pieces * 512 * 4 <= 150 * 1024; }
 
-template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int KSPLIT>
+// NI = 32-wide tiles of the plain operand's channels a block owns (its A tile is NI * 32 channels wide): with NI = 2 the tapped
+// operand -- the large fine-grid tensor of a ConvTranspose weight gradient -- is read half as often.
+template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int KSPLIT, int NI>
 __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     using F = Frag<T>;
     constexpr int NTHR = 512, NWAVE = 8;
     constexpr int PE = F::PE;
     constexpr int CT = 32;
     constexpr int PPV = CT / PE;
+    constexpr int CTA = CT * NI, PPVA = CTA / PE, RSA = CTA * (int)sizeof(T);
     constexpr int PD = (KD == 3) ? 1 : 0;
     constexpr int PHW = (KHW == 3) ? 1 : 0;
     constexpr int SD = (KD == 1) ? 1 : S;
@@ -1055,7 +1058,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     constexpr int IPW = (TAPS + WPQ - 1) / WPQ;            // taps per wave
     static_assert(NWAVE % KSPLIT == 0, "K split must divide the wave count");
     constexpr int RS = CT * (int)sizeof(T);
-    constexpr int NA = (BV * PPV + NTHR - 1) / NTHR;
+    constexpr int NA = (BV * PPVA + NTHR - 1) / NTHR;
     constexpr int NB = (HV * PPV + NTHR - 1) / NTHR;
     constexpr int KUNIT = (sizeof(T) == 2) ? 16 : 2;       // voxels per MFMA k-step
     constexpr int NKG = BV / KUNIT;
@@ -1063,48 +1066,54 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
 
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     char* at = (char*)lds;                           // [BV][CT]
-    char* bt = at + BV * RS;                         // [HV][CT]
-    float* lxf = (float*)(bt + HV * RS);             // [6][CT] transform constants of the A / B channel tiles, then [6][CT] BN-bwd
+    char* bt = at + BV * RSA;                        // [HV][CT]
+    float* lxf = (float*)(bt + HV * RS);             // [3][CTA] transform of A, [3][CT] transform of B, [6][CT] BN-bwd (NI == 1)
+    constexpr int LA = 0, LB = 3 * CTA, LBN = 3 * CTA + 3 * CT;
     // packed piece coordinates of every thread (brick-invariant): in LDS [NA + NB][NTHR] when they fit next to the tiles
     // (the big-tile kernels have no registers to spare), else in registers
-    constexpr bool TAB_LDS = wgrad_tab_in_lds((size_t)(HV + BV) * RS, NA + NB);
-    unsigned* ltab = (unsigned*)(lxf + 12 * CT);
+    constexpr bool TAB_LDS = wgrad_tab_in_lds((size_t)HV * RS + (size_t)BV * RSA, NA + NB);
+    unsigned* ltab = (unsigned*)(lxf + LBN + 6 * CT);
     unsigned xa_[TAB_LDS ? 1 : NA], xb_[TAB_LDS ? 1 : NB];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: item tables live in SGPRs
     const int it = blockIdx.y / a.jt_count, jt = a.jt_begin + blockIdx.y % a.jt_count;
     const size_t esz = sizeof(T);
-    const int piece = tid % PPV;
-    const int ac0 = it * CT + piece * PE, bc0 = jt * CT + piece * PE;
+    const int piece = tid % PPV, pieceA = tid % PPVA;
+    const int ac0 = it * CTA + pieceA * PE, bc0 = jt * CT + piece * PE;
     const bool apiece_ok = ac0 < a.CA, bpiece_ok = bc0 < a.CB;
     const bool a_xf = a.as_ != nullptr, b_xf = a.bs_ != nullptr;
     const bool bn_fused = a.py != nullptr;
     if (tid < CT && bn_fused) {
-        const int ca = it * CT + tid;
+        const int ca = it * CTA + tid;
         const bool ok = ca < a.CA;
-        lxf[6 * CT + tid] = ok ? a.bn_scale[ca] : 1.f;
-        lxf[7 * CT + tid] = ok ? a.bn_shift[ca] : 0.f;
-        lxf[8 * CT + tid] = (ok && a.bn_slope) ? a.bn_slope[ca] : 1.f;
-        lxf[9 * CT + tid] = ok ? a.bn_cA[ca] : 0.f;
-        lxf[10 * CT + tid] = ok ? a.bn_cB[ca] : 0.f;
-        lxf[11 * CT + tid] = ok ? a.bn_cC[ca] : 0.f;
+        lxf[LBN + 0 * CT + tid] = ok ? a.bn_scale[ca] : 1.f;
+        lxf[LBN + 1 * CT + tid] = ok ? a.bn_shift[ca] : 0.f;
+        lxf[LBN + 2 * CT + tid] = (ok && a.bn_slope) ? a.bn_slope[ca] : 1.f;
+        lxf[LBN + 3 * CT + tid] = ok ? a.bn_cA[ca] : 0.f;
+        lxf[LBN + 4 * CT + tid] = ok ? a.bn_cB[ca] : 0.f;
+        lxf[LBN + 5 * CT + tid] = ok ? a.bn_cC[ca] : 0.f;
+    }
+    if (tid < CTA) {
+        const int ca = it * CTA + tid;
+        lxf[LA + 0 * CTA + tid] = (a_xf && ca < a.CA) ? a.as_[ca] : 1.f;
+        lxf[LA + 1 * CTA + tid] = (a_xf && ca < a.CA) ? a.ab_[ca] : 0.f;
+        lxf[LA + 2 * CTA + tid] = (a_xf && ca < a.CA) ? a.al_[ca] : 1.f;
     }
     if (tid < CT) {
-        const int ca = it * CT + tid, cb = jt * CT + tid;
-        lxf[0 * CT + tid] = (a_xf && ca < a.CA) ? a.as_[ca] : 1.f;
-        lxf[1 * CT + tid] = (a_xf && ca < a.CA) ? a.ab_[ca] : 0.f;
-        lxf[2 * CT + tid] = (a_xf && ca < a.CA) ? a.al_[ca] : 1.f;
-        lxf[3 * CT + tid] = (b_xf && cb < a.CB) ? a.bs_[cb] : 1.f;
-        lxf[4 * CT + tid] = (b_xf && cb < a.CB) ? a.bb_[cb] : 0.f;
-        lxf[5 * CT + tid] = (b_xf && cb < a.CB) ? a.bl_[cb] : 1.f;
+        const int cb = jt * CT + tid;
+        lxf[LB + 0 * CT + tid] = (b_xf && cb < a.CB) ? a.bs_[cb] : 1.f;
+        lxf[LB + 1 * CT + tid] = (b_xf && cb < a.CB) ? a.bb_[cb] : 0.f;
+        lxf[LB + 2 * CT + tid] = (b_xf && cb < a.CB) ? a.bl_[cb] : 1.f;
     }
 
-    floatx16 acc[IPW];
+    floatx16 acc[IPW][NI];
 #pragma unroll
     for (int t = 0; t < IPW; ++t)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][ni][e] = 0.f;
 
     // Work split: wave w owns K split q = w % KSPLIT (a contiguous run of this brick's k-groups) and the taps
     // w / KSPLIT + WPQ * t, t < IPW -- every wave runs the same branch-free loop over ITS k-groups with IPW MFMAs per A
@@ -1121,10 +1130,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     int a_lane, b_lane;
     if constexpr (sizeof(T) == 2) {
         const int g = lane >> 4, li = lane & 15, qrow = li >> 2, p = li & 3, cg = g & 1, h = g >> 1;
-        a_lane = (8 * h + qrow) * RS + (16 * cg + 4 * p) * 2;
+        a_lane = (8 * h + qrow) * RSA + (16 * cg + 4 * p) * 2;
         b_lane = (8 * h + qrow) * S * RS + (16 * cg + 4 * p) * 2;
     } else {
-        a_lane = (lane >> 5) * RS + (lane & 31) * 4;
+        a_lane = (lane >> 5) * RSA + (lane & 31) * 4;
         b_lane = (lane >> 5) * S * RS + (lane & 31) * 4;
     }
 
@@ -1138,10 +1147,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
         const int i = tid + NTHR * j;
-        const int q = i / PPV;
+        const int q = i / PPVA;
         const int lw = q % TW;
         const int t = q / TW;
-        const unsigned xv = (i < BV * PPV && apiece_ok) ? (unsigned)((t / TH) | ((t % TH) << 10) | (lw << 20)) : 511u;
+        const unsigned xv = (i < BV * PPVA && apiece_ok) ? (unsigned)((t / TH) | ((t % TH) << 10) | (lw << 20)) : 511u;
         if constexpr (TAB_LDS) ltab[j * NTHR + tid] = xv; else xa_[j] = xv;
     }
 #pragma unroll
@@ -1210,7 +1219,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         float sc[PE], sh[PE], sl[PE];
         if (a_xf) {
 #pragma unroll
-            for (int e = 0; e < PE; ++e) { sc[e] = lxf[piece * PE + e]; sh[e] = lxf[CT + piece * PE + e]; sl[e] = lxf[2 * CT + piece * PE + e]; }
+            for (int e = 0; e < PE; ++e) { sc[e] = lxf[LA + pieceA * PE + e]; sh[e] = lxf[LA + CTA + pieceA * PE + e]; sl[e] = lxf[LA + 2 * CTA + pieceA * PE + e]; }
         }
         if (bn_fused) {
             // BatchNorm + LeakyReLU backward of this thread's channel piece, in two sweeps so that only three of the six
@@ -1218,7 +1227,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
             {
                 float ks[PE], kh[PE], kl[PE];
 #pragma unroll
-                for (int e = 0; e < PE; ++e) { ks[e] = lxf[6 * CT + piece * PE + e]; kh[e] = lxf[7 * CT + piece * PE + e]; kl[e] = lxf[8 * CT + piece * PE + e]; }
+                for (int e = 0; e < PE; ++e) { ks[e] = lxf[LBN + piece * PE + e]; kh[e] = lxf[LBN + CT + piece * PE + e]; kl[e] = lxf[LBN + 2 * CT + piece * PE + e]; }
 #pragma unroll
                 for (int j = 0; j < NA; ++j) {
                     if ((amask >> j) & 1u) {
@@ -1234,7 +1243,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
             {
                 float ka[PE], kb[PE], kc[PE];
 #pragma unroll
-                for (int e = 0; e < PE; ++e) { ka[e] = lxf[9 * CT + piece * PE + e]; kb[e] = lxf[10 * CT + piece * PE + e]; kc[e] = lxf[11 * CT + piece * PE + e]; }
+                for (int e = 0; e < PE; ++e) { ka[e] = lxf[LBN + 3 * CT + piece * PE + e]; kb[e] = lxf[LBN + 4 * CT + piece * PE + e]; kc[e] = lxf[LBN + 5 * CT + piece * PE + e]; }
 #pragma unroll
                 for (int j = 0; j < NA; ++j) {
                     if ((amask >> j) & 1u) {
@@ -1257,7 +1266,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int i = tid + NTHR * j;
-            if (i < BV * PPV) {
+            if (i < BV * PPVA) {
                 uint4 v = pa[j];
                 if (a_xf && ((amask >> j) & 1u)) v = apply_xf16<T, PE>(v, sc, sh, sl);
                 ((uint4*)at)[i] = v;
@@ -1265,7 +1274,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         }
         if (b_xf) {
 #pragma unroll
-            for (int e = 0; e < PE; ++e) { sc[e] = lxf[3 * CT + piece * PE + e]; sh[e] = lxf[4 * CT + piece * PE + e]; sl[e] = lxf[5 * CT + piece * PE + e]; }
+            for (int e = 0; e < PE; ++e) { sc[e] = lxf[LB + piece * PE + e]; sh[e] = lxf[LB + CT + piece * PE + e]; sl[e] = lxf[LB + 2 * CT + piece * PE + e]; }
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -1322,10 +1331,14 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                     const int hbase = ((ld * SD * HH + lh * S) * HW + lw0 * S) * RS;
                     if constexpr (sizeof(T) == 2) {
                         typedef bf16x4 __attribute__((address_space(3))) * lp;
-                        const char* ap = at + q0 * RS + a_lane;
-                        bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap));
-                        bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap + 4 * RS));
-                        bf16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        bf16x8 af[NI];
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            const char* ap = at + q0 * RSA + a_lane + ni * CT * 2;
+                            bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap));
+                            bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap + 4 * RSA));
+                            af[ni] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
 #pragma unroll
                         for (int t2 = 0; t2 < IPW; ++t2) {
                             {
@@ -1333,16 +1346,20 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                                 bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp));
                                 bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp + 4 * S * RS));
                                 bf16x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-                                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t2], 0, 0, 0);
+#pragma unroll
+                                for (int ni = 0; ni < NI; ++ni) acc[t2][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ni], bf, acc[t2][ni], 0, 0, 0);
                             }
                         }
                     } else {
-                        const float af = *(const float*)(at + q0 * RS + a_lane);
+                        float af[NI];
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) af[ni] = *(const float*)(at + q0 * RSA + a_lane + ni * CT * 4);
 #pragma unroll
                         for (int t2 = 0; t2 < IPW; ++t2) {
                             {
                                 const float bf = *(const float*)(bt + hbase + tapoff[t2] + b_lane);
-                                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[t2], 0, 0, 0);
+#pragma unroll
+                                for (int ni = 0; ni < NI; ++ni) acc[t2][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ni], bf, acc[t2][ni], 0, 0, 0);
                             }
                         }
                     }
@@ -1378,10 +1395,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
             const int tap = wtap0 + WPQ * t2;
             if (tap < TAPS) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int ii = it * CT + (e & 3) + 8 * (e >> 2) + 4 * hf;
-                    if (ii < a.CA) atomicAdd(a.ws + ((size_t)tap * a.CA + ii) * a.CB + jj, acc[t2][e]);
-                }
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int ii = it * CTA + ni * CT + (e & 3) + 8 * (e >> 2) + 4 * hf;
+                        if (ii < a.CA) atomicAdd(a.ws + ((size_t)tap * a.CA + ii) * a.CB + jj, acc[t2][ni][e]);
+                    }
             }
         }
     }
@@ -1431,23 +1450,23 @@ bool biu_mfma_convt_wgrad_ok(const biu_act* x, const biu_act* dy, int kd, int dt
     return (kd == 1 || kd == 2) && wgrad_chan_ok(x->c, dy->c) && wgrad_ptrs_ok(x, dy, dtype);
 }
 
-template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int KSPLIT>
+template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int KSPLIT, int NI = 1>
 static int launch_wgrad(WgradArgs a, hipStream_t st) {
     constexpr int SD = (KD == 1) ? 1 : S;
     constexpr int HV = ((TD - 1) * SD + KD) * ((TH - 1) * S + KHW) * ((TW - 1) * S + KHW);
     constexpr int BV = TD * TH * TW;
     constexpr int PPV_ = 32 / (16 / (int)sizeof(T));
-    constexpr int NA_ = (BV * PPV_ + 511) / 512, NB_ = (HV * PPV_ + 511) / 512;
-    const size_t tile_bytes = (size_t)(HV + BV) * 32 * sizeof(T);
-    const size_t lds_bytes = tile_bytes + 12 * 32 * sizeof(float) + (wgrad_tab_in_lds(tile_bytes, NA_ + NB_) ? (size_t)(NA_ + NB_) * 512 * sizeof(unsigned) : 0);
+    constexpr int NA_ = (BV * PPV_ * NI + 511) / 512, NB_ = (HV * PPV_ + 511) / 512;
+    const size_t tile_bytes = (size_t)(HV + BV * NI) * 32 * sizeof(T);
+    const size_t lds_bytes = tile_bytes + (9 + 3 * NI) * 32 * sizeof(float) + (wgrad_tab_in_lds(tile_bytes, NA_ + NB_) ? (size_t)(NA_ + NB_) * 512 * sizeof(unsigned) : 0);
     a.nbd = (a.GD + TD - 1) / TD;
     a.nbh = (a.GH + TH - 1) / TH;
     a.nbw = (a.GW + TW - 1) / TW;
     a.nbricks = a.N * a.nbd * a.nbh * a.nbw;
-    const int nit = (a.CA + 31) / 32;
+    const int nit = (a.CA + 32 * NI - 1) / (32 * NI);
     a.njt = (a.CB + 31) / 32;
     a.bricks_per_block = 0;
-    auto kern = k_wgrad_pipe<T, KD, KHW, S, TD, TH, TW, KSPLIT>;
+    auto kern = k_wgrad_pipe<T, KD, KHW, S, TD, TH, TW, KSPLIT, NI>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
@@ -1543,8 +1562,15 @@ int biu_mfma_convt_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* d
     const size_t need = wgrad_acc_bytes(a.CA, a.CB, taps);
     BIU_REQUIRE(ws_bytes >= need + (dbias ? biu_chan_sum_workspace(dy->c) : 0), BIU_ERR_WORKSPACE, "convt_wgrad_mfma: workspace %zu too small", ws_bytes);
     if (hipMemsetAsync(ws, 0, need, st) != hipSuccess) return biu_fail(BIU_ERR_LAUNCH, "convt_wgrad_mfma: memset failed");
-    if (dtype == BIU_BF16) rc = (kd == 2) ? launch_wgrad<bf16_t, 2, 2, 2, 2, 4, 16, 2>(a, st) : launch_wgrad<bf16_t, 1, 2, 2, 1, 8, 16, 4>(a, st);
-    else rc = (kd == 2) ? launch_wgrad<float, 2, 2, 2, 2, 4, 16, 2>(a, st) : launch_wgrad<float, 1, 2, 2, 1, 8, 16, 4>(a, st);
+    // two 32-wide tiles of x's channels per block when x has them: the fine-grid dy is then read half as often
+    const bool wide = a.CA > 32;
+    if (dtype == BIU_BF16) {
+        if (wide) rc = (kd == 2) ? launch_wgrad<bf16_t, 2, 2, 2, 2, 4, 16, 2, 2>(a, st) : launch_wgrad<bf16_t, 1, 2, 2, 1, 8, 16, 4, 2>(a, st);
+        else rc = (kd == 2) ? launch_wgrad<bf16_t, 2, 2, 2, 2, 4, 16, 2>(a, st) : launch_wgrad<bf16_t, 1, 2, 2, 1, 8, 16, 4>(a, st);
+    } else {
+        if (wide && kd == 1) rc = launch_wgrad<float, 1, 2, 2, 1, 8, 16, 4, 2>(a, st);      // (the fp32 3-D tiles leave no LDS for a second A tile)
+        else rc = (kd == 2) ? launch_wgrad<float, 2, 2, 2, 2, 4, 16, 2>(a, st) : launch_wgrad<float, 1, 2, 2, 1, 8, 16, 4>(a, st);
+    }
     if (rc != BIU_OK) return rc;
     hipLaunchKernelGGL(k_wgrad_finalize, dim3(grid_for((i64)a.CA * a.CB * taps, 256, 2048)), dim3(256), 0, st, (const float*)ws,
                        a.CA, a.CB, taps, dw);
