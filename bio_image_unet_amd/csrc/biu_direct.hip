@@ -616,6 +616,63 @@ __global__ void k_head_fwd(DAct x, DXf xf, const float* __restrict__ w, const fl
             }
     }
 }
+// vectorised form: one voxel per thread, its C channels as 16-byte packs; transform vectors and weights sit in LDS
+// (broadcast reads).  C is a compile-time 8/16/32/64.
+template <typename T, int C, int O>
+__global__ __launch_bounds__(TPB) void k_head_fwd_vec(DAct x, DXf xf, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      int cout, int act, float* __restrict__ logits, float* __restrict__ activated) {
+    constexpr int G = 16 / sizeof(T);
+    __shared__ float sm[3 * C + O * C + O];
+    float* sc = sm; float* sh = sm + C; float* sl = sm + 2 * C; float* ws = sm + 3 * C; float* bs = ws + O * C;
+    for (int i = threadIdx.x; i < C; i += TPB) {
+        sc[i] = xf.scale ? xf.scale[i] : 1.f;
+        sh[i] = xf.shift ? xf.shift[i] : 0.f;
+        sl[i] = xf.slope ? xf.slope[i] : 1.f;
+    }
+    for (int i = threadIdx.x; i < O * C; i += TPB) ws[i] = (i / C) < cout ? w[i] : 0.f;
+    for (int i = threadIdx.x; i < O; i += TPB) bs[i] = (bias && i < cout) ? bias[i] : 0.f;
+    __syncthreads();
+    const i64 S = (i64)x.d * x.h * x.w;
+    const i64 total = (i64)x.n * S;
+    for (i64 v = (i64)blockIdx.x * TPB + threadIdx.x; v < total; v += (i64)gridDim.x * TPB) {
+        const T* src = (const T*)x.p + v * x.pitch;
+        Pack<T, G> in[C / G];
+#pragma unroll
+        for (int q = 0; q < C / G; ++q) in[q] = *(const Pack<T, G>*)(src + q * G);
+        float acc[O];
+#pragma unroll
+        for (int o = 0; o < O; ++o) acc[o] = bs[o];
+#pragma unroll
+        for (int q = 0; q < C / G; ++q)
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int c = q * G + j;
+                float t = fmaf(sc[c], to_f(in[q].v[j]), sh[c]);
+                t = t > 0.f ? t : sl[c] * t;
+#pragma unroll
+                for (int o = 0; o < O; ++o) acc[o] = fmaf(t, ws[o * C + c], acc[o]);
+            }
+        const i64 n = v / S, sidx = v % S;
+#pragma unroll
+        for (int o = 0; o < O; ++o)
+            if (o < cout) {
+                const i64 idx = (n * cout + o) * S + sidx;
+                if (logits) logits[idx] = acc[o];
+                if (activated) activated[idx] = head_act(act, acc[o]);
+            }
+    }
+}
+template <typename T, int C>
+static bool head_fwd_vec_launch(const biu_act* x, const biu_xform* xf, const float* w, const float* bias, int cout, int act, float* logits,
+                                float* activated, hipStream_t st) {
+    const int grid = grid_for(nvox(x), TPB, 8192);
+    if (cout == 1) hipLaunchKernelGGL((k_head_fwd_vec<T, C, 1>), dim3(grid), dim3(TPB), 0, st, dact(x), dxf(xf), w, bias, cout, act, logits, activated);
+    else if (cout == 2) hipLaunchKernelGGL((k_head_fwd_vec<T, C, 2>), dim3(grid), dim3(TPB), 0, st, dact(x), dxf(xf), w, bias, cout, act, logits, activated);
+    else if (cout <= 4) hipLaunchKernelGGL((k_head_fwd_vec<T, C, 4>), dim3(grid), dim3(TPB), 0, st, dact(x), dxf(xf), w, bias, cout, act, logits, activated);
+    else return false;
+    return true;
+}
+
 template <typename T>
 __global__ void k_head_bwd_data(int cin, const float* __restrict__ w, int cout, const float* __restrict__ dl, DAct dx) {
     const i64 S = (i64)dx.d * dx.h * dx.w;
@@ -1061,6 +1118,22 @@ extern "C" int biu_head_fwd(const biu_act* x, const biu_xform* xf, const float* 
                 "head_fwd: cout must be in 1..%d", HEAD_MAX_COUT);
     BIU_REQUIRE(act >= 0 && act <= 3, BIU_ERR_UNSUPPORTED, "head_fwd: unknown activation %d", act);
     hipStream_t st = (hipStream_t)stream;
+    if (vec_ok(x, 16 / (int)dsize(dtype), dtype)) {
+        bool done = false;
+        BIU_DISPATCH_DTYPE(dtype, {
+            switch (x->c) {
+                case 8: done = head_fwd_vec_launch<T, 8>(x, xf, w, bias, cout, act, logits, activated, st); break;
+                case 16: done = head_fwd_vec_launch<T, 16>(x, xf, w, bias, cout, act, logits, activated, st); break;
+                case 32: done = head_fwd_vec_launch<T, 32>(x, xf, w, bias, cout, act, logits, activated, st); break;
+                case 64: done = head_fwd_vec_launch<T, 64>(x, xf, w, bias, cout, act, logits, activated, st); break;
+                default: break;
+            }
+        });
+        if (done) {
+            BIU_CHECK_LAUNCH("head_fwd_vec");
+            return BIU_OK;
+        }
+    }
     BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_head_fwd<T>, dim3(grid_for(nvox(x), TPB, 8192)), dim3(TPB), 0, st,
                                                  dact(x), dxf(xf), w, bias, cout, act, logits, activated));
     BIU_CHECK_LAUNCH("head_fwd");
