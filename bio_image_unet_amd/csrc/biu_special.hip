@@ -529,8 +529,14 @@ __global__ __launch_bounds__(TPB) void k_head_bwd_fused(DAct x, DXf xf, const fl
                                                         float* __restrict__ partial /* [nblk][O*C + O] */) {
     constexpr int G = 16 / sizeof(T);
     __shared__ float wsm[O * C];
+    __shared__ float xsc[C], xsh[C], xsl[C];
     __shared__ float red[4][O * C + O];
     for (int i = threadIdx.x; i < O * C; i += TPB) wsm[i] = (i / C) < cout ? w[i] : 0.f;
+    for (int i = threadIdx.x; i < C; i += TPB) {
+        xsc[i] = xf.scale ? xf.scale[i] : 1.f;
+        xsh[i] = xf.shift ? xf.shift[i] : 0.f;
+        xsl[i] = xf.slope ? xf.slope[i] : 1.f;
+    }
     __syncthreads();
     const i64 S = (i64)x.d * x.h * x.w;
     const i64 total = (i64)x.n * S;
@@ -558,7 +564,8 @@ __global__ __launch_bounds__(TPB) void k_head_bwd_fused(DAct x, DXf xf, const fl
 #pragma unroll
             for (int j = 0; j < G; ++j) {
                 const int c = c0 + j;
-                const float t = xf_apply(xf, c, to_f(in.v[j]));
+                float t = fmaf(xsc[c], to_f(in.v[j]), xsh[c]);
+                t = t > 0.f ? t : xsl[c] * t;
                 float d = 0.f;
 #pragma unroll
                 for (int o = 0; o < O; ++o) {
