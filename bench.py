@@ -177,7 +177,10 @@ def main():
 
     from bio_image_unet_amd import ddp
     from bio_image_unet_amd._lib import lib
-    rank, local, world = ddp.init_from_env("nccl")
+    # rehearsal switches for a one-GPU box: BIU_DDP_BACKEND=gloo, BIU_SINGLE_DEVICE=1 (every rank on cuda:0)
+    if os.environ.get("BIU_SINGLE_DEVICE") == "1":
+        os.environ["LOCAL_RANK"] = "0"
+    rank, local, world = ddp.init_from_env(os.environ.get("BIU_DDP_BACKEND", "nccl"))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)

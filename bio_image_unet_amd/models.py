@@ -67,6 +67,8 @@ class _HipNet(nn.Module):
             for nd_ in eng.nodes:       # labels for profiling: the reference attribute name of the layer
                 mod = getattr(nd_, "conv", None) or getattr(nd_, "up", None)
                 base = names.get(id(mod), type(nd_).__name__)
+                if isinstance(nd_, E.ResampleNode):
+                    base = f"{nd_.kind}@{'x'.join(str(v) for v in nd_.xin.space[1:])}"
                 nd_.label = base[:-2] if base.endswith(".0") and not base.startswith("final") else base
             self._engines[key] = eng
             while len(self._engines) > self._max_cached:
