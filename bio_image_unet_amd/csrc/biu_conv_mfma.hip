@@ -1296,15 +1296,22 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
 #else
 #define WSTAMP(k_) do { } while (0)
 #endif
+    // brick walk: round k hands bricks [k*G, (k+1)*G) out so that the blocks of one XCD (block id mod 8) get a contiguous run --
+    // neighbouring bricks share their halo through that XCD's L2 (same scheme as k_conv_pipe)
     const int G = gridDim.x;
-    int brick = blockIdx.x;
+    auto brick_of = [&](int k) -> int {
+        if ((G & 7) == 0) return k * G + (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);
+        return k * G + (int)blockIdx.x;
+    };
+    int kround = 0;
+    int brick = brick_of(0);
     if (brick < a.nbricks) {
         issue(brick, true);
         __syncthreads();             // lxf visible
         commit();
         __syncthreads();
         while (true) {
-            const int nbrick = brick + G;
+            const int nbrick = brick_of(kround + 1);
             const bool have_next = nbrick < a.nbricks;
             // the next brick's loads go out in NG slices between the k-group slices of this brick's MFMA work
             constexpr int KPW = NKG / KSPLIT;                  // k-groups a wave walks per brick
@@ -1383,6 +1390,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
             __syncthreads();
             WSTAMP(4);
             brick = nbrick;
+            ++kround;
         }
     }
 
@@ -1484,6 +1492,7 @@ static int launch_wgrad(WgradArgs a, hipStream_t st) {
         b.jt_begin = jt_begin; b.jt_count = jt_count; b.write_back = write_back;
         const int pairs = nit * jt_count;
         int g = num_cus() / pairs;                        // persistent: about one block per CU in total
+        if (g >= 16) g &= ~7;                             // multiple of 8: linear block id mod 8 (the XCD) == blockIdx.x mod 8
         if (g < 1) g = 1;
         if (g > b.nbricks) g = b.nbricks;
         hipLaunchKernelGGL(kern, dim3(g, pairs), dim3(512), lds_bytes, st, b);
