@@ -279,7 +279,7 @@ def main():
                           "kernel_time_ms_one_step": total_kernel_ms},
         "roofline": roof,
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores, bounded sample)
         out["cpu_baseline"] = cpu_baseline(args.workload)
     print(json.dumps(out))
 
