@@ -240,6 +240,8 @@ def main():
         fwd_ms = (time.perf_counter() - t1) / nf * 1e3
 
     if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
         return
     dom_launch_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in watched) / max(len(watched), 1)
     fl, by = call_cost(eng, *dom_key)
@@ -281,7 +283,9 @@ def main():
     }
     if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores, bounded sample)
         out["cpu_baseline"] = cpu_baseline(args.workload)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
