@@ -1,0 +1,134 @@
+"""Parity at BASELINE.json's full size (cfg4: UNet3D(1,1,32) on 4 x 128^3) through properties that do not need a reference
+run of that size (the CPU oracle takes minutes there):
+
+* a conv followed by train-mode BatchNorm is invariant to a positive rescaling of the conv's weights and to its bias
+  (exercises the fused statistics / transform path of every MFMA kernel at full extent);
+* the analytic gradient agrees with a central finite difference of the loss along a random direction (fp32);
+* bf16 and fp32 runs of the same weights agree on the predicted mask outside a narrow band around the threshold;
+* two runs of the same step agree (the only non-determinism is the summation order of float atomics: LDS merges of the
+  BatchNorm partial sums, fp32 global atomics in the weight gradient);
+* a block of the volume computed alone (with enough context) equals the same block of the full volume in eval mode --
+  translation equivariance of the whole stack, which pins the brick / halo / XCD walk indexing at full size.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import bio_image_unet_amd as B  # noqa: E402
+from bio_image_unet_amd.losses import BCEDiceLoss  # noqa: E402
+
+SHAPE = (4, 1, 128, 128, 128)
+
+
+def make(dtype, seed=0, n_filter=32):
+    torch.manual_seed(seed)
+    m = B.UNet3D(1, 1, n_filter).cuda()
+    if dtype == "bf16":
+        m.set_compute_dtype(torch.bfloat16)
+    return m
+
+
+def data(seed=1, shape=SHAPE):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.rand(shape, device="cuda", generator=g)
+    y = (torch.rand(shape, device="cuda", generator=g) > 0.5).float()
+    return x, y
+
+
+def step_loss(m, x, y):
+    _, logits = m(x)
+    return BCEDiceLoss(0.5, 0.5)(logits, y) + torch.nn.functional.smooth_l1_loss(logits[1:], logits[:-1]) * 0.1, logits
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_conv_scale_and_bias_invariance_under_batchnorm(dtype):
+    m = make(dtype)
+    m.train()
+    x, _ = data()
+    with torch.no_grad():
+        _, ref = m(x)
+        for name in ("encode2", "decode5", "middle_conv1"):
+            conv = getattr(m, name)[0]
+            conv.weight.mul_(3.0)
+            conv.bias.add_(0.7)
+        _, got = m(x)
+    tol = 2e-2 if dtype == "bf16" else 2e-4
+    err = float((got - ref).abs().max()) / float(ref.abs().max())
+    assert err < tol, err
+
+
+def test_directional_derivative_fp32():
+    m = make("f32", n_filter=16)
+    m.train()
+    x, y = data(shape=(2, 1, 128, 128, 128))
+    params = [p for n, p in m.named_parameters() if n.endswith("weight") and p.dim() > 1]
+    loss, _ = step_loss(m, x, y)
+    grads = torch.autograd.grad(loss, params)
+    torch.manual_seed(3)
+    dirs = [torch.randn_like(p) * p.detach().abs().mean() for p in params]
+    analytic = sum(float((g.double() * d.double()).sum()) for g, d in zip(grads, dirs))
+    eps = 1e-2
+    vals = []
+    with torch.no_grad():
+        for sgn in (+1.0, -1.0):
+            for p, d in zip(params, dirs):
+                p.add_(d, alpha=sgn * eps)
+            vals.append(float(step_loss(m, x, y)[0].double()))
+            for p, d in zip(params, dirs):
+                p.sub_(d, alpha=sgn * eps)
+    numeric = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(numeric - analytic) < 5e-2 * max(abs(analytic), 1e-3) + 1e-4, (numeric, analytic)
+
+
+def test_bf16_mask_agrees_with_fp32():
+    x, _ = data()
+    mb, mf = make("bf16"), make("f32")
+    mf.load_state_dict(mb.state_dict())
+    mb.train(); mf.train()
+    with torch.no_grad():
+        _, lb = mb(x)
+        _, lf = mf(x)
+    band = 0.05 * float(lf.abs().max())
+    safe = lf.abs() > band
+    assert float(safe.float().mean()) > 0.5
+    assert bool(((lb > 0) == (lf > 0))[safe].all())
+    assert float((lb - lf).abs().max()) < 0.1 * float(lf.abs().max())
+
+
+def test_step_is_reproducible():
+    m = make("bf16")
+    m.train()
+    x, y = data()
+    outs = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        loss, logits = step_loss(m, x, y)
+        loss.backward()
+        outs.append((float(loss), logits.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()}))
+    # forward: the BatchNorm statistics merge per-wave partial sums with LDS float atomics (order varies): 1e-7-level noise
+    # that a bf16 rounding boundary may amplify to one ulp of a few activations
+    assert abs(outs[0][0] - outs[1][0]) < 1e-5 * abs(outs[0][0])
+    assert float((outs[0][1] - outs[1][1]).abs().max()) < 2e-2 * float(outs[0][1].abs().max())
+    # backward: the gradient of this network is ill-conditioned (a train-mode BatchNorm after every conv amplifies a
+    # one-ulp bf16 change of an activation), so compare the whole gradient in norm, not element-wise
+    ga = torch.cat([outs[0][2][n].flatten().double() for n in outs[0][2]])
+    gb = torch.cat([outs[1][2][n].flatten().double() for n in outs[0][2]])
+    assert float((ga - gb).norm() / ga.norm()) < 2e-2
+    assert float(torch.dot(ga, gb) / (ga.norm() * gb.norm())) > 0.9995
+
+
+def test_translation_equivariance_eval():
+    """Eval mode (running statistics): the network is a fixed shift-equivariant map for shifts that are multiples of 8
+    (three 2x poolings); a crop with >= 48 voxels of context reproduces the interior of the full result."""
+    m = make("bf16")
+    with torch.no_grad():                 # one training forward gives the running statistics non-trivial values
+        m.train()
+        m(data(seed=5)[0])
+        m.eval()
+        x, _ = data(seed=6, shape=(1, 1, 128, 128, 128))
+        _, full = m(x)
+        _, crop = m(x[:, :, :, 16:128, 8:120].contiguous())
+    a = full[:, :, 48:80, 64:80, 56:72]
+    b = crop[:, :, 48:80, 48:64, 48:64]
+    assert float((a - b).abs().max()) < 3e-2 * float(full.abs().max())
