@@ -82,6 +82,7 @@ SIGNATURES = {
     "biu_head_fwd": (_I, [_A, _X, _P, _P, _I, _I, _P, _P, _I, _P]),
     "biu_head_bwd_workspace": (_Z, [_I]),
     "biu_head_bwd": (_I, [_A, _X, _P, _I, _P, _A, _P, _P, _P, _Z, _I, _P]),
+    "biu_head_bwd_bnred": (_I, [_A, _X, _P, _I, _P, _A, _P, _P, _P, _Z, _P, _P, _P, _Z, C.POINTER(C.c_int), _I, _P]),
     "biu_max_join_fwd": (_I, [_A, _X, _A, _X, _A, _I, _P]),
     "biu_max_join_bwd": (_I, [_A, _X, _A, _X, _A, _A, _A, _I, _I, _P]),
     "biu_act_add": (_I, [_A, _A, _I, _I, _P]),

@@ -1181,6 +1181,22 @@ extern "C" int biu_head_bwd(const biu_act* x, const biu_xform* xf, const float* 
     return BIU_OK;
 }
 
+// head backward that also emits biu_bn_bwd_reduce's partial sums for the block that produced x (the head being its only reader)
+extern "C" int biu_head_bwd_bnred(const biu_act* x, const biu_xform* xf, const float* w, int cout, const float* dlogits,
+                                  const biu_act* dx, float* dw, float* dbias, void* ws, size_t ws_bytes, const float* mean,
+                                  const float* invstd, float* partial, size_t partial_floats, int* nblk, int dtype,
+                                  biu_stream stream) {
+    BIU_REQUIRE(valid_act(x) && w && dlogits && dx && valid_act(dx) && same_space(x, dx) && dx->c == x->c && cout > 0 &&
+                    cout <= HEAD_MAX_COUT, BIU_ERR_SHAPE, "head_bwd_bnred: bad arguments");
+    BIU_REQUIRE(xf && xf->scale && xf->shift && mean && invstd && partial && nblk, BIU_ERR_SHAPE, "head_bwd_bnred: null vector");
+    BIU_REQUIRE(partial_floats >= (size_t)BIU_BN_MAX_PARTIALS * x->c * 2, BIU_ERR_WORKSPACE, "head_bwd_bnred: partial buffer too small");
+    if (!getenv("BIU_NO_HEAD_BNRED") && biu_head_bwd_bnred_ok(x, dx, cout, dtype) && ws && ws_bytes >= biu_head_bwd_fused_workspace(x->c))
+        return biu_head_bwd_bnred_fused(x, xf, w, cout, dlogits, dx, dw, dbias, ws, mean, invstd, partial, nblk, dtype, (hipStream_t)stream);
+    int rc = biu_head_bwd(x, xf, w, cout, dlogits, dx, dw, dbias, ws, ws_bytes, dtype, stream);
+    if (rc != BIU_OK) return rc;
+    return biu_bn_bwd_reduce(dx, x, xf->scale, xf->shift, xf->slope, mean, invstd, partial, nblk, dtype, stream);
+}
+
 // ---- element-wise ----------------------------------------------------------------------------------
 extern "C" int biu_max_join_fwd(const biu_act* a, const biu_xform* xa, const biu_act* b, const biu_xform* xb,
                                 const biu_act* out, int dtype, biu_stream stream) {

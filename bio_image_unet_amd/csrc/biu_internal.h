@@ -65,6 +65,10 @@ size_t biu_chan_sum_workspace(int c);
 int biu_chan_sum_vec(const biu_act* a, float* out, void* ws, int dtype, hipStream_t st);
 bool biu_head_bwd_fused_ok(const biu_act* x, const biu_act* dx, int cout, int dtype);
 size_t biu_head_bwd_fused_workspace(int cin);
+bool biu_head_bwd_bnred_ok(const biu_act* x, const biu_act* dx, int cout, int dtype);
+int biu_head_bwd_bnred_fused(const biu_act* x, const biu_xform* xf, const float* w, int cout, const float* dl, const biu_act* dx, float* dw,
+                             float* db, void* ws, const float* mean, const float* invstd, float* bn_partial, int* bn_nblk, int dtype,
+                             hipStream_t st);
 int biu_head_bwd_fused(const biu_act* x, const biu_xform* xf, const float* w, int cout, const float* dl, const biu_act* dx, float* dw,
                        float* db, void* ws, size_t ws_bytes, int dtype, hipStream_t st);
 bool biu_rowvec_ok(const biu_act* a, int dtype);

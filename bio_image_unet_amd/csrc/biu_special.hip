@@ -523,10 +523,14 @@ int biu_chan_sum_vec(const biu_act* a, float* out, void* ws, int dtype, hipStrea
 // fused 1x1 head backward: one pass over (x, dlogits) produces dx, and per-block partials of dW and dbias
 //   dx[v, c] = sum_o dl[n, o, s] * w[o, c];  dW[o, c] = sum_v dl * T(x)[v, c];  db[o] = sum_v dl
 // =====================================================================================================================
-template <typename T, int C, int O>
+// RED: also the BatchNorm-backward sums (sum dz, sum dz * yhat) of the block that produced x, reduced from the dx values this
+//      kernel writes (the head is that tensor's only reader): bn_partial[block][C][2]
+template <typename T, int C, int O, bool RED>
 __global__ __launch_bounds__(TPB) void k_head_bwd_fused(DAct x, DXf xf, const float* __restrict__ w, int cout,
                                                         const float* __restrict__ dl, DAct dx, int want_dx,
-                                                        float* __restrict__ partial /* [nblk][O*C + O] */) {
+                                                        float* __restrict__ partial /* [nblk][O*C + O] */,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        float* __restrict__ bn_partial) {
     constexpr int G = 16 / sizeof(T);
     __shared__ float wsm[O * C];
     __shared__ float xsc[C], xsh[C], xsl[C];
@@ -541,11 +545,16 @@ __global__ __launch_bounds__(TPB) void k_head_bwd_fused(DAct x, DXf xf, const fl
     const i64 S = (i64)x.d * x.h * x.w;
     const i64 total = (i64)x.n * S;
     float aw[O][C], ab[O];
+    float r1[RED ? C : 1], r2[RED ? C : 1];
 #pragma unroll
     for (int o = 0; o < O; ++o) {
         ab[o] = 0.f;
 #pragma unroll
         for (int c = 0; c < C; ++c) aw[o][c] = 0.f;
+    }
+    if (RED) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) r1[c] = r2[c] = 0.f;
     }
     for (i64 v = (i64)blockIdx.x * TPB + threadIdx.x; v < total; v += (i64)gridDim.x * TPB) {
         const i64 n = v / S, s = v % S;
@@ -573,6 +582,12 @@ __global__ __launch_bounds__(TPB) void k_head_bwd_fused(DAct x, DXf xf, const fl
                     d = fmaf(g[o], wsm[o * C + c], d);
                 }
                 od.v[j] = from_f<T>(d);
+                if (RED) {
+                    const float yv = to_f(in.v[j]);
+                    const float dz = to_f(od.v[j]) * (fmaf(xsc[c], yv, xsh[c]) > 0.f ? 1.f : xsl[c]);
+                    r1[c] += dz;
+                    r2[c] = fmaf(dz, yv, r2[c]);          // raw; centred below
+                }
             }
             if (want_dx) *(Pack<T, G>*)(dst + c0) = od;
         }
@@ -591,6 +606,21 @@ __global__ __launch_bounds__(TPB) void k_head_bwd_fused(DAct x, DXf xf, const fl
     __syncthreads();
     for (int i = threadIdx.x; i < O * C + O; i += TPB)
         partial[(i64)blockIdx.x * (O * C + O) + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    if (RED) {
+        __shared__ float redb[4][2 * C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float a1 = wave_sum(r1[c]), a2 = wave_sum(r2[c]);
+            if (lane == 0) { redb[wave][2 * c] = a1; redb[wave][2 * c + 1] = a2; }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += TPB) {
+            const float s1v = redb[0][2 * c] + redb[1][2 * c] + redb[2][2 * c] + redb[3][2 * c];
+            const float s2v = redb[0][2 * c + 1] + redb[1][2 * c + 1] + redb[2][2 * c + 1] + redb[3][2 * c + 1];
+            bn_partial[((i64)blockIdx.x * C + c) * 2 + 0] = s1v;
+            bn_partial[((i64)blockIdx.x * C + c) * 2 + 1] = invstd[c] * (s2v - mean[c] * s1v);
+        }
+    }
 }
 
 __global__ void k_head_bwd_finalize(const float* __restrict__ partial, int nblk, int C, int O, int cout, float* dw, float* db) {
@@ -629,21 +659,46 @@ size_t biu_head_bwd_fused_workspace(int cin) { return (size_t)HEAD_FUSED_BLOCKS 
 
 template <typename T, int C>
 static int head_fused_t(const biu_act* x, const biu_xform* xf, const float* w, int cout, const float* dl, const biu_act* dx, float* dw,
-                        float* db, void* ws, hipStream_t st) {
+                        float* db, void* ws, hipStream_t st, const float* mean = nullptr, const float* invstd = nullptr,
+                        float* bn_partial = nullptr, int* bn_nblk = nullptr) {
     const i64 total = nvox(x);
     int nblk = (int)((total + TPB * 8 - 1) / (TPB * 8));
     if (nblk > HEAD_FUSED_BLOCKS) nblk = HEAD_FUSED_BLOCKS;
     if (nblk < 1) nblk = 1;
     DAct dxa = dx ? dact(dx) : dact(x);
     const int O = cout == 3 ? 4 : cout;
-    if constexpr (C <= 32) {
-        if (O == 4) hipLaunchKernelGGL((k_head_bwd_fused<T, C, 4>), dim3(nblk), dim3(TPB), 0, st, dact(x), dxf(xf), w, cout, dl, dxa, dx ? 1 : 0, (float*)ws);
+    if (bn_partial) {
+        if constexpr (C <= 32) {
+            if (O == 2) hipLaunchKernelGGL((k_head_bwd_fused<T, C, 2, true>), dim3(nblk), dim3(TPB), 0, st, dact(x), dxf(xf), w, cout, dl, dxa, 1, (float*)ws, mean, invstd, bn_partial);
+            else hipLaunchKernelGGL((k_head_bwd_fused<T, C, 1, true>), dim3(nblk), dim3(TPB), 0, st, dact(x), dxf(xf), w, cout, dl, dxa, 1, (float*)ws, mean, invstd, bn_partial);
+            *bn_nblk = nblk;
+        }
+    } else {
+        if constexpr (C <= 32) {
+            if (O == 4) hipLaunchKernelGGL((k_head_bwd_fused<T, C, 4, false>), dim3(nblk), dim3(TPB), 0, st, dact(x), dxf(xf), w, cout, dl, dxa, dx ? 1 : 0, (float*)ws, nullptr, nullptr, nullptr);
+        }
+        if (O == 2) hipLaunchKernelGGL((k_head_bwd_fused<T, C, 2, false>), dim3(nblk), dim3(TPB), 0, st, dact(x), dxf(xf), w, cout, dl, dxa, dx ? 1 : 0, (float*)ws, nullptr, nullptr, nullptr);
+        if (O == 1) hipLaunchKernelGGL((k_head_bwd_fused<T, C, 1, false>), dim3(nblk), dim3(TPB), 0, st, dact(x), dxf(xf), w, cout, dl, dxa, dx ? 1 : 0, (float*)ws, nullptr, nullptr, nullptr);
     }
-    if (O == 2) hipLaunchKernelGGL((k_head_bwd_fused<T, C, 2>), dim3(nblk), dim3(TPB), 0, st, dact(x), dxf(xf), w, cout, dl, dxa, dx ? 1 : 0, (float*)ws);
-    if (O == 1) hipLaunchKernelGGL((k_head_bwd_fused<T, C, 1>), dim3(nblk), dim3(TPB), 0, st, dact(x), dxf(xf), w, cout, dl, dxa, dx ? 1 : 0, (float*)ws);
     BIU_CHECK_LAUNCH("head_bwd_fused");
     hipLaunchKernelGGL(k_head_bwd_finalize, dim3(O * C + O), dim3(TPB), 0, st, (const float*)ws, nblk, C, O, cout, dw, db);
     BIU_CHECK_LAUNCH("head_bwd_finalize");
+    return BIU_OK;
+}
+// fused head backward + BatchNorm-backward sums of x's producer: C <= 32, cout <= 2, dx required; partial rows <= 1024
+bool biu_head_bwd_bnred_ok(const biu_act* x, const biu_act* dx, int cout, int dtype) {
+    return dx && x->c <= 32 && cout <= 2 && biu_head_bwd_fused_ok(x, dx, cout, dtype);
+}
+int biu_head_bwd_bnred_fused(const biu_act* x, const biu_xform* xf, const float* w, int cout, const float* dl, const biu_act* dx, float* dw,
+                             float* db, void* ws, const float* mean, const float* invstd, float* bn_partial, int* bn_nblk, int dtype,
+                             hipStream_t st) {
+    BIU_DISPATCH_DTYPE(dtype, {
+        switch (x->c) {
+            case 8: return head_fused_t<T, 8>(x, xf, w, cout, dl, dx, dw, db, ws, st, mean, invstd, bn_partial, bn_nblk);
+            case 16: return head_fused_t<T, 16>(x, xf, w, cout, dl, dx, dw, db, ws, st, mean, invstd, bn_partial, bn_nblk);
+            default: return head_fused_t<T, 32>(x, xf, w, cout, dl, dx, dw, db, ws, st, mean, invstd, bn_partial, bn_nblk);
+        }
+    });
     return BIU_OK;
 }
 int biu_head_bwd_fused(const biu_act* x, const biu_xform* xf, const float* w, int cout, const float* dl, const biu_act* dx, float* dw,

@@ -508,9 +508,20 @@ class HeadNode(Node):
         dw, db = eng.new_grad(self.conv.weight), eng.new_grad(self.conv.bias)
         want_dx = eng.wants_grad(self.xin)
         assert not self.xin.g_written(), "heads that share a trunk go through Engine._backward_heads"
-        check(lib.biu_head_bwd(self.xin.a(), self.xin.xf(), _ptr(self.conv.weight.data), self.cout, _ptr(dl),
-                               self.xin.g() if want_dx else None, _ptr(dw), _ptr(db), _ptr(eng.ws), eng.ws_bytes,
-                               eng.dtype, st), "head_bwd")
+        up = self.xin.last_writer_producer() if (want_dx and self.xin.xf() is not None) else None
+        if up is not None:
+            # the head is the only reader of its input: its dx pass also reduces the producer's BatchNorm-backward sums
+            part = up.red_buffer(eng, up.kd, 0)
+            n_up = C.c_int(0)
+            check(lib.biu_head_bwd_bnred(self.xin.a(), self.xin.xf(), _ptr(self.conv.weight.data), self.cout, _ptr(dl),
+                                         self.xin.g(), _ptr(dw), _ptr(db), _ptr(eng.ws), eng.ws_bytes, _ptr(up.save_mean),
+                                         _ptr(up.save_invstd), _ptr(part), part.numel(), C.byref(n_up), eng.dtype, st),
+                  "head_bwd_bnred")
+            up.red_nblk = n_up.value
+        else:
+            check(lib.biu_head_bwd(self.xin.a(), self.xin.xf(), _ptr(self.conv.weight.data), self.cout, _ptr(dl),
+                                   self.xin.g() if want_dx else None, _ptr(dw), _ptr(db), _ptr(eng.ws), eng.ws_bytes,
+                                   eng.dtype, st), "head_bwd")
         eng.add_grad(self.conv.weight, dw)
         eng.add_grad(self.conv.bias, db)
         if want_dx:

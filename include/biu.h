@@ -238,6 +238,11 @@ size_t biu_head_bwd_workspace(int cin);
 int biu_head_bwd(const biu_act* x, const biu_xform* xf, const float* w, int cout, const float* dlogits,
                  const biu_act* dx, float* dw, float* dbias, void* ws, size_t ws_bytes, int dtype,
                  biu_stream stream);
+/* biu_head_bwd that also emits biu_bn_bwd_reduce's partial sums of the conv block that produced x (xf = its BatchNorm transform,
+ * mean / invstd its saved statistics); valid when the head is x's only reader.  partial: >= BIU_BN_MAX_PARTIALS * C * 2 floats. */
+int biu_head_bwd_bnred(const biu_act* x, const biu_xform* xf, const float* w, int cout, const float* dlogits, const biu_act* dx,
+                       float* dw, float* dbias, void* ws, size_t ws_bytes, const float* mean, const float* invstd,
+                       float* partial, size_t partial_floats, int* nblk, int dtype, biu_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Element-wise helpers on activation slices

@@ -698,3 +698,35 @@ def test_conv_mfma_sample_beyond_2gb():
     dw = torch.full_like(wd, float("nan"))
     check(lib.biu_conv_bwd_weight(xd.a(), None, gd.a(), 3, 3, 3, 1, ptr(dw), None, ptr(ws), ws.numel(), code, stream()), "conv_bwd_weight")
     torch.testing.assert_close(dw.cpu(), wq.grad, rtol=1e-2, atol=1e-2 * float(wq.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(3, 2, 16, 1, (4, 6, 8)), (2, 2, 32, 2, (12, 10)), (3, 1, 8, 1, (2, 4, 4))])
+def test_head_bwd_bnred(case, dtype):
+    """Head backward with the producer's BatchNorm-backward sums in the same pass == head_bwd followed by bn_bwd_reduce."""
+    nd, n, c, cout, sp = case
+    code = DT[dtype][1]
+    xf = XF(c, seed=3)
+    xd = Dev(rnd(n, c, *sp, seed=1), dtype=dtype)
+    w = (rnd(cout, c, seed=2) * 0.3).cuda()
+    dl = rnd(n, cout, *sp, seed=4).cuda().contiguous()
+    mean, invstd = (rnd(c, seed=8) * 0.1).cuda(), (rnd(c, seed=9).abs() + 0.5).cuda()
+    shp = (n, c) + ((1,) + sp if nd == 2 else sp)
+    dxa, dxb = Dev(shape=shp, dtype=dtype), Dev(shape=shp, dtype=dtype)
+    wsz = lib.biu_head_bwd_workspace(c)
+    ws = torch.empty(wsz, dtype=torch.uint8, device="cuda")
+    dwa, dba, dwb, dbb = (torch.empty_like(w), torch.empty(cout, device="cuda"), torch.empty_like(w), torch.empty(cout, device="cuda"))
+    nfl = 1024 * c * 2
+    pa, pb = torch.zeros(nfl, device="cuda"), torch.zeros(nfl, device="cuda")
+    na, nb = C.c_int(0), C.c_int(0)
+    check(lib.biu_head_bwd(xd.a(), xf.x(), ptr(w), cout, ptr(dl), dxa.a(), ptr(dwa), ptr(dba), ptr(ws), wsz, code, stream()), "head_bwd")
+    check(lib.biu_bn_bwd_reduce(dxa.a(), xd.a(), ptr(xf.d[0]), ptr(xf.d[1]), ptr(xf.d[2]), ptr(mean), ptr(invstd), ptr(pa), C.byref(na),
+                                code, stream()), "bn_bwd_reduce")
+    check(lib.biu_head_bwd_bnred(xd.a(), xf.x(), ptr(w), cout, ptr(dl), dxb.a(), ptr(dwb), ptr(dbb), ptr(ws), wsz, ptr(mean), ptr(invstd),
+                                 ptr(pb), nfl, C.byref(nb), code, stream()), "head_bwd_bnred")
+    assert torch.equal(dxa.buf, dxb.buf)
+    torch.testing.assert_close(dwb, dwa, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dbb, dba, rtol=1e-5, atol=1e-6)
+    sa = pa[:na.value * c * 2].view(na.value, c, 2).double().sum(0).cpu()
+    sb = pb[:nb.value * c * 2].view(nb.value, c, 2).double().sum(0).cpu()
+    torch.testing.assert_close(sb, sa, rtol=1e-4, atol=1e-4 * float(sa.abs().max()) + 1e-9)
