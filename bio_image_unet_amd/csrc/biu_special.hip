@@ -853,7 +853,7 @@ __global__ __launch_bounds__(TPB) void k_pool_rv(DAct x, DXf xf, DAct small, DAc
 // BatchNorm-backward sums of the layer that produced x reduced from the finished gradient in the same pass:
 //   (sum dz, sum dz * yhat),  dz = dx_final * T'(scale*x + shift),  yhat = (x - mean) * invstd      -> partial[block][C][2]
 template <typename T, bool RED, int PE>       // PE channels per thread: 4 keeps the fully unrolled window inside 128 registers
-__global__ __launch_bounds__(TPB, 4) void k_maxpool_bwd_rv(DAct x, DXf xf, DAct dout, DAct dx, int pd, int accumulate, int cg, int rows,
+__global__ __launch_bounds__(TPB, RED ? 3 : 4) void k_maxpool_bwd_rv(DAct x, DXf xf, DAct dout, DAct dx, int pd, int accumulate, int cg, int rows,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            float* __restrict__ partial) {
     extern __shared__ float sm[];                 // RED: [rows][cg*PE][2]
