@@ -259,7 +259,7 @@ class ConvBlockNode(Node):
         # d loss / d conv-bias: the bias is removed again by the batch mean, so sum_v dy == 0 identically
         # (A*S1 + B*M*mean + C*M cancels term by term); the reference's value is pure rounding noise (~1e-8).
         # Emit the exact zero instead of spending a pass over dy on it.
-        db = torch.zeros_like(self.conv.bias) if self.conv.bias is not None else None
+        db = eng.zero_like_bias(self.conv.bias) if self.conv.bias is not None else None
         # BatchNorm+LeakyReLU backward (da -> dy, in place) rides inside the weight-gradient kernel's tile loader
         check(lib.biu_conv_bwd_weight_bn(self.xin.a(), self.xin.xf(), y.g(), y.a(), scale, shift, slope, _ptr(A), _ptr(B),
                                          _ptr(Cc), self.kd, self.kh, self.kw, self.dil, _ptr(dw), _ptr(eng.ws), eng.ws_bytes,
@@ -554,6 +554,7 @@ class Engine:
         self.module_training = True
         self.input_requires_grad = False
         self._packed: Dict[int, dict] = {}
+        self._zero_flat, self._zero_used = None, 0
 
     # ---- build helpers -------------------------------------------------------------------------------
     def new_buf(self, n, d, h, w, c) -> Buf:
@@ -643,6 +644,17 @@ class Engine:
     def new_grad(self, p: nn.Parameter) -> torch.Tensor:
         return torch.empty(p.shape, dtype=torch.float32, device=self.device)
 
+    def zero_like_bias(self, b: torch.Tensor) -> torch.Tensor:
+        """Fresh zeros shaped like ``b``, carved from one flat buffer filled once per backward (one fill kernel per step
+        instead of one per conv block)."""
+        n = b.numel()
+        if self._zero_flat is None or self._zero_used + n > self._zero_flat.numel() or self._zero_flat.dtype != b.dtype:
+            self._zero_flat = torch.zeros(max(4096, 4 * n), dtype=b.dtype, device=b.device)
+            self._zero_used = 0
+        v = self._zero_flat[self._zero_used:self._zero_used + n].view_as(b)
+        self._zero_used += n
+        return v
+
     def add_grad(self, p: nn.Parameter, g: torch.Tensor):
         if p in self.grads:
             self.grads[p] = self.grads[p] + g
@@ -677,6 +689,7 @@ class Engine:
     def backward(self, head_grads: Sequence[Optional[torch.Tensor]]):
         """head_grads[i] = d loss / d logits of head i (already combined with the activation's gradient)."""
         self.grads = {}
+        self._zero_flat, self._zero_used = None, 0
         for b in self.bufs:
             for k in b.leaves:
                 b.leaves[k] = False
