@@ -91,3 +91,116 @@ def test_gradient_averager_two_gloo_ranks(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert all("OK" in o for o in outs)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# host logic of the Predict counterparts (tiling, quantisation, stitching) with a stub network on the CPU
+# ---------------------------------------------------------------------------------------------------------------
+class _Stub2D(torch.nn.Module):
+    """prob = a fixed smooth function of the input patch; accepts the reference constructor kwargs."""
+
+    def __init__(self, **_):
+        super().__init__()
+        self.dummy = torch.nn.Parameter(torch.zeros(1))
+
+    def forward(self, x, prev=None):
+        p = 0.25 + 0.5 * x if prev is None else 0.2 + 0.3 * x + 0.3 * prev
+        return p, p
+
+
+class _StubHeads(torch.nn.Module):
+    def __init__(self, in_channels=1, n_filter=4, output_heads=None, use_interpolation=True):
+        super().__init__()
+        self.heads = output_heads
+        self.dummy = torch.nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        return {k: (0.1 * (i + 1) + 0.5 * x).repeat(1, v["channels"], 1, 1, 1) for i, (k, v) in enumerate(self.heads.items())}
+
+
+def _nanmean_stitch(shape, tiles, starts, tile):
+    import numpy as np
+    stack = np.full((len(tiles),) + shape, np.nan)
+    for k, (st, t) in enumerate(zip(starts, tiles)):
+        sl = tuple(slice(s, s + e) for s, e in zip(st, tile))
+        stack[(k,) + sl] = t
+    return np.nanmean(stack, axis=0).astype("uint8")
+
+
+def test_predict2d_tiling_and_stitch_cpu(tmp_path):
+    import numpy as np
+    from bio_image_unet_amd.workflow import Predict2D, normalise_stack, tile_starts
+    imgs = (np.random.RandomState(0).rand(2, 50, 70) * 900).astype("float32")
+    net = _Stub2D()
+    ck = {"n_filter": 4, "in_channels": 1, "out_channels": 1, "state_dict": net.state_dict()}
+    p = Predict2D(imgs.copy(), None, ck, network=_Stub2D, resize_dim=(32, 32), add_tile=1, show_progress=False, device="cpu")
+    norm = normalise_stack(imgs.astype("float64"), "single", (0., 99.8), False)
+    xs, ys = tile_starts(50, 32, 3), tile_starts(70, 32, 4)
+    for i in range(2):
+        tiles, starts = [], []
+        for a in xs:
+            for b in ys:
+                patch = norm[i, a:a + 32, b:b + 32].astype("uint8").astype("float32") / 255
+                tiles.append(((0.25 + 0.5 * patch) * 255).astype("uint8"))
+                starts.append((a, b))
+        want = _nanmean_stitch((50, 70), tiles, starts, (32, 32))
+        assert np.abs(p.imgs_result[i].astype(int) - want.astype(int)).max() <= 1
+
+
+def test_predict3d_three_layer_stitch_cpu():
+    import numpy as np
+    from bio_image_unet_amd.workflow import Predict3D, tile_starts
+    vol = (np.random.RandomState(1).rand(10, 40, 36) * 500).astype("float32")
+
+    class Net(_Stub2D):
+        def __init__(self, n_filter=4, in_channels=1, out_channels=1, use_interpolation=False):
+            super().__init__()
+
+    ck = {"n_filter": 4, "in_channels": 1, "out_channels": 1, "state_dict": Net().state_dict()}
+    p = Predict3D(vol.copy(), None, ck, network=Net, resize_dim=(8, 16, 16), add_patch=0, progress_bar=False, device="cpu")
+    v = np.clip(vol, np.nanpercentile(vol, 0.), np.percentile(vol, 99.8))
+    v = v - v.min()
+    v = v / v.max() * 255
+    zs, xs, ys = tile_starts(10, 8, 2), tile_starts(40, 16, 3), tile_starts(36, 16, 3)
+    buf = np.full((3, 10, 40, 36), np.nan, dtype="float16")
+    n = 0
+    for z in zs:
+        for x in xs:
+            for y in ys:
+                patch = v[z:z + 8, x:x + 16, y:y + 16].astype("uint8").astype("float32") / 255
+                buf[n % 3, z:z + 8, x:x + 16, y:y + 16] = ((0.25 + 0.5 * patch) * 255).astype("uint8")
+                n += 1
+    want = np.nanmean(buf, axis=0).astype("uint8")
+    assert p.N == 18 and np.abs(p.vol_result.astype(int) - want.astype(int)).max() <= 1
+
+
+def test_predict_siam_pairs_cpu(monkeypatch):
+    import numpy as np
+    import bio_image_unet_amd.workflow as W
+    monkeypatch.setattr(W, "Siam_UNet", lambda n_filter, mode: _Stub2D())
+    movie = (np.random.RandomState(2).rand(3, 20, 24) * 300).astype("float32")
+    ck = {"n_filter": 4, "mode": "max", "state_dict": _Stub2D().state_dict()}
+    p = W.PredictSiam(movie.copy(), None, ck, resize_dim=(32, 32), show_progress=False, device="cpu")     # tiles larger than frames: zero padding
+    assert p.imgs_result.shape == movie.shape
+    for i in range(3):
+        prev = movie[1] if i == 0 else movie[i - 1]
+        pair = W.normalise_stack(np.array([prev, movie[i]], dtype=np.float64), "single", (0., 99.8), False).astype("uint8")
+        want = ((0.2 + 0.3 * pair[1].astype("float32") / 255 + 0.3 * pair[0].astype("float32") / 255) * 255).astype("uint8")
+        assert np.abs(p.imgs_result[i].astype(int) - want.astype(int)).max() <= 1
+
+
+def test_predict_mo3d_blend_cpu():
+    import numpy as np
+    from bio_image_unet_amd.workflow import PredictMo3d
+    heads = {"a": {"channels": 1, "activation": "sigmoid", "loss": "BCEDiceLoss"}, "b": {"channels": 2, "activation": None, "loss": "DiceLoss"}}
+    vol = np.random.RandomState(3).rand(12, 40, 24).astype("float32") * 50
+    ck = {"in_channels": 1, "n_filter": 4, "output_heads": heads, "use_interpolation": True, "state_dict": _StubHeads(output_heads=heads).state_dict()}
+    p = PredictMo3d(vol.copy(), ck, network=_StubHeads, max_patch_size=(8, 16, 16), overlap_factor=0.25, batch_size=4, show_progress=False,
+                    device="cpu")
+    c = np.clip(vol, np.percentile(vol, 0.), np.percentile(vol, 99.98))
+    c = (c - c.min()) / (np.ptp(c) + 1e-8)
+    # the stub is point-wise, so every patch predicts the same value for a voxel and any convex blend returns it
+    assert p.Z_start == [0, 4] and p.Y_start == [0, 12, 24] and p.X_start == [0, 8]
+    np.testing.assert_allclose(p.result["a"], 0.1 + 0.5 * c, rtol=1e-5, atol=1e-6)
+    assert p.result["b"].shape == (2, 12, 40, 24)
+    np.testing.assert_allclose(p.result["b"][1], 0.2 + 0.5 * c, rtol=1e-5, atol=1e-6)
