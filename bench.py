@@ -106,7 +106,8 @@ def call_cost(eng, api, label):
     node = next((n for n in eng.nodes if n.label == label.split(":")[0]), None)
     if node is None:
         return 0.0, 0.0
-    if isinstance(node, E.ConvBlockNode) and api in ("biu_conv_fwd", "biu_conv_fwd_stats", "biu_conv_bwd_data", "biu_conv_bwd_weight", "biu_conv_bwd_weight_bn"):
+    if isinstance(node, E.ConvBlockNode) and api in ("biu_conv_fwd", "biu_conv_fwd_stats", "biu_conv_bwd_data", "biu_conv_bwd_data_bnred",
+                                                     "biu_conv_bwd_weight", "biu_conv_bwd_weight_bn"):
         taps = node.kd * node.kh * node.kw
         v = node.y.nvox
         return 2.0 * v * taps * node.xin.c * node.y.c, float(v) * (node.xin.c + node.y.c) * esz
@@ -117,7 +118,8 @@ def call_cost(eng, api, label):
     if isinstance(node, E.ConvBlockNode):      # BN / element-wise passes over y
         return 0.0, float(node.y.nvox) * node.y.c * esz * (3 if api == "biu_bn_bwd_apply" else (2 if api == "biu_bn_bwd_reduce" else 1))
     if isinstance(node, E.ResampleNode):
-        return 0.0, float(node.xin.nvox * node.xin.c + node.y.nvox * node.y.c) * esz
+        bwd = api.endswith("_bwd") or "_bwd_" in api          # backward of a 2x pool: x, dx in, dx out (+ the pooled gradient)
+        return 0.0, float(node.xin.nvox * node.xin.c * (3 if bwd else 1) + node.y.nvox * node.y.c) * esz
     return 0.0, 0.0
 
 
