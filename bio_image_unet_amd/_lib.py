@@ -24,6 +24,11 @@ class biu_act(C.Structure):
                 ("c", C.c_int32), ("pitch", C.c_int32)]
 
 
+class biu_pack_job(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("packed", C.c_void_p), ("transposed", C.c_int32), ("kind", C.c_int32), ("cin", C.c_int32),
+                ("cout", C.c_int32), ("kd", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("reserved", C.c_int32)]
+
+
 class biu_xform(C.Structure):
     _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("slope", C.c_void_p)]
 
@@ -42,6 +47,7 @@ SIGNATURES = {
     "biu_version": (_I, []),
     "biu_conv_packed_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "biu_conv_pack": (_I, [_I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "biu_pack_batch": (_I, [_P, _I, _I, _P]),
     "biu_conv_fwd": (_I, [_A, _X, _P, _P, _P, _I, _I, _I, _I, _A, _I, _P]),
     "biu_conv_fwd_stats_floats": (_Z, [_A, _I]),
     "biu_conv_fwd_stats": (_I, [_A, _X, _P, _P, _P, _I, _I, _I, _I, _A, _P, _Z, C.POINTER(C.c_int), _I, _P]),

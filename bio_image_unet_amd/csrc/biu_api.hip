@@ -41,6 +41,12 @@ extern "C" int biu_conv_pack(int kind, const float* w, int cin, int cout, int kd
     return biu_mfma_pack(kind, w, cin, cout, kd, kh, kw, dtype, packed, (hipStream_t)stream);
 }
 
+extern "C" int biu_pack_batch(const biu_pack_job* jobs, int n, int dtype, biu_stream stream) {
+    BIU_REQUIRE(n >= 0 && (jobs || n == 0), BIU_ERR_SHAPE, "pack_batch: null job table");
+    BIU_REQUIRE(n <= 65535, BIU_ERR_UNSUPPORTED, "pack_batch: more than 65535 jobs");
+    return biu_mfma_pack_batch(jobs, n, dtype, (hipStream_t)stream);
+}
+
 extern "C" int biu_conv_fwd_stats(const biu_act* x, const biu_xform* xf, const float* w, const void* packed,
                                   const float* bias, int kd, int kh, int kw, int dilation, const biu_act* y,
                                   float* bn_partial, size_t bn_partial_floats, int* bn_nblk, int dtype, biu_stream stream) {

@@ -867,6 +867,51 @@ int biu_mfma_convt_pack(int kind, const float* w, int cin, int cout, int kd, int
     return BIU_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// batched packing: every layer's weights of a network in ONE launch (blockIdx.y = job); same layouts as k_pack_weights /
+// k_pack_convt.  A training step re-packs ~30 small tensors; one launch instead of ~30 removes their launch latencies
+// from the step's critical path.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_pack_batch(const biu_pack_job* __restrict__ jobs) {
+    using F = Frag<T>;
+    constexpr int PE = F::PE;
+    const biu_pack_job j = jobs[blockIdx.y];
+    const float* __restrict__ w = (const float*)j.w;
+    uint4* __restrict__ out = (uint4*)j.packed;
+    const int cin = j.cin, cout = j.cout, kind = j.kind;
+    const int Kc = kind == 0 ? cin : cout, Nc = kind == 0 ? cout : cin;
+    const int nKS = Kc / (2 * PE), ntiles = (Nc + 31) / 32;
+    const int taps = j.transposed ? j.kd * 4 : j.kd * j.kh * j.kw;
+    const size_t total = (size_t)ntiles * nKS * taps * 64;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx % 64);
+        size_t t = idx / 64;
+        int tap, ks, nt;
+        if (j.transposed && kind == 0) { ks = (int)(t % nKS); t /= nKS; nt = (int)(t % ntiles); tap = (int)(t / ntiles); }
+        else { tap = (int)(t % taps); t /= taps; ks = (int)(t % nKS); nt = (int)(t / nKS); }
+        const int i = nt * 32 + (lane & 31);
+        float f[PE];
+#pragma unroll
+        for (int e = 0; e < PE; ++e) {
+            const int k = ks * 2 * PE + (lane >> 5) * PE + e;
+            float v = 0.f;
+            if (i < Nc && k < Kc) {
+                if (j.transposed) v = kind == 0 ? w[((size_t)k * cout + i) * taps + tap] : w[((size_t)i * cout + k) * taps + tap];
+                else v = kind == 0 ? w[((size_t)i * cin + k) * taps + tap] : w[((size_t)k * cin + i) * taps + (taps - 1 - tap)];
+            }
+            f[e] = v;
+        }
+        out[idx] = F::pack(f);
+    }
+}
+int biu_mfma_pack_batch(const biu_pack_job* jobs_device, int n, int dtype, hipStream_t st) {
+    if (n <= 0) return BIU_OK;
+    BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_batch<T>, dim3(64, n), dim3(256), 0, st, jobs_device));
+    BIU_CHECK_LAUNCH("pack_batch");
+    return BIU_OK;
+}
+
 static bool ptrs_ok(const biu_act* x, const biu_act* y, int dtype) {
     const size_t es = dsize(dtype);
     if ((uintptr_t)x->p % 16 || (uintptr_t)y->p % 16 || ((size_t)x->pitch * es) % 16 || ((size_t)y->pitch * es) % 16) return false;

@@ -30,6 +30,7 @@ struct BnRedFuse {            // BatchNorm-backward sums of the layer that PRODU
 int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, int kh, int kw,
                   const biu_act* y, int accumulate, float* bn_partial, int dtype, hipStream_t st, const BnRedFuse* red = nullptr);
 int biu_mfma_convt_dgrad_bricks(const biu_act* dx, int kd);
+int biu_mfma_pack_batch(const biu_pack_job* jobs_device, int n, int dtype, hipStream_t st);
 int biu_mfma_conv_stat_rows(const biu_act* y, int kd);
 int biu_mfma_conv_bricks(const biu_act* y, int kd);
 size_t biu_mfma_wgrad_workspace(int cin, int cout, int kd, int kh, int kw, int dtype);

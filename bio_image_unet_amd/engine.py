@@ -555,6 +555,8 @@ class Engine:
         self.input_requires_grad = False
         self._packed: Dict[int, dict] = {}
         self._zero_flat, self._zero_used = None, 0
+        self._slots: List[dict] = []
+        self._job_key, self._job_tab = None, None
 
     # ---- build helpers -------------------------------------------------------------------------------
     def new_buf(self, n, d, h, w, c) -> Buf:
@@ -599,11 +601,15 @@ class Engine:
         nbytes = lib.biu_conv_packed_bytes(kind, cin, cout, kd, kh, kw, dil, self.dtype)
         if nbytes == 0:
             return None
-        return {"buf": torch.empty(nbytes, dtype=torch.uint8, device=self.device), "ver": None}
+        slot = {"buf": torch.empty(nbytes, dtype=torch.uint8, device=self.device), "ver": None,
+                "job": (0, kind, cin, cout, kd, kh, kw), "weight": None}
+        self._slots.append(slot)
+        return slot
 
     def pack(self, slot, kind, weight: nn.Parameter, cin, cout, kd, kh, kw):
         if slot is None:
             return None
+        slot["weight"] = weight
         ver = (weight.data_ptr(), weight._version)
         if slot["ver"] != ver:
             check(lib.biu_conv_pack(kind, _ptr(weight.data), cin, cout, kd, kh, kw, self.dtype, _ptr(slot["buf"]), _stream()),
@@ -615,17 +621,42 @@ class Engine:
         nbytes = lib.biu_convt_packed_bytes(kind, cin, cout, kd, self.dtype)
         if nbytes == 0:
             return None
-        return {"buf": torch.empty(nbytes, dtype=torch.uint8, device=self.device), "ver": None}
+        slot = {"buf": torch.empty(nbytes, dtype=torch.uint8, device=self.device), "ver": None,
+                "job": (1, kind, cin, cout, kd, 2, 2), "weight": None}
+        self._slots.append(slot)
+        return slot
 
     def pack_convt(self, slot, kind, weight: nn.Parameter, cin, cout, kd):
         if slot is None:
             return None
+        slot["weight"] = weight
         ver = (weight.data_ptr(), weight._version)
         if slot["ver"] != ver:
             check(lib.biu_convt_pack(kind, _ptr(weight.data), cin, cout, kd, self.dtype, _ptr(slot["buf"]), _stream()),
                   "convt_pack")
             slot["ver"] = ver
         return _ptr(slot["buf"])
+
+    def pack_all(self):
+        """Re-pack every stale weight tensor of the network in ONE launch (a step changes all of them; ~30 separate pack
+        launches otherwise).  Slots learn their weight on first use, so the very first pass still packs one by one."""
+        stale = [s for s in self._slots if s["weight"] is not None and s["ver"] != (s["weight"].data_ptr(), s["weight"]._version)]
+        if len(stale) < 2:
+            return
+        key = tuple((id(s), s["weight"].data_ptr()) for s in stale)
+        if self._job_key != key:                       # (re)build the device job table only when the set or a pointer changed
+            from ._lib import biu_pack_job
+            arr = (biu_pack_job * len(stale))()
+            for j, s in zip(arr, stale):
+                tr, kind, cin, cout, kd, kh, kw = s["job"]
+                j.w, j.packed = s["weight"].data_ptr(), s["buf"].data_ptr()
+                j.transposed, j.kind, j.cin, j.cout, j.kd, j.kh, j.kw, j.reserved = tr, kind, cin, cout, kd, kh, kw, 0
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self._job_tab = raw.to(self.device)
+            self._job_key = key
+        check(lib.biu_pack_batch(_ptr(self._job_tab), len(stale), self.dtype, _stream()), "pack_batch")
+        for s in stale:
+            s["ver"] = (s["weight"].data_ptr(), s["weight"]._version)
 
     # ---- run-time helpers --------------------------------------------------------------------------------
     def bn_training(self, bn: nn.Module) -> bool:
@@ -673,6 +704,8 @@ class Engine:
 
     def forward(self):
         self.nbt_bump = []
+        lib.label = "pack:fwd"
+        self.pack_all()
         for nd_ in self.nodes:
             lib.label = nd_.label + ":fwd"
             nd_.fwd(self)

@@ -75,6 +75,16 @@ size_t biu_conv_packed_bytes(int kind, int cin, int cout, int kd, int kh, int kw
 int    biu_conv_pack(int kind, const float* w, int cin, int cout, int kd, int kh, int kw, int dtype,
                      void* packed, biu_stream stream);
 
+/* All packings of a network in one launch.  jobs is DEVICE memory (n entries); each job packs one weight tensor exactly as
+ * biu_conv_pack (transposed = 0: PyTorch (Cout, Cin, kd, kh, kw)) or biu_convt_pack (transposed = 1: (Cin, Cout, [2,] 2, 2),
+ * kd = 1 | 2) would into `packed` (sized by the matching *_packed_bytes query).                                          */
+typedef struct biu_pack_job {
+    const void* w;
+    void* packed;
+    int32_t transposed, kind, cin, cout, kd, kh, kw, reserved;
+} biu_pack_job;
+int biu_pack_batch(const biu_pack_job* jobs, int n, int dtype, biu_stream stream);
+
 /* y = conv(T(x), w) + bias.  w: PyTorch layout fp32; packed: result of biu_conv_pack(kind 0), or NULL
  * when biu_conv_packed_bytes() returned 0 for this shape.                                                */
 int biu_conv_fwd(const biu_act* x, const biu_xform* xf, const float* w, const void* packed,
