@@ -165,6 +165,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     uint4* lw = lds + CKP * PSV;             // [NWB][NSTEP][NT][64]
     float* lxf = (float*)(lw + NWB * WN);    // [3][Cin] transform vectors (if any)
     float* lred = lxf + 3 * a.Cin;           // [NT*32][2] BatchNorm partial sums of the current brick
+    float* lbias = lred + NT * 32 * 2;       // [NT*32] bias of this block's output channels (zero when there is none)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hf = lane >> 5;
@@ -175,6 +176,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     const int p_mine = tid % CKP;
 
     if (tid < NT * 32 * 2) lred[tid] = 0.f;
+    if (tid < NT * 32) {
+        const int co = blockIdx.y * NT * 32 + tid;
+        lbias[tid] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    }
     if (has_xf) {
         for (int i = tid; i < a.Cin; i += NTHR) {
             lxf[i] = a.xs[i];
@@ -405,8 +410,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int co = (blockIdx.y * NT + nt) * 32 + 8 * (e >> 2) + 4 * hf + (e & 3);
-                    const float b0 = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+                    const float b0 = lbias[nt * 32 + 8 * (e >> 2) + 4 * hf + (e & 3)];     // LDS: a global load here is exposed latency
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) acc[nt][mt][e] = b0;
                 }
@@ -673,7 +677,7 @@ static int launch_cfg_r(const ConvArgs& a0, int ntiles, int nz, hipStream_t st) 
     constexpr int PSV = cpad_planes(HV, CKP);
     constexpr int WN = KD * KHW * KHW * (CKP / 2) * NT * 64;
     constexpr int NWB = ((size_t)(CKP * PSV + 2 * WN) * 16 <= conv_lds_budget(NW)) ? 2 : 1;        // must mirror k_conv_pipe::W2
-    const size_t lds_bytes = (size_t)(CKP * PSV + NWB * WN) * 16 + (size_t)3 * a.Cin * sizeof(float) + (size_t)NT * 32 * 2 * sizeof(float);
+    const size_t lds_bytes = (size_t)(CKP * PSV + NWB * WN) * 16 + (size_t)3 * a.Cin * sizeof(float) + (size_t)NT * 32 * 3 * sizeof(float);
     if (lds_bytes > (size_t)(NW == 8 ? 160 : 80) * 1024) return biu_fail(BIU_ERR_UNSUPPORTED, "conv_pipe: %zu bytes of LDS (Cin=%d)", lds_bytes, a.Cin);
     a.nbd = (a.GD + TD - 1) / TD;
     a.nbh = (a.GH + TH - 1) / TH;
