@@ -50,7 +50,25 @@ class Adam(torch.optim.Optimizer):
                 assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
             gkey = tuple(p.grad.data_ptr() for p in ps)
             if t["gkey"] != gkey:
-                t["g"] = torch.tensor(gkey, dtype=torch.int64, device=ps[0].device)
+                # The gradient tensors are new allocations every step, so this table changes every step: upload it from
+                # pinned memory without blocking (a pageable torch.tensor(..., device=) copy waits for the whole stream and
+                # would keep the host from ever running ahead of the GPU).  Four rotating buffers, each guarded by the event
+                # of its previous upload.
+                if "g_host" not in t:
+                    n = len(ps)
+                    t["g_host"] = [torch.empty(n, dtype=torch.int64).pin_memory() for _ in range(4)]
+                    t["g_dev"] = [torch.empty(n, dtype=torch.int64, device=ps[0].device) for _ in range(4)]
+                    t["g_ev"] = [None] * 4
+                    t["rot"] = -1
+                r = t["rot"] = (t["rot"] + 1) % 4
+                if t["g_ev"][r] is not None:
+                    t["g_ev"][r].synchronize()
+                t["g_host"][r].copy_(torch.tensor(gkey, dtype=torch.int64))
+                t["g_dev"][r].copy_(t["g_host"][r], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                t["g_ev"][r] = ev
+                t["g"] = t["g_dev"][r]
                 t["gkey"] = gkey
             step = self.state[ps[0]]["step"] + 1
             for p in ps:
