@@ -79,6 +79,10 @@ SIGNATURES = {
     "biu_trilinear_up_bwd": (_I, [_A, _A, _I, _I, _P]),
     "biu_xcorr_fwd": (_I, [_A, _X, _A, _X, _A, _I, _P]),
     "biu_xcorr_bwd": (_I, [_A, _X, _A, _X, _A, _A, _A, _I, _I, _P]),
+    "biu_conv_cat_ok": (_I, [_A, _A, _A, _I, _I, _I, _I, _I]),
+    "biu_conv_fwd_cat": (_I, [_A, _X, _A, _X, _P, _P, _P, _I, _I, _I, _I, _A, _P, _Z, C.POINTER(C.c_int), _I, _P]),
+    "biu_conv_bwd_data_cat": (_I, [_A, _P, _P, _I, _I, _I, _I, _A, _I, _A, _I, _I, _P]),
+    "biu_conv_bwd_weight_cat": (_I, [_A, _X, _A, _X, _A, _A, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _Z, _I, _P]),
     "biu_convt_packed_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "biu_convt_pack": (_I, [_I, _P, _I, _I, _I, _I, _P, _P]),
     "biu_convt_fwd": (_I, [_A, _X, _P, _P, _P, _I, _A, _I, _P]),

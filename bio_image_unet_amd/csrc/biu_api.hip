@@ -199,6 +199,61 @@ extern "C" int biu_conv_bwd_weight_bn(const biu_act* x, const biu_xform* xf, con
     return biu_conv_bwd_weight(x, xf, da, kd, kh, kw, dilation, dw, nullptr, ws, ws_bytes, dtype, stream);
 }
 
+// ---- conv block on a channel concatenation (x0 | x1) held in two buffers ------------------------------------------------
+// The decoder's torch.cat (unet/unet.py:62-67, unet3d/unet3d.py:60-61) without a concat buffer: both tensors stay dense, the
+// K loop of the forward kernel walks x0's chunks then x1's, the weight gradient takes its input-channel tile from whichever
+// holds it, the data gradient writes each output tile to its tensor.  MFMA shapes only (biu_conv_cat_ok says which).
+extern "C" int biu_conv_cat_ok(const biu_act* x0, const biu_act* x1, const biu_act* y, int kd, int kh, int kw, int dilation, int dtype) {
+    if (!x0 || !x1 || !y || !valid_act(x0) || !valid_act(x1) || !valid_act(y) || !same_space(x0, y) || !same_space(x1, y)) return 0;
+    if (disabled("conv_fwd") || disabled("conv_dgrad") || disabled("conv_wgrad") || disabled("cat")) return 0;
+    return biu_mfma_conv_cat_ok(x0, x1, y, kd, kh, kw, dilation, dtype) ? 1 : 0;
+}
+extern "C" int biu_conv_fwd_cat(const biu_act* x0, const biu_xform* xf0, const biu_act* x1, const biu_xform* xf1, const float* w,
+                                const void* packed, const float* bias, int kd, int kh, int kw, int dilation, const biu_act* y,
+                                float* bn_partial, size_t bn_partial_floats, int* bn_nblk, int dtype, biu_stream stream) {
+    BIU_REQUIRE(biu_conv_cat_ok(x0, x1, y, kd, kh, kw, dilation, dtype) && w && packed, BIU_ERR_UNSUPPORTED,
+                "conv_fwd_cat: shapes not served by the two-source kernels (ask biu_conv_cat_ok)");
+    ConvCat cat{x1, xf1, nullptr, 0};
+    if (bn_partial) {
+        BIU_REQUIRE(bn_nblk, BIU_ERR_SHAPE, "conv_fwd_cat: null bn_nblk");
+        const int nb = biu_mfma_conv_stat_rows(y, kd);
+        BIU_REQUIRE((size_t)nb * y->c * 2 <= bn_partial_floats, BIU_ERR_WORKSPACE, "conv_fwd_cat: partial buffer too small");
+        int rc = biu_mfma_conv(x0, xf0, packed, bias, kd, kh, kw, y, 0, bn_partial, dtype, (hipStream_t)stream, nullptr, &cat);
+        if (rc == BIU_OK) *bn_nblk = nb;
+        return rc;
+    }
+    return biu_mfma_conv(x0, xf0, packed, bias, kd, kh, kw, y, 0, nullptr, dtype, (hipStream_t)stream, nullptr, &cat);
+}
+extern "C" int biu_conv_bwd_data_cat(const biu_act* dy, const float* w, const void* packed, int kd, int kh, int kw, int dilation,
+                                     const biu_act* dx0, int accumulate0, const biu_act* dx1, int accumulate1, int dtype,
+                                     biu_stream stream) {
+    BIU_REQUIRE(biu_conv_cat_ok(dx0, dx1, dy, kd, kh, kw, dilation, dtype) && w && packed, BIU_ERR_UNSUPPORTED,
+                "conv_bwd_data_cat: shapes not served by the two-source kernels (ask biu_conv_cat_ok)");
+    ConvCat cat{nullptr, nullptr, dx1, accumulate1};
+    return biu_mfma_conv(dy, nullptr, packed, nullptr, kd, kh, kw, dx0, accumulate0, nullptr, dtype, (hipStream_t)stream, nullptr, &cat);
+}
+// y == NULL: plain weight gradient (da is dy); y != NULL: BatchNorm backward fused as in biu_conv_bwd_weight_bn
+extern "C" int biu_conv_bwd_weight_cat(const biu_act* x0, const biu_xform* xf0, const biu_act* x1, const biu_xform* xf1,
+                                       const biu_act* da, const biu_act* y, const float* scale, const float* shift,
+                                       const float* slope, const float* coefA, const float* coefB, const float* coefC, int kd,
+                                       int kh, int kw, int dilation, float* dw, void* ws, size_t ws_bytes, int dtype,
+                                       biu_stream stream) {
+    BIU_REQUIRE(biu_conv_cat_ok(x0, x1, da, kd, kh, kw, dilation, dtype) && dw, BIU_ERR_UNSUPPORTED,
+                "conv_bwd_weight_cat: shapes not served by the two-source kernels (ask biu_conv_cat_ok)");
+    BIU_REQUIRE(ws && ws_bytes >= biu_mfma_wgrad_workspace(x0->c + x1->c, da->c, kd, kh, kw, dtype), BIU_ERR_WORKSPACE,
+                "conv_bwd_weight_cat: workspace too small");
+    if (y) {
+        const size_t es = dsize(dtype);
+        BIU_REQUIRE(valid_act(y) && same_space(y, da) && y->c == da->c && scale && shift && coefA && coefB && coefC, BIU_ERR_SHAPE,
+                    "conv_bwd_weight_cat: BatchNorm operands missing");
+        BIU_REQUIRE(((uintptr_t)y->p % 16) == 0 && ((size_t)y->pitch * es) % 16 == 0 && (i64)y->d * y->h * y->w * y->pitch * (i64)es < (1LL << 32) - 65536,
+                    BIU_ERR_UNSUPPORTED, "conv_bwd_weight_cat: y alignment / size");
+        BnBwdFuse bn{y, scale, shift, slope, coefA, coefB, coefC};
+        return biu_mfma_wgrad(x0, xf0, da, kd, kh, kw, dw, nullptr, ws, ws_bytes, dtype, (hipStream_t)stream, &bn, x1, xf1);
+    }
+    return biu_mfma_wgrad(x0, xf0, da, kd, kh, kw, dw, nullptr, ws, ws_bytes, dtype, (hipStream_t)stream, nullptr, x1, xf1);
+}
+
 // ---- ConvTranspose k2 s2 ---------------------------------------------------------------------------
 extern "C" size_t biu_convt_packed_bytes(int kind, int cin, int cout, int kd, int dtype) {
     return biu_mfma_convt_packed_bytes(kind, cin, cout, kd, dtype);

@@ -82,6 +82,12 @@ struct ConvArgs {
     //             (sum dz, sum dz * yhat), dz = da * T'(scale*y + shift), yhat = (y - mean) * invstd  (BatchNorm backward sums)
     int red_mode;
     const char* red_y; int red_ypitch;
+    // Channel concatenation without a concat buffer.  Input: channels [0, csplit) come from x (xpitch, transform xs/xb/xl),
+    // channels [csplit, Cin) from x1 (xpitch1, transform xs1/xb1/xl1); csplit is a multiple of the channel chunk.  Output (data
+    // gradient of such a conv): channels [0, osplit) go to y, the rest to y1; osplit is a multiple of the block's channel tile.
+    const char* x1; int xpitch1; int csplit;
+    const float* xs1; const float* xb1; const float* xl1;
+    char* y1; int ypitch1; int osplit; int accumulate1;
     const float* red_scale; const float* red_shift; const float* red_slope; const float* red_mean; const float* red_invstd;
 };
 
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hf = lane >> 5;
-    const bool has_xf = a.xs != nullptr;
+    const bool has_xf = a.xs != nullptr || a.xs1 != nullptr;
     const size_t esz = sizeof(T);
     const int nchunks = a.Cin / CK;
     const int nbricks = a.N * a.nbd * a.nbh * a.nbw;
@@ -181,10 +187,15 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
         lbias[tid] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
     }
     if (has_xf) {
-        for (int i = tid; i < a.Cin; i += NTHR) {
-            lxf[i] = a.xs[i];
-            lxf[a.Cin + i] = a.xb[i];
-            lxf[2 * a.Cin + i] = a.xl[i];
+        for (int i = tid; i < a.Cin; i += NTHR) {      // logical channel order; a source without a transform reads as identity
+            const bool s1 = a.x1 && i >= a.csplit;
+            const float* ps = s1 ? a.xs1 : a.xs;
+            const float* pb = s1 ? a.xb1 : a.xb;
+            const float* pl = s1 ? a.xl1 : a.xl;
+            const int k = s1 ? i - a.csplit : i;
+            lxf[i] = ps ? ps[k] : 1.f;
+            lxf[a.Cin + i] = ps ? pb[k] : 0.f;
+            lxf[2 * a.Cin + i] = ps ? pl[k] : 1.f;
         }
     }
 
@@ -230,9 +241,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     // sample relative to the tile's first voxel.  Per brick only a field-wise range test (two adds, guard bits) and one
     // add remain; out-of-volume pieces read through the buffer descriptor's range check and come back as zeros.
     constexpr unsigned GBITS = (1u << 9) | (1u << 19) | (1u << 29);
-    const int xrowb = a.xpitch * (int)esz;
     unsigned xs_[NPA];
-    int lofb[NPA];
+    unsigned lvox[NPA];                      // voxel offset of the piece relative to the tile's first voxel (< 2^24)
+    const unsigned cpb = (unsigned)(p_mine * PE * (int)esz);
 #pragma unroll
     for (int j = 0; j < NPA; ++j) {
         const int i = tid + NTHR * j;
@@ -242,9 +253,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
         const int hh = t % HH;
         const int hd = t / HH;
         xs_[j] = (hv < HV) ? (unsigned)(hd | (hh << 10) | (hw << 20)) : 511u;
-        lofb[j] = ((hd * a.IH + hh) * a.IW + hw) * xrowb + p_mine * PE * (int)esz;
+        lvox[j] = (unsigned)((hd * a.IH + hh) * a.IW + hw);
     }
-    const size_t sample_bytes = (size_t)a.ID * a.IH * a.IW * xrowb;          // < 2^32 - 64 Ki (checked on the host)
     // weight slab of chunk ch: async global->LDS copy into the buffer the NEXT item reads (or into registers)
     auto issue_wpiece = [&](int ch, bool live, int j) {
         const uint4* wch = wgrp + (size_t)(ch * SPC) * TAPS * 64;
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     unsigned inb_mask = 0;
     // `live` = false issues nothing but still (re)defines pa: the prefetch registers must not be loop-carried PHIs,
     // or the register allocator copies them -- and waits for the loads -- in front of the MFMA phase
-    unsigned c_lo = 0, c_hi = 0;
+    unsigned c_lo = 0, c_hi = 0, rowb = 0;
     int brb = 0;
     __amdgpu_buffer_rsrc_t rs;
     auto issue_prep = [&](int brick, int ch, bool live) {
@@ -283,15 +293,20 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
         c_hi = GBITS + (unsigned)(hid | (hih << 10) | (hiw << 20));     // c_hi - x keeps a guard bit iff x <= hi
         // byte offsets inside a sample are taken mod 2^32 (samples up to 4 GB): the base may be negative (halo above the
         // volume) or beyond 2^31, the sum for an in-volume piece is the true offset
-        brb = (int)(unsigned)((long long)((gd0 * a.IH + gh0) * a.IW + gw0) * xrowb + (long long)ch * CK * (int)esz);
+        const bool s1 = a.x1 && ch * CK >= a.csplit;          // which source tensor this channel chunk lives in
+        const char* xbase = s1 ? a.x1 : a.x;
+        rowb = (unsigned)((s1 ? a.xpitch1 : a.xpitch) * (int)esz);
+        const int cch = ch * CK - (s1 ? a.csplit : 0);
+        brb = (int)(unsigned)((long long)((gd0 * a.IH + gh0) * a.IW + gw0) * rowb + (long long)cch * (int)esz);
+        const size_t sample_bytes = (size_t)a.ID * a.IH * a.IW * rowb;        // < 2^32 - 64 Ki (checked on the host)
         // a dead prefetch (nothing follows) reads through an empty descriptor: every piece is zero, nothing is fetched
-        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)o.n * sample_bytes), 0, live ? (int)(unsigned)sample_bytes : 0, 0x00020000);
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(xbase + (size_t)o.n * sample_bytes), 0, live ? (int)(unsigned)sample_bytes : 0, 0x00020000);
         inb_mask = 0;
     };
     auto issue_piece = [&](int j) {
         const unsigned in_lo = xs_[j] + c_lo, in_hi = c_hi - xs_[j];
         const bool ok = ((in_lo & in_hi) & GBITS) == GBITS;
-        const int off = ok ? (int)((unsigned)lofb[j] + (unsigned)brb) : -1;
+        const int off = ok ? (int)(__umul24(lvox[j], rowb) + cpb + (unsigned)brb) : -1;
         const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
         pa[j] = make_uint4(v[0], v[1], v[2], v[3]);
         inb_mask |= ok ? (1u << j) : 0u;
@@ -481,6 +496,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
             constexpr int QPB = 4 / NHB;                 // accumulator quads per block
             constexpr int ROWB = 80;                     // staged row: 64 B + 16 B pad (spreads the rows over the banks)
             char* stg = (char*)lact + wave * (16 * ROWB);
+            // destination of this block's channel tile (the second tensor of a split output when the tile lies beyond osplit)
+            const bool o1 = a.y1 && (int)(blockIdx.y * NT * 32) >= a.osplit;
+            char* ybase = o1 ? a.y1 : a.y;
+            const int ypitch_o = o1 ? a.ypitch1 : a.ypitch;
+            const int coff = o1 ? a.osplit : 0;
+            const int accum_o = o1 ? a.accumulate1 : a.accumulate;
             const int prow = lane >> 2, pcol = lane & 3; // read-back: lane -> (voxel row, piece)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -524,9 +545,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
                             const int oh = gh * a.osh + ((a.osh == 2) ? (int)((blockIdx.z >> 1) & 1) : 0);
                             const int ow = gw * a.osw + ((a.osw == 2) ? (int)(blockIdx.z & 1) : 0);
                             const size_t vox = ((size_t)(o.n * a.OD + od) * a.OH + oh) * a.OW + ow;
-                            uint4* dst = (uint4*)((T*)a.y + vox * a.ypitch + cl);
+                            uint4* dst = (uint4*)((T*)ybase + vox * ypitch_o + (cl - coff));
                             float f[CPP];
-                            if (a.accumulate) {
+                            if (accum_o) {
                                 float g[CPP];
                                 F::unpack(piece, f);
                                 F::unpack(*dst, g);
@@ -773,6 +794,12 @@ int biu_mfma_conv_stat_rows(const biu_act* y, int kd) {
     return g > nbricks ? nbricks : g;
 }
 
+static void clear_cat(ConvArgs& a) {
+    a.x1 = nullptr; a.xpitch1 = 0; a.csplit = 0;
+    a.xs1 = a.xb1 = a.xl1 = nullptr;
+    a.y1 = nullptr; a.ypitch1 = 0; a.osplit = 0; a.accumulate1 = 0;
+}
+
 static int fill_xf(ConvArgs& a, const biu_xform* xf) {
     const bool has = xf && (xf->scale || xf->shift || xf->slope);
     if (has) BIU_REQUIRE(xf->scale && xf->shift && xf->slope, BIU_ERR_UNSUPPORTED, "conv_mfma: partial biu_xform (need all three vectors)");
@@ -782,9 +809,23 @@ static int fill_xf(ConvArgs& a, const biu_xform* xf) {
     return BIU_OK;
 }
 
+// channel-concatenated input (x0 | x1) -> y through the two-source forms of the three MFMA kernels
+bool biu_mfma_conv_cat_ok(const biu_act* x0, const biu_act* x1, const biu_act* y, int kd, int kh, int kw, int dilation, int dtype) {
+    if (!biu_mfma_conv_ok(x0, y, kd, kh, kw, dilation, dtype) || !biu_mfma_conv_ok(x1, y, kd, kh, kw, dilation, dtype)) return false;
+    if (!biu_mfma_wgrad_ok(x0, y, kd, kh, kw, dilation, dtype) || !biu_mfma_wgrad_ok(x1, y, kd, kh, kw, dilation, dtype)) return false;
+    // x0's channels must end on a chunk boundary (forward), a 32-wide tile (weight gradient) and on the data gradient's
+    // block tile, which is 64 wide when the total tile count is even
+    const int ntiles = (x0->c + x1->c + 31) / 32;
+    const int need = pick_nt(ntiles) * 32;
+    if (x0->c % need != 0 || x1->c % 32 != 0) return false;
+    const i64 plane = (i64)x0->h * x0->w;
+    return 10 * plane < (1LL << 24);                    // tile-local voxel offsets go through 24-bit multiplies
+}
+
 int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, int kh, int kw,
-                  const biu_act* y, int accumulate, float* bn_partial, int dtype, hipStream_t st, const BnRedFuse* red) {
+                  const biu_act* y, int accumulate, float* bn_partial, int dtype, hipStream_t st, const BnRedFuse* red, const ConvCat* cat) {
     ConvArgs a;
+    clear_cat(a);
     a.bn_partial = bn_partial;
     a.red_mode = 0; a.red_y = nullptr; a.red_ypitch = 0;
     a.red_scale = a.red_shift = a.red_slope = a.red_mean = a.red_invstd = nullptr;
@@ -804,7 +845,19 @@ int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, con
     a.GD = a.ID = a.OD = x->d; a.GH = a.IH = a.OH = x->h; a.GW = a.IW = a.OW = x->w;
     a.osd = a.osh = a.osw = 1;
     a.Cin = x->c; a.Cout = y->c;
-    a.nKS = x->c / ks_of(dtype);
+    if (cat && cat->x1) {                       // input = concat(x, x1) along the channels
+        a.x1 = (const char*)cat->x1->p; a.xpitch1 = cat->x1->pitch; a.csplit = x->c;
+        a.Cin = x->c + cat->x1->c;
+        const biu_xform* f1 = cat->xf1;
+        const bool has1 = f1 && (f1->scale || f1->shift || f1->slope);
+        if (has1) BIU_REQUIRE(f1->scale && f1->shift && f1->slope, BIU_ERR_UNSUPPORTED, "conv_mfma: partial biu_xform (second source)");
+        a.xs1 = has1 ? f1->scale : nullptr; a.xb1 = has1 ? f1->shift : nullptr; a.xl1 = has1 ? f1->slope : nullptr;
+    }
+    if (cat && cat->y1) {                       // output = concat(y, y1) along the channels
+        a.y1 = (char*)cat->y1->p; a.ypitch1 = cat->y1->pitch; a.osplit = y->c; a.accumulate1 = cat->accumulate1;
+        a.Cout = y->c + cat->y1->c;
+    }
+    a.nKS = a.Cin / ks_of(dtype);
     a.wz_stride = 0;
     a.accumulate = accumulate;
     a.nbd = a.nbh = a.nbw = 0;
@@ -966,6 +1019,7 @@ static int launch_convt_dgrad(const ConvArgs& a, int kd, hipStream_t st) {
 int biu_mfma_convt_fwd(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, const biu_act* y,
                        int dtype, hipStream_t st) {
     ConvArgs a;
+    clear_cat(a);
     a.bn_partial = nullptr;
     a.red_mode = 0; a.red_y = nullptr; a.red_ypitch = 0;
     a.red_scale = a.red_shift = a.red_slope = a.red_mean = a.red_invstd = nullptr;
@@ -993,6 +1047,7 @@ int biu_mfma_convt_fwd(const biu_act* x, const biu_xform* xf, const void* packed
 int biu_mfma_convt_dgrad(const biu_act* dy, const void* packed, int kd, const biu_act* dx, int accumulate, int dtype, hipStream_t st,
                          float* bn_partial, const BnRedFuse* red) {
     ConvArgs a;
+    clear_cat(a);
     a.bn_partial = red ? bn_partial : nullptr;
     a.red_mode = 0; a.red_y = nullptr; a.red_ypitch = 0;
     a.red_scale = a.red_shift = a.red_slope = a.red_mean = a.red_invstd = nullptr;
@@ -1053,6 +1108,10 @@ struct WgradArgs {
     int jt_begin, jt_count;   // j tiles this launch covers: blockIdx.y = it * jt_count + (jt - jt_begin)
     int write_back;           // fused BatchNorm backward: this launch overwrites da with dy
     unsigned long long* diag; // BIU_DIAG builds only
+    // tapped operand = concat(pb, pb1) along the channels (no concat buffer): channels [0, bsplit) live in pb, the rest in pb1;
+    // bsplit is a multiple of 32, so a block's 32-wide j tile lies in one of the two
+    const char* pb1; int bpitch1; int bsplit;
+    const float* bs1_; const float* bb1_; const float* bl1_;
     int bricks_per_block;
     // optional fused BatchNorm backward on the plain operand: A = dy is computed on the fly from (da = pa, y = py):
     //   dz = da * T'(scale*y + shift),  dy = cA*dz + cB*y + cC ; blocks with jt == 0 also write dy back over da
@@ -1131,7 +1190,14 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     const int piece = tid % PPV, pieceA = tid % PPVA;
     const int ac0 = it * CTA + pieceA * PE, bc0 = jt * CT + piece * PE;
     const bool apiece_ok = ac0 < a.CA, bpiece_ok = bc0 < a.CB;
-    const bool a_xf = a.as_ != nullptr, b_xf = a.bs_ != nullptr;
+    const bool b_src1 = a.pb1 && jt * CT >= a.bsplit;              // this block's B tile comes from the second tensor
+    const char* pb_ = b_src1 ? a.pb1 : a.pb;
+    const int bpitch_ = b_src1 ? a.bpitch1 : a.bpitch;
+    const int bc_local = bc0 - (b_src1 ? a.bsplit : 0);
+    const float* bs_ = b_src1 ? a.bs1_ : a.bs_;
+    const float* bb_ = b_src1 ? a.bb1_ : a.bb_;
+    const float* bl_ = b_src1 ? a.bl1_ : a.bl_;
+    const bool a_xf = a.as_ != nullptr, b_xf = bs_ != nullptr;
     const bool bn_fused = a.py != nullptr;
     if (tid < CT && bn_fused) {
         const int ca = it * CTA + tid;
@@ -1151,9 +1217,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     }
     if (tid < CT) {
         const int cb = jt * CT + tid;
-        lxf[LB + 0 * CT + tid] = (b_xf && cb < a.CB) ? a.bs_[cb] : 1.f;
-        lxf[LB + 1 * CT + tid] = (b_xf && cb < a.CB) ? a.bb_[cb] : 0.f;
-        lxf[LB + 2 * CT + tid] = (b_xf && cb < a.CB) ? a.bl_[cb] : 1.f;
+        const int cbl = cb - (b_src1 ? a.bsplit : 0);
+        lxf[LB + 0 * CT + tid] = (b_xf && cb < a.CB) ? bs_[cbl] : 1.f;
+        lxf[LB + 1 * CT + tid] = (b_xf && cb < a.CB) ? bb_[cbl] : 0.f;
+        lxf[LB + 2 * CT + tid] = (b_xf && cb < a.CB) ? bl_[cbl] : 1.f;
     }
 
     floatx16 acc[IPW][NI];
@@ -1211,7 +1278,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         const unsigned xv = (i < HV * PPV && bpiece_ok) ? (unsigned)((t / HH) | ((t % HH) << 10) | (hw << 20)) : 511u;
         if constexpr (TAB_LDS) ltab[(NA + j) * NTHR + tid] = xv; else xb_[j] = xv;
     }
-    const int rowA = a.apitch * (int)esz, rowY = a.ypitch * (int)esz, rowB = a.bpitch * (int)esz;
+    const int rowA = a.apitch * (int)esz, rowY = a.ypitch * (int)esz, rowB = bpitch_ * (int)esz;
     const size_t sampA = (size_t)a.GD * a.GH * a.GW * rowA, sampY = (size_t)a.GD * a.GH * a.GW * rowY;
     const size_t sampB = (size_t)a.BD * a.BH * a.BW * rowB;                  // all < 2^31 (checked on the host)
     unsigned ca_hi = 0, cb_lo = 0, cb_hi = 0;
@@ -1231,11 +1298,11 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         const int gd0 = d0 * SD - PD, gh0 = h0 * S - PHW, gw0 = w0 * S - PHW;
         cb_lo = GBITS - (unsigned)(max(0, -gd0) | (max(0, -gh0) << 10) | (max(0, -gw0) << 20));
         cb_hi = GBITS + (unsigned)(min(HD - 1, a.BD - 1 - gd0) | (min(HH - 1, a.BH - 1 - gh0) << 10) | (min(HW - 1, a.BW - 1 - gw0) << 20));
-        brB = (int)(unsigned)((long long)((gd0 * a.BH + gh0) * a.BW + gw0) * rowB + bc0 * (int)esz);
+        brB = (int)(unsigned)((long long)((gd0 * a.BH + gh0) * a.BW + gw0) * rowB + bc_local * (int)esz);
         // a dead prefetch reads through empty descriptors: zeros, nothing fetched
         rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pa + (size_t)n * sampA), 0, live ? (int)(unsigned)sampA : 0, 0x00020000);
         rsY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.py + (size_t)n * sampY), 0, (live && bn_fused) ? (int)(unsigned)sampY : 0, 0x00020000);
-        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pb + (size_t)n * sampB), 0, live ? (int)(unsigned)sampB : 0, 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(pb_ + (size_t)n * sampB), 0, live ? (int)(unsigned)sampB : 0, 0x00020000);
         amask = bmask = 0;
     };
     auto ld128 = [&](const __amdgpu_buffer_rsrc_t& rs, int off) -> uint4 {
@@ -1570,8 +1637,9 @@ static int wgrad_xf(const biu_xform* xf, const float** s, const float** b, const
 }
 
 int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, int kh, int kw, float* dw, float* dbias,
-                   void* ws, size_t ws_bytes, int dtype, hipStream_t st, const BnBwdFuse* bn) {
+                   void* ws, size_t ws_bytes, int dtype, hipStream_t st, const BnBwdFuse* bn, const biu_act* x1, const biu_xform* xf1) {
     WgradArgs a;
+    int rc_ = BIU_OK;
     if (bn) {
         a.py = (const char*)bn->y->p; a.ypitch = bn->y->pitch;
         a.bn_scale = bn->scale; a.bn_shift = bn->shift; a.bn_slope = bn->slope;
@@ -1582,6 +1650,12 @@ int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int
     }
     a.pa = (const char*)dy->p;  a.apitch = dy->pitch;  a.CA = dy->c;      // plain operand: dy  (rows i = co)
     a.pb = (const char*)x->p;   a.bpitch = x->pitch;   a.CB = x->c;       // tapped operand: x (cols j = ci)
+    a.pb1 = nullptr; a.bpitch1 = 0; a.bsplit = 0; a.bs1_ = a.bb1_ = a.bl1_ = nullptr;
+    if (x1) {                                                              // x = concat(x, x1)
+        a.pb1 = (const char*)x1->p; a.bpitch1 = x1->pitch; a.bsplit = x->c; a.CB = x->c + x1->c;
+        rc_ = wgrad_xf(xf1, &a.bs1_, &a.bb1_, &a.bl1_);
+        if (rc_) return rc_;
+    }
     a.ws = (float*)ws;
     a.as_ = a.ab_ = a.al_ = nullptr;
     int rc = wgrad_xf(xf, &a.bs_, &a.bb_, &a.bl_);
@@ -1609,6 +1683,7 @@ int biu_mfma_convt_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* d
     a.bn_scale = a.bn_shift = a.bn_slope = a.bn_cA = a.bn_cB = a.bn_cC = nullptr;
     a.pa = (const char*)x->p;   a.apitch = x->pitch;   a.CA = x->c;       // plain operand: x on the coarse grid (rows i = ci)
     a.pb = (const char*)dy->p;  a.bpitch = dy->pitch;  a.CB = dy->c;      // tapped operand: dy on the fine grid (cols j = co)
+    a.pb1 = nullptr; a.bpitch1 = 0; a.bsplit = 0; a.bs1_ = a.bb1_ = a.bl1_ = nullptr;
     a.ws = (float*)ws;
     int rc = wgrad_xf(xf, &a.as_, &a.ab_, &a.al_);
     if (rc) return rc;

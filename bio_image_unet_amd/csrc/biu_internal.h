@@ -27,8 +27,14 @@ struct BnRedFuse {            // BatchNorm-backward sums of the layer that PRODU
     const biu_act* y;
     const float *scale, *shift, *slope, *mean, *invstd;
 };
+bool biu_mfma_conv_cat_ok(const biu_act* x0, const biu_act* x1, const biu_act* y, int kd, int kh, int kw, int dilation, int dtype);
+struct ConvCat {              // channel concatenation without a concat buffer: second input source and / or second output
+    const biu_act* x1; const biu_xform* xf1;
+    const biu_act* y1; int accumulate1;
+};
 int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, int kh, int kw,
-                  const biu_act* y, int accumulate, float* bn_partial, int dtype, hipStream_t st, const BnRedFuse* red = nullptr);
+                  const biu_act* y, int accumulate, float* bn_partial, int dtype, hipStream_t st, const BnRedFuse* red = nullptr,
+                  const ConvCat* cat = nullptr);
 int biu_mfma_convt_dgrad_bricks(const biu_act* dx, int kd);
 int biu_mfma_pack_batch(const biu_pack_job* jobs_device, int n, int dtype, hipStream_t st);
 int biu_mfma_conv_stat_rows(const biu_act* y, int kd);
@@ -40,7 +46,8 @@ struct BnBwdFuse {            // BatchNorm(+LeakyReLU) backward fused into the w
     const float *scale, *shift, *slope, *cA, *cB, *cC;
 };
 int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, int kh, int kw, float* dw,
-                   float* dbias, void* ws, size_t ws_bytes, int dtype, hipStream_t st, const BnBwdFuse* bn = nullptr);
+                   float* dbias, void* ws, size_t ws_bytes, int dtype, hipStream_t st, const BnBwdFuse* bn = nullptr,
+                   const biu_act* x1 = nullptr, const biu_xform* xf1 = nullptr);
 
 size_t biu_mfma_convt_packed_bytes(int kind, int cin, int cout, int kd, int dtype);
 int biu_mfma_convt_pack(int kind, const float* w, int cin, int cout, int kd, int dtype, void* packed, hipStream_t st);

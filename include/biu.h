@@ -220,6 +220,25 @@ int biu_xcorr_fwd(const biu_act* cur, const biu_xform* xc, const biu_act* prev, 
 int biu_xcorr_bwd(const biu_act* cur, const biu_xform* xc, const biu_act* prev, const biu_xform* xp, const biu_act* dout,
                   const biu_act* dcur, const biu_act* dprev, int accumulate, int dtype, biu_stream stream);
 
+/* The same conv block on a channel CONCATENATION (x0 | x1) whose two parts stay in separate dense buffers -- the decoder's
+ * torch.cat (unet/unet.py:62-67, unet3d/unet3d.py:60-61) without a concat buffer.  w / packed / dw have Cin = x0->c + x1->c in
+ * that order.  Only shapes the MFMA kernels serve: biu_conv_cat_ok returns 1 when all three calls will succeed (channel counts
+ * that are multiples of 32 -- x0's of 64 when the total is an even number of 32-tiles --, dilation 1, aligned dense rows).
+ * fwd: bn_partial may be NULL (no statistics).  bwd_weight: y == NULL gives the plain weight gradient (da is dy), otherwise the
+ * BatchNorm backward is fused exactly as in biu_conv_bwd_weight_bn.  bwd_data writes dx0 and dx1 (each with its own
+ * accumulate flag).                                                                                                     */
+int biu_conv_cat_ok(const biu_act* x0, const biu_act* x1, const biu_act* y, int kd, int kh, int kw, int dilation, int dtype);
+int biu_conv_fwd_cat(const biu_act* x0, const biu_xform* xf0, const biu_act* x1, const biu_xform* xf1, const float* w,
+                     const void* packed, const float* bias, int kd, int kh, int kw, int dilation, const biu_act* y,
+                     float* bn_partial, size_t bn_partial_floats, int* bn_nblk, int dtype, biu_stream stream);
+int biu_conv_bwd_data_cat(const biu_act* dy, const float* w, const void* packed, int kd, int kh, int kw, int dilation,
+                          const biu_act* dx0, int accumulate0, const biu_act* dx1, int accumulate1, int dtype,
+                          biu_stream stream);
+int biu_conv_bwd_weight_cat(const biu_act* x0, const biu_xform* xf0, const biu_act* x1, const biu_xform* xf1,
+                            const biu_act* da, const biu_act* y, const float* scale, const float* shift, const float* slope,
+                            const float* coefA, const float* coefB, const float* coefC, int kd, int kh, int kw, int dilation,
+                            float* dw, void* ws, size_t ws_bytes, int dtype, biu_stream stream);
+
 /* MFMA operand packing, as for the 3x3 kernels.  kind 0 = forward operand, 1 = data-gradient operand.          */
 size_t biu_convt_packed_bytes(int kind, int cin, int cout, int kd, int dtype);
 int    biu_convt_pack(int kind, const float* w, int cin, int cout, int kd, int dtype, void* packed, biu_stream stream);

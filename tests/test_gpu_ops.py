@@ -730,3 +730,81 @@ def test_head_bwd_bnred(case, dtype):
     sa = pa[:na.value * c * 2].view(na.value, c, 2).double().sum(0).cpu()
     sb = pb[:nb.value * c * 2].view(nb.value, c, 2).double().sum(0).cpu()
     torch.testing.assert_close(sb, sa, rtol=1e-4, atol=1e-4 * float(sa.abs().max()) + 1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# conv block on a channel concatenation held in two dense buffers (no concat buffer)
+# ---------------------------------------------------------------------------------------------------------------
+CAT_CASES = [
+    # (nd, N, c0, c1, Cout, spatial)
+    (3, 1, 64, 32, 32, (8, 16, 32)),      # 3 input tiles -> block tile 32
+    (3, 2, 64, 64, 64, (6, 10, 20)),      # 4 tiles -> block tile 64
+    (2, 2, 128, 64, 64, (24, 40)),
+    (3, 1, 64, 32, 48, (5, 7, 9)),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CAT_CASES)
+def test_conv_cat_forms_match_concat_buffer(case, dtype):
+    nd, n, c0, c1, cout, sp = case
+    kd = 3 if nd == 3 else 1
+    code = DT[dtype][1]
+    cin = c0 + c1
+    x0, x1 = rnd(n, c0, *sp, seed=1), rnd(n, c1, *sp, seed=2)
+    w = rnd(cout, cin, *([3] * nd), seed=3) * (1.0 / (cin * 3 ** nd) ** 0.5)
+    b = rnd(cout, seed=4)
+    xf0, xf1 = XF(c0, seed=5), XF(c1, seed=6, identity=True)                 # second source: no transform (ConvT output)
+    d0, d1 = Dev(x0, dtype=dtype), Dev(x1, dtype=dtype)
+    dc = Dev(torch.cat([x0, x1], 1), dtype=dtype)                            # the concat-buffer reference layout
+    xfc_vec = [torch.cat([a, bb]).cuda() for a, bb in zip((xf0.scale, xf0.shift, xf0.slope), (xf1.scale, xf1.shift, xf1.slope))]
+    from bio_image_unet_amd._lib import biu_xform
+    xfc = biu_xform(*[t.data_ptr() for t in xfc_vec])
+    yshape = (n, cout, 1 if nd == 2 else sp[0], sp[-2], sp[-1])
+    wd, bd = w.cuda(), b.cuda()
+    pk0 = torch.empty(lib.biu_conv_packed_bytes(0, cin, cout, kd, 3, 3, 1, code), dtype=torch.uint8, device="cuda")
+    pk1 = torch.empty(lib.biu_conv_packed_bytes(1, cin, cout, kd, 3, 3, 1, code), dtype=torch.uint8, device="cuda")
+    check(lib.biu_conv_pack(0, ptr(wd), cin, cout, kd, 3, 3, code, ptr(pk0), stream()), "pack0")
+    check(lib.biu_conv_pack(1, ptr(wd), cin, cout, kd, 3, 3, code, ptr(pk1), stream()), "pack1")
+    ya = Dev(shape=yshape, dtype=dtype)
+    assert lib.biu_conv_cat_ok(d0.a(), d1.a(), ya.a(), kd, 3, 3, 1, code) == 1
+    # forward (+ statistics)
+    yb = Dev(shape=yshape, dtype=dtype)
+    nfl = lib.biu_conv_fwd_stats_floats(ya.a(), kd)
+    pa, pb = torch.zeros(nfl, device="cuda"), torch.zeros(nfl, device="cuda")
+    na, nb = C.c_int(0), C.c_int(0)
+    check(lib.biu_conv_fwd_stats(dc.a(), C.byref(xfc), ptr(wd), ptr(pk0), ptr(bd), kd, 3, 3, 1, ya.a(), ptr(pa), nfl, C.byref(na), code, stream()), "fwd")
+    check(lib.biu_conv_fwd_cat(d0.a(), xf0.x(), d1.a(), None, ptr(wd), ptr(pk0), ptr(bd), kd, 3, 3, 1, yb.a(), ptr(pb), nfl, C.byref(nb), code,
+                               stream()), "fwd_cat")
+    assert torch.equal(ya.buf, yb.buf)
+    sa = pa[:na.value * cout * 2].view(na.value, cout, 2).double().sum(0)
+    sb = pb[:nb.value * cout * 2].view(nb.value, cout, 2).double().sum(0)
+    torch.testing.assert_close(sb, sa, rtol=1e-5, atol=1e-5 * float(sa.abs().max()))
+    # data gradient into two tensors (second one accumulating)
+    gd = Dev(rnd(*yshape, seed=7).squeeze(2) if nd == 2 else rnd(*yshape, seed=7), dtype=dtype)
+    dxc = Dev(shape=dc.buf.permute(0, 4, 1, 2, 3).shape, dtype=dtype)
+    check(lib.biu_conv_bwd_data(gd.a(), ptr(wd), ptr(pk1), kd, 3, 3, 1, dxc.a(), 0, code, stream()), "dgrad")
+    base1 = rnd(n, c1, *sp, seed=8)
+    g0, g1 = Dev(shape=d0.buf.permute(0, 4, 1, 2, 3).shape, dtype=dtype), Dev(base1, dtype=dtype)
+    check(lib.biu_conv_bwd_data_cat(gd.a(), ptr(wd), ptr(pk1), kd, 3, 3, 1, g0.a(), 0, g1.a(), 1, code, stream()), "dgrad_cat")
+    assert torch.equal(g0.buf, dxc.buf[..., :c0])
+    want1 = (dxc.buf[..., c0:].float() + Dev(base1, dtype=dtype).buf.float())
+    torch.testing.assert_close(g1.buf.float(), want1, rtol=2e-2 if dtype == "bf16" else 1e-5, atol=(2e-2 if dtype == "bf16" else 1e-5) * float(want1.abs().max()))
+    # weight gradient, plain and with the fused BatchNorm backward
+    wsz = lib.biu_conv_bwd_weight_workspace(cin, cout, kd, 3, 3, code)
+    ws = torch.empty(wsz, dtype=torch.uint8, device="cuda")
+    dwa, dwb = torch.empty_like(wd), torch.empty_like(wd)
+    check(lib.biu_conv_bwd_weight(dc.a(), C.byref(xfc), gd.a(), kd, 3, 3, 1, ptr(dwa), None, ptr(ws), wsz, code, stream()), "wgrad")
+    check(lib.biu_conv_bwd_weight_cat(d0.a(), xf0.x(), d1.a(), None, gd.a(), None, None, None, None, None, None, None, kd, 3, 3, 1, ptr(dwb),
+                                      ptr(ws), wsz, code, stream()), "wgrad_cat")
+    torch.testing.assert_close(dwb, dwa, rtol=1e-4, atol=1e-5 * float(dwa.abs().max()))
+    yxf = XF(cout, seed=9)
+    coef = [t.cuda() for t in ((rnd(cout, seed=10) * 0.3 + 1.0), rnd(cout, seed=11) * 0.05, rnd(cout, seed=12) * 0.05)]
+    da0 = rnd(*yshape, seed=13).squeeze(2) if nd == 2 else rnd(*yshape, seed=13)
+    daa, dab = Dev(da0, dtype=dtype), Dev(da0, dtype=dtype)
+    check(lib.biu_conv_bwd_weight_bn(dc.a(), C.byref(xfc), daa.a(), ya.a(), ptr(yxf.d[0]), ptr(yxf.d[1]), ptr(yxf.d[2]), ptr(coef[0]), ptr(coef[1]),
+                                     ptr(coef[2]), kd, 3, 3, 1, ptr(dwa), ptr(ws), wsz, code, stream()), "wgrad_bn")
+    check(lib.biu_conv_bwd_weight_cat(d0.a(), xf0.x(), d1.a(), None, dab.a(), ya.a(), ptr(yxf.d[0]), ptr(yxf.d[1]), ptr(yxf.d[2]), ptr(coef[0]),
+                                      ptr(coef[1]), ptr(coef[2]), kd, 3, 3, 1, ptr(dwb), ptr(ws), wsz, code, stream()), "wgrad_bn_cat")
+    assert torch.equal(daa.buf, dab.buf)
+    torch.testing.assert_close(dwb, dwa, rtol=1e-4, atol=1e-5 * float(dwa.abs().max()))
