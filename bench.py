@@ -107,7 +107,8 @@ def call_cost(eng, api, label):
     if node is None:
         return 0.0, 0.0
     if isinstance(node, E.ConvBlockNode) and api in ("biu_conv_fwd", "biu_conv_fwd_stats", "biu_conv_bwd_data", "biu_conv_bwd_data_bnred",
-                                                     "biu_conv_bwd_weight", "biu_conv_bwd_weight_bn"):
+                                                     "biu_conv_bwd_weight", "biu_conv_bwd_weight_bn", "biu_conv_fwd_cat",
+                                                     "biu_conv_bwd_data_cat", "biu_conv_bwd_weight_cat"):
         taps = node.kd * node.kh * node.kw
         v = node.y.nvox
         return 2.0 * v * taps * node.xin.c * node.y.c, float(v) * (node.xin.c + node.y.c) * esz

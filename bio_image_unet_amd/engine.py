@@ -151,6 +151,50 @@ class Act:
         return self.buf.producer.get(self.leaves[0])
 
 
+class CatAct:
+    """Channel concatenation (part0 | part1) of two dense tensors that stay in separate buffers: what the decoder's
+    ``torch.cat`` becomes when the two-source kernels can serve its consumer (``biu_conv_*_cat``).  Only a ConvBlockNode reads it."""
+
+    def __init__(self, p0: Act, p1: Act):
+        assert p0.space == p1.space
+        self.parts = (p0, p1)
+        self.c = p0.c + p1.c
+        self.n, self.d, self.h, self.w = p0.n, p0.d, p0.h, p0.w
+        self.is_input = False
+
+    @property
+    def nvox(self):
+        return self.parts[0].nvox
+
+    @property
+    def space(self):
+        return self.parts[0].space
+
+    def consumed(self):
+        for p in self.parts:
+            p.consumed()
+
+
+class CatBuf:
+    """Stand-in for the concat Buf of a decoder level: ``slice`` hands out the two dense parts, ``full`` their concatenation."""
+
+    def __init__(self, eng: "Engine", space, c_first, c_second):
+        n, d, h, w = space
+        self.c_first, self.c_second = c_first, c_second
+        self.bufs = (eng.new_buf(n, d, h, w, c_first), eng.new_buf(n, d, h, w, c_second))
+        self.acts = [None, None]
+
+    def slice(self, c0: int, c: int, lazy: bool) -> Act:
+        k = 0 if (c0, c) == (0, self.c_first) else 1
+        assert (c0, c) == ((0, self.c_first) if k == 0 else (self.c_first, self.c_second)), "a planar concat has exactly two slices"
+        self.acts[k] = self.bufs[k].slice(0, c, lazy)
+        return self.acts[k]
+
+    def full(self) -> CatAct:
+        assert self.acts[0] is not None and self.acts[1] is not None, "both parts must be produced before the concatenation is read"
+        return CatAct(self.acts[0], self.acts[1])
+
+
 # ======================================================================================================
 # nodes
 # ======================================================================================================
@@ -212,12 +256,18 @@ class ConvBlockNode(Node):
         packed = eng.pack(self.pk_f, 0, self.conv.weight, self.xin.c, self.y.c, self.kd, self.kh, self.kw)
         bn = self.bn
         scale, shift = self.y.vec("scale"), self.y.vec("shift")
+        cat = self.xin.parts if isinstance(self.xin, CatAct) else None
         if eng.bn_training(bn):
             # convolution + BatchNorm statistics in one call (the MFMA kernel reduces them in its epilogue)
             nblk = C.c_int(0)
-            check(lib.biu_conv_fwd_stats(self.xin.a(), self.xin.xf(), _ptr(w), packed, _ptr(b), self.kd, self.kh, self.kw,
-                                         self.dil, self.y.a(), _ptr(eng.partial), eng.partial.numel(), C.byref(nblk),
-                                         eng.dtype, st), "conv_fwd_stats")
+            if cat:
+                check(lib.biu_conv_fwd_cat(cat[0].a(), cat[0].xf(), cat[1].a(), cat[1].xf(), _ptr(w), packed, _ptr(b), self.kd,
+                                           self.kh, self.kw, self.dil, self.y.a(), _ptr(eng.partial), eng.partial.numel(),
+                                           C.byref(nblk), eng.dtype, st), "conv_fwd_cat")
+            else:
+                check(lib.biu_conv_fwd_stats(self.xin.a(), self.xin.xf(), _ptr(w), packed, _ptr(b), self.kd, self.kh, self.kw,
+                                             self.dil, self.y.a(), _ptr(eng.partial), eng.partial.numel(), C.byref(nblk),
+                                             eng.dtype, st), "conv_fwd_stats")
             mom = bn.momentum if bn.momentum is not None else 0.1
             track = bn.track_running_stats and bn.running_mean is not None
             check(lib.biu_bn_finalize(_ptr(eng.partial), nblk.value, self.y.c, float(self.y.nvox), _ptr(bn.weight.data),
@@ -228,8 +278,12 @@ class ConvBlockNode(Node):
                 eng.nbt_bump.append(bn.num_batches_tracked)
             self.batch_stats = True
         else:
-            check(lib.biu_conv_fwd(self.xin.a(), self.xin.xf(), _ptr(w), packed, _ptr(b), self.kd, self.kh, self.kw,
-                                   self.dil, self.y.a(), eng.dtype, st), "conv_fwd")
+            if cat:
+                check(lib.biu_conv_fwd_cat(cat[0].a(), cat[0].xf(), cat[1].a(), cat[1].xf(), _ptr(w), packed, _ptr(b), self.kd,
+                                           self.kh, self.kw, self.dil, self.y.a(), None, 0, None, eng.dtype, st), "conv_fwd_cat")
+            else:
+                check(lib.biu_conv_fwd(self.xin.a(), self.xin.xf(), _ptr(w), packed, _ptr(b), self.kd, self.kh, self.kw,
+                                       self.dil, self.y.a(), eng.dtype, st), "conv_fwd")
             check(lib.biu_bn_eval_affine(self.y.c, _ptr(bn.weight.data), _ptr(bn.bias.data), _ptr(bn.running_mean),
                                          _ptr(bn.running_var), bn.eps, _ptr(scale), _ptr(shift), st), "bn_eval_affine")
             self.batch_stats = False
@@ -261,15 +315,28 @@ class ConvBlockNode(Node):
         # Emit the exact zero instead of spending a pass over dy on it.
         db = eng.zero_like_bias(self.conv.bias) if self.conv.bias is not None else None
         # BatchNorm+LeakyReLU backward (da -> dy, in place) rides inside the weight-gradient kernel's tile loader
-        check(lib.biu_conv_bwd_weight_bn(self.xin.a(), self.xin.xf(), y.g(), y.a(), scale, shift, slope, _ptr(A), _ptr(B),
-                                         _ptr(Cc), self.kd, self.kh, self.kw, self.dil, _ptr(dw), _ptr(eng.ws), eng.ws_bytes,
-                                         eng.dtype, st), "conv_bwd_weight_bn")
+        cat = self.xin.parts if isinstance(self.xin, CatAct) else None
+        if cat:
+            check(lib.biu_conv_bwd_weight_cat(cat[0].a(), cat[0].xf(), cat[1].a(), cat[1].xf(), y.g(), y.a(), scale, shift, slope,
+                                              _ptr(A), _ptr(B), _ptr(Cc), self.kd, self.kh, self.kw, self.dil, _ptr(dw), _ptr(eng.ws),
+                                              eng.ws_bytes, eng.dtype, st), "conv_bwd_weight_cat")
+        else:
+            check(lib.biu_conv_bwd_weight_bn(self.xin.a(), self.xin.xf(), y.g(), y.a(), scale, shift, slope, _ptr(A), _ptr(B),
+                                             _ptr(Cc), self.kd, self.kh, self.kw, self.dil, _ptr(dw), _ptr(eng.ws), eng.ws_bytes,
+                                             eng.dtype, st), "conv_bwd_weight_bn")
         eng.add_grad(self.conv.weight, dw)
         if db is not None:
             eng.add_grad(self.conv.bias, db)
         eng.add_grad(self.bn.weight, dgamma)
         eng.add_grad(self.bn.bias, dbeta)
-        if eng.wants_grad(self.xin):
+        if cat:
+            packed = eng.pack(self.pk_b, 1, self.conv.weight, self.xin.c, cout, self.kd, self.kh, self.kw)
+            check(lib.biu_conv_bwd_data_cat(y.g(), _ptr(self.conv.weight.data), packed, self.kd, self.kh, self.kw, self.dil,
+                                            cat[0].g(), int(cat[0].g_written()), cat[1].g(), int(cat[1].g_written()), eng.dtype, st),
+                  "conv_bwd_data_cat")
+            cat[0].mark_g()
+            cat[1].mark_g()
+        elif eng.wants_grad(self.xin):
             packed = eng.pack(self.pk_b, 1, self.conv.weight, self.xin.c, cout, self.kd, self.kh, self.kw)
             up = _fusable_producer(self.xin)
             if up is not None:
@@ -563,6 +630,16 @@ class Engine:
         b = Buf(self, n, d, h, w, c)
         self.bufs.append(b)
         return b
+
+    def new_cat(self, space, c_first, c_second, consumer_cout, kd):
+        """Buffer(s) of a decoder level's concatenation (first | second).  Two dense buffers read through the two-source
+        kernels when those can serve the consuming conv block, else one [.., c_first + c_second] buffer with channel slices."""
+        n, d, h, w = space
+        probe = lambda c: biu_act(256, n, d, h, w, c, c)              # dense rows, aligned dummy pointer
+        a0, a1, ay = probe(c_first), probe(c_second), probe(consumer_cout)
+        if lib.biu_conv_cat_ok(C.byref(a0), C.byref(a1), C.byref(ay), kd, 3, 3, 1, self.dtype) == 1:
+            return CatBuf(self, space, c_first, c_second)
+        return self.new_buf(n, d, h, w, c_first + c_second)
 
     def new_act(self, space, c, lazy: bool) -> Act:
         n, d, h, w = space

@@ -178,7 +178,10 @@ class Unet(_HipNet):
         assert cin == self.encode1[0].in_channels, f"expected {self.encode1[0].in_channels} input channels, got {cin}"
         self._check_divisible(space)
         spaces = self._spaces(space)
-        cat_bufs = [eng.new_buf(*spaces[l], 2 * getattr(self, f"encode{2 * l + 2}")[0].out_channels) for l in range(4)]
+        # level l's decoder concat = (up-sampled | skip), each encode{2l+2}.out_channels wide; its reader is decode{7-2l}
+        cat_bufs = [eng.new_cat(spaces[l], getattr(self, f"encode{2 * l + 2}")[0].out_channels,
+                                getattr(self, f"encode{2 * l + 2}")[0].out_channels, getattr(self, f"decode{7 - 2 * l}")[0].out_channels, 1)
+                    for l in range(4)]
         x = eng.new_input(space, cin)
         m4, _ = self._build_encoder(eng, x, spaces, cat_bufs)
         mid1 = eng.new_act(spaces[4], self.middle_conv1[0].out_channels, lazy=True)
@@ -214,7 +217,10 @@ class Siam_UNet(Unet):
         space, cin = self._space(xshape)
         self._check_divisible(space)
         spaces = self._spaces(space)
-        cat_bufs = [eng.new_buf(*spaces[l], 2 * getattr(self, f"encode{2 * l + 2}")[0].out_channels) for l in range(4)]
+        # level l's decoder concat = (up-sampled | skip), each encode{2l+2}.out_channels wide; its reader is decode{7-2l}
+        cat_bufs = [eng.new_cat(spaces[l], getattr(self, f"encode{2 * l + 2}")[0].out_channels,
+                                getattr(self, f"encode{2 * l + 2}")[0].out_channels, getattr(self, f"decode{7 - 2 * l}")[0].out_channels, 1)
+                    for l in range(4)]
         x = eng.new_input(space, 1)
         px = eng.new_input(space, 1)
         c8 = self.encode8[0].out_channels
@@ -282,7 +288,8 @@ class _Body3D(_HipNet):
             spaces.append(_half(spaces[-1]))
         up_c = [self.middle_conv2[0].out_channels, self.decode2[0].out_channels, self.decode4[0].out_channels]
         skip_c = [self.encode6[0].out_channels, self.encode4[0].out_channels, self.encode2[0].out_channels]
-        cat_bufs = [eng.new_buf(*spaces[2 - i], up_c[i] + skip_c[i]) for i in range(3)]   # level 2,1,0
+        cat_bufs = [eng.new_cat(spaces[2 - i], up_c[i], skip_c[i], getattr(self, f"decode{2 * i + 1}")[0].out_channels, 3)
+                    for i in range(3)]                                                    # level 2,1,0
         x = eng.new_input(space, cin)
         t = x
         for lvl in range(3):
