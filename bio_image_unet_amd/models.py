@@ -225,7 +225,7 @@ class Siam_UNet(Unet):
         px = eng.new_input(space, 1)
         c8 = self.encode8[0].out_channels
         if self.mode == "concat":
-            jbuf = eng.new_buf(*spaces[4], 2 * c8)
+            jbuf = eng.new_cat(spaces[4], c8, c8, self.conv_concat[0].out_channels, 1)
             m4, _ = self._build_encoder(eng, x, spaces, cat_bufs, pool_out_slices=jbuf.slice(0, c8, lazy=False))
             mm4, _ = self._build_encoder(eng, px, spaces, None, pool_out_slices=jbuf.slice(c8, c8, lazy=False))
             join = eng.new_act(spaces[4], self.conv_concat[0].out_channels, lazy=True)

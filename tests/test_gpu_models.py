@@ -83,8 +83,11 @@ def _oracle_run(kind, sd, x, y, dt, perturb=0.0, **kw):
             if k.endswith(".0.weight"):
                 osd[k] = osd[k] * (1 + perturb * torch.randn(osd[k].shape, generator=g, dtype=dt))
     osd = O.clone_state(osd, requires_grad=True)
-    fwd = O.unet2d_forward if kind == "unet2d" else O.unet3d_forward
-    prob, logits = fwd(osd, x.to(dt), training=True, **kw)
+    if kind == "siam_concat":
+        prob, logits = O.siam_forward(osd, x[0].to(dt), x[1].to(dt), mode="concat", training=True)
+    else:
+        fwd = O.unet2d_forward if kind == "unet2d" else O.unet3d_forward
+        prob, logits = fwd(osd, x.to(dt), training=True, **kw)
     loss = O.bce_dice_loss(logits, y.to(dt))
     return logits.detach(), loss.detach(), O.grads_of(loss, osd), osd
 
@@ -101,7 +104,8 @@ def _grad_errors(grads, truth):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("kind,nf,shape", [("unet2d", 16, (2, 1, 128, 128)), ("unet3d", 32, (2, 1, 16, 32, 32))])
+@pytest.mark.parametrize("kind,nf,shape", [("unet2d", 16, (2, 1, 128, 128)), ("unet3d", 32, (2, 1, 16, 32, 32)),
+                                           ("siam_concat", 16, (2, 1, 64, 64))])
 def test_seeded_midsize_vs_oracle(kind, nf, shape, dtype):
     """Channel counts that are multiples of 16 -- the shapes the MFMA implicit-GEMM kernels serve.
 
@@ -117,6 +121,10 @@ def test_seeded_midsize_vs_oracle(kind, nf, shape, dtype):
     if kind == "unet2d":
         sd = O.init_unet2d(1, 1, nf, seed=3)
         m = B.Unet(1, 1, nf)
+    elif kind == "siam_concat":           # two frames; bottleneck join and three decoder levels go through the two-source kernels
+        sd = O.init_unet2d(1, 1, nf, seed=3, siam_mode="concat")
+        m = B.Siam_UNet(nf, mode="concat")
+        x = torch.stack([x, torch.rand(*shape)])
     else:
         sd = O.init_unet3d(1, 1, nf, seed=3)
         m = B.UNet3D(1, 1, nf)
@@ -129,7 +137,7 @@ def test_seeded_midsize_vs_oracle(kind, nf, shape, dtype):
     if dtype == "bf16":
         m.set_compute_dtype(torch.bfloat16)
     m.train()
-    prob, logits = m(x.cuda())
+    prob, logits = m(x[0].cuda(), x[1].cuda()) if kind == "siam_concat" else m(x.cuda())
     loss = O.bce_dice_loss(logits, y.cuda())
     loss.backward()
     rel = REL if dtype == "f32" else 5e-2
