@@ -166,6 +166,17 @@ def test_seeded_midsize_vs_oracle(kind, nf, shape, dtype):
     for k in sd:
         if "running_" in k:
             torch.testing.assert_close(m.state_dict()[k].cpu(), osd[k].detach(), rtol=rel, atol=rel)
+    # eval-mode forward (running statistics; no-statistics form of every kernel, including the two-source ones)
+    m.eval()
+    with torch.no_grad():
+        _, le = m(x[0].cuda(), x[1].cuda()) if kind == "siam_concat" else m(x.cuda())
+        od = {k: v.detach() for k, v in osd.items()}
+        if kind == "siam_concat":
+            _, re_ = O.siam_forward(od, x[0], x[1], mode="concat", training=False)
+        else:
+            _, re_ = (O.unet2d_forward if kind == "unet2d" else O.unet3d_forward)(od, x, training=False)
+    e = relerr(le.cpu(), re_)
+    assert e < (2e-3 if dtype == "f32" else 6e-2), f"eval logits rel err {e}"
 
 
 def test_divisibility_errors_match_reference():
