@@ -202,7 +202,7 @@ def main():
     step()
     torch.cuda.synchronize()
     prof, lib.prof = lib.prof, None
-    eng = list(model._engines.values())[-1]
+    eng = list(model._engines.values())[-1][-1]
     agg = {}
     for api, label, e0, e1 in prof:
         agg.setdefault((api, label), []).append(e0.elapsed_time(e1))

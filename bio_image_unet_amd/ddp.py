@@ -48,7 +48,11 @@ class GradAverager:
         if self.world > 1:
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
-                    dist.broadcast(t.data, src=0)
+                    # through a detached alias, NOT .data: the alias shares the version counter, so the in-place receive
+                    # bumps Tensor._version and the engines' cached MFMA weight packings are rebuilt on ranks != 0
+                    dist.broadcast(t.detach(), src=0)
+            if hasattr(module, "invalidate_packed"):
+                module.invalidate_packed()
 
     def average(self):
         """Call after backward(): leaves p.grad = mean over ranks (views of one flat fp32 bucket)."""

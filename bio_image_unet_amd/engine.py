@@ -15,6 +15,7 @@ in place (BatchNorm backward), then runs the weight- and data-gradient kernels.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -551,11 +552,10 @@ class HeadNode(Node):
         check(lib.biu_head_fwd(self.xin.a(), self.xin.xf(), _ptr(w), _ptr(self.conv.bias.data), self.cout, self.act,
                                _ptr(self.logits), _ptr(self.activated), eng.dtype, _stream()), "head_fwd")
 
-    def dlogits(self, g_logits, g_act):
-        """Combine the caller's gradients wrt (logits, activated output) into d logits (tiny fp32 tensors)."""
+    def dlogits(self, g_logits, g_act, a=None):
+        """Combine the caller's gradients wrt (logits, activated output ``a``) into d logits."""
         tot = g_logits
         if g_act is not None:
-            a = self.activated
             if self.act == 1:
                 t = g_act * a * (1 - a)
             elif self.act == 2:
@@ -624,6 +624,20 @@ class Engine:
         self._zero_flat, self._zero_used = None, 0
         self._slots: List[dict] = []
         self._job_key, self._job_tab = None, None
+        self.trace = None            # test hook: trace(phase, node, when) around every node ("fwd"/"bwd", node, "pre"/"post")
+        self.generation = 0          # bumped by every forward: a backward must see the generation of ITS forward
+        self._live = None            # weakref to the token of the autograd node that still needs this engine's buffers
+
+    def busy(self) -> bool:
+        """A forward under autograd ran on this engine and its backward has neither run nor been dropped: the saved
+        activations, statistics and partial sums are still owed to that node."""
+        return self._live is not None and self._live() is not None
+
+    def invalidate_packed(self):
+        """Forget the cached MFMA weight packings (needed after a raw ``param.data`` write, which does not bump
+        ``Tensor._version``)."""
+        for s in self._slots:
+            s["ver"] = None
 
     # ---- build helpers -------------------------------------------------------------------------------
     def new_buf(self, n, d, h, w, c) -> Buf:
@@ -780,12 +794,17 @@ class Engine:
             check(lib.biu_from_nchw(_ptr(x), act.a(), self.dtype, st), "from_nchw")
 
     def forward(self):
+        self.generation += 1
         self.nbt_bump = []
         lib.label = "pack:fwd"
         self.pack_all()
         for nd_ in self.nodes:
             lib.label = nd_.label + ":fwd"
+            if self.trace:
+                self.trace("fwd", nd_, "pre")
             nd_.fwd(self)
+            if self.trace:
+                self.trace("fwd", nd_, "post")
         if self.nbt_bump:       # a weight-shared block (Siam encoder) appears once per application
             counts: Dict[int, list] = {}
             for t in self.nbt_bump:
@@ -805,12 +824,20 @@ class Engine:
                 b.leaves[k] = False
                 b.nwr[k] = 0
         lib.label = "head:bwd"
+        if self.trace:
+            self.trace("bwd", ("heads", head_grads), "pre")
         self._backward_heads(head_grads)
+        if self.trace:
+            self.trace("bwd", ("heads", head_grads), "post")
         for nd_ in reversed(self.nodes):
             if isinstance(nd_, HeadNode):
                 continue
             lib.label = nd_.label + ":bwd"
+            if self.trace:
+                self.trace("bwd", nd_, "pre")
             nd_.bwd(self)
+            if self.trace:
+                self.trace("bwd", nd_, "post")
         return self.grads
 
     def _backward_heads(self, head_grads):
@@ -855,37 +882,64 @@ class Engine:
 # ======================================================================================================
 # autograd glue at the module boundary
 # ======================================================================================================
+class _Token:
+    """Lifetime marker of one autograd node: alive while that node can still ask the engine for its backward."""
+    __slots__ = ("__weakref__",)
+
+
 class _NetFn(torch.autograd.Function):
     """One autograd node for the whole network: forward/backward are the engine's kernel sequences."""
 
     @staticmethod
     def forward(ctx, eng: Engine, n_inputs: int, out_spec, *tensors):
         xs, ctx.n_inputs = tensors[:n_inputs], n_inputs
+        if eng.busy():
+            raise RuntimeError("engine re-entered while an earlier forward still awaits its backward (models take a second "
+                               "engine for that case: this is a bug in the caller of engine.run)")
         eng.load_inputs(xs)
         eng.forward()
         ctx.eng, ctx.out_spec = eng, out_spec
+        ctx.generation = eng.generation
+        if eng.grad_mode:
+            ctx.token = _Token()
+            eng._live = weakref.ref(ctx.token)
+        else:
+            eng._live = None
         outs = []
         for hi, kind in out_spec:
             h = eng.heads[hi]
             outs.append(h.logits if kind == "logits" else h.activated)
+        # the activated outputs are needed by the activations' backward; they are OUTPUTS of this node, so they go through
+        # save_for_backward (a plain reference from the engine would keep the node -- and its claim on the engine -- alive)
+        ctx.act_slot = {hi: i for i, (hi, kind) in enumerate(out_spec) if kind == "act"}
+        ctx.save_for_backward(*[outs[i] for i in ctx.act_slot.values()])
+        for h in eng.heads:
+            h.logits = h.activated = None
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gouts):
         eng: Engine = ctx.eng
+        if ctx.generation != eng.generation:
+            raise RuntimeError("backward of a forward whose activations were overwritten: the engine ran another forward of the "
+                               "same input shape in between (generation %d, now %d)" % (ctx.generation, eng.generation))
         per_head: Dict[int, List[Optional[torch.Tensor]]] = {}
         for (hi, kind), g in zip(ctx.out_spec, gouts):
             slot = per_head.setdefault(hi, [None, None])
             slot[0 if kind == "logits" else 1] = g
+        saved = dict(zip(ctx.act_slot.keys(), ctx.saved_tensors))
         head_grads = []
         for hi, h in enumerate(eng.heads):
             gl, ga = per_head.get(hi, [None, None])
-            head_grads.append(h.dlogits(gl, ga) if (gl is not None or ga is not None) else None)
+            head_grads.append(h.dlogits(gl, ga, saved.get(hi)) if (gl is not None or ga is not None) else None)
         grads = eng.backward(head_grads)
         dxs = eng.input_grads()
         pg = [grads.pop(p, None) for p in eng.params]
         eng.grads = {}              # sole owner is now autograd: AccumulateGrad can take the tensors without copying
         del grads
+        ctx.token = None            # the engine's buffers are free again (a second backward of this node is not supported)
+        eng._live = None
+        eng.generation += 1
         return (None, None, None, *dxs, *pg)
 
 

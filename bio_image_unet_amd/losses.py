@@ -129,6 +129,31 @@ class weightedBCELoss(nn.Module):
         return torch.mean(nn.functional.binary_cross_entropy(probs, targets, reduction="none") * weights)
 
 
+class BCELoss2dProb(nn.Module):
+    """The Siam package's ``BCELoss2d`` (``siam_unet/losses.py:73-105``): ``nn.BCELoss`` on ``sigmoid(logits)`` -- NOT
+    ``BCEWithLogitsLoss``.  Same value in the bulk; where fp32 ``sigmoid`` saturates (|logit| > ~17) its log terms clamp at
+    -100 and the gradient vanishes, which ``BCEWithLogits`` does not do, so the reference arithmetic is kept verbatim."""
+
+    def __init__(self, weight=None, reduction="mean", **kwargs):
+        super().__init__()
+        self.bce_loss = nn.BCELoss(weight, reduction=reduction)
+
+    def forward(self, logits, targets):
+        return self.bce_loss(torch.sigmoid(logits).view(-1), targets.view(-1))
+
+
+class BCEDiceLossSiam(nn.Module):
+    """``siam_unet.BCEDiceLoss`` (``siam_unet/losses.py:5-39``): alpha * BCELoss(sigmoid) + beta * SoftDice
+    (``score.sum() / num``, the same number as the 2-D package's ``score.mean()``)."""
+
+    def __init__(self, alpha, beta):
+        super().__init__()
+        self.bce, self.dice, self.alpha, self.beta = BCELoss2dProb(), SoftDiceLoss(), alpha, beta
+
+    def forward(self, logits, targets):
+        return self.alpha * self.bce(logits, targets) + self.beta * self.dice(logits, targets)
+
+
 class TemporalConsistencyLoss(nn.Module):
     """L1 between consecutive slices of axis 2 of a (B, C, Z, X, Y) prediction (``multi_output_unet3d/losses.py``)."""
 

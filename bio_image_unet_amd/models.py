@@ -35,12 +35,35 @@ def _block(nd: int, cin: int, cout: int, dilation: int = 1, dropout: float = 0.0
 class _HipNet(nn.Module):
     """Shared plumbing: engine cache keyed by input shape, compute dtype switch, loud CPU refusal."""
     nd = 2
-    _max_cached = 2
+    _max_cached = 2          # input shapes kept
+    _max_live = 4            # engines per shape: forwards whose backward is still pending each hold one
 
     def __init__(self):
         super().__init__()
-        self._engines: "OrderedDict[tuple, E.Engine]" = OrderedDict()
+        self._engines: "OrderedDict[tuple, list]" = OrderedDict()
         self.compute_dtype = torch.float32
+
+    # engines hold ctypes structs and device buffers: they are caches, never part of a copy or a pickle
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_engines"] = OrderedDict()
+        return st
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = OrderedDict() if k == "_engines" else copy.deepcopy(v, memo)
+        return new
+
+    def invalidate_packed(self):
+        """Call after writing parameters through ``.data`` (EMA, clipping, manual broadcast): such writes do not bump
+        ``Tensor._version``, which is what the cached MFMA weight packings are keyed on.  In-place ops under ``no_grad``,
+        optimizers and ``load_state_dict`` need nothing."""
+        for engs in self._engines.values():
+            for e in engs:
+                e.invalidate_packed()
 
     def set_compute_dtype(self, dtype):
         """torch.float32 (reference numerics) or torch.bfloat16 (bf16 storage, fp32 accumulate)."""
@@ -58,8 +81,17 @@ class _HipNet(nn.Module):
         if p.device != x.device:
             raise RuntimeError(f"parameters are on {p.device} but the input is on {x.device}")
         key = (tuple(x.shape), str(x.device), self.compute_dtype)
-        eng = self._engines.get(key)
+        pool = self._engines.get(key)
+        eng = next((e for e in pool if not e.busy()), None) if pool else None
         if eng is None:
+            if pool and len(pool) >= self._max_live:
+                raise RuntimeError(f"{type(self).__name__}: {len(pool)} forwards of input shape {tuple(x.shape)} are waiting for "
+                                   "their backward; each holds a full set of activation buffers (raise _max_live to allow more)")
+            for name, t in list(self.named_parameters()) + list(self.named_buffers()):
+                if t.is_floating_point() and (t.dtype != torch.float32 or not t.is_contiguous()):
+                    raise RuntimeError(f"{type(self).__name__}.{name} is {t.dtype}, contiguous={t.is_contiguous()}: the kernels read "
+                                       "parameters and BatchNorm buffers as dense fp32. Keep the module in fp32 and select the "
+                                       "activation storage type with set_compute_dtype(torch.bfloat16).")
             eng = E.Engine(x.device, self.compute_dtype, self.nd)
             self._build(eng, *[tuple(t.shape) for t in xs])
             eng.finalize()
@@ -70,11 +102,10 @@ class _HipNet(nn.Module):
                 if isinstance(nd_, E.ResampleNode):
                     base = f"{nd_.kind}@{'x'.join(str(v) for v in nd_.xin.space[1:])}"
                 nd_.label = base[:-2] if base.endswith(".0") and not base.startswith("final") else base
-            self._engines[key] = eng
+            self._engines.setdefault(key, []).append(eng)
             while len(self._engines) > self._max_cached:
                 self._engines.popitem(last=False)
-        else:
-            self._engines.move_to_end(key)
+        self._engines.move_to_end(key)
         return eng
 
     def _space(self, shape):

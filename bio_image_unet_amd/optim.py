@@ -18,18 +18,32 @@ class Adam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._tables = {}
 
+    def load_state_dict(self, state_dict):
+        """Moments are replaced by new tensors: drop the device pointer tables built over the old ones.  Checkpoints of
+        ``torch.optim.Adam`` carry ``step`` as a tensor; the kernel takes a C int."""
+        super().load_state_dict(state_dict)
+        self._tables = {}
+        for st in self.state.values():
+            if "step" in st:
+                st["step"] = int(st["step"])
+            for k in ("exp_avg", "exp_avg_sq"):
+                if k in st:
+                    st[k] = st[k].to(dtype=torch.float32).contiguous()
+
     def _group_tables(self, gi, group):
         ps = [p for p in group["params"] if p.requires_grad]
-        key = (gi, tuple(p.data_ptr() for p in ps))
+        for p in ps:
+            st = self.state[p]
+            if "exp_avg" not in st:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32)
+                st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32)
+        # the kernel writes through raw pointers: the tables are valid only for exactly these parameter AND moment tensors
+        key = (gi, tuple(p.data_ptr() for p in ps), tuple(self.state[p]["exp_avg"].data_ptr() for p in ps),
+               tuple(self.state[p]["exp_avg_sq"].data_ptr() for p in ps))
         t = self._tables.get(gi)
         if t is None or t["key"] != key:
             dev = ps[0].device
-            for p in ps:
-                st = self.state[p]
-                if "exp_avg" not in st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32)
-                    st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32)
             mk = lambda ts: torch.tensor([x.data_ptr() for x in ts], dtype=torch.int64, device=dev)
             t = {"key": key, "ps": ps, "p": mk(ps), "m": mk([self.state[p]["exp_avg"] for p in ps]),
                  "v": mk([self.state[p]["exp_avg_sq"] for p in ps]),
@@ -70,7 +84,7 @@ class Adam(torch.optim.Optimizer):
                 t["g_ev"][r] = ev
                 t["g"] = t["g_dev"][r]
                 t["gkey"] = gkey
-            step = self.state[ps[0]]["step"] + 1
+            step = int(self.state[ps[0]]["step"]) + 1
             for p in ps:
                 self.state[p]["step"] = step
             b1, b2 = group["betas"]

@@ -25,7 +25,7 @@ import torch
 from torch import nn, optim
 from torch.utils.data import DataLoader, random_split
 
-from .losses import BCEDiceLoss, BCEDiceTemporalLoss, TverskyLoss, logcoshTverskyLoss, weightedBCELoss
+from .losses import BCEDiceLoss, BCEDiceLossSiam, BCEDiceTemporalLoss, TverskyLoss, logcoshTverskyLoss, weightedBCELoss
 from .models import MultiOutputUnet3D, Siam_UNet, UNet3D, Unet
 from .optim import Adam
 from .utils import get_device, init_weights
@@ -220,7 +220,8 @@ class TrainerSiam(_EpochLoop):
         self.model = Siam_UNet(n_filter=n_filter, mode=mode).to(self.device)      # no init_weights here (reference :61)
         self.n_filter, self.mode = n_filter, mode
         self.loss_function, self.loss_params = loss_function, loss_params
-        self.criterion = _make_criterion(loss_function, loss_params, extra={"weightedBCELoss": weightedBCELoss})
+        # the Siam package's own criteria: its BCEDice takes nn.BCELoss on sigmoid(logits) (siam_unet/losses.py:5-39,73-105)
+        self.criterion = _make_criterion(loss_function, loss_params, extra={"BCEDice": BCEDiceLossSiam, "weightedBCELoss": weightedBCELoss})
         self._setup(dataset, num_epochs, batch_size, lr, val_split, save_dir, save_name, save_iter)
         if load_weights is not None:
             self.state = torch.load(load_weights)

@@ -42,6 +42,158 @@ State = Dict[str, torch.Tensor]
 
 
 # --------------------------------------------------------------------------------------------------
+# bf16-storage emulation (checker for the engine's bf16 mode; the reference itself is fp32 only)
+# --------------------------------------------------------------------------------------------------
+# With ``emulate_bf16()`` active the forwards below round to bfloat16 at exactly the points where the HIP engine
+# stores a tensor in HBM as bf16 or packs an MFMA operand, and their autograd graphs round the activation
+# gradients where the engine stores those: arithmetic stays fp32 (the engine accumulates in fp32).  It is what the
+# engine's bf16 mode computes, restated with torch CPU ops; the unemulated functions stay the reference's arithmetic.
+#   * a raw convolution / ConvTranspose output y is stored in bf16; its gradient dy likewise;
+#   * BatchNorm statistics are those of the stored y; BatchNorm-affine + LeakyReLU run in fp32 on it;
+#   * MFMA layers (Cin a multiple of 16, Cout >= 16) take operands T(y) and weights rounded to bf16; the Cin = 1
+#     first layer, odd widths and the 1x1 heads multiply the unrounded fp32 T(y) with fp32 weights;
+#   * max-pool / nearest / trilinear compare and interpolate the unrounded T(y) and store the result in bf16;
+#   * an activation gradient is rounded when a kernel writes it and once more after a second writer accumulates.
+class _Emu:
+    on = False
+    fwd = True      # round values (ablation switches for tools/bf16_error_budget.py; both True = the engine)
+    bwd = True      # round activation gradients
+
+
+class emulate_bf16:
+    def __init__(self, on: bool = True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev, _Emu.on = _Emu.on, self.on
+        return self
+
+    def __exit__(self, *exc):
+        _Emu.on = self.prev
+        return False
+
+
+def _r(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def _rf(t):
+    return _r(t) if _Emu.fwd else t.view_as(t)
+
+
+def _rb(t):
+    return _r(t) if _Emu.bwd else t
+
+
+class _RoundBoth(torch.autograd.Function):      # a tensor stored as bf16 whose gradient twin is stored as bf16 too
+    @staticmethod
+    def forward(ctx, x):
+        return _rf(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _rb(g)
+
+
+class _RoundFwd(torch.autograd.Function):       # an MFMA weight operand: rounded copy, fp32 gradient
+    @staticmethod
+    def forward(ctx, x):
+        return _rf(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundBwd(torch.autograd.Function):       # fp32 view of a stored tensor: only its gradient twin is bf16
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _rb(g)
+
+
+# --------------------------------------------------------------------------------------------------
+# forced decisions (checker for whole-network gradients)
+# --------------------------------------------------------------------------------------------------
+# LeakyReLU's branch and max-pool's / torch.maximum's winner are discontinuities of the gradient: an element within
+# fp32 rounding of the boundary falls either way in any fp32 implementation -- the reference's CPU path included -- and
+# one such voxel moves a bottleneck weight gradient by 1e-3 .. 1e-2 (tests/test_gpu_models.py).  With
+# ``forced_decisions(q)`` the forwards below take these decisions from ``q`` -- lists, in execution order, of the masks /
+# argmax indices an implementation under test actually took -- instead of re-deciding, so its gradients can be compared
+# with fp64 arithmetic on the SAME piecewise-linear branch of the network.
+class _Forced:
+    q = None
+
+
+class forced_decisions:
+    def __init__(self, q):
+        self.q = {k: list(v) for k, v in q.items()} if q is not None else None
+
+    def __enter__(self):
+        self.prev, _Forced.q = _Forced.q, self.q
+        return self
+
+    def __exit__(self, *exc):
+        left = {k: len(v) for k, v in (_Forced.q or {}).items() if v}
+        _Forced.q = self.prev
+        if exc[0] is None and left:
+            raise AssertionError(f"forced decisions not consumed: {left}")
+        return False
+
+
+def _lrelu(t):
+    if _Forced.q is not None:
+        m = _Forced.q["lrelu"].pop(0)
+        return torch.where(m, t, LRELU_SLOPE * t)
+    return F.leaky_relu(t, LRELU_SLOPE)
+
+
+def _maxpool(t):
+    nd3 = t.dim() == 5
+    if _Forced.q is not None:
+        idx = _Forced.q["pool"].pop(0)                       # flat index into the (D*)H*W plane of each (n, c), as max_pool returns
+        return t.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+    return F.max_pool3d(t, 2, 2) if nd3 else F.max_pool2d(t, 2, 2)
+
+
+def _maximum(a, b):
+    if _Forced.q is not None:
+        return torch.where(_Forced.q["max"].pop(0), a, b)
+    return torch.maximum(a, b)
+
+
+def st(x):
+    """Tensor as stored in HBM (value and gradient)."""
+    return _RoundBoth.apply(x) if _Emu.on else x
+
+
+def st_grad(x):
+    """fp32 value, stored gradient."""
+    return _RoundBwd.apply(x) if _Emu.on else x
+
+
+def emu_input(x):
+    """Network input as the engine holds it (biu_from_nchw converts to the storage type)."""
+    return _rf(x) if _Emu.on else x
+
+
+def mfma_layer(cin: int, cout: int, dilation: int = 1) -> bool:
+    """Which conv / ConvTranspose layers run on the MFMA kernels in bf16 mode (csrc/biu_conv_mfma.hip: chan_ok)."""
+    return dilation == 1 and cin >= 16 and cin % 16 == 0 and cout >= 16 and cout % 8 == 0
+
+
+def _operands(x, w, cin, cout, dilation=1):
+    if not _Emu.on:
+        return x, w
+    if mfma_layer(cin, cout, dilation):
+        return _RoundBoth.apply(x), _RoundFwd.apply(w)
+    return _RoundBwd.apply(x), w
+
+
+# --------------------------------------------------------------------------------------------------
 # building blocks
 # --------------------------------------------------------------------------------------------------
 def conv_block(sd: State, name: str, x: torch.Tensor, *, training: bool, dilation: int = 1) -> torch.Tensor:
@@ -54,7 +206,8 @@ def conv_block(sd: State, name: str, x: torch.Tensor, *, training: bool, dilatio
     w = sd[f"{name}.0.weight"]
     b = sd[f"{name}.0.bias"]
     conv = F.conv3d if w.dim() == 5 else F.conv2d
-    y = conv(x, w, b, padding=dilation, dilation=dilation)
+    xo, wo = _operands(x, w, w.shape[1], w.shape[0], dilation)
+    y = st(conv(xo, wo, b, padding=dilation, dilation=dilation))
     rm, rv = sd[f"{name}.1.running_mean"], sd[f"{name}.1.running_var"]
     if training:
         nbt = sd.get(f"{name}.1.num_batches_tracked")
@@ -62,14 +215,15 @@ def conv_block(sd: State, name: str, x: torch.Tensor, *, training: bool, dilatio
             nbt += 1
     y = F.batch_norm(y, rm, rv, sd[f"{name}.1.weight"], sd[f"{name}.1.bias"],
                      training=training, momentum=BN_MOMENTUM, eps=BN_EPS)
-    return F.leaky_relu(y, LRELU_SLOPE)
+    return st_grad(_lrelu(y))
 
 
 def up_conv_t(sd: State, name: str, x: torch.Tensor) -> torch.Tensor:
     """``nn.ConvTranspose{2,3}d(k=2, stride=2)`` (unet/unet.py:38, unet3d/unet3d.py:40)."""
     w = sd[f"{name}.weight"]
     f = F.conv_transpose3d if w.dim() == 5 else F.conv_transpose2d
-    return f(x, w, sd[f"{name}.bias"], stride=2)
+    xo, wo = _operands(x, w, w.shape[0], w.shape[1])
+    return st(f(xo, wo, sd[f"{name}.bias"], stride=2))
 
 
 def checked_concat(x1: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
@@ -113,13 +267,13 @@ def _encoder2d(sd: State, x, training: bool, dilation: int):
         t = conv_block(sd, f"encode{2 * lvl + 1}", t, training=training, dilation=dilation)
         t = conv_block(sd, f"encode{2 * lvl + 2}", t, training=training, dilation=dilation)
         skips.append(t)
-        t = F.max_pool2d(t, 2, 2)
+        t = st(_maxpool(t))
     return t, skips
 
 
 def unet2d_forward(sd: State, x: torch.Tensor, *, dilation: int = 1, training: bool = True):
     """``Unet.forward`` -> (sigmoid(logits), logits)."""
-    m4, skips = _encoder2d(sd, x, training, dilation)
+    m4, skips = _encoder2d(sd, emu_input(x), training, dilation)
     mid = conv_block(sd, "middle_conv1", m4, training=training, dilation=dilation)
     mid = conv_block(sd, "middle_conv2", mid, training=training, dilation=dilation)
     return _decoder2d(sd, mid, skips, training)
@@ -135,12 +289,12 @@ def depthwise_xcorr(cur: torch.Tensor, prev: torch.Tensor) -> torch.Tensor:
 def siam_forward(sd: State, x: torch.Tensor, prev_x: torch.Tensor, *, mode: str = "concat",
                  training: bool = True):
     """``Siam_UNet.forward``: weight-shared encoder applied to x then prev_x (BN stats per call)."""
-    m4, skips = _encoder2d(sd, x, training, 1)
-    mm4, _ = _encoder2d(sd, prev_x, training, 1)
+    m4, skips = _encoder2d(sd, emu_input(x), training, 1)
+    mm4, _ = _encoder2d(sd, emu_input(prev_x), training, 1)
     if mode == "corr":
-        join = depthwise_xcorr(m4, mm4)
+        join = st(depthwise_xcorr(m4, mm4))
     elif mode == "max":
-        join = torch.maximum(m4, mm4)
+        join = st(_maximum(m4, mm4))
     elif mode == "concat":
         join = conv_block(sd, "conv_concat", checked_concat(m4, mm4), training=training)
     elif mode == "control":
@@ -159,19 +313,19 @@ def _body3d(sd: State, x, *, training: bool, down: str, up: str):
     """
     def pool(t):
         if down == "maxpool":
-            return F.max_pool3d(t, 2, 2)
-        return F.interpolate(t, scale_factor=0.5, mode="nearest")
+            return st(_maxpool(t))
+        return st(F.interpolate(t, scale_factor=0.5, mode="nearest"))
 
     def upsample(t, lvl):
         if up == "convT":
             return up_conv_t(sd, f"up{lvl}", t)
         if up == "trilinear":
-            return F.interpolate(t, scale_factor=2, mode="trilinear", align_corners=False)
-        t = F.interpolate(t, scale_factor=2, mode="nearest")
+            return st(F.interpolate(t, scale_factor=2, mode="trilinear", align_corners=False))
+        t = st(F.interpolate(t, scale_factor=2, mode="nearest"))
         return conv_block(sd, f"up{lvl}_conv", t, training=training)
 
     skips = []
-    t = x
+    t = emu_input(x)
     for lvl in range(3):
         t = conv_block(sd, f"encode{2 * lvl + 1}", t, training=training)
         t = conv_block(sd, f"encode{2 * lvl + 2}", t, training=training)
@@ -221,6 +375,12 @@ def soft_dice_loss(logits, targets, smooth: float = 1.0):
 
 def bce_dice_loss(logits, targets, alpha: float = 0.5, beta: float = 0.5):
     return alpha * F.binary_cross_entropy_with_logits(logits, targets) + beta * soft_dice_loss(logits, targets)
+
+
+def siam_bce_dice_loss(logits, targets, alpha: float = 1.0, beta: float = 1.0):
+    """siam_unet/losses.py:5-39 with its own BCELoss2d (:73-105): nn.BCELoss on sigmoid(logits), flattened."""
+    bce = F.binary_cross_entropy(torch.sigmoid(logits).view(-1), targets.view(-1))
+    return alpha * bce + beta * soft_dice_loss(logits, targets)
 
 
 def tversky_loss(logits, targets, alpha: float = 0.5, beta: float = 0.5, smooth: float = 1.0):

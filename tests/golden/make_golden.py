@@ -44,6 +44,7 @@ unet3d_mod = load("ref_unet3d", "unet3d/unet3d.py")
 siam_mod = load("ref_siam", "siam_unet/siam_unet.py")
 mo3d_mod = load("ref_mo3d", "multi_output_unet3d/multi_output_unet3d.py")
 losses_mod = load("ref_losses", "unet/losses.py")
+siam_losses_mod = load("ref_siam_losses", "siam_unet/losses.py")     # the Siam package's own criteria (BCELoss on probabilities)
 
 
 def ref_init_weights(m):
@@ -128,15 +129,16 @@ def main():
              m, {"x": x}, y, loss_fn, ["prob", "logits"], lambda mod, x=x: mod(x))
 
     # ---- (iii) Siam_UNet -----------------------------------------------------------------------
+    siam_bce_dice = siam_losses_mod.BCEDiceLoss(1, 1)          # siam_unet/train.py: loss_function='BCEDice', loss_params=(1, 1)
     for mode in ("concat", "max", "corr", "control"):
         torch.manual_seed(2)
         m = siam_mod.Siam_UNet(n_filter=4, mode=mode)
         x = torch.rand(2, 1, 32, 32)
         px = torch.rand(2, 1, 32, 32)
         y = (torch.rand(2, 1, 32, 32) > 0.5).float()
-        loss_fn = lambda outs, y=y: bce_dice(outs[1], y)     # criterion(y_logits, y_i), siam_unet/train.py:110
+        loss_fn = lambda outs, y=y: siam_bce_dice(outs[1], y)     # criterion(y_logits, y_i), siam_unet/train.py:110
         dump(f"siam_f4_{mode}", dict(model="Siam_UNet", ctor=dict(n_filter=4, mode=mode), seed=2,
-                                     loss="BCEDice(0.5,0.5) on logits (unet/losses.py)", init="default"),
+                                     loss="siam_unet/losses.py BCEDiceLoss(1,1): BCELoss(sigmoid(logits)) + SoftDice", init="default"),
              m, {"x": x, "prev_x": px}, y, loss_fn, ["prob", "logits"], lambda mod, x=x, px=px: mod(x, px))
 
     # ---- (iv) MultiOutputUnet3D ----------------------------------------------------------------

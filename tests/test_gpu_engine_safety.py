@@ -1,0 +1,145 @@
+"""Module-API patterns the reference's plain nn.Module allows and a cached static engine must not silently break:
+several forwards before a backward, a logging forward between forward and backward, raw ``.data`` writes next to the
+packed-weight cache, optimizer state round trips, dtype casts and copies of a model that already ran."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import bio_image_unet_amd as B  # noqa: E402
+from bio_image_unet_amd.optim import Adam  # noqa: E402
+from oracle import unet_oracle as O  # noqa: E402
+
+
+def _model(nf=16, seed=3):
+    sd = O.init_unet2d(1, 1, nf, seed=seed)
+    m = B.Unet(1, 1, nf).cuda()
+    m.load_state_dict(sd)
+    m.train()
+    return m, sd
+
+
+def _grads(m):
+    return {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+
+def test_two_forwards_then_one_backward():
+    """o1 = m(a); o2 = m(b); (f(o1) + f(o2)).backward() -- the second forward must not overwrite what the first one's
+    backward needs (each pending forward holds its own engine)."""
+    torch.manual_seed(0)
+    a, b = torch.rand(2, 1, 64, 64).cuda(), torch.rand(2, 1, 64, 64).cuda()
+    y = (torch.rand(2, 1, 64, 64) > 0.5).float().cuda()
+    m, sd = _model()
+    ref = {}
+    for x in (a, b):                                     # separate forward/backward pairs from the same initial buffers
+        m.load_state_dict(sd)
+        m.zero_grad()
+        O.bce_dice_loss(m(x)[1], y).backward()
+        for k, g in _grads(m).items():
+            ref[k] = ref.get(k, 0) + g
+    m.load_state_dict(sd)
+    m.zero_grad()
+    _, l1 = m(a)
+    _, l2 = m(b)
+    (O.bce_dice_loss(l1, y) + O.bce_dice_loss(l2, y)).backward()
+    for k, g in _grads(m).items():
+        torch.testing.assert_close(g, ref[k], rtol=1e-3, atol=1e-5 * float(ref[k].abs().max()) + 1e-9, msg=lambda s: f"{k}: {s}")
+
+
+def test_logging_forward_between_forward_and_backward():
+    torch.manual_seed(1)
+    a, b = torch.rand(2, 1, 64, 64).cuda(), torch.rand(2, 1, 64, 64).cuda()
+    y = (torch.rand(2, 1, 64, 64) > 0.5).float().cuda()
+    m, sd = _model()
+    O.bce_dice_loss(m(a)[1], y).backward()
+    ref = _grads(m)
+    m.load_state_dict(sd)
+    m.zero_grad()
+    _, l1 = m(a)
+    with torch.no_grad():
+        m(b)                                             # same shape: would have reused the pending engine's buffers
+    O.bce_dice_loss(l1, y).backward()
+    for k, g in _grads(m).items():
+        torch.testing.assert_close(g, ref[k], rtol=1e-3, atol=1e-5 * float(ref[k].abs().max()) + 1e-10, msg=lambda s: f"{k}: {s}")   # (wgrad sums with fp32 atomics: order varies)
+
+
+def test_pending_forwards_are_bounded_and_released():
+    m, _ = _model(nf=4)
+    x = torch.rand(1, 1, 32, 32).cuda()
+    outs = [m(x) for _ in range(m._max_live)]
+    with pytest.raises(RuntimeError, match="waiting for their backward"):
+        m(x)
+    del outs                                             # dropping the outputs frees the autograd nodes and their engines
+    m(x)
+
+
+def test_data_write_needs_invalidate_and_inplace_op_does_not():
+    """The packed MFMA weights are cached on (data_ptr, _version).  In-place ops under no_grad bump the version; a raw
+    ``.data`` write does not and needs ``invalidate_packed()`` (what ddp.GradAverager does after its broadcast)."""
+    torch.manual_seed(2)
+    x = torch.rand(2, 1, 64, 64)
+    m, sd = _model()
+    m.eval()
+    with torch.no_grad():
+        m(x.cuda())                                      # packs
+        for p in m.parameters():
+            p.mul_(0.5)                                  # in place: version bump -> re-packed on the next forward
+        _, got = m(x.cuda())
+        sd2 = {k: (v * 0.5 if (k.endswith(".weight") or k.endswith(".bias")) else v) for k, v in sd.items()}
+        _, want = O.unet2d_forward(sd2, x, training=False)
+        assert float((got.cpu() - want).abs().max()) < 1e-3 * float(want.abs().max())
+        for p in m.parameters():
+            p.data.copy_(p.data * 2.0)                   # raw .data write: invisible to the cache
+        m.invalidate_packed()
+        _, got = m(x.cuda())
+        _, want = O.unet2d_forward(sd, x, training=False)
+        assert float((got.cpu() - want).abs().max()) < 1e-3 * float(want.abs().max())
+
+
+def test_adam_state_dict_round_trip_and_torch_checkpoint():
+    torch.manual_seed(3)
+    x = torch.rand(2, 1, 32, 32).cuda()
+    y = (torch.rand(2, 1, 32, 32) > 0.5).float().cuda()
+
+    def run(n_before, reload_, opt_cls_first=Adam):
+        m, sd = _model(nf=4)
+        opt = opt_cls_first(m.parameters(), lr=1e-3)
+        for _ in range(n_before):
+            opt.zero_grad()
+            O.bce_dice_loss(m(x)[1], y).backward()
+            opt.step()
+        if reload_:
+            state = copy.deepcopy(opt.state_dict())
+            opt = Adam(m.parameters(), lr=1e-3)
+            opt.load_state_dict(state)                   # new moment tensors; torch.optim.Adam stores `step` as a tensor
+        for _ in range(2):
+            opt.zero_grad()
+            O.bce_dice_loss(m(x)[1], y).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    straight = run(1, False)
+    for first in (Adam, torch.optim.Adam):
+        again = run(1, True, first)
+        for k, v in straight.items():
+            if v.is_floating_point() and not (k.endswith(".0.bias") and not k.startswith("final")):
+                torch.testing.assert_close(again[k], v, rtol=1e-4, atol=2e-5, msg=lambda s: f"{first.__name__} {k}: {s}")
+
+
+def test_dtype_cast_is_refused_and_copies_drop_engines():
+    m, _ = _model(nf=4)
+    x = torch.rand(1, 1, 32, 32).cuda()
+    m(x)
+    m2 = copy.deepcopy(m)                                # after a forward: engines hold ctypes structs
+    assert len(m2._engines) == 0
+    with torch.no_grad():
+        torch.testing.assert_close(m2(x)[1], m(x)[1])
+    import io
+    buf = io.BytesIO()
+    torch.save(m, buf)                                   # whole-module pickle
+    mh = copy.deepcopy(m).half()
+    with pytest.raises(RuntimeError, match="set_compute_dtype"):
+        mh(x)

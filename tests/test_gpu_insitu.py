@@ -1,0 +1,79 @@
+"""Whole-network steps verified kernel call by kernel call on the operands the engine actually holds (tests/insitu.py):
+the sharp form of network parity -- ~1 ulp of the storage type per call, in fp32 AND bf16 -- that a comparison of final
+gradients cannot give (discrete LeakyReLU / max-pool decisions, chaotic bf16 rounding; see profiles/r02_bf16_error_budget.md).
+
+Shapes are the MFMA widths of the BASELINE configs at reduced extent: cfg2 (Unet F=64, 2 outputs), cfg3 (Siam 'max' F=32),
+cfg4 (UNet3D F=32), cfg5 (MultiOutputUnet3D, 3 heads, both up-sampling modes; F=32 keeps the 16-channel layers of cfg4 and
+the stacked-head backward), plus Siam 'concat' (two-source bottleneck join)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import bio_image_unet_amd as B  # noqa: E402
+from oracle import unet_oracle as O  # noqa: E402
+from tests import insitu  # noqa: E402
+
+HEADS = {"seg": {"channels": 1, "activation": "sigmoid"}, "flow": {"channels": 2, "activation": None},
+         "dist": {"channels": 1, "activation": "tanh"}}
+
+CASES = {
+    "unet2d_f16": (lambda: B.Unet(1, 1, 16), lambda: O.init_unet2d(1, 1, 16, seed=3), (2, 1, 64, 64), 1),
+    "cfg2_unet2d_f64_o2": (lambda: B.Unet(1, 2, 64), lambda: O.init_unet2d(1, 2, 64, seed=4), (2, 1, 64, 64), 1),
+    "cfg3_siam_max_f32": (lambda: B.Siam_UNet(32, "max"), lambda: O.init_unet2d(1, 1, 32, seed=5, init_weights=False), (2, 1, 64, 64), 2),
+    "siam_concat_f16": (lambda: B.Siam_UNet(16, "concat"), lambda: O.init_unet2d(1, 1, 16, seed=6, init_weights=False, siam_mode="concat"), (2, 1, 64, 64), 2),
+    "cfg4_unet3d_f32": (lambda: B.UNet3D(1, 1, 32), lambda: O.init_unet3d(1, 1, 32, seed=7), (2, 1, 16, 32, 32), 1),
+    "cfg5_mo3d_f32_interp": (lambda: B.MultiOutputUnet3D(1, HEADS, 32, True), lambda: O.init_mo3d(1, HEADS, 32, True, seed=8), (1, 1, 16, 32, 32), 1),
+    "cfg5_mo3d_f32_convT": (lambda: B.MultiOutputUnet3D(1, HEADS, 32, False), lambda: O.init_mo3d(1, HEADS, 32, False, seed=9), (1, 1, 16, 32, 32), 1),
+}
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", list(CASES))
+def test_every_kernel_call_of_a_train_step(case, dtype, capsys):
+    mk, init, shape, nin = CASES[case]
+    torch.manual_seed(0)
+    m = mk().cuda()
+    m.load_state_dict(init())
+    if dtype == "bf16":
+        m.set_compute_dtype(torch.bfloat16)
+    m.train()
+    xs = [torch.rand(*shape).cuda() for _ in range(nin)]
+    chk = insitu.attach(m, xs, dtype == "bf16")
+    outs = m(*xs)
+    if isinstance(outs, dict):
+        tg = {k: torch.rand_like(v) for k, v in outs.items()}
+        loss = sum(((outs[k] - tg[k]) ** 2).mean() * w for k, w in (("seg", 1.0), ("flow", 0.5), ("dist", 0.25)))
+    else:
+        y = (torch.rand_like(outs[1]) > 0.5).float()
+        loss = O.bce_dice_loss(outs[1], y) + 0.05 * outs[0].mean()          # both outputs carry gradient
+    loss.backward()
+    torch.cuda.synchronize()
+    w = chk.rep.worst()
+    with capsys.disabled():
+        print(f"\n[insitu {case} {dtype}] {len(chk.rep.rows)} checks, worst: {w[0]} / {w[1]} = {w[2]:.3f}x tolerance, {w[3]:.6f} within")
+    assert len(chk.rep.rows) > 100
+    assert not chk.failures, "\n".join(chk.failures[:20]) + "\n" + chk.rep.table()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_every_kernel_call_of_an_eval_forward(dtype):
+    """Eval mode: running statistics, no statistics epilogue -- the other form of every forward kernel."""
+    torch.manual_seed(1)
+    m = B.UNet3D(1, 1, 32).cuda()
+    sd = O.init_unet3d(1, 1, 32, seed=7)
+    for k in sd:
+        if k.endswith("running_mean"):
+            sd[k] = torch.randn_like(sd[k]) * 0.1
+        if k.endswith("running_var"):
+            sd[k] = torch.rand_like(sd[k]) + 0.5
+    m.load_state_dict(sd)
+    if dtype == "bf16":
+        m.set_compute_dtype(torch.bfloat16)
+    m.eval()
+    x = torch.rand(1, 1, 16, 32, 32).cuda()
+    chk = insitu.attach(m, [x], dtype == "bf16")
+    with torch.no_grad():
+        m(x)
+    assert len(chk.rep.rows) > 30
+    assert not chk.failures, "\n".join(chk.failures[:20])

@@ -1,8 +1,8 @@
 """Whole-network parity on the GPU: the HIP engine against the CPU oracle (pinned to the reference by
 tests/golden) on the golden inputs themselves and on larger seeded cases.
 
-Tolerance (north_star): 1e-3 relative in fp32, stated per assertion below; thresholded masks must agree wherever
-the oracle's |logit| exceeds the tolerance band.  bf16: storage is 8-bit mantissa -> 5e-2 of the tensor's max."""
+Tolerance (north_star): 1e-3 relative in fp32, stated per assertion below; thresholded masks are bit-exact on the golden
+cases.  bf16: storage is 8-bit mantissa -> 5e-2 of the tensor's max, masks equal outside that band."""
 import pytest
 import torch
 
@@ -50,8 +50,9 @@ def test_golden_train_step_fp32(case):
     od = outs if isinstance(outs, dict) else dict(zip(("prob", "logits"), outs))
     for k in names:
         assert relerr(od[k].detach().cpu(), g["train"][k]) < REL, f"train.{k}"
-    if "logits" in od:
-        assert masks_agree(od["logits"].detach().cpu(), g["train"]["logits"], REL * float(g["train"]["logits"].abs().max()))
+    if "logits" in od:       # argmax masks bit-exact (north star): thresholded logits equal at EVERY voxel
+        assert torch.equal(od["logits"].detach().cpu() > 0, g["train"]["logits"] > 0), "fp32 masks differ from the reference"
+        assert torch.equal(od["prob"].detach().cpu() > 0.5, g["train"]["prob"] > 0.5)
     gi = {"meta": meta, "in": {k: v.cuda() for k, v in g["in"].items()}}
     loss = oracle_loss(gi, od)
     assert abs(float(loss) - float(g["loss"])) < REL * max(1.0, abs(float(g["loss"])))
@@ -73,110 +74,250 @@ def test_golden_train_step_fp32(case):
     oe = outs_e if isinstance(outs_e, dict) else dict(zip(("prob", "logits"), outs_e))
     for k, v in g["eval"].items():
         assert relerr(oe[k].cpu(), v) < REL, f"eval.{k}"
+    if "logits" in oe:
+        assert torch.equal(oe["logits"].cpu() > 0, g["eval"]["logits"] > 0), "fp32 eval masks differ from the reference"
 
 
-def _oracle_run(kind, sd, x, y, dt, perturb=0.0, **kw):
-    osd = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
-    if perturb:
-        g = torch.Generator().manual_seed(7)
-        for k in osd:
-            if k.endswith(".0.weight"):
-                osd[k] = osd[k] * (1 + perturb * torch.randn(osd[k].shape, generator=g, dtype=dt))
-    osd = O.clone_state(osd, requires_grad=True)
-    if kind == "siam_concat":
-        prob, logits = O.siam_forward(osd, x[0].to(dt), x[1].to(dt), mode="concat", training=True)
+# ------------------------------------------------------------------------------------------------------------------
+# seeded mid-size networks at the MFMA widths of the BASELINE configs
+# ------------------------------------------------------------------------------------------------------------------
+HEADS = {"seg": {"channels": 1, "activation": "sigmoid"}, "flow": {"channels": 2, "activation": None},
+         "dist": {"channels": 1, "activation": "tanh"}}
+
+# kind -> (product ctor, oracle init, oracle forward(sd, xs, training) -> dict of outputs, input shape, number of inputs)
+KINDS = {
+    "unet2d_f16": (lambda: B.Unet(1, 1, 16), lambda s: O.init_unet2d(1, 1, 16, seed=s), "unet2d", (2, 1, 128, 128), 1),
+    "cfg1_unet2d_f32": (lambda: B.Unet(1, 1, 32), lambda s: O.init_unet2d(1, 1, 32, seed=s), "unet2d", (2, 1, 256, 256), 1),       # cfg1 verbatim
+    "cfg2_unet2d_f64_o2": (lambda: B.Unet(1, 2, 64), lambda s: O.init_unet2d(1, 2, 64, seed=s), "unet2d", (2, 1, 64, 64), 1),        # cfg2 widths
+    "cfg3_siam_max_f32": (lambda: B.Siam_UNet(32, "max"), lambda s: O.init_unet2d(1, 1, 32, seed=s, init_weights=False), "siam_max", (2, 1, 64, 64), 2),
+    "siam_concat_f16": (lambda: B.Siam_UNet(16, "concat"), lambda s: O.init_unet2d(1, 1, 16, seed=s, init_weights=False, siam_mode="concat"), "siam_concat", (2, 1, 64, 64), 2),
+    "cfg4_unet3d_f32": (lambda: B.UNet3D(1, 1, 32), lambda s: O.init_unet3d(1, 1, 32, seed=s), "unet3d", (2, 1, 16, 32, 32), 1),
+    "cfg5_mo3d_f32_interp": (lambda: B.MultiOutputUnet3D(1, HEADS, 32, True), lambda s: O.init_mo3d(1, HEADS, 32, True, seed=s), "mo3d_interp", (1, 1, 16, 32, 32), 1),
+    "cfg5_mo3d_f32_convT": (lambda: B.MultiOutputUnet3D(1, HEADS, 32, False), lambda s: O.init_mo3d(1, HEADS, 32, False, seed=s), "mo3d_convT", (1, 1, 16, 32, 32), 1),
+}
+
+
+def _oracle_forward(fkind, sd, xs, training):
+    if fkind == "unet2d":
+        return dict(zip(("prob", "logits"), O.unet2d_forward(sd, xs[0], training=training)))
+    if fkind == "unet3d":
+        return dict(zip(("prob", "logits"), O.unet3d_forward(sd, xs[0], training=training)))
+    if fkind.startswith("siam"):
+        return dict(zip(("prob", "logits"), O.siam_forward(sd, xs[0], xs[1], mode=fkind.split("_")[1], training=training)))
+    return O.mo3d_forward(sd, xs[0], HEADS, use_interpolation=fkind.endswith("interp"), training=training)
+
+
+def _loss(outs, tg):
+    if "logits" in outs:
+        return O.bce_dice_loss(outs["logits"], tg["y"])
+    return sum(((outs[k] - tg[k]) ** 2).mean() * w for k, w in (("seg", 1.0), ("flow", 0.5), ("dist", 0.25)))
+
+
+def _problem(kind, seed):
+    mk, init, fkind, shape, nin = KINDS[kind]
+    g = torch.Generator().manual_seed(100 + seed)
+    xs = [torch.rand(*shape, generator=g) for _ in range(nin)]
+    if fkind.startswith("mo3d"):
+        tg = {k: torch.rand((shape[0], v["channels"]) + tuple(shape[2:]), generator=g) for k, v in HEADS.items()}
     else:
-        fwd = O.unet2d_forward if kind == "unet2d" else O.unet3d_forward
-        prob, logits = fwd(osd, x.to(dt), training=True, **kw)
-    loss = O.bce_dice_loss(logits, y.to(dt))
-    return logits.detach(), loss.detach(), O.grads_of(loss, osd), osd
+        oc = 2 if "o2" in kind else 1
+        tg = {"y": (torch.rand((shape[0], oc) + tuple(shape[2:]), generator=g) > 0.5).float()}
+    return mk, init(3 + seed), fkind, xs, tg
 
 
-def _grad_errors(grads, truth):
-    gscale = max(float(v.abs().max()) for v in truth.values())
-    out = {}
-    for k, want in truth.items():
-        got = grads[k].double()
-        e = float((got - want).abs().max()) / (float(want.abs().max()) + 1e-2 * gscale)
-        cos = float((got * want).sum() / (got.norm() * want.norm() + 1e-300))
-        out[k] = (e, cos)
-    return out
+def _oracle_run(fkind, sd, xs, tg, dt, emu=False):
+    osd = O.clone_state({k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in sd.items()}, requires_grad=True)
+    with O.emulate_bf16(emu):
+        outs = _oracle_forward(fkind, osd, [x.to(dt) for x in xs], True)
+        loss = _loss(outs, {k: v.to(dt) for k, v in tg.items()})
+        grads = O.grads_of(loss, osd)
+    return {k: v.detach() for k, v in outs.items()}, loss.detach(), grads, osd
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("kind,nf,shape", [("unet2d", 16, (2, 1, 128, 128)), ("unet3d", 32, (2, 1, 16, 32, 32)),
-                                           ("siam_concat", 16, (2, 1, 64, 64))])
-def test_seeded_midsize_vs_oracle(kind, nf, shape, dtype):
-    """Channel counts that are multiples of 16 -- the shapes the MFMA implicit-GEMM kernels serve.
-
-    Forward outputs keep the plain 1e-3 bound against the fp32 oracle.  Gradients of this network are intrinsically
-    ill-conditioned (train-mode BatchNorm after every conv): in exact fp64 arithmetic a 1e-6 relative perturbation of
-    the conv weights -- the size of one fp32 convolution's rounding error -- already moves individual parameter
-    gradients by up to ~7e-3 of their scale, and the reference's own fp32 CPU path is up to ~5e-3 away from the fp64
-    gradient.  So the yardstick is the fp64 oracle and the fp32 bar is conditioning-aware:
-        err_k <= 1e-3 + 3 * max(sensitivity_k(2e-6 perturbation), reference-fp32 error_k)."""
-    torch.manual_seed(0)
-    x = torch.rand(*shape)
-    y = (torch.rand(*shape) > 0.5).float()
-    if kind == "unet2d":
-        sd = O.init_unet2d(1, 1, nf, seed=3)
-        m = B.Unet(1, 1, nf)
-    elif kind == "siam_concat":           # two frames; bottleneck join and three decoder levels go through the two-source kernels
-        sd = O.init_unet2d(1, 1, nf, seed=3, siam_mode="concat")
-        m = B.Siam_UNet(nf, mode="concat")
-        x = torch.stack([x, torch.rand(*shape)])
-    else:
-        sd = O.init_unet3d(1, 1, nf, seed=3)
-        m = B.UNet3D(1, 1, nf)
-    ref_logits, ref_loss, ref_grads, osd = _oracle_run(kind, sd, x, y, torch.float32)
-    _, _, true_grads, _ = _oracle_run(kind, sd, x, y, torch.float64)
-    _, _, pert_grads, _ = _oracle_run(kind, sd, x, y, torch.float64, perturb=2e-6)
-    sens = _grad_errors(pert_grads, true_grads)
-    m = m.cuda()
+def _hip_run(mk, sd, xs, tg, dtype):
+    m = mk().cuda()
     m.load_state_dict(sd)
     if dtype == "bf16":
         m.set_compute_dtype(torch.bfloat16)
     m.train()
-    prob, logits = m(x[0].cuda(), x[1].cuda()) if kind == "siam_concat" else m(x.cuda())
-    loss = O.bce_dice_loss(logits, y.cuda())
+    outs = m(*[x.cuda() for x in xs])
+    od = outs if isinstance(outs, dict) else dict(zip(("prob", "logits"), outs))
+    loss = _loss(od, {k: v.cuda() for k, v in tg.items()})
     loss.backward()
-    rel = REL if dtype == "f32" else 5e-2
-    e = relerr(logits.detach().cpu(), ref_logits)
-    assert e < rel, f"logits rel err {e}"
-    assert masks_agree(logits.detach().cpu(), ref_logits, rel * float(ref_logits.abs().max()))
-    assert abs(float(loss) - float(ref_loss)) < rel
-    mine = _grad_errors({k: p.grad.cpu() for k, p in m.named_parameters()}, true_grads)
-    cpu32 = _grad_errors(ref_grads, true_grads)
-    top = sorted(mine.items(), key=lambda kv: -kv[1][0])[:5]
-    print("worst HIP gradient errors vs fp64 (err, cos):", top)
-    print("worst CPU-fp32 gradient errors vs fp64:", sorted(cpu32.items(), key=lambda kv: -kv[1][0])[:3])
-    print("worst fp64 sensitivity to a 2e-6 weight perturbation:", sorted(sens.items(), key=lambda kv: -kv[1][0])[:3])
-    if dtype == "f32":
-        for k, (err, cos) in mine.items():
-            bound = REL + 3 * max(sens[k][0], cpu32[k][0])
-            assert err <= bound, f"grad {k}: err {err} > {bound} (sensitivity {sens[k][0]}, reference-fp32 err {cpu32[k][0]})"
-            if float(true_grads[k].abs().max()) > 1e-3 * max(float(v.abs().max()) for v in true_grads.values()):
-                assert cos > 0.999, f"grad {k}: cosine {cos}"      # (conv biases before a BN have zero gradient)
-    else:
-        # bf16 storage of activations and activation gradients: direction must be right, magnitude within 35 %
-        for k, (err, cos) in mine.items():
-            if float(true_grads[k].abs().max()) > 1e-3 * max(float(v.abs().max()) for v in true_grads.values()):
-                assert cos > 0.85, f"grad {k}: cosine {cos}"
-            assert err < 0.4, f"grad {k}: err {err}"
+    torch.cuda.synchronize()
+    return m, {k: v.detach().cpu() for k, v in od.items()}, float(loss), {k: p.grad.cpu() for k, p in m.named_parameters()}
+
+
+def _dead(k):
+    """Conv biases in front of a train-mode BatchNorm: true gradient exactly 0 (the reference value is rounding noise)."""
+    return k.endswith(".0.bias") and not k.startswith("final")
+
+
+def _grad_errors(grads, truth):
+    """per parameter: (max-abs error / (max|truth| + 1e-2 of the largest gradient in the net), relative L2 error, cosine)"""
+    gscale = max(float(v.abs().max()) for v in truth.values())
+    out = {}
+    for k, want in truth.items():
+        got, want = grads[k].double(), want.double()
+        e = float((got - want).abs().max()) / (float(want.abs().max()) + 1e-2 * gscale)
+        l2 = float((got - want).norm() / (want.norm() + 1e-3 * gscale * want.numel() ** 0.5))
+        cos = float((got * want).sum() / (got.norm() * want.norm() + 1e-300))
+        out[k] = (e, l2, cos)
+    return out
+
+
+def _record(name, text):
+    """Measured errors go to gpurun_out/ (copied to profiles/ by hand when they are to be judged)."""
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, name), "a") as f:
+        f.write(text + "\n")
+
+
+@pytest.mark.parametrize("kind", list(KINDS))
+def test_midsize_fp32_vs_oracle(kind):
+    """fp32 engine against the fp64 oracle: outputs, loss, masks, BN buffers, eval forward and EVERY parameter gradient within
+    the north star's 1e-3 -- a flat bound, no conditioning terms.
+
+    The gradient of this network is piecewise: a LeakyReLU or max-pool decision that sits within fp32 rounding of its boundary
+    falls either way in ANY fp32 implementation (the reference's CPU path included: its own gradient is 1e-3 .. 2e-2 from the
+    fp64 one on most of these seeds), and one flipped voxel moves a bottleneck weight gradient by that much -- an event, not
+    an error level.  So the fp64 oracle is evaluated on the branch the engine took (``oracle.forced_decisions`` with the
+    masks / argmax indices read back from the engine's stored activations); forward values do not depend on that choice and
+    are compared with the free-running oracle."""
+    from tests import insitu
+    mk, sd, fkind, xs, tg = _problem(kind, 0)
+    m, outs, loss, grads = _hip_run(mk, sd, xs, tg, "f32")
+    q = insitu.extract_decisions(list(m._engines.values())[-1][-1])
+    f_outs, f_loss, _, osd = _oracle_run(fkind, sd, xs, tg, torch.float32)            # free-running fp32 oracle: the reference's arithmetic
+    with O.forced_decisions(q):
+        t_outs, t_loss, t_grads, _ = _oracle_run(fkind, sd, xs, tg, torch.float64)
+    with O.forced_decisions(q):
+        _, _, r_grads, _ = _oracle_run(fkind, sd, xs, tg, torch.float32)
+    for k, want in f_outs.items():
+        assert relerr(outs[k], want) < REL, f"{k} rel err {relerr(outs[k], want)}"
+        assert relerr(outs[k], t_outs[k].float()) < REL, f"{k} rel err vs fp64 {relerr(outs[k], t_outs[k].float())}"
+    if "logits" in outs:
+        assert masks_agree(outs["logits"], t_outs["logits"].float(), 1e-5 * float(t_outs["logits"].abs().max()))
+    assert abs(loss - float(f_loss)) < REL * max(1.0, abs(float(f_loss)))
+    mine, cpu32 = _grad_errors(grads, t_grads), _grad_errors(r_grads, t_grads)
+    gmax = max(float(v.abs().max()) for v in t_grads.values())
+    rows = sorted(((v[0], k, cpu32[k][0], v[2]) for k, v in mine.items() if not _dead(k)), reverse=True)
+    _record("parity_fp32_grad_errors.txt", f"{kind}: worst " + "; ".join(f"{k} {e:.2e} (cpu32 {c:.2e})" for e, k, c, _ in rows[:6]))
+    for e, k, c, cos in rows:
+        assert e <= REL, f"grad {k}: err {e} > 1e-3 (CPU fp32 on the same branch: {c})"
+        if float(t_grads[k].abs().max()) > 1e-3 * gmax:
+            assert cos > 0.99999, f"grad {k}: cosine {cos}"
     for k in sd:
         if "running_" in k:
-            torch.testing.assert_close(m.state_dict()[k].cpu(), osd[k].detach(), rtol=rel, atol=rel)
-    # eval-mode forward (running statistics; no-statistics form of every kernel, including the two-source ones)
-    m.eval()
+            torch.testing.assert_close(m.state_dict()[k].cpu(), osd[k].detach(), rtol=REL, atol=REL)
+    m.eval()                # eval-mode forward from the updated buffers (no-statistics form of every kernel)
     with torch.no_grad():
-        _, le = m(x[0].cuda(), x[1].cuda()) if kind == "siam_concat" else m(x.cuda())
-        od = {k: v.detach() for k, v in osd.items()}
-        if kind == "siam_concat":
-            _, re_ = O.siam_forward(od, x[0], x[1], mode="concat", training=False)
-        else:
-            _, re_ = (O.unet2d_forward if kind == "unet2d" else O.unet3d_forward)(od, x, training=False)
-    e = relerr(le.cpu(), re_)
-    assert e < (2e-3 if dtype == "f32" else 6e-2), f"eval logits rel err {e}"
+        oe = m(*[x.cuda() for x in xs])
+        oe = oe if isinstance(oe, dict) else dict(zip(("prob", "logits"), oe))
+        re_ = _oracle_forward(fkind, {k: v.detach() for k, v in osd.items()}, xs, False)
+    for k, want in re_.items():
+        assert relerr(oe[k].cpu(), want) < 2e-3, f"eval {k}"
+
+
+@pytest.mark.parametrize("kind", list(KINDS))
+def test_midsize_bf16_vs_oracle(kind):
+    """bf16 engine (bf16 storage of activations, gradients and MFMA operands; fp32 accumulation).
+
+    What bf16 storage costs is a property of the network, not of the kernels: the oracle's own bf16-storage emulation
+    (pure torch CPU, rounding where the engine stores / packs bf16) is 15 - 40 % (relative L2) away from the fp64 gradient
+    on these problems, all of it from rounding the forward values (rounding only the gradients costs 0.7 %), and fp64
+    arithmetic with the conv weights perturbed by 2^-9 -- one bf16 rounding -- is already 14 % away
+    (profiles/r02_bf16_error_budget.md).  Two correct bf16 implementations also differ from each other at that level
+    (rounding is chaotic), so the sharp per-kernel statement for bf16 is tests/test_gpu_insitu.py; here:
+      * outputs within 8e-2 (worst element) of the fp64 oracle, rms deviation <= 1.5 x the emulation's, masks equal outside a 5e-2 band;
+      * the engine is no further from the fp64 gradient than bf16 storage itself puts the emulation:
+        per parameter L2 error <= 1.6 x the emulation's + 0.03, over all parameters (rms) <= 1.25 x."""
+    mk, sd, fkind, xs, tg = _problem(kind, 0)
+    t_outs, t_loss, t_grads, _ = _oracle_run(fkind, sd, xs, tg, torch.float64)
+    e_outs, e_loss, e_grads, _ = _oracle_run(fkind, sd, xs, tg, torch.float32, emu=True)
+    m, outs, loss, grads = _hip_run(mk, sd, xs, tg, "bf16")
+    for k, want in t_outs.items():
+        assert relerr(outs[k], want.float()) < 8e-2, f"{k} rel err {relerr(outs[k], want.float())}"     # worst element, of the tensor's max
+        d_h = float((outs[k].double() - want).pow(2).mean().sqrt())
+        d_e = float((e_outs[k].double() - want).pow(2).mean().sqrt())
+        assert d_h <= 1.5 * d_e + 1e-3 * float(want.abs().max()), f"{k}: rms deviation {d_h} vs the emulation's {d_e}"
+    if "logits" in outs:
+        assert masks_agree(outs["logits"], t_outs["logits"].float(), 5e-2 * float(t_outs["logits"].abs().max()))
+    assert abs(loss - float(t_loss)) < 5e-2
+    mine, emu = _grad_errors(grads, t_grads), _grad_errors(e_grads, t_grads)
+    gmax = max(float(v.abs().max()) for v in t_grads.values())
+    num = den = 0.0
+    rows = []
+    for k, (e, l2, cos) in mine.items():
+        if _dead(k):
+            continue
+        rows.append((l2, k, emu[k][1], cos, emu[k][2]))
+        assert l2 <= 1.6 * emu[k][1] + 0.03, f"grad {k}: L2 error {l2} vs the bf16 emulation's {emu[k][1]}"
+        if float(t_grads[k].abs().max()) > 1e-3 * gmax:
+            assert cos >= min(0.99, emu[k][2] - 0.05), f"grad {k}: cosine {cos} vs the emulation's {emu[k][2]}"
+        num += l2 * l2
+        den += emu[k][1] ** 2
+    rows.sort(reverse=True)
+    ratio = (num / max(den, 1e-30)) ** 0.5
+    _record("parity_bf16_grad_errors.txt", f"{kind}: rms L2-error ratio engine/emulation {ratio:.3f}; worst " +
+            "; ".join(f"{k} l2 {a:.3f} (emu {b:.3f}) cos {c:.4f} (emu {d:.4f})" for a, k, b, c, d in rows[:5]))
+    assert ratio <= 1.25, f"engine gradients are {ratio:.2f}x as far from fp64 as bf16 storage itself explains"
+
+
+def _blobs(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    z = torch.randn(shape, generator=g)
+    k = torch.ones(1, 1, 9, 9) / 81
+    for _ in range(2):
+        z = torch.nn.functional.conv2d(z, k, padding=4)
+    return z / z.std()
+
+
+def test_training_curves_fp32_bf16_oracle():
+    """25 Adam steps on a learnable problem (noisy blobs -> blob mask): the bf16 engine's loss curve follows the fp32
+    engine's, which follows the CPU oracle's (unet/train.py:130-139 loop: forward, BCEDice, zero_grad, backward, step)."""
+    from bio_image_unet_amd.optim import Adam
+    shape, nf, steps = (4, 1, 64, 64), 16, 25
+    b = _blobs(shape, 1)
+    x = ((b - b.min()) / (b.max() - b.min()) + 0.1 * torch.randn(shape, generator=torch.Generator().manual_seed(2))).clamp(0, 1)
+    y = (b > 0.3).float()
+    sd = O.init_unet2d(1, 1, nf, seed=3)
+    osd = O.clone_state(sd, requires_grad=True)
+    opt = torch.optim.Adam([v for v in osd.values() if v.requires_grad], lr=1e-3)
+    ref = []
+    for _ in range(steps):
+        _, lg = O.unet2d_forward(osd, x, training=True)
+        loss = O.bce_dice_loss(lg, y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        ref.append(float(loss))
+    curves = {}
+    for dtype in ("f32", "bf16"):
+        m = B.Unet(1, 1, nf).cuda()
+        m.load_state_dict(sd)
+        if dtype == "bf16":
+            m.set_compute_dtype(torch.bfloat16)
+        m.train()
+        o = Adam(m.parameters(), lr=1e-3)
+        xc, yc = x.cuda(), y.cuda()
+        cur = []
+        for _ in range(steps):
+            loss = O.bce_dice_loss(m(xc)[1], yc)
+            o.zero_grad()
+            loss.backward()
+            o.step()
+            cur.append(float(loss))
+        curves[dtype] = cur
+    _record("parity_training_curves.txt", "oracle " + " ".join(f"{v:.4f}" for v in ref) + "\nfp32   " + " ".join(f"{v:.4f}" for v in curves["f32"]) +
+            "\nbf16   " + " ".join(f"{v:.4f}" for v in curves["bf16"]))
+    assert ref[-1] < 0.7 * ref[0], "the problem must be learnable"
+    for t in range(steps):
+        assert abs(curves["f32"][t] - ref[t]) <= (0.005 if t < 10 else 0.03) * ref[0], f"fp32 step {t}: {curves['f32'][t]} vs oracle {ref[t]}"
+        assert abs(curves["bf16"][t] - curves["f32"][t]) <= 0.04 * ref[0], f"bf16 step {t}: {curves['bf16'][t]} vs fp32 {curves['f32'][t]}"
+    assert curves["bf16"][-1] < 0.7 * curves["bf16"][0]
 
 
 def test_divisibility_errors_match_reference():

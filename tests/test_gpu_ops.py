@@ -777,6 +777,15 @@ def test_conv_cat_forms_match_concat_buffer(case, dtype):
     check(lib.biu_conv_fwd_cat(d0.a(), xf0.x(), d1.a(), None, ptr(wd), ptr(pk0), ptr(bd), kd, 3, 3, 1, yb.a(), ptr(pb), nfl, C.byref(nb), code,
                                stream()), "fwd_cat")
     assert torch.equal(ya.buf, yb.buf)
+    # ... and against torch: conv of the concatenation of the two transformed sources (operands as the MFMA kernel packs them)
+    q = (lambda t: t.bfloat16().float()) if dtype == "bf16" else (lambda t: t)
+    r0, r1 = (d.ref().squeeze(2) if nd == 2 else d.ref() for d in (d0, d1))
+    xa = q(torch.cat([xf0.apply(r0), r1], 1)).requires_grad_(True)
+    wq = q(w).requires_grad_(True)
+    yref = conv_ref(xa, wq, b, 1)
+    tl = (lambda ref, k=1.0: dict(rtol=1e-4 * k, atol=1e-4 * k * float(ref.abs().max()))) if dtype == "f32" else \
+         (lambda ref, k=1.0: dict(rtol=1e-2 * k, atol=1e-2 * k * float(ref.abs().max())))
+    torch.testing.assert_close(yb.get(squeeze2d=(nd == 2)), yref.detach(), **tl(yref))
     sa = pa[:na.value * cout * 2].view(na.value, cout, 2).double().sum(0)
     sb = pb[:nb.value * cout * 2].view(nb.value, cout, 2).double().sum(0)
     torch.testing.assert_close(sb, sa, rtol=1e-5, atol=1e-5 * float(sa.abs().max()))
@@ -788,6 +797,10 @@ def test_conv_cat_forms_match_concat_buffer(case, dtype):
     g0, g1 = Dev(shape=d0.buf.permute(0, 4, 1, 2, 3).shape, dtype=dtype), Dev(base1, dtype=dtype)
     check(lib.biu_conv_bwd_data_cat(gd.a(), ptr(wd), ptr(pk1), kd, 3, 3, 1, g0.a(), 0, g1.a(), 1, code, stream()), "dgrad_cat")
     assert torch.equal(g0.buf, dxc.buf[..., :c0])
+    gr = gd.ref().squeeze(2) if nd == 2 else gd.ref()
+    (gx_ref,) = torch.autograd.grad(yref, xa, gr, retain_graph=True)                 # torch: data gradient of the concatenation
+    torch.testing.assert_close(g0.get(squeeze2d=(nd == 2)), gx_ref[:, :c0], **tl(gx_ref))
+    torch.testing.assert_close(g1.get(squeeze2d=(nd == 2)), gx_ref[:, c0:] + Dev(base1, dtype=dtype).get(squeeze2d=(nd == 2)), **tl(gx_ref, 2.0))
     want1 = (dxc.buf[..., c0:].float() + Dev(base1, dtype=dtype).buf.float())
     torch.testing.assert_close(g1.buf.float(), want1, rtol=2e-2 if dtype == "bf16" else 1e-5, atol=(2e-2 if dtype == "bf16" else 1e-5) * float(want1.abs().max()))
     # weight gradient, plain and with the fused BatchNorm backward
@@ -798,6 +811,8 @@ def test_conv_cat_forms_match_concat_buffer(case, dtype):
     check(lib.biu_conv_bwd_weight_cat(d0.a(), xf0.x(), d1.a(), None, gd.a(), None, None, None, None, None, None, None, kd, 3, 3, 1, ptr(dwb),
                                       ptr(ws), wsz, code, stream()), "wgrad_cat")
     torch.testing.assert_close(dwb, dwa, rtol=1e-4, atol=1e-5 * float(dwa.abs().max()))
+    (gw_ref,) = torch.autograd.grad(yref, wq, gr)                                    # torch: weight gradient over both sources
+    torch.testing.assert_close(dwb.cpu(), gw_ref, **tl(gw_ref, 2.0))
     yxf = XF(cout, seed=9)
     coef = [t.cuda() for t in ((rnd(cout, seed=10) * 0.3 + 1.0), rnd(cout, seed=11) * 0.05, rnd(cout, seed=12) * 0.05)]
     da0 = rnd(*yshape, seed=13).squeeze(2) if nd == 2 else rnd(*yshape, seed=13)
@@ -808,3 +823,15 @@ def test_conv_cat_forms_match_concat_buffer(case, dtype):
                                       ptr(coef[1]), ptr(coef[2]), kd, 3, 3, 1, ptr(dwb), ptr(ws), wsz, code, stream()), "wgrad_bn_cat")
     assert torch.equal(daa.buf, dab.buf)
     torch.testing.assert_close(dwb, dwa, rtol=1e-4, atol=1e-5 * float(dwa.abs().max()))
+    # torch: dy = cA * da * T'(scale*y+shift) + cB * y + cC on the stored operands, then the weight gradient w.r.t. it
+    yr = ya.ref()
+    dar = Dev(da0, dtype=dtype).ref()
+    shp = (1, -1, 1, 1, 1)
+    tt = yxf.scale.view(shp) * yr + yxf.shift.view(shp)
+    dy_ref = coef[0].cpu().view(shp) * dar * torch.where(tt > 0, torch.ones_like(tt), yxf.slope.view(shp).expand_as(tt)) + \
+        coef[1].cpu().view(shp) * yr + coef[2].cpu().view(shp)
+    tb = dict(rtol=1e-5, atol=1e-5) if dtype == "f32" else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(dab.get(), dy_ref, **tb)
+    dyr2 = dab.get(squeeze2d=(nd == 2))                                              # the dy the kernel stored is what it multiplied
+    (gw2,) = torch.autograd.grad(conv_ref(xa.detach(), wq, None, 1), wq, dyr2)
+    torch.testing.assert_close(dwb.cpu(), gw2, **tl(gw2, 2.0))

@@ -72,6 +72,78 @@ def test_trainer2d_one_step_matches_oracle(tmp_path):
     assert worst < 2e-4, worst
 
 
+def _adam_update_matches(new, osd, sd0, tol=2e-4):
+    """After one Adam step every weight moved by lr * g / (|g| + eps) ~ lr * sign(g): compare the UPDATES of the entries whose
+    oracle gradient is well away from zero (an entry with |g| ~ eps moves by a rounding-dependent fraction of lr in the
+    reference too; conv biases in front of a BatchNorm have true gradient 0: a random +-lr walk there, exact 0 here)."""
+    worst = 0.0
+    for k, v in osd.items():
+        is_dead_bias = k.endswith(".0.bias") and not k.startswith("final")
+        if v.requires_grad and not is_dead_bias and v.grad is not None:
+            du_ref, du = v.detach() - sd0[k], new[k].cpu() - sd0[k]
+            big = v.grad.abs() > 1e-3 * float(v.grad.abs().max())
+            if big.any():
+                worst = max(worst, float((du - du_ref)[big].abs().max()))
+    assert worst < tol, worst
+
+
+def test_trainer3d_one_step_matches_oracle(tmp_path):
+    """unet3d/train.py:129-150: BCEDice + SmoothL1 between neighbouring BATCH entries * time_loss_weight, Adam."""
+    torch.manual_seed(0)
+    ds = Tiles(8, (8, 16, 16), ["volume"])
+    tr = unet3d.Trainer(ds, 1, batch_size=2, n_filter=8, save_dir=str(tmp_path), time_loss_weight=0.1, device="cuda")
+    sd0 = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
+    batch = next(iter(tr.train_loader))
+    osd = O.clone_state(sd0, requires_grad=True)
+    x, y = batch["volume"].view(2, 1, 8, 16, 16), batch["mask"].view(2, 1, 8, 16, 16)
+    _, ol = O.unet3d_forward(osd, x, training=True)
+    oloss = O.trainer3d_loss(ol, y, 0.1)
+    opt = torch.optim.Adam([v for v in osd.values() if v.requires_grad], lr=1e-3)
+    oloss.backward()
+    opt.step()
+    loss = tr._forward_loss(batch, validating=False)
+    assert abs(float(loss) - float(oloss)) < 1e-4
+    tr.optimizer.zero_grad()
+    loss.backward()
+    tr.optimizer.step()
+    torch.cuda.synchronize()
+    _adam_update_matches(tr.model.state_dict(), osd, sd0)
+    # validation hard-codes the time weight 0.1 whatever the trainer was given (unet3d/train.py:163-169)
+    tr.time_loss_weight = 0.7
+    with torch.no_grad():
+        v = tr._forward_loss(batch, validating=True)
+        t = tr._forward_loss(batch, validating=False)
+    assert float(t) > float(v)
+
+
+@pytest.mark.parametrize("mode", ["max", "concat"])
+def test_trainer_siam_one_step_matches_oracle(tmp_path, mode):
+    """siam_unet/train.py:100-114 with the Siam package's own BCEDice (BCELoss on sigmoid(logits), loss_params (1, 1)); no
+    init_weights (reference :61)."""
+    torch.manual_seed(0)
+    ds = Tiles(8, (32, 32), ["image", "prev_image"])
+    tr = siam.Trainer(ds, 1, batch_size=2, n_filter=8, mode=mode, save_dir=str(tmp_path), device="cuda")
+    assert type(tr.criterion).__name__ == "BCEDiceLossSiam" and siam.BCEDiceLoss is type(tr.criterion)
+    sd0 = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
+    batch = next(iter(tr.train_loader))
+    osd = O.clone_state(sd0, requires_grad=True)
+    x, px, y = (batch[k].view(2, 1, 32, 32) for k in ("image", "prev_image", "mask"))
+    _, ol = O.siam_forward(osd, x, px, mode=mode, training=True)
+    oloss = O.siam_bce_dice_loss(ol, y, 1.0, 1.0)
+    opt = torch.optim.Adam([v for v in osd.values() if v.requires_grad], lr=1e-3)
+    oloss.backward()
+    opt.step()
+    loss = tr._forward_loss(batch, validating=False)
+    assert abs(float(loss) - float(oloss)) < 1e-4
+    tr.optimizer.zero_grad()
+    loss.backward()
+    tr.optimizer.step()
+    torch.cuda.synchronize()
+    _adam_update_matches(tr.model.state_dict(), osd, sd0)
+    # BatchNorm buffers of the weight-shared encoder were updated twice (x, then prev_x)
+    assert int(tr.model.state_dict()["encode1.1.num_batches_tracked"]) == 2
+
+
 def test_trainers_run_and_checkpoint(tmp_path):
     torch.manual_seed(1)
     tr = unet.Trainer(Tiles(10, (32, 32), ["image"]), 2, batch_size=2, n_filter=4, save_dir=str(tmp_path / "a"), device="cuda")

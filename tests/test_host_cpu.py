@@ -204,3 +204,65 @@ def test_predict_mo3d_blend_cpu():
     np.testing.assert_allclose(p.result["a"], 0.1 + 0.5 * c, rtol=1e-5, atol=1e-6)
     assert p.result["b"].shape == (2, 12, 40, 24)
     np.testing.assert_allclose(p.result["b"][1], 0.2 + 0.5 * c, rtol=1e-5, atol=1e-6)
+
+
+def test_init_weights_kaiming_normal_on_conv2d_only():
+    """utils/utils.py:76-78: kaiming_normal_(nonlinearity='leaky_relu') (a = 0 => gain sqrt(2), fan_in) on nn.Conv2d weights
+    and nothing else: biases, Conv3d, ConvTranspose and BatchNorm keep PyTorch's defaults (Trainer.apply(init_weights))."""
+    import math
+    from torch import nn
+    from bio_image_unet_amd.utils import init_weights
+    torch.manual_seed(0)
+    mods = dict(c2=nn.Conv2d(64, 96, 3), c3=nn.Conv3d(8, 8, 3), t2=nn.ConvTranspose2d(8, 8, 2, 2), t3=nn.ConvTranspose3d(8, 8, 2, 2),
+                bn=nn.BatchNorm2d(8), c1=nn.Conv1d(4, 4, 3), lin=nn.Linear(4, 4))
+    before = {k: {n: p.detach().clone() for n, p in m.named_parameters()} for k, m in mods.items()}
+    for m in mods.values():
+        init_weights(m)
+    w = mods["c2"].weight.detach()
+    std = math.sqrt(2.0 / (64 * 9))
+    assert abs(float(w.std()) / std - 1) < 0.02 and abs(float(w.mean())) < 0.02 * std
+    kurt = float(((w - w.mean()) ** 4).mean() / w.var() ** 2)
+    assert 2.8 < kurt < 3.2, f"normal, not uniform (kurtosis {kurt})"
+    assert torch.equal(mods["c2"].bias, before["c2"]["bias"])
+    for k in ("c3", "t2", "t3", "bn", "c1", "lin"):
+        for n, p in mods[k].named_parameters():
+            assert torch.equal(p, before[k][n]), f"{k}.{n} was touched"
+    # through the module tree, as the trainers do: a 2-D net gets new conv weights (its 1x1 head included), a 3-D net none
+    import bio_image_unet_amd as B
+    torch.manual_seed(1)
+    m2, m3 = B.Unet(1, 1, 4), B.UNet3D(1, 1, 4)
+    b2 = {k: v.clone() for k, v in m2.state_dict().items()}
+    b3 = {k: v.clone() for k, v in m3.state_dict().items()}
+    m2.apply(init_weights)
+    m3.apply(init_weights)
+    changed = {k for k, v in m2.state_dict().items() if not torch.equal(v, b2[k])}
+    assert changed == {k for k in b2 if k.endswith(".0.weight")}, changed          # encode*/middle*/decode* convs and final.0
+    assert all(torch.equal(v, b3[k]) for k, v in m3.state_dict().items())
+
+
+def test_get_device_rule(monkeypatch, capsys):
+    """utils/utils.py:56-73: cuda:0 whenever torch was BUILT with CUDA/ROCm (even with no GPU visible), else mps, else cpu
+    with a warning."""
+    from bio_image_unet_amd.utils import get_device
+    monkeypatch.setattr(torch.backends.cuda, "is_built", lambda: True)
+    assert get_device() == torch.device("cuda:0")
+    get_device(print_device=True)
+    assert "Using device: cuda:0" in capsys.readouterr().out
+    monkeypatch.setattr(torch.backends.cuda, "is_built", lambda: False)
+    monkeypatch.setattr(torch.backends.mps, "is_built", lambda: True)
+    assert get_device() == torch.device("mps")
+    monkeypatch.setattr(torch.backends.mps, "is_built", lambda: False)
+    assert get_device() == torch.device("cpu")
+    assert "Warning" in capsys.readouterr().out
+
+
+def test_engine_cache_is_not_copied_or_pickled():
+    import copy, io
+    import bio_image_unet_amd as B
+    m = B.Unet(1, 1, 4)
+    m._engines[("fake",)] = [object()]
+    assert len(copy.deepcopy(m)._engines) == 0
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    assert len(torch.load(buf, weights_only=False)._engines) == 0

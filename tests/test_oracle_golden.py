@@ -37,8 +37,8 @@ def oracle_loss(g, outs):
         return O.trainer2d_loss(outs["logits"], g["in"]["target"], meta["ctor"]["out_channels"], criterion=crit)
     if meta["model"] == "UNet3D":
         return O.trainer3d_loss(outs["logits"], g["in"]["target"], 0.1)
-    if meta["model"] == "Siam_UNet":
-        return O.bce_dice_loss(outs["logits"], g["in"]["target"])
+    if meta["model"] == "Siam_UNet":       # the Siam package's own BCEDice (BCELoss on probabilities), loss_params (1, 1)
+        return O.siam_bce_dice_loss(outs["logits"], g["in"]["target"], 1.0, 1.0)
     tg = {k.split(".", 1)[1]: v for k, v in g["in"].items() if k.startswith("target.")}
     return sum(((outs[k] - tg[k]) ** 2).mean() * w for k, w in (("seg", 1.0), ("flow", 0.5), ("dist", 0.25)))
 
