@@ -59,7 +59,7 @@ def make_step(wl, device):
     x = torch.rand(shape, device=device)
     px = torch.rand(shape, device=device) if wl["model"] == "Siam_UNet" else None
     crit = BCEDiceLoss(0.5, 0.5)
-    smooth_l1 = torch.nn.SmoothL1Loss()
+    head_crit = BCEDiceLoss(1, 1)          # multi_output_unet3d/train.py: output_heads[name]['loss'] = 'BCEDiceLoss' -> BCEDiceLoss(1, 1)
     opt = Adam(model.parameters(), lr=1e-3)
     if wl["model"] == "MultiOutputUnet3D":
         tgt = {k: (torch.rand((shape[0], v["channels"]) + tuple(shape[2:]), device=device) > 0.5).float() for k, v in HEADS5.items()}
@@ -70,11 +70,12 @@ def make_step(wl, device):
         if wl["model"] == "Unet":            # unet/train.py:133-134 (indexes the batch axis with the channel index)
             oc = wl["out"]
             return sum(crit(outs[1][ch], y[ch]) for ch in range(oc)) / oc
-        if wl["model"] == "UNet3D":          # unet3d/train.py:140-145
-            return crit(outs[1], y) + smooth_l1(outs[1][1:], outs[1][:-1]) * 0.1
+        if wl["model"] == "UNet3D":          # unet3d/train.py:140-145: criterion + SmoothL1(logits[1:], logits[:-1]) * 0.1, one fused pass
+            return crit(outs[1], y, time_weight=0.1)
         if wl["model"] == "Siam_UNet":       # siam_unet/train.py:110
             return crit(outs[1], y)
-        return sum(torch.nn.functional.mse_loss(outs[k], tgt[k]) for k in outs)   # mo3d: weighted per-head losses
+        # multi_output_unet3d/train.py:183-195: per-head criterion on the (already activated) output, weighted sum (weights 1)
+        return sum(head_crit(outs[k], tgt[k]) for k in outs)
 
     def fwd():
         return model(x, px) if px is not None else model(x)
@@ -124,8 +125,40 @@ def call_cost(eng, api, label):
     return 0.0, 0.0
 
 
-def cpu_baseline(wl_name, budget_s=25.0):
-    """The oracle (CPU restatement of the reference path, fp32, torch CPU threads = host cores) on a bounded sample."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown CPU"
+
+
+def _time_oracle_steps(fwd, sd, shape, steps, budget_s, loss_of):
+    """fwd + loss + bwd + Adam on the CPU oracle; returns (best seconds per step, timed steps)."""
+    opt = torch.optim.Adam([v for v in sd.values() if v.requires_grad], lr=1e-3)
+    x = torch.rand(shape)
+    y = (torch.rand(shape) > 0.5).float()
+    times, t_start = [], time.time()
+    for i in range(steps + 1):
+        t0 = time.time()
+        _, logits = fwd(x)
+        loss = loss_of(logits, y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if i > 0:
+            times.append(time.time() - t0)
+        if time.time() - t_start > budget_s and times:
+            break
+    return min(times), len(times)
+
+
+def cpu_baseline(wl_name, budget_s=22.0):
+    """The oracle (CPU restatement of the reference path, fp32, torch CPU threads = host cores): cfg1 verbatim (SURVEY 8d:
+    Unet(1,1,32), 2 x 256^2, >= 5 timed steps) and a bounded sample of the benchmarked workload beside it."""
     from oracle import unet_oracle as O
     try:
         ncores = len(os.sched_getaffinity(0))
@@ -134,38 +167,23 @@ def cpu_baseline(wl_name, budget_s=25.0):
     ncores = min(ncores, 16)            # the GPU box's CPU share for one GPU is 16 cores
     torch.set_num_threads(ncores)
     torch.manual_seed(1234)
+    cpu = _cpu_model()
+    sd1 = O.clone_state(O.init_unet2d(1, 1, 32, seed=0), requires_grad=True)
+    t1, n1 = _time_oracle_steps(lambda x: O.unet2d_forward(sd1, x, training=True), sd1, (2, 1, 256, 256), 5, 8.0,
+                                lambda lg, y: O.trainer2d_loss(lg, y, 1))
+    cfg1 = {"value": 2 * 256 * 256 / t1, "unit": "voxels/s", "ms_per_step": t1 * 1e3,
+            "sample": f"cfg1 verbatim: Unet(1,1,32) oracle, (2,1,256,256) fp32, fwd+loss+bwd+Adam, best of {n1} timed steps"}
     if wl_name in ("cfg4", "cfg5"):
         sd = O.clone_state(O.init_unet3d(1, 1, 32, seed=0), requires_grad=True)
         shape = (1, 1, 64, 128, 128)
-        fwd = lambda x: O.unet3d_forward(sd, x, training=True)
-        name = "UNet3D(1,1,32) oracle, (1,1,64,128,128) fp32, fwd+loss+bwd+Adam"
+        t, n = _time_oracle_steps(lambda x: O.unet3d_forward(sd, x, training=True), sd, shape, 3, budget_s, O.bce_dice_loss)
+        name = "UNet3D(1,1,32) oracle, (1,1,64,128,128) fp32 (1/8 of one cfg4 batch entry x 1), fwd+loss+bwd+Adam"
+        nvox = 64 * 128 * 128
     else:
-        sd = O.clone_state(O.init_unet2d(1, 1, 32, seed=0), requires_grad=True)
-        shape = (2, 1, 256, 256)
-        fwd = lambda x: O.unet2d_forward(sd, x, training=True)
-        name = "Unet(1,1,32) oracle, (2,1,256,256) fp32, fwd+loss+bwd+Adam"
-    params = [v for v in sd.values() if v.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-3)
-    x = torch.rand(shape)
-    y = (torch.rand(shape) > 0.5).float()
-    nvox = x.numel()
-    times = []
-    t_start = time.time()
-    for i in range(4):
-        t0 = time.time()
-        _, logits = fwd(x)
-        loss = O.bce_dice_loss(logits, y)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        dt = time.time() - t0
-        if i > 0:
-            times.append(dt)
-        if time.time() - t_start > budget_s and times:
-            break
-    best = min(times)
-    return {"value": nvox / best, "unit": "voxels/s", "cores": ncores, "kind": "port",
-            "sample": f"{name}; {len(times)} timed steps after 1 warm-up, best {best:.3f} s/step; torch {torch.__version__} CPU threads={ncores}"}
+        t, n, name, nvox = t1, n1, cfg1["sample"], 2 * 256 * 256
+    return {"value": nvox / t, "unit": "voxels/s", "cores": ncores, "cpu": cpu, "kind": "port",
+            "sample": f"{name}; best of {n} timed steps after 1 warm-up ({t:.3f} s/step); torch {torch.__version__} CPU threads={ncores} on {cpu}",
+            "cfg1_verbatim": cfg1}
 
 
 def main():

@@ -5,6 +5,6 @@
 the C ABI of ``include/biu.h``; importing the package fails if ``libbiu_hip.so`` has not been built.
 """
 from . import _lib                      # noqa: F401  (raises ImportError when the HIP library is missing)
-from .models import MultiOutputUnet3D, Siam_UNet, UNet3D, Unet  # noqa: F401
+from .models import AttentionUnet, BabyUnet, MultiOutputUnet3D, Siam_UNet, UNet3D, Unet, Unet_v0  # noqa: F401
 
 __version__ = "0.1.0"

@@ -75,6 +75,10 @@ SIGNATURES = {
     "biu_bce_dice_blocks": (_I, [C.c_longlong]),
     "biu_bce_dice_fwd": (_I, [_P, _P, _I, C.c_longlong, _P, _P]),
     "biu_bce_dice_bwd": (_I, [_P, _P, _I, C.c_longlong, _P, _P, _I, _P]),
+    "biu_pair_smooth_l1_blocks": (_I, [C.c_longlong]),
+    "biu_pair_smooth_l1_fwd": (_I, [_P, _I, C.c_longlong, _P, _P]),
+    "biu_pair_smooth_l1_bwd": (_I, [_P, _I, C.c_longlong, _P, _P, _I, _P]),
+    "biu_head_dlogits": (_I, [_P, _P, _P, _I, _I, _I, C.c_longlong, _P, _I, _I, _P]),
     "biu_trilinear_up_fwd": (_I, [_A, _X, _A, _I, _P]),
     "biu_trilinear_up_bwd": (_I, [_A, _A, _I, _I, _P]),
     "biu_xcorr_fwd": (_I, [_A, _X, _A, _X, _A, _I, _P]),
@@ -96,6 +100,10 @@ SIGNATURES = {
     "biu_max_join_fwd": (_I, [_A, _X, _A, _X, _A, _I, _P]),
     "biu_max_join_bwd": (_I, [_A, _X, _A, _X, _A, _A, _A, _I, _I, _P]),
     "biu_act_add": (_I, [_A, _A, _I, _I, _P]),
+    "biu_add_relu_fwd": (_I, [_A, _X, _A, _X, _A, _I, _P]),
+    "biu_add_relu_bwd": (_I, [_A, _A, _A, _A, _I, _I, _P]),
+    "biu_gate_fwd": (_I, [_A, _X, _A, _X, _A, _I, _P]),
+    "biu_gate_bwd": (_I, [_A, _X, _A, _X, _A, _A, _I, _A, _I, _P]),
     "biu_from_nchw": (_I, [_P, _A, _I, _P]),
     "biu_to_nchw": (_I, [_A, _X, _P, _I, _P]),
     "biu_adam_step": (_I, [_I, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _F, _P]),

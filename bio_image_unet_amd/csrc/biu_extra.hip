@@ -252,7 +252,84 @@ __global__ __launch_bounds__(256) void k_bce_dice_bwd(const float* __restrict__ 
         dl[base + i] = g;
     }
 }
+
+// SmoothL1 (beta = 1, mean) between neighbouring BATCH entries of the logits -- the 3-D trainer's "time" term
+// nn.SmoothL1Loss()(y_logits[1:], y_logits[:-1]) (unet3d/train.py:140-145).  d_i = l[i+1] - l[i] for i < (n-1)*per_sample.
+__device__ __forceinline__ float sl1(float d) { const float a = fabsf(d); return a < 1.f ? 0.5f * d * d : a - 0.5f; }
+__device__ __forceinline__ float dsl1(float d) { return d > 1.f ? 1.f : (d < -1.f ? -1.f : d); }
+__global__ __launch_bounds__(256) void k_pair_sl1_fwd(const float* __restrict__ lg, i64 per_sample, i64 pairs, float* __restrict__ partial) {
+    float s = 0.f;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (i64)gridDim.x * blockDim.x) s += sl1(lg[i + per_sample] - lg[i]);
+    __shared__ float red[16];
+    const float r = block_sum(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+// dl[j] (+)= c * (h'(l[j] - l[j - P]) [j >= P]  -  h'(l[j + P] - l[j]) [j < pairs]),  c = upstream gradient * weight / pairs
+__global__ __launch_bounds__(256) void k_pair_sl1_bwd(const float* __restrict__ lg, i64 per_sample, i64 total, const float* __restrict__ coef,
+                                                      float* __restrict__ dl, int accumulate) {
+    const float c = coef[0];
+    const i64 pairs = total - per_sample;
+    for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (i64)gridDim.x * blockDim.x) {
+        const float x = lg[j];
+        float g = 0.f;
+        if (j >= per_sample) g += dsl1(x - lg[j - per_sample]);
+        if (j < pairs) g -= dsl1(lg[j + per_sample] - x);
+        g *= c;
+        dl[j] = accumulate ? dl[j] + g : g;
+    }
+}
+
+// d loss / d logits of one head from the caller's gradients w.r.t. (logits, activated output), written into channels
+// [c0, c0 + ch) of a [n, ctot, S] buffer (the stacked operand of the multi-head backward): out = g_logits + g_act * f'(.)
+__global__ __launch_bounds__(256) void k_head_dlogits(const float* __restrict__ gl, const float* __restrict__ ga, const float* __restrict__ av,
+                                                      int act, int ch, i64 S, float* __restrict__ dst, int ctot, int c0, i64 total) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
+        const i64 s = i % S;
+        const i64 t = i / S;
+        const int c = (int)(t % ch);
+        const i64 n = t / ch;
+        float g = gl ? gl[i] : 0.f;
+        if (ga) {
+            const float a = av ? av[i] : 0.f;
+            const float d = act == 1 ? a * (1.f - a) : (act == 2 ? 1.f - a * a : (act == 3 ? (a > 0.f ? 1.f : 0.f) : 1.f));
+            g = fmaf(ga[i], d, g);
+        }
+        dst[(n * ctot + c0 + c) * S + s] = g;
+    }
+}
 }  // namespace
+
+extern "C" int biu_pair_smooth_l1_blocks(long long pairs) {
+    long long b = (pairs + 256 * 8 - 1) / (256 * 8);
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+extern "C" int biu_pair_smooth_l1_fwd(const float* logits, int n, long long per_sample, float* partial, biu_stream stream) {
+    BIU_REQUIRE(logits && partial && n > 1 && per_sample > 0, BIU_ERR_SHAPE, "pair_smooth_l1_fwd: needs at least two batch entries");
+    const i64 pairs = (i64)(n - 1) * per_sample;
+    hipLaunchKernelGGL(k_pair_sl1_fwd, dim3(biu_pair_smooth_l1_blocks(pairs)), dim3(256), 0, (hipStream_t)stream, logits, (i64)per_sample, pairs, partial);
+    BIU_CHECK_LAUNCH("pair_smooth_l1_fwd");
+    return BIU_OK;
+}
+extern "C" int biu_pair_smooth_l1_bwd(const float* logits, int n, long long per_sample, const float* coef, float* dlogits, int accumulate,
+                                      biu_stream stream) {
+    BIU_REQUIRE(logits && coef && dlogits && n > 1 && per_sample > 0, BIU_ERR_SHAPE, "pair_smooth_l1_bwd: bad arguments");
+    const i64 total = (i64)n * per_sample;
+    hipLaunchKernelGGL(k_pair_sl1_bwd, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, logits, (i64)per_sample, total, coef,
+                       dlogits, accumulate);
+    BIU_CHECK_LAUNCH("pair_smooth_l1_bwd");
+    return BIU_OK;
+}
+extern "C" int biu_head_dlogits(const float* g_logits, const float* g_act, const float* activated, int act, int n, int ch, long long spatial,
+                                float* dst, int dst_channels, int dst_c0, biu_stream stream) {
+    BIU_REQUIRE((g_logits || g_act) && dst && n > 0 && ch > 0 && spatial > 0 && dst_c0 >= 0 && dst_c0 + ch <= dst_channels, BIU_ERR_SHAPE,
+                "head_dlogits: bad arguments");
+    BIU_REQUIRE(!g_act || act == 0 || activated, BIU_ERR_SHAPE, "head_dlogits: the activation's gradient needs the activated output");
+    const i64 total = (i64)n * ch * spatial;
+    hipLaunchKernelGGL(k_head_dlogits, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, g_logits, g_act, activated, act, ch,
+                       (i64)spatial, dst, dst_channels, dst_c0, total);
+    BIU_CHECK_LAUNCH("head_dlogits");
+    return BIU_OK;
+}
 
 extern "C" int biu_bce_dice_blocks(long long per_sample) {
     long long b = (per_sample + 256 * 8 - 1) / (256 * 8);

@@ -223,9 +223,13 @@ class ConvBlockNode(Node):
     backward: d a -> d y (BatchNorm + LeakyReLU backward, in place) ; dW, db ; d x.
     """
 
-    def __init__(self, eng, seq: nn.Sequential, xin: Act, yout: Act):
+    def __init__(self, eng, seq: nn.Sequential, xin: Act, yout: Act, dropout_follows: bool = False):
         conv, bn = seq[0], seq[1]
         self.conv, self.bn, self.xin, self.y = conv, bn, xin, yout
+        # the block's activation as a leaky slope: LeakyReLU(s) -> s, ReLU -> 0 (Unet_v0 / BabyUnet), none or a later
+        # non-piecewise-linear one (the attention gate's Sigmoid, applied by GateNode) -> 1
+        act = seq[2] if len(seq) > 2 else None
+        self.slope = float(act.negative_slope) if isinstance(act, nn.LeakyReLU) else (0.0 if isinstance(act, nn.ReLU) else 1.0)
         xin.consumed()
         if len(yout.leaves) == 1:
             yout.buf.producer[yout.leaves[0]] = self
@@ -234,8 +238,8 @@ class ConvBlockNode(Node):
         self.kd, self.kh, self.kw = _ksize(conv.weight)
         self.dil = int(conv.dilation[0])
         drop = seq[3] if len(seq) > 3 else None
-        if drop is not None and getattr(drop, "p", 0.0) != 0.0:
-            raise NotImplementedError("Dropout p != 0 is outside the hot path (reference default dropout=0.)")
+        if drop is not None and getattr(drop, "p", 0.0) != 0.0 and not dropout_follows:
+            raise NotImplementedError("Dropout p != 0 needs a DropoutNode behind the block (models.Unet_v0 / BabyUnet build one)")
         assert tuple(conv.weight.shape[:2]) == (yout.c, xin.c), (conv.weight.shape, yout.c, xin.c)
         assert xin.space == yout.space
         self.params = [conv.weight, conv.bias, bn.weight, bn.bias]
@@ -243,7 +247,7 @@ class ConvBlockNode(Node):
         dev = eng.device
         self.save_mean = torch.empty(cout, dtype=torch.float32, device=dev)
         self.save_invstd = torch.empty(cout, dtype=torch.float32, device=dev)
-        yout.vec("slope").fill_(LRELU_SLOPE)
+        yout.vec("slope").fill_(self.slope)
         eng.need_partial(cout)
         eng.need_partial_floats(lib.biu_conv_fwd_stats_floats(yout.a(), self.kd))
         self.pk_f = eng.packed_slot(0, xin.c, cout, self.kd, self.kh, self.kw, self.dil)
@@ -520,6 +524,101 @@ class CopyNode(Node):
         self.xin.mark_g()
 
 
+class DropoutNode(Node):
+    """nn.Dropout2d(p) behind a conv block (Unet_v0 / BabyUnet ``middle_conv2``, unet/unet_v0.py:31): whole channels of a
+    sample are zeroed with probability p, the rest scaled by 1/(1-p).  ReLU / LeakyReLU commute with a non-negative factor,
+    so sample n is materialised as T_n(y) with (scale, shift) * m[n, :] -- one ``biu_xform_apply`` per sample on the (small)
+    bottleneck tensor; eval mode is the plain T.  ``mask_override`` ([N, C] of 0/1) pins the draw for parity tests."""
+
+    def __init__(self, eng, drop: nn.Module, xin: Act, out: Act):
+        self.drop, self.xin, self.y = drop, xin, out
+        xin.consumed()
+        self.mask_override: Optional[torch.Tensor] = None
+        self.factor: Optional[torch.Tensor] = None           # [N, C] multiplier of the last forward
+        self._keep = []
+
+    def _sample(self, act: Act, tensor: torch.Tensor, n: int) -> biu_act:
+        per = act.d * act.h * act.w * act.buf.shape[4] * tensor.element_size()
+        return biu_act(tensor.data_ptr() + act.c0 * tensor.element_size() + n * per, 1, act.d, act.h, act.w, act.c, act.buf.shape[4])
+
+    def fwd(self, eng):
+        x, st = self.xin, _stream()
+        p = float(self.drop.p)
+        if self.drop.training and p > 0.0:
+            if self.mask_override is not None:
+                keep = self.mask_override.to(device=eng.device, dtype=torch.float32)
+            else:
+                keep = torch.bernoulli(torch.full((x.n, x.c), 1.0 - p, device=eng.device))
+            self.factor = keep / (1.0 - p)
+        else:
+            self.factor = torch.ones((x.n, x.c), device=eng.device)
+        sc = (x.vec("scale")[None, :] * self.factor).contiguous()
+        sh = (x.vec("shift")[None, :] * self.factor).contiguous()
+        sl = x.vec("slope").contiguous()
+        self._keep = [sc, sh, sl]
+        for n in range(x.n):
+            xf = biu_xform(sc[n].data_ptr(), sh[n].data_ptr(), sl.data_ptr())
+            a_in, a_out = self._sample(x, x.buf.t, n), self._sample(self.y, self.y.buf.t, n)
+            check(lib.biu_xform_apply(C.byref(a_in), C.byref(xf), C.byref(a_out), eng.dtype, st), "dropout_fwd")
+
+    def bwd(self, eng):
+        if not self.y.g_written() or not eng.wants_grad(self.xin):
+            return
+        assert not self.xin.g_written(), "DropoutNode is the only reader of its input"
+        st = _stream()
+        f = self.factor.contiguous()
+        zero, one = torch.zeros_like(f[0]), torch.ones_like(f[0])
+        self._keep += [f, zero, one]
+        for n in range(self.xin.n):
+            xf = biu_xform(f[n].data_ptr(), zero.data_ptr(), one.data_ptr())           # T(v) = factor * v
+            g_out, g_in = self._sample(self.y, self.y.buf.grad(), n), self._sample(self.xin, self.xin.buf.grad(), n)
+            check(lib.biu_xform_apply(C.byref(g_out), C.byref(xf), C.byref(g_in), eng.dtype, st), "dropout_bwd")
+        self.xin.mark_g()
+
+
+class AddReluNode(Node):
+    """relu(T(a) + T(b)) -- attention gate, ``psi = self.relu(g1 + x1)`` [unet/attention_unet.py:177]; materialised."""
+
+    def __init__(self, eng, a: Act, b: Act, out: Act):
+        self.a_, self.b_, self.y = a, b, out
+        a.consumed()
+        b.consumed()
+
+    def fwd(self, eng):
+        check(lib.biu_add_relu_fwd(self.a_.a(), self.a_.xf(), self.b_.a(), self.b_.xf(), self.y.a(), eng.dtype, _stream()), "add_relu_fwd")
+
+    def bwd(self, eng):
+        if not self.y.g_written():
+            return
+        assert self.a_.g_written() == self.b_.g_written()
+        check(lib.biu_add_relu_bwd(self.y.a(), self.y.g(), self.a_.g(), self.b_.g(), int(self.a_.g_written()), eng.dtype, _stream()),
+              "add_relu_bwd")
+        self.a_.mark_g()
+        self.b_.mark_g()
+
+
+class GateNode(Node):
+    """skip * sigmoid(T(psi)) -- attention gate output [unet/attention_unet.py:178-179]; psi has one channel; materialised."""
+
+    def __init__(self, eng, e: Act, psi: Act, out: Act):
+        assert psi.c == 1 and e.c == out.c
+        self.e_, self.psi_, self.y = e, psi, out
+        e.consumed()
+        psi.consumed()
+
+    def fwd(self, eng):
+        check(lib.biu_gate_fwd(self.e_.a(), self.e_.xf(), self.psi_.a(), self.psi_.xf(), self.y.a(), eng.dtype, _stream()), "gate_fwd")
+
+    def bwd(self, eng):
+        if not self.y.g_written():
+            return
+        assert not self.psi_.g_written()
+        check(lib.biu_gate_bwd(self.e_.a(), self.e_.xf(), self.psi_.a(), self.psi_.xf(), self.y.g(), self.e_.g(),
+                               int(self.e_.g_written()), self.psi_.g(), eng.dtype, _stream()), "gate_bwd")
+        self.e_.mark_g()
+        self.psi_.mark_g()
+
+
 _ACT_CODE = {None: 0, "none": 0, "sigmoid": 1, "tanh": 2, "relu": 3}
 
 
@@ -552,20 +651,23 @@ class HeadNode(Node):
         check(lib.biu_head_fwd(self.xin.a(), self.xin.xf(), _ptr(w), _ptr(self.conv.bias.data), self.cout, self.act,
                                _ptr(self.logits), _ptr(self.activated), eng.dtype, _stream()), "head_fwd")
 
-    def dlogits(self, g_logits, g_act, a=None):
-        """Combine the caller's gradients wrt (logits, activated output ``a``) into d logits."""
-        tot = g_logits
-        if g_act is not None:
-            if self.act == 1:
-                t = g_act * a * (1 - a)
-            elif self.act == 2:
-                t = g_act * (1 - a * a)
-            elif self.act == 3:
-                t = g_act * (a > 0).to(g_act.dtype)
-            else:
-                t = g_act
-            tot = t if tot is None else tot + t
-        return tot
+    def dlogits(self, eng, g_logits, g_act, a, dst=None, ctot=None, c0=0):
+        """d loss / d logits from the caller's gradients w.r.t. (logits, activated output ``a``) in one kernel pass, written to
+        ``dst`` (channels [c0, c0 + cout) of a [N, ctot, spatial] fp32 tensor); a gradient on the logits alone is used as is."""
+        if g_act is None and dst is None and g_logits.dtype == torch.float32 and g_logits.is_contiguous():
+            return g_logits
+        shp = self.out_shape(eng)
+        n, spatial = shp[0], 1
+        for v in shp[2:]:
+            spatial *= v
+        if dst is None:
+            dst, ctot, c0 = torch.empty(shp, dtype=torch.float32, device=eng.device), self.cout, 0
+        f32 = lambda t: None if t is None else t.contiguous().float()
+        gl, ga = f32(g_logits), f32(g_act)
+        self._keep = (gl, ga, a)
+        check(lib.biu_head_dlogits(_ptr(gl), _ptr(ga), _ptr(a) if ga is not None else None, self.act, n, self.cout, spatial,
+                                   _ptr(dst), ctot, c0, _stream()), "head_dlogits")
+        return dst
 
     def bwd_with(self, eng, dl: Optional[torch.Tensor]):
         if dl is None:
@@ -816,7 +918,7 @@ class Engine:
                 torch._foreach_add_(ts, k)
 
     def backward(self, head_grads: Sequence[Optional[torch.Tensor]]):
-        """head_grads[i] = d loss / d logits of head i (already combined with the activation's gradient)."""
+        """head_grads[i] = None or (d loss / d logits, d loss / d activated output, activated output) of head i."""
         self.grads = {}
         self._zero_flat, self._zero_used = None, 0
         for b in self.bufs:
@@ -841,22 +943,49 @@ class Engine:
         return self.grads
 
     def _backward_heads(self, head_grads):
+        """head_grads[i] = None or (g_logits, g_act, activated output) of head i."""
         live = [(h, g) for h, g in zip(self.heads, head_grads) if g is not None]
         if not live:
             return
         if len(live) == 1:
-            live[0][0].bwd_with(self, live[0][1])
+            h, (gl, ga, a) = live[0]
+            h.bwd_with(self, h.dlogits(self, gl, ga, a))
             return
-        # several heads read the same trunk output: one fused (cout-stacked) backward keeps d x single-pass
+        # several heads read the same trunk output: one fused (cout-stacked) backward keeps d x single-pass; every head's
+        # d logits goes straight into its channel slice of the stacked operand
         x = live[0][0].xin
         assert all(h.xin is x for h, _ in live)
-        w = torch.cat([h.conv.weight.data.reshape(h.cout, x.c) for h, _ in live], 0).contiguous()
-        dl = torch.cat([g.contiguous().float() for _, g in live], 1).contiguous()
-        cout = w.shape[0]
+        cout = sum(h.cout for h, _ in live)
+        shp = live[0][0].out_shape(self)
+        dl = torch.empty((shp[0], cout) + tuple(shp[2:]), dtype=torch.float32, device=self.device)
+        key = tuple(id(h) for h, _ in live)
+        if getattr(self, "_stack_key", None) != key:
+            self._stack_key = key
+            self._stack_w = torch.empty((cout, x.c), dtype=torch.float32, device=self.device)
+        w, o = self._stack_w, 0
+        for h, (gl, ga, a) in live:
+            w[o:o + h.cout].copy_(h.conv.weight.data.reshape(h.cout, x.c))          # (cout x cin floats: tiny)
+            h.dlogits(self, gl, ga, a, dst=dl, ctot=cout, c0=o)
+            o += h.cout
         dw = torch.empty_like(w)
         db = torch.empty(cout, dtype=torch.float32, device=self.device)
-        check(lib.biu_head_bwd(x.a(), x.xf(), _ptr(w), cout, _ptr(dl), x.g(), _ptr(dw), _ptr(db), _ptr(self.ws),
-                               self.ws_bytes, self.dtype, _stream()), "head_bwd(stacked)")
+        up = None
+        if self.wants_grad(x) and x.xf() is not None and not x.g_written() and len(x.leaves) == 1:
+            k = x.leaves[0]        # the heads are the trunk output's only readers: this one write completes its gradient
+            cand = x.buf.producer.get(k)
+            if (x.buf.ncons.get(k, 0) == len(live) and cand is not None and getattr(cand, "batch_stats", False)
+                    and cand.y.c == x.c and cand.y.c0 == x.c0):
+                up = cand
+        if up is not None:
+            part = up.red_buffer(self, up.kd, 0)
+            n_up = C.c_int(0)
+            check(lib.biu_head_bwd_bnred(x.a(), x.xf(), _ptr(w), cout, _ptr(dl), x.g(), _ptr(dw), _ptr(db), _ptr(self.ws), self.ws_bytes,
+                                         _ptr(up.save_mean), _ptr(up.save_invstd), _ptr(part), part.numel(), C.byref(n_up), self.dtype,
+                                         _stream()), "head_bwd_bnred(stacked)")
+            up.red_nblk = n_up.value
+        else:
+            check(lib.biu_head_bwd(x.a(), x.xf(), _ptr(w), cout, _ptr(dl), x.g(), _ptr(dw), _ptr(db), _ptr(self.ws),
+                                   self.ws_bytes, self.dtype, _stream()), "head_bwd(stacked)")
         x.mark_g()
         o = 0
         for h, _ in live:
@@ -931,7 +1060,7 @@ class _NetFn(torch.autograd.Function):
         head_grads = []
         for hi, h in enumerate(eng.heads):
             gl, ga = per_head.get(hi, [None, None])
-            head_grads.append(h.dlogits(gl, ga, saved.get(hi)) if (gl is not None or ga is not None) else None)
+            head_grads.append((gl, ga, saved.get(hi)) if (gl is not None or ga is not None) else None)
         grads = eng.backward(head_grads)
         dxs = eng.input_grads()
         pg = [grads.pop(p, None) for p in eng.params]

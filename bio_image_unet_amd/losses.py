@@ -31,12 +31,22 @@ class SoftDiceLoss(nn.Module):
         return 1 - score.mean()
 
 
-class _FusedBCEDice(torch.autograd.Function):
-    """alpha * BCEWithLogits(mean) + beta * (1 - mean_n[2 (I_n + s) / (P_n + T_n + s)]) through ``biu_bce_dice_fwd/bwd``:
-    one pass over (logits, targets) each way instead of the eager graph's full-tensor reductions with ``n`` output rows."""
+def _fusable(logits, targets):
+    return (logits.is_cuda and logits.dtype == torch.float32 and targets.dtype == torch.float32 and logits.shape == targets.shape
+            and logits.is_contiguous() and targets.is_contiguous() and logits.numel() > 0)
+
+
+class _FusedSegLoss(torch.autograd.Function):
+    """One autograd node, one pass over (logits, targets) each way (``biu_bce_dice_fwd/bwd``, ``biu_pair_smooth_l1_fwd/bwd``) for
+
+        a_bce * BCEWithLogits(mean) + a_dice * (1 - mean_n[2 (I_n + s) / (P_n + T_n + s)])          (unet/losses.py:78-112)
+      + a_tv * (1 - Tversky) | a_tv * log cosh(1 - Tversky),  Tversky = (TP + s) / (TP + al FP + be FN + s)   (:145-239)
+      + w_time * SmoothL1(logits[1:], logits[:-1])                                                   (unet3d/train.py:140-145)
+
+    instead of the eager graph's ~15 full-tensor element-wise / reduction kernels.  ``cfg`` selects the terms."""
 
     @staticmethod
-    def forward(ctx, logits, targets, alpha, beta, smooth):
+    def forward(ctx, logits, targets, cfg):
         import ctypes as C
         from ._lib import check, lib
         n = targets.size(0)
@@ -47,27 +57,68 @@ class _FusedBCEDice(torch.autograd.Function):
         check(lib.biu_bce_dice_fwd(C.c_void_p(logits.data_ptr()), C.c_void_p(targets.data_ptr()), n, per,
                                    C.c_void_p(partial.data_ptr()), st), "bce_dice_fwd")
         sums = partial.sum(1)                                    # [n, 4]: bce, p, t, p*t
-        den = sums[:, 1] + sums[:, 2] + smooth
-        score = 2.0 * (sums[:, 3] + smooth) / den
-        ctx.save_for_backward(logits, targets, sums, den)
-        ctx.cfg = (alpha, beta, smooth, n, per)
-        return alpha * sums[:, 0].sum() / (n * per) + beta * (1 - score.mean())
+        loss = logits.new_zeros(())
+        saved = {"sums": sums}
+        a_bce, a_dice, smooth = cfg.get("bce", 0.0), cfg.get("dice", 0.0), cfg.get("smooth", 1.0)
+        if a_bce:
+            loss = loss + a_bce * sums[:, 0].sum() / (n * per)
+        if a_dice:
+            den = sums[:, 1] + sums[:, 2] + smooth
+            saved["den"] = den
+            loss = loss + a_dice * (1 - (2.0 * (sums[:, 3] + smooth) / den).mean())
+        if "tversky" in cfg:
+            al, be, sm, logcosh = cfg["tversky"]
+            tp, ps, ts = sums[:, 3].sum(), sums[:, 1].sum(), sums[:, 2].sum()
+            tden = tp + al * (ps - tp) + be * (ts - tp) + sm
+            tv = (tp + sm) / tden
+            saved.update(tp=tp, tden=tden, tv=tv)
+            loss = loss + (torch.log(torch.cosh(1 - tv)) if logcosh else (1 - tv))
+        w_time = cfg.get("time", 0.0)
+        if w_time and n > 1:
+            pairs = (n - 1) * per
+            pt = torch.empty(lib.biu_pair_smooth_l1_blocks(pairs), dtype=torch.float32, device=logits.device)
+            check(lib.biu_pair_smooth_l1_fwd(C.c_void_p(logits.data_ptr()), n, per, C.c_void_p(pt.data_ptr()), st), "pair_smooth_l1_fwd")
+            loss = loss + w_time * pt.sum() / pairs
+        elif w_time:                 # a batch of one: nn.SmoothL1Loss over empty slices is nan in the reference, and so here
+            loss = loss + float("nan")
+        ctx.save_for_backward(logits, targets)
+        ctx.saved, ctx.cfg, ctx.np = saved, cfg, (n, per)
+        return loss
 
     @staticmethod
     def backward(ctx, g):
         import ctypes as C
         from ._lib import check, lib
-        logits, targets, sums, den = ctx.saved_tensors
-        alpha, beta, smooth, n, per = ctx.cfg
-        coef = torch.empty((n, 3), dtype=torch.float32, device=logits.device)
-        coef[:, 0] = g * (alpha / (n * per))
-        coef[:, 1] = g * (beta / n) * 2.0 * (sums[:, 3] + smooth) / (den * den)
-        coef[:, 2] = -g * (beta / n) * 2.0 / den
+        logits, targets = ctx.saved_tensors
+        cfg, sv, (n, per) = ctx.cfg, ctx.saved, ctx.np
+        sums = sv["sums"]
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        # d/dl_i = c0 * (p_i - t_i) + (c1 + c2 * t_i) * p_i (1 - p_i), per sample
+        coef = torch.zeros((n, 3), dtype=torch.float32, device=logits.device)
+        a_bce, a_dice, smooth = cfg.get("bce", 0.0), cfg.get("dice", 0.0), cfg.get("smooth", 1.0)
+        if a_bce:
+            coef[:, 0] = g * (a_bce / (n * per))
+        if a_dice:
+            den = sv["den"]
+            coef[:, 1] += g * (a_dice / n) * 2.0 * (sums[:, 3] + smooth) / (den * den)
+            coef[:, 2] += -g * (a_dice / n) * 2.0 / den
+        if "tversky" in cfg:
+            al, be, sm, logcosh = cfg["tversky"]
+            tp, tden, tv = sv["tp"], sv["tden"], sv["tv"]
+            outer = -g * (torch.tanh(1 - tv) if logcosh else 1.0)           # d loss / d Tversky
+            d_tp = (tden - (tp + sm) * (1 - al - be)) / (tden * tden)       # Tversky = (TP + s) / den, den = TP(1-al-be) + al P + be T + s
+            d_ps = -(tp + sm) * al / (tden * tden)
+            coef[:, 1] += outer * d_ps
+            coef[:, 2] += outer * d_tp
         dl = torch.empty_like(logits)
         check(lib.biu_bce_dice_bwd(C.c_void_p(logits.data_ptr()), C.c_void_p(targets.data_ptr()), n, per,
-                                   C.c_void_p(coef.data_ptr()), C.c_void_p(dl.data_ptr()), 0,
-                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "bce_dice_bwd")
-        return dl, None, None, None, None
+                                   C.c_void_p(coef.data_ptr()), C.c_void_p(dl.data_ptr()), 0, st), "bce_dice_bwd")
+        w_time = cfg.get("time", 0.0)
+        if w_time and n > 1:
+            c = (g * (w_time / ((n - 1) * per))).reshape(1).float().contiguous()
+            check(lib.biu_pair_smooth_l1_bwd(C.c_void_p(logits.data_ptr()), n, per, C.c_void_p(c.data_ptr()), C.c_void_p(dl.data_ptr()), 1, st),
+                  "pair_smooth_l1_bwd")
+        return dl, None, None
 
 
 class BCEDiceLoss(nn.Module):
@@ -75,11 +126,15 @@ class BCEDiceLoss(nn.Module):
         super().__init__()
         self.bce, self.dice, self.alpha, self.beta = BCELoss2d(), SoftDiceLoss(), alpha, beta
 
-    def forward(self, logits, targets):
-        if (logits.is_cuda and logits.dtype == torch.float32 and targets.dtype == torch.float32 and logits.shape == targets.shape
-                and logits.is_contiguous() and targets.is_contiguous() and logits.numel() > 0):
-            return _FusedBCEDice.apply(logits, targets, float(self.alpha), float(self.beta), float(self.dice.smooth))
-        return self.alpha * self.bce(logits, targets) + self.beta * self.dice(logits, targets)
+    def forward(self, logits, targets, time_weight: float = 0.0):
+        """``time_weight`` adds the 3-D trainer's ``SmoothL1(logits[1:], logits[:-1]) * time_weight`` to the same fused pass."""
+        if _fusable(logits, targets):
+            return _FusedSegLoss.apply(logits, targets, dict(bce=float(self.alpha), dice=float(self.beta), smooth=float(self.dice.smooth),
+                                                             time=float(time_weight)))
+        loss = self.alpha * self.bce(logits, targets) + self.beta * self.dice(logits, targets)
+        if time_weight:
+            loss = loss + nn.functional.smooth_l1_loss(logits[1:], logits[:-1]) * time_weight
+        return loss
 
 
 class logcoshDiceLoss(nn.Module):
@@ -106,13 +161,21 @@ class TverskyLoss(nn.Module):
         super().__init__()
         self.alpha, self.beta, self.smooth = alpha, beta, smooth
 
-    def forward(self, inputs, targets):
-        return 1 - _tversky_index(inputs, targets, self.alpha, self.beta, self.smooth)
+    _logcosh = False
+
+    def forward(self, inputs, targets, time_weight: float = 0.0):
+        if _fusable(inputs, targets):
+            return _FusedSegLoss.apply(inputs, targets, dict(tversky=(float(self.alpha), float(self.beta), float(self.smooth), self._logcosh),
+                                                             time=float(time_weight)))
+        x = 1 - _tversky_index(inputs, targets, self.alpha, self.beta, self.smooth)
+        loss = torch.log(torch.cosh(x)) if self._logcosh else x
+        if time_weight:
+            loss = loss + nn.functional.smooth_l1_loss(inputs[1:], inputs[:-1]) * time_weight
+        return loss
 
 
 class logcoshTverskyLoss(TverskyLoss):
-    def forward(self, inputs, targets):
-        return torch.log(torch.cosh(1 - _tversky_index(inputs, targets, self.alpha, self.beta, self.smooth)))
+    _logcosh = True
 
 
 class weightedBCELoss(nn.Module):

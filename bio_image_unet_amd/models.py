@@ -411,3 +411,177 @@ class MultiOutputUnet3D(_Body3D):
         eng = self._engine_for(x)
         outs = E.run(eng, [x], [(i, "act") for i in range(len(self.output_heads))])
         return {name: o for name, o in zip(self.output_heads, outs)}
+
+
+# ------------------------------------------------------------------------------------------------------
+# the remaining bio_image_unet.unet variants: legacy v0, three-level "baby", attention-gated decoder
+# ------------------------------------------------------------------------------------------------------
+def _block_relu(cin: int, cout: int, dropout: float = 0.0) -> nn.Sequential:
+    """``Conv2d(k3, padding=1) -> BatchNorm2d -> ReLU -> Dropout2d(p)`` (unet/unet_v0.py:54-61, unet/baby_unet.py:51-58)."""
+    return nn.Sequential(nn.Conv2d(kernel_size=3, in_channels=cin, out_channels=cout, padding=1), nn.BatchNorm2d(cout), nn.ReLU(),
+                         nn.Dropout2d(dropout))
+
+
+class _LegacyUnet(_HipNet):
+    """Shared graph of Unet_v0 (4 pools) and BabyUnet (3 pools): ReLU blocks, ``Dropout2d(0.5)`` behind ``middle_conv2``, skips
+    taken from the FIRST conv of each level (``concat(u1, e7)`` ..., unet/unet_v0.py:89-101), a last ``conv(F -> 1)`` block and a
+    1 -> 1 channel 1x1 head."""
+    nd = 2
+    levels = 4
+
+    def _make(self, f: int):
+        c = 1
+        for lvl in range(self.levels):
+            wd = f << lvl
+            setattr(self, f"encode{2 * lvl + 1}", _block_relu(c, wd))
+            setattr(self, f"encode{2 * lvl + 2}", _block_relu(wd, wd))
+            setattr(self, f"maxpool{lvl + 1}", nn.MaxPool2d(kernel_size=2, stride=2))
+            c = wd
+        top = f << self.levels
+        self.middle_conv1 = _block_relu(c, top)
+        self.middle_conv2 = _block_relu(top, top, dropout=0.5)
+        c = top
+        for lvl in range(1, self.levels + 1):
+            setattr(self, f"up{lvl}", nn.ConvTranspose2d(c, c // 2, kernel_size=2, stride=2))
+            setattr(self, f"decode{2 * lvl - 1}", _block_relu(c, c // 2))
+            setattr(self, f"decode{2 * lvl}", _block_relu(c // 2, c // 2))
+            c //= 2
+        setattr(self, f"decode{2 * self.levels + 1}", _block_relu(f, 1))
+        self.final = nn.Sequential(nn.Conv2d(1, 1, kernel_size=1, padding=0))
+
+    def _build(self, eng, xshape):
+        L = self.levels
+        space, cin = self._space(xshape)
+        assert cin == 1, f"{type(self).__name__} takes one input channel, got {cin}"
+        n, d, h, w = space
+        if h % (1 << L) or w % (1 << L):
+            raise ValueError("concatenation failed: wrong dimensions")
+        spaces = [space]
+        for _ in range(L):
+            spaces.append(_half(spaces[-1]))
+        width = lambda l: getattr(self, f"encode{2 * l + 1}")[0].out_channels
+        cat_bufs = [eng.new_cat(spaces[l], width(l), width(l), getattr(self, f"decode{2 * (L - l) - 1}")[0].out_channels, 1) for l in range(L)]
+        t = eng.new_input(space, 1)
+        for lvl in range(L):
+            b1, b2 = getattr(self, f"encode{2 * lvl + 1}"), getattr(self, f"encode{2 * lvl + 2}")
+            skip = cat_bufs[lvl].slice(width(lvl), width(lvl), lazy=True)           # e1 / e3 / e5 / e7: read by the next conv AND the decoder
+            eng.add(E.ConvBlockNode(eng, b1, t, skip))
+            a = eng.new_act(spaces[lvl], width(lvl), lazy=True)
+            eng.add(E.ConvBlockNode(eng, b2, skip, a))
+            t = eng.new_act(spaces[lvl + 1], width(lvl), lazy=False)
+            eng.add(E.ResampleNode(eng, "maxpool", a, t))
+        mid1 = eng.new_act(spaces[L], self.middle_conv1[0].out_channels, lazy=True)
+        eng.add(E.ConvBlockNode(eng, self.middle_conv1, t, mid1))
+        mid2 = eng.new_act(spaces[L], self.middle_conv2[0].out_channels, lazy=True)
+        eng.add(E.ConvBlockNode(eng, self.middle_conv2, mid1, mid2, dropout_follows=True))
+        t = eng.new_act(spaces[L], mid2.c, lazy=False)
+        self._dropout_node = E.DropoutNode(eng, self.middle_conv2[3], mid2, t)
+        eng.add(self._dropout_node)
+        for lvl in range(1, L + 1):
+            buf = cat_bufs[L - lvl]
+            up = getattr(self, f"up{lvl}")
+            u = buf.slice(0, up.out_channels, lazy=False)
+            eng.add(E.ConvTNode(eng, up, t, u))
+            b1, b2 = getattr(self, f"decode{2 * lvl - 1}"), getattr(self, f"decode{2 * lvl}")
+            a = eng.new_act(spaces[L - lvl], b1[0].out_channels, lazy=True)
+            eng.add(E.ConvBlockNode(eng, b1, buf.full(), a))
+            t = eng.new_act(spaces[L - lvl], b2[0].out_channels, lazy=True)
+            eng.add(E.ConvBlockNode(eng, b2, a, t))
+        last = getattr(self, f"decode{2 * L + 1}")
+        d9 = eng.new_act(space, 1, lazy=True)
+        eng.add(E.ConvBlockNode(eng, last, t, d9))
+        head = E.HeadNode(eng, self.final[0], d9, "sigmoid", want_logits=True, want_act=True)
+        eng.add(head)
+        eng.heads.append(head)
+
+    def forward(self, x):
+        eng = self._engine_for(x)
+        logits, prob = E.run(eng, [x], [(0, "logits"), (0, "act")])
+        return prob, logits
+
+
+class Unet_v0(_LegacyUnet):
+    """``Unet_v0(n_filter=32, **kwargs)`` (unet/unet_v0.py:5-106) -> ``forward(x) = (sigmoid(logits), logits)``."""
+    levels = 4
+
+    def __init__(self, n_filter=32, **kwargs):
+        super().__init__()
+        self._make(n_filter)
+
+
+class BabyUnet(_LegacyUnet):
+    """``BabyUnet(n_filter=4)`` (unet/baby_unet.py:5-93): three max-pools."""
+    levels = 3
+
+    def __init__(self, n_filter=4):
+        super().__init__()
+        self._make(n_filter)
+
+
+class AttentionBlock(nn.Module):
+    """Parameter container of the attention gate (unet/attention_unet.py:112-181): ``W_gate`` / ``W_x`` = 1x1 conv + BatchNorm,
+    ``psi`` = 1x1 conv to one channel + BatchNorm + Sigmoid.  Same child names and indices as the reference (state_dict keys)."""
+
+    def __init__(self, F_g, F_l, n_coefficients):
+        super().__init__()
+        self.W_gate = nn.Sequential(nn.Conv2d(F_g, n_coefficients, kernel_size=1, stride=1, padding=0, bias=True), nn.BatchNorm2d(n_coefficients))
+        self.W_x = nn.Sequential(nn.Conv2d(F_l, n_coefficients, kernel_size=1, stride=1, padding=0, bias=True), nn.BatchNorm2d(n_coefficients))
+        self.psi = nn.Sequential(nn.Conv2d(n_coefficients, 1, kernel_size=1, stride=1, padding=0, bias=True), nn.BatchNorm2d(1), nn.Sigmoid())
+        self.relu = nn.ReLU(inplace=True)
+
+
+class AttentionUnet(Unet):
+    """``AttentionUnet(in_channels=1, out_channels=1, n_filter=32, dilation=1)`` (unet/attention_unet.py:5-109): the 2-D U-Net
+    with every skip multiplied by an attention coefficient computed from the up-sampled tensor; concat order is
+    (attended skip, up-sampled) -- the reverse of ``Unet`` (``self.concat(a1, u1)``, :90)."""
+
+    def __init__(self, in_channels=1, out_channels=1, n_filter=32, dilation=1):
+        super().__init__(in_channels, out_channels, n_filter, dilation)
+        f = n_filter
+        # registration order of the reference (:38-52): up1, attention1, decode1, decode2, up2, ... -- state_dict order follows it
+        mods = dict(self._modules)
+        for k in [k for k in mods if k.startswith(("up", "decode")) or k == "final"]:
+            del self._modules[k]
+        for lvl, c in ((1, 8 * f), (2, 4 * f), (3, 2 * f), (4, f)):
+            self._modules[f"up{lvl}"] = mods[f"up{lvl}"]
+            setattr(self, f"attention{lvl}", AttentionBlock(c, c, n_coefficients=c // 2))
+            self._modules[f"decode{2 * lvl - 1}"] = mods[f"decode{2 * lvl - 1}"]
+            self._modules[f"decode{2 * lvl}"] = mods[f"decode{2 * lvl}"]
+        self._modules["final"] = mods["final"]
+
+    def _build(self, eng, xshape):
+        space, cin = self._space(xshape)
+        assert cin == self.encode1[0].in_channels, f"expected {self.encode1[0].in_channels} input channels, got {cin}"
+        self._check_divisible(space)
+        spaces = self._spaces(space)
+        x = eng.new_input(space, cin)
+        m4, skips = self._build_encoder(eng, x, spaces, None)          # skips are free-standing tensors here (gated, not concatenated)
+        mid1 = eng.new_act(spaces[4], self.middle_conv1[0].out_channels, lazy=True)
+        eng.add(E.ConvBlockNode(eng, self.middle_conv1, m4, mid1))
+        t = eng.new_act(spaces[4], self.middle_conv2[0].out_channels, lazy=True)
+        eng.add(E.ConvBlockNode(eng, self.middle_conv2, mid1, t))
+        for lvl in (1, 2, 3, 4):
+            sp, e = spaces[4 - lvl], skips[4 - lvl]
+            up, att = getattr(self, f"up{lvl}"), getattr(self, f"attention{lvl}")
+            b1, b2 = getattr(self, f"decode{2 * lvl - 1}"), getattr(self, f"decode{2 * lvl}")
+            buf = eng.new_cat(sp, e.c, up.out_channels, b1[0].out_channels, 1)      # (attended skip | up-sampled)
+            u = buf.slice(e.c, up.out_channels, lazy=False)
+            eng.add(E.ConvTNode(eng, up, t, u))
+            nco = att.W_gate[0].out_channels
+            g1 = eng.new_act(sp, nco, lazy=True)
+            eng.add(E.ConvBlockNode(eng, att.W_gate, u, g1))
+            x1 = eng.new_act(sp, nco, lazy=True)
+            eng.add(E.ConvBlockNode(eng, att.W_x, e, x1))
+            s = eng.new_act(sp, nco, lazy=False)
+            eng.add(E.AddReluNode(eng, g1, x1, s))
+            psi = eng.new_act(sp, 1, lazy=True)
+            eng.add(E.ConvBlockNode(eng, att.psi, s, psi))
+            a_att = buf.slice(0, e.c, lazy=False)
+            eng.add(E.GateNode(eng, e, psi, a_att))
+            a = eng.new_act(sp, b1[0].out_channels, lazy=True)
+            eng.add(E.ConvBlockNode(eng, b1, buf.full(), a))
+            t = eng.new_act(sp, b2[0].out_channels, lazy=True)
+            eng.add(E.ConvBlockNode(eng, b2, a, t))
+        head = E.HeadNode(eng, self.final[0], t, "sigmoid", want_logits=True, want_act=True)
+        eng.add(head)
+        eng.heads.append(head)

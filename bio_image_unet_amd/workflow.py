@@ -26,7 +26,7 @@ from torch import nn, optim
 from torch.utils.data import DataLoader, random_split
 
 from .losses import BCEDiceLoss, BCEDiceLossSiam, BCEDiceTemporalLoss, TverskyLoss, logcoshTverskyLoss, weightedBCELoss
-from .models import MultiOutputUnet3D, Siam_UNet, UNet3D, Unet
+from .models import AttentionUnet, MultiOutputUnet3D, Siam_UNet, UNet3D, Unet, Unet_v0
 from .optim import Adam
 from .utils import get_device, init_weights
 
@@ -186,7 +186,8 @@ class Trainer3D(_EpochLoop):
         y = batch["mask"].view(self.batch_size, self.out_channels, d[0], d[1], d[2]).to(self.device)
         _, logits = self.model(x)
         w = 0.1 if validating else self.time_loss_weight         # validation hard-codes 0.1
-        return self.criterion(logits, y) + self.criterion_time(logits[1:, :, :], logits[:-1, :, :]) * w
+        # criterion(y_logits, y_i) + SmoothL1(y_logits[1:], y_logits[:-1]) * w (unet3d/train.py:140-145), one fused pass each way
+        return self.criterion(logits, y, time_weight=w)
 
     def _validate(self, epoch):
         print("\nStarting validation epoch %s ..." % epoch)
@@ -442,8 +443,15 @@ class Predict2D:
                 raise ValueError("network is not defined")
         if network == "Unet":
             network = Unet
+        elif network == "AttentionUnet":
+            network = AttentionUnet
+        elif network == "Unet_v0":                       # legacy checkpoints carry no channel counts (unet/predict.py:93-97)
+            network = Unet_v0
+            if "in_channels" not in self.model_params:
+                self.model_params["in_channels"] = 1
+                self.model_params["out_channels"] = 1
         elif isinstance(network, str):
-            raise NotImplementedError(f"network '{network}' is outside the hot path of this package")
+            raise ValueError(f"network '{network}' is not one of 'Unet', 'AttentionUnet', 'Unet_v0' (or pass a class)")
         mp = self.model_params
         # (the reference ignores the checkpoint's 'dilation' here, unet/predict.py:98-99 -- so does this)
         self.model = network(n_filter=mp["n_filter"], in_channels=mp["in_channels"], out_channels=mp["out_channels"]).to(self.device)

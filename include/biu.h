@@ -206,6 +206,19 @@ int biu_bce_dice_fwd(const float* logits, const float* target, int n, long long 
 int biu_bce_dice_bwd(const float* logits, const float* target, int n, long long per_sample, const float* coef, float* dlogits,
                      int accumulate, biu_stream stream);
 
+/* SmoothL1 (beta 1, mean) between neighbouring BATCH entries of fp32 logits -- nn.SmoothL1Loss()(y_logits[1:], y_logits[:-1]),
+ * the "time" term of the 3-D trainer (unet3d/train.py:140-145).  fwd: partial[biu_pair_smooth_l1_blocks(pairs)] block sums of
+ * h(l[i + per_sample] - l[i]), pairs = (n - 1) * per_sample.  bwd: dlogits (+)= coef[0] * d sum / d logits (coef on the device).      */
+int biu_pair_smooth_l1_blocks(long long pairs);
+int biu_pair_smooth_l1_fwd(const float* logits, int n, long long per_sample, float* partial, biu_stream stream);
+int biu_pair_smooth_l1_bwd(const float* logits, int n, long long per_sample, const float* coef, float* dlogits, int accumulate,
+                           biu_stream stream);
+/* d loss / d logits of one head from the caller's gradients w.r.t. its logits and / or its activated output (act as in
+ * biu_head_fwd; multi_output_unet3d.py:97-104), written to channels [dst_c0, dst_c0 + ch) of a fp32 [n, dst_channels, spatial]
+ * tensor -- the stacked operand of one biu_head_bwd over all heads that share a trunk.                                    */
+int biu_head_dlogits(const float* g_logits, const float* g_act, const float* activated, int act, int n, int ch, long long spatial,
+                     float* dst, int dst_channels, int dst_c0, biu_stream stream);
+
 /* Trilinear x2 up-sampling, align_corners = False (F.interpolate(scale_factor=2, mode='trilinear'),
  * unet3d/unet3d.py:82,89,96): out = interp(T(x)); depth is doubled when out->d == 2 * x->d, kept when equal.
  * bwd: dx (+)= adjoint(dout).                                                                                        */
@@ -276,7 +289,8 @@ int biu_head_bwd_bnred(const biu_act* x, const biu_xform* xf, const float* w, in
 /* ------------------------------------------------------------------------------------------------
  * Element-wise helpers on activation slices
  * ---------------------------------------------------------------------------------------------- */
-/* out = max(T1(a), T2(b))  -- Siam 'max' join, siam_unet/siam_unet.py:117; bwd routes to a on ties.      */
+/* out = max(T1(a), T2(b))  -- Siam 'max' join, siam_unet/siam_unet.py:117; bwd: the winner takes dout, an exact tie
+ * splits it evenly (torch.maximum's backward).                                                              */
 int biu_max_join_fwd(const biu_act* a, const biu_xform* xa, const biu_act* b, const biu_xform* xb,
                      const biu_act* out, int dtype, biu_stream stream);
 int biu_max_join_bwd(const biu_act* a, const biu_xform* xa, const biu_act* b, const biu_xform* xb,
@@ -287,6 +301,24 @@ int biu_act_add(const biu_act* src, const biu_act* dst, int accumulate, int dtyp
 /* NC[D]HW fp32 <-> channels-last activation (network input / gradient at the module boundary).           */
 int biu_from_nchw(const float* src, const biu_act* dst, int dtype, biu_stream stream);
 int biu_to_nchw(const biu_act* src, const biu_xform* xf, float* dst, int dtype, biu_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Attention gate of AttentionUnet (unet/attention_unet.py:112-181; the 1x1 conv + BatchNorm stages are biu_conv_* calls
+ * with kernel size 1 and slope 1):
+ *   add_relu: out = relu(T(a) + T(b))                               (:177, psi = self.relu(g1 + x1))
+ *             bwd: da, db (+)= dout where the stored out > 0
+ *   gate:     out[v, c] = T(e)[v, c] * sigmoid(T(psi)[v, 0])         (:178-179, psi has ONE channel)
+ *             bwd: de[v, c] (+)= dout[v, c] * s ;  dpsi[v] = s (1 - s) * sum_c dout[v, c] * T(e)[v, c]   (gradient w.r.t. T(psi));
+ *             de may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int biu_add_relu_fwd(const biu_act* a, const biu_xform* xa, const biu_act* b, const biu_xform* xb, const biu_act* out, int dtype,
+                     biu_stream stream);
+int biu_add_relu_bwd(const biu_act* out, const biu_act* dout, const biu_act* da, const biu_act* db, int accumulate, int dtype,
+                     biu_stream stream);
+int biu_gate_fwd(const biu_act* e, const biu_xform* xe, const biu_act* psi, const biu_xform* xpsi, const biu_act* out, int dtype,
+                 biu_stream stream);
+int biu_gate_bwd(const biu_act* e, const biu_xform* xe, const biu_act* psi, const biu_xform* xpsi, const biu_act* dout,
+                 const biu_act* de, int accumulate_e, const biu_act* dpsi, int dtype, biu_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused multi-tensor Adam                                                               [K14]

@@ -144,11 +144,22 @@ class forced_decisions:
         return False
 
 
-def _lrelu(t):
+def _lrelu(t, slope=None):
+    slope = LRELU_SLOPE if slope is None else slope
+    if slope == 1.0:
+        if _Forced.q is not None:
+            _Forced.q["lrelu"].pop(0)            # the engine records a (meaningless) branch for every conv block
+        return t
     if _Forced.q is not None:
         m = _Forced.q["lrelu"].pop(0)
-        return torch.where(m, t, LRELU_SLOPE * t)
-    return F.leaky_relu(t, LRELU_SLOPE)
+        return torch.where(m, t, slope * t)
+    return F.leaky_relu(t, slope) if slope else F.relu(t)
+
+
+def _relu(t):
+    if _Forced.q is not None:
+        return torch.where(_Forced.q["relu"].pop(0), t, torch.zeros_like(t))
+    return F.relu(t)
 
 
 def _maxpool(t):
@@ -160,8 +171,9 @@ def _maxpool(t):
 
 
 def _maximum(a, b):
-    if _Forced.q is not None:
-        return torch.where(_Forced.q["max"].pop(0), a, b)
+    if _Forced.q is not None:               # sign(a - b) as the implementation under test saw it; a tie splits the gradient
+        sgn = _Forced.q["max"].pop(0)
+        return torch.where(sgn > 0, a, torch.where(sgn < 0, b, 0.5 * (a + b)))
     return torch.maximum(a, b)
 
 
@@ -180,15 +192,16 @@ def emu_input(x):
     return _rf(x) if _Emu.on else x
 
 
-def mfma_layer(cin: int, cout: int, dilation: int = 1) -> bool:
-    """Which conv / ConvTranspose layers run on the MFMA kernels in bf16 mode (csrc/biu_conv_mfma.hip: chan_ok)."""
-    return dilation == 1 and cin >= 16 and cin % 16 == 0 and cout >= 16 and cout % 8 == 0
+def mfma_layer(cin: int, cout: int, dilation: int = 1, ksize: int = 3) -> bool:
+    """Which conv / ConvTranspose layers run on the MFMA kernels in bf16 mode (csrc/biu_conv_mfma.hip: chan_ok); 1x1 convs
+    (attention gates) and dilated ones take the any-shape kernels, which multiply unrounded fp32 operands."""
+    return dilation == 1 and ksize != 1 and cin >= 16 and cin % 16 == 0 and cout >= 16 and cout % 8 == 0
 
 
-def _operands(x, w, cin, cout, dilation=1):
+def _operands(x, w, cin, cout, dilation=1, ksize=3):
     if not _Emu.on:
         return x, w
-    if mfma_layer(cin, cout, dilation):
+    if mfma_layer(cin, cout, dilation, ksize):
         return _RoundBoth.apply(x), _RoundFwd.apply(w)
     return _RoundBwd.apply(x), w
 
@@ -196,18 +209,24 @@ def _operands(x, w, cin, cout, dilation=1):
 # --------------------------------------------------------------------------------------------------
 # building blocks
 # --------------------------------------------------------------------------------------------------
-def conv_block(sd: State, name: str, x: torch.Tensor, *, training: bool, dilation: int = 1) -> torch.Tensor:
+def conv_block(sd: State, name: str, x: torch.Tensor, *, training: bool, dilation: int = 1, slope=None,
+               dropout_factor: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``nn.Sequential(ConvNd(k=3, padding=d, dilation=d), BatchNormNd, LeakyReLU(0.1), Dropout(0))``.
 
     Train mode: batch statistics (biased var) normalise, running stats updated with unbiased var and
     momentum 0.1, ``num_batches_tracked += 1`` -- exactly what ``F.batch_norm`` does when handed the
     running buffers.  Eval mode: running statistics.
+
+    Variants of the other ``bio_image_unet.unet`` networks: ``slope`` = 0 for the ReLU blocks of Unet_v0 / BabyUnet, 1 for the
+    attention gate's activation-free ``Conv2d(k=1) -> BatchNorm2d`` pairs (a 1x1 kernel takes padding 0);
+    ``dropout_factor`` = the [N, C] multiplier (0 or 1/(1-p)) ``Dropout2d`` applied, when it is active.
     """
     w = sd[f"{name}.0.weight"]
     b = sd[f"{name}.0.bias"]
     conv = F.conv3d if w.dim() == 5 else F.conv2d
-    xo, wo = _operands(x, w, w.shape[1], w.shape[0], dilation)
-    y = st(conv(xo, wo, b, padding=dilation, dilation=dilation))
+    k = w.shape[-1]
+    xo, wo = _operands(x, w, w.shape[1], w.shape[0], dilation, k)
+    y = st(conv(xo, wo, b, padding=dilation if k == 3 else 0, dilation=dilation))
     rm, rv = sd[f"{name}.1.running_mean"], sd[f"{name}.1.running_var"]
     if training:
         nbt = sd.get(f"{name}.1.num_batches_tracked")
@@ -215,7 +234,10 @@ def conv_block(sd: State, name: str, x: torch.Tensor, *, training: bool, dilatio
             nbt += 1
     y = F.batch_norm(y, rm, rv, sd[f"{name}.1.weight"], sd[f"{name}.1.bias"],
                      training=training, momentum=BN_MOMENTUM, eps=BN_EPS)
-    return st_grad(_lrelu(y))
+    a = st_grad(_lrelu(y, slope))
+    if dropout_factor is not None:
+        a = st(a * dropout_factor.view(dropout_factor.shape + (1,) * (a.dim() - 2)))
+    return a
 
 
 def up_conv_t(sd: State, name: str, x: torch.Tensor) -> torch.Tensor:
@@ -304,6 +326,55 @@ def siam_forward(sd: State, x: torch.Tensor, prev_x: torch.Tensor, *, mode: str 
     mid = conv_block(sd, "middle_conv1", join, training=training)
     mid = conv_block(sd, "middle_conv2", mid, training=training)
     return _decoder2d(sd, mid, skips, training)
+
+
+def legacy_unet_forward(sd: State, x: torch.Tensor, *, levels: int = 4, training: bool = True,
+                        dropout_factor: Optional[torch.Tensor] = None):
+    """``Unet_v0.forward`` (unet/unet_v0.py:69-106, levels=4) / ``BabyUnet.forward`` (unet/baby_unet.py:66-93, levels=3): ReLU
+    blocks, skips from the FIRST conv of each level, ``Dropout2d(0.5)`` behind ``middle_conv2`` (``dropout_factor`` [N, C] =
+    the multiplier it applied in this call; None = inactive / eval), a final ``conv(F -> 1)`` block and a 1x1 head."""
+    skips = []
+    t = emu_input(x)
+    for lvl in range(levels):
+        e = conv_block(sd, f"encode{2 * lvl + 1}", t, training=training, slope=0.0)
+        skips.append(e)
+        t = conv_block(sd, f"encode{2 * lvl + 2}", e, training=training, slope=0.0)
+        t = st(_maxpool(t))
+    t = conv_block(sd, "middle_conv1", t, training=training, slope=0.0)
+    t = conv_block(sd, "middle_conv2", t, training=training, slope=0.0, dropout_factor=dropout_factor)
+    if dropout_factor is None:
+        t = st(t)                                   # the engine materialises the bottleneck behind the (inactive) dropout
+    for lvl, skip in zip(range(1, levels + 1), reversed(skips)):
+        t = checked_concat(up_conv_t(sd, f"up{lvl}", t), skip)
+        t = conv_block(sd, f"decode{2 * lvl - 1}", t, training=training, slope=0.0)
+        t = conv_block(sd, f"decode{2 * lvl}", t, training=training, slope=0.0)
+    t = conv_block(sd, f"decode{2 * levels + 1}", t, training=training, slope=0.0)
+    logits = F.conv2d(t, sd["final.0.weight"], sd["final.0.bias"])
+    return torch.sigmoid(logits), logits
+
+
+def attention_gate(sd: State, name: str, gate: torch.Tensor, skip: torch.Tensor, *, training: bool) -> torch.Tensor:
+    """``AttentionBlock.forward`` (unet/attention_unet.py:159-181)."""
+    g1 = conv_block(sd, f"{name}.W_gate", gate, training=training, slope=1.0)
+    x1 = conv_block(sd, f"{name}.W_x", skip, training=training, slope=1.0)
+    p = st(_relu(g1 + x1))
+    psi = torch.sigmoid(conv_block(sd, f"{name}.psi", p, training=training, slope=1.0))
+    return st(skip * psi)
+
+
+def attention_unet_forward(sd: State, x: torch.Tensor, *, dilation: int = 1, training: bool = True):
+    """``AttentionUnet.forward`` (unet/attention_unet.py:71-109): concat order is (attended skip, up-sampled)."""
+    m4, skips = _encoder2d(sd, emu_input(x), training, dilation)
+    t = conv_block(sd, "middle_conv1", m4, training=training, dilation=dilation)
+    t = conv_block(sd, "middle_conv2", t, training=training, dilation=dilation)
+    for lvl, skip in zip((1, 2, 3, 4), reversed(skips)):
+        u = up_conv_t(sd, f"up{lvl}", t)
+        a = attention_gate(sd, f"attention{lvl}", u, skip, training=training)
+        t = checked_concat(a, u)
+        t = conv_block(sd, f"decode{2 * lvl - 1}", t, training=training)
+        t = conv_block(sd, f"decode{2 * lvl}", t, training=training)
+    logits = F.conv2d(t, sd["final.0.weight"], sd["final.0.bias"])
+    return torch.sigmoid(logits), logits
 
 
 def _body3d(sd: State, x, *, training: bool, down: str, up: str):

@@ -44,6 +44,9 @@ unet3d_mod = load("ref_unet3d", "unet3d/unet3d.py")
 siam_mod = load("ref_siam", "siam_unet/siam_unet.py")
 mo3d_mod = load("ref_mo3d", "multi_output_unet3d/multi_output_unet3d.py")
 losses_mod = load("ref_losses", "unet/losses.py")
+att_mod = load("ref_attention_unet", "unet/attention_unet.py")
+v0_mod = load("ref_unet_v0", "unet/unet_v0.py")
+baby_mod = load("ref_baby_unet", "unet/baby_unet.py")
 siam_losses_mod = load("ref_siam_losses", "siam_unet/losses.py")     # the Siam package's own criteria (BCELoss on probabilities)
 
 
@@ -114,6 +117,50 @@ def main():
             crit(outs[1][ch], y[ch]) * torch.ones(oc)[j] for j, ch in enumerate(range(oc))) / sum(torch.ones(oc))
         dump(case, dict(model="Unet", ctor=kw, seed=0, loss=f"unet/train.py:133-134 with {crit_name}", init="init_weights"),
              m, {"x": x}, y, loss_fn, ["prob", "logits"], lambda mod, x=x: mod(x))
+
+    # ---- (i-b) the other bio_image_unet.unet networks: attention-gated, legacy v0, three-level "baby" --------------
+    torch.manual_seed(4)
+    kw = dict(in_channels=2, out_channels=2, n_filter=4, dilation=1)
+    m = att_mod.AttentionUnet(**kw)
+    m.apply(ref_init_weights)
+    x = torch.rand(2, 2, 32, 48)
+    y = (torch.rand(2, 2, 32, 48) > 0.5).float()
+    loss_fn = lambda outs, y=y: sum(bce_dice(outs[1][ch], y[ch]) * torch.ones(2)[j] for j, ch in enumerate(range(2))) / sum(torch.ones(2))
+    dump("attention_f4", dict(model="AttentionUnet", ctor=kw, seed=4, loss="unet/train.py:133-134 with BCEDice(0.5,0.5)", init="init_weights"),
+         m, {"x": x}, y, loss_fn, ["prob", "logits"], lambda mod, x=x: mod(x))
+    for case, cls, kw, hw in (("unet_v0_f4", v0_mod.Unet_v0, dict(n_filter=4), (32, 48)), ("baby_f4", baby_mod.BabyUnet, dict(n_filter=4), (24, 40))):
+        torch.manual_seed(5)
+        m = cls(**kw)
+        m.apply(ref_init_weights)
+        x = torch.rand(2, 1, *hw)
+        y = (torch.rand(2, 1, *hw) > 0.5).float()
+        # Dropout2d(0.5) behind middle_conv2 draws from torch's RNG: record the factor it applied in the train-mode forward
+        seen = {}
+        def hook(mod, inp, out, seen=seen):
+            if mod.training:
+                dead = (inp[0] == 0).flatten(2).all(2)
+                zeroed = (out == 0).flatten(2).all(2)
+                seen["f"] = torch.where(zeroed & ~dead, torch.zeros(()), torch.full((), 1.0 / (1.0 - mod.p)))
+        h = m.middle_conv2[3].register_forward_hook(hook)
+        loss_fn = lambda outs, y=y: bce_dice(outs[1][0], y[0])          # unet/train.py:133-134 with out_channels = 1
+        class _In(dict):
+            pass
+        ins = _In(x=x)
+        def call(mod, x=x):
+            return mod(x)
+        # the factor is only known after the forward: dump() stores inputs first, so run one throw-away forward with the same seed state
+        st = torch.get_rng_state()
+        m.train()
+        with torch.no_grad():
+            sd_keep = {k: v.clone() for k, v in m.state_dict().items()}
+            m(x)
+            m.load_state_dict(sd_keep)
+        torch.set_rng_state(st)
+        ins["dropout_factor"] = seen["f"].clone()
+        dump(case, dict(model=cls.__name__, ctor=kw, seed=5, loss="unet/train.py:133-134 with BCEDice(0.5,0.5), out_channels=1", init="init_weights"),
+             m, ins, y, loss_fn, ["prob", "logits"], call)
+        assert torch.equal(seen["f"], ins["dropout_factor"]), "the recorded Dropout2d draw must be the one of the dumped forward"
+        h.remove()
 
     # ---- (ii) UNet3D ---------------------------------------------------------------------------
     smooth_l1 = torch.nn.SmoothL1Loss()

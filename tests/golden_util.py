@@ -23,4 +23,4 @@ def load_case(case):
 
 
 ALL_CASES = ["unet2d_f4", "unet2d_f4_o2_dil2", "unet3d_f4", "unet3d_f4_interp", "siam_f4_concat", "siam_f4_max",
-             "siam_f4_corr", "siam_f4_control", "mo3d_f4_interp", "mo3d_f4_convT"]
+             "siam_f4_corr", "siam_f4_control", "mo3d_f4_interp", "mo3d_f4_convT", "attention_f4", "unet_v0_f4", "baby_f4"]

@@ -127,8 +127,8 @@ class InSitu:
             self.failures.append(f"{label}: {what}: deviation {dev:.2f}x tolerance (rel {rel})")
 
     # ---- helpers ---------------------------------------------------------------------------------------------------
-    def _mfma(self, cin, cout, dil=1):
-        return dil == 1 and cin >= 16 and cin % (16 if self.bf16 else 8) == 0 and cout >= 16 and cout % 8 == 0
+    def _mfma(self, cin, cout, dil=1, k=3):
+        return dil == 1 and k != 1 and cin >= 16 and cin % (16 if self.bf16 else 8) == 0 and cout >= 16 and cout % 8 == 0
 
     def _conv(self, x, w, b, dil, transposed=False):
         nd3 = w.dim() == 5
@@ -137,7 +137,7 @@ class InSitu:
         if transposed:
             y = (F.conv_transpose3d if nd3 else F.conv_transpose2d)(x, w, b, stride=2)
         else:
-            y = (F.conv3d if nd3 else F.conv2d)(x, w, b, padding=dil, dilation=dil)
+            y = (F.conv3d if nd3 else F.conv2d)(x, w, b, padding=dil if w.shape[-1] == 3 else 0, dilation=dil)
         return y if nd3 else y.unsqueeze(2)
 
     def _parts(self, xin):
@@ -180,7 +180,7 @@ class InSitu:
         a = self._T_cat(nd.xin)
         w = nd.conv.weight.detach().cpu().double()
         b = nd.conv.bias.detach().cpu().double() if nd.conv.bias is not None else None
-        mf = self._mfma(nd.xin.c, nd.y.c, nd.dil)
+        mf = self._mfma(nd.xin.c, nd.y.c, nd.dil, nd.kw)
         if self.bf16 and mf:
             a, w = _r(a.float(), True).double(), _r(w.float(), True).double()
         want = self._conv(a, w, b, nd.dil)
@@ -261,8 +261,17 @@ class InSitu:
     # ================================================================================================================
     def bwd_Heads_pre(self, hg):
         _, head_grads = hg
-        live = [(h, g) for h, g in zip(self.eng.heads, head_grads) if g is not None]
-        return dict(live=[(h, g.detach().float().cpu().double()) for h, g in live])
+        live = []
+        for h, g in zip(self.eng.heads, head_grads):
+            if g is None:
+                continue
+            gl, ga, a = (None if t is None else t.detach().float().cpu().double() for t in g)
+            dl = gl if gl is not None else 0.0
+            if ga is not None:                     # the activation's derivative from the activated output (engine.HeadNode.dlogits)
+                d = {0: lambda a: torch.ones_like(ga), 1: lambda a: a * (1 - a), 2: lambda a: 1 - a * a, 3: lambda a: (a > 0).double()}[h.act](a)
+                dl = dl + ga * d
+            live.append((h, dl))
+        return dict(live=live)
 
     def bwd_Heads_post(self, hg, s):
         if not s["live"]:
@@ -336,13 +345,13 @@ class InSitu:
         self.close(lab, "dy (BN+LReLU bwd)", dy_got, dy, abs_frac=(2.0 ** -8 if self.bf16 else 1e-5) * float(dz.pow(2).mean().sqrt() * gis.abs().max() / (dy.pow(2).mean().sqrt() + 1e-30) + 1.0), ignore=near)
         # weight gradient from the dy the engine actually stored
         a = self._T_cat(nd.xin)
-        wgrad_mfma = nd.xin.c >= 16 and nd.xin.c % 8 == 0 and nd.y.c >= 16 and nd.y.c % 8 == 0 and nd.dil == 1
+        wgrad_mfma = nd.xin.c >= 16 and nd.xin.c % 8 == 0 and nd.y.c >= 16 and nd.y.c % 8 == 0 and nd.dil == 1 and nd.kw == 3
         if self.bf16 and wgrad_mfma:
             a = _r(a.float(), True).double()
         w = nd.conv.weight.detach().cpu().double()
         wv = w.clone().requires_grad_(True)
         av = a.clone().requires_grad_(True)
-        wq = _r(w.float(), True).double() if (self.bf16 and self._mfma(nd.y.c, nd.xin.c, nd.dil)) else w     # dgrad: K = Cout
+        wq = _r(w.float(), True).double() if (self.bf16 and self._mfma(nd.y.c, nd.xin.c, nd.dil, nd.kw)) else w     # dgrad: K = Cout
         out = self._conv(av, wv, None, nd.dil)
         (gw,) = torch.autograd.grad(out, wv, dy_got, retain_graph=False)
         self.vec_close(lab, "dW", self._pgrad(nd, s, nd.conv.weight), gw, rel=2e-4, floor=3e-5)
@@ -417,12 +426,63 @@ class InSitu:
             return
         ta, tb = act_T(nd.a_), act_T(nd.b_)
         g = act_grad(nd.y)
-        to_a = ta >= tb                                   # ties go to a (biu.h)
-        wa, wb = torch.where(to_a, g, torch.zeros_like(g)), torch.where(to_a, torch.zeros_like(g), g)
+        # torch.maximum's backward: the winner takes the gradient, an exact tie splits it evenly (frequent in bf16)
+        wa = torch.where(ta > tb, g, torch.where(ta == tb, 0.5 * g, torch.zeros_like(g)))
+        wb = torch.where(tb > ta, g, torch.where(ta == tb, 0.5 * g, torch.zeros_like(g)))
         if s["ga"] is not None:
             wa, wb = wa + s["ga"], wb + s["gb"]
         self.close(nd.label + ":bwd", "max join da", act_grad(nd.a_), wa, rel=2.0 ** -8 if self.bf16 else 1e-6)
         self.close(nd.label + ":bwd", "max join db", act_grad(nd.b_), wb, rel=2.0 ** -8 if self.bf16 else 1e-6)
+
+
+def _nc(t):
+    return t.detach().cpu().double()[:, :, None, None, None]
+
+
+def _fwd_DropoutNode_post(self, nd, s):
+    self.close(nd.label + ":fwd", "dropout", act_raw(nd.y), act_T(nd.xin) * _nc(nd.factor), rel=2.0 ** -8 if self.bf16 else 1e-6)
+
+
+def _bwd_DropoutNode_post(self, nd, s):
+    if nd.y.g_written():
+        self.close(nd.label + ":bwd", "dropout dx", act_grad(nd.xin), act_grad(nd.y) * _nc(nd.factor), rel=2.0 ** -8 if self.bf16 else 1e-6)
+        self._check_red(nd.xin, nd.label + ":bwd")
+
+
+def _fwd_AddReluNode_post(self, nd, s):
+    self.close(nd.label + ":fwd", "relu(a + b)", act_raw(nd.y), F.relu(act_T(nd.a_) + act_T(nd.b_)), rel=2.0 ** -8 if self.bf16 else 1e-6)
+
+
+def _bwd_AddReluNode_post(self, nd, s):
+    if nd.y.g_written():
+        g = torch.where(act_raw(nd.y) > 0, act_grad(nd.y), torch.zeros_like(act_grad(nd.y)))
+        for who, a in (("da", nd.a_), ("db", nd.b_)):
+            self.close(nd.label + ":bwd", "add_relu " + who, act_grad(a), g, rel=2.0 ** -8 if self.bf16 else 1e-6)
+
+
+def _bwd_GateNode_pre(self, nd):
+    return dict(ge=self._gsnap(nd.e_)) if nd.y.g_written() else None
+
+
+def _fwd_GateNode_post(self, nd, s):
+    self.close(nd.label + ":fwd", "skip * sigmoid(psi)", act_raw(nd.y), act_T(nd.e_) * torch.sigmoid(act_T(nd.psi_)))
+
+
+def _bwd_GateNode_post(self, nd, s):
+    if s is None:
+        return
+    sg, te, g = torch.sigmoid(act_T(nd.psi_)), act_T(nd.e_), act_grad(nd.y)
+    de = g * sg
+    if s["ge"] is not None:
+        de = de + s["ge"]
+    self.close(nd.label + ":bwd", "gate de", act_grad(nd.e_), de)
+    dpsi = (g * te).sum(1, keepdim=True) * sg * (1 - sg)
+    self.close(nd.label + ":bwd", "gate dpsi", act_grad(nd.psi_), dpsi, abs_frac=(2.0 ** -8 if self.bf16 else 1e-5) * float((g * te).abs().sum(1).mean() / (dpsi.pow(2).mean().sqrt() + 1e-30) + 1.0))
+
+
+for _n, _f in list(globals().items()):
+    if _n.startswith(("_fwd_", "_bwd_")) and callable(_f):
+        setattr(InSitu, _n[1:], _f)
 
 
 def attach(model, xs, bf16):
@@ -434,7 +494,7 @@ def attach(model, xs, bf16):
 def extract_decisions(eng):
     """The discrete decisions the engine's last forward took, in execution order, in the form ``oracle.forced_decisions``
     consumes: LeakyReLU branch masks (sign of fma(scale, y, shift) on the stored y -- the expression every kernel evaluates),
-    max-pool argmax indices (first maximum in scan order) and the winner mask of the Siam 'max' join."""
+    max-pool argmax indices (first maximum in scan order) and the comparison sign (+1 / 0 / -1) of the Siam 'max' join."""
     q = {"lrelu": [], "pool": [], "max": []}
     sq = (lambda t: t) if eng.nd == 3 else (lambda t: t.squeeze(2))
     for nd in eng.nodes:
@@ -446,5 +506,7 @@ def extract_decisions(eng):
             _, idx = (F.max_pool3d if eng.nd == 3 else F.max_pool2d)(a, 2, 2, return_indices=True)
             q["pool"].append(idx)
         elif isinstance(nd, E.MaxJoinNode):
-            q["max"].append(sq(act_T(nd.a_) >= act_T(nd.b_)))
+            q["max"].append(sq(torch.sign(act_T(nd.a_) - act_T(nd.b_))))
+        elif isinstance(nd, E.AddReluNode):
+            q.setdefault("relu", []).append(sq(act_raw(nd.y) > 0))
     return q

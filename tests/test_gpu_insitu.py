@@ -17,11 +17,24 @@ from tests import insitu  # noqa: E402
 HEADS = {"seg": {"channels": 1, "activation": "sigmoid"}, "flow": {"channels": 2, "activation": None},
          "dist": {"channels": 1, "activation": "tanh"}}
 
+def _init_like(module, seed):
+    """state_dict with the module's own (PyTorch default + Kaiming-normal Conv2d) initialisation under a fixed seed."""
+    from bio_image_unet_amd.utils import init_weights
+    torch.manual_seed(seed)
+    for mod in module.modules():
+        if hasattr(mod, "reset_parameters"):
+            mod.reset_parameters()
+    module.apply(init_weights)
+    return {k: v.clone() for k, v in module.state_dict().items()}
+
+
 CASES = {
     "unet2d_f16": (lambda: B.Unet(1, 1, 16), lambda: O.init_unet2d(1, 1, 16, seed=3), (2, 1, 64, 64), 1),
     "cfg2_unet2d_f64_o2": (lambda: B.Unet(1, 2, 64), lambda: O.init_unet2d(1, 2, 64, seed=4), (2, 1, 64, 64), 1),
     "cfg3_siam_max_f32": (lambda: B.Siam_UNet(32, "max"), lambda: O.init_unet2d(1, 1, 32, seed=5, init_weights=False), (2, 1, 64, 64), 2),
     "siam_concat_f16": (lambda: B.Siam_UNet(16, "concat"), lambda: O.init_unet2d(1, 1, 16, seed=6, init_weights=False, siam_mode="concat"), (2, 1, 64, 64), 2),
+    "attention_f16": (lambda: B.AttentionUnet(1, 1, 16), lambda: _init_like(B.AttentionUnet(1, 1, 16), 10), (2, 1, 64, 64), 1),
+    "unet_v0_f16": (lambda: B.Unet_v0(16), lambda: _init_like(B.Unet_v0(16), 11), (2, 1, 64, 64), 1),
     "cfg4_unet3d_f32": (lambda: B.UNet3D(1, 1, 32), lambda: O.init_unet3d(1, 1, 32, seed=7), (2, 1, 16, 32, 32), 1),
     "cfg5_mo3d_f32_interp": (lambda: B.MultiOutputUnet3D(1, HEADS, 32, True), lambda: O.init_mo3d(1, HEADS, 32, True, seed=8), (1, 1, 16, 32, 32), 1),
     "cfg5_mo3d_f32_convT": (lambda: B.MultiOutputUnet3D(1, HEADS, 32, False), lambda: O.init_mo3d(1, HEADS, 32, False, seed=9), (1, 1, 16, 32, 32), 1),

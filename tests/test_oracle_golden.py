@@ -18,6 +18,12 @@ def run_oracle(g, sd, training):
     x = g["in"]["x"]
     if meta["model"] == "Unet":
         return dict(zip(("prob", "logits"), O.unet2d_forward(sd, x, dilation=ctor["dilation"], training=training)))
+    if meta["model"] == "AttentionUnet":
+        return dict(zip(("prob", "logits"), O.attention_unet_forward(sd, x, dilation=ctor["dilation"], training=training)))
+    if meta["model"] in ("Unet_v0", "BabyUnet"):
+        f = g["in"]["dropout_factor"] if training else None
+        return dict(zip(("prob", "logits"), O.legacy_unet_forward(sd, x, levels=4 if meta["model"] == "Unet_v0" else 3, training=training,
+                                                                  dropout_factor=f)))
     if meta["model"] == "UNet3D":
         return dict(zip(("prob", "logits"),
                         O.unet3d_forward(sd, x, use_interpolation=ctor["use_interpolation"], training=training)))
@@ -32,9 +38,11 @@ def run_oracle(g, sd, training):
 
 def oracle_loss(g, outs):
     meta = g["meta"]
-    if meta["model"] == "Unet":
+    if meta["model"] in ("Unet", "AttentionUnet"):
         crit = O.bce_dice_loss if "BCEDice" in meta["loss"] else O.tversky_loss
         return O.trainer2d_loss(outs["logits"], g["in"]["target"], meta["ctor"]["out_channels"], criterion=crit)
+    if meta["model"] in ("Unet_v0", "BabyUnet"):
+        return O.trainer2d_loss(outs["logits"], g["in"]["target"], 1)
     if meta["model"] == "UNet3D":
         return O.trainer3d_loss(outs["logits"], g["in"]["target"], 0.1)
     if meta["model"] == "Siam_UNet":       # the Siam package's own BCEDice (BCELoss on probabilities), loss_params (1, 1)
