@@ -97,7 +97,7 @@ def make_step(wl, device):
     nvox = 1
     for s in (shape[0],) + tuple(shape[2:]):
         nvox *= s
-    return model, step, fwd, nvox
+    return model, step, fwd, nvox, avg
 
 
 def call_cost(eng, api, label):
@@ -206,7 +206,7 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     wl = WORKLOADS[args.workload]
-    model, step, fwd, nvox = make_step(wl, device)
+    model, step, fwd, nvox, avg = make_step(wl, device)
 
     def barrier():
         if world > 1:
@@ -302,6 +302,9 @@ def main():
                           "kernel_time_ms_one_step": total_kernel_ms},
         "roofline": roof,
     }
+    if world > 1:           # gradient all-reduce: decoder -> encoder buckets, issued from inside backward (bio_image_unet_amd/ddp.py)
+        out["ddp"] = {"buckets": len(avg.buckets), "launched_in_backward": avg.launched_in_backward,
+                      "bucket_mbytes": [round(b.flat.numel() * 4 / 2 ** 20, 2) for b in avg.buckets]}
     if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores, bounded sample)
         out["cpu_baseline"] = cpu_baseline(args.workload)
     print(json.dumps(out), flush=True)

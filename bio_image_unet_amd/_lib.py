@@ -105,6 +105,11 @@ SIGNATURES = {
     "biu_gate_fwd": (_I, [_A, _X, _A, _X, _A, _I, _P]),
     "biu_gate_bwd": (_I, [_A, _X, _A, _X, _A, _A, _I, _A, _I, _P]),
     "biu_from_nchw": (_I, [_P, _A, _I, _P]),
+    "biu_from_nchw_u8": (_I, [_P, _F, _A, _I, _P]),
+    "biu_u8_to_f32": (_I, [_P, _F, _P, C.c_longlong, _P]),
+    "biu_quantize_u8": (_I, [_P, _F, _P, C.c_longlong, _P]),
+    "biu_stitch_add": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "biu_stitch_finish": (_I, [_P, _P, _I, _I, C.c_longlong, _P, _I, _P]),
     "biu_to_nchw": (_I, [_A, _X, _P, _I, _P]),
     "biu_adam_step": (_I, [_I, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _F, _P]),
 }

@@ -1235,6 +1235,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     // w / KSPLIT + WPQ * t, t < IPW -- every wave runs the same branch-free loop over ITS k-groups with IPW MFMAs per A
     // fragment; a tap index past the last one multiplies into an accumulator nobody flushes.
     const int wq = wave % KSPLIT, wtap0 = wave / KSPLIT;
+    // TAPS is rarely a multiple of the tap slots (27 taps on 8 x 4 slots, 9 on 2 x 5): the waves whose last slot has no tap
+    // skip its LDS reads and MFMA (wave-uniform scalar branch) instead of multiplying into an accumulator nobody flushes --
+    // the SIMD they share with a full wave issues 7 MFMAs per k-group instead of 8
+    const bool last_tap_live = (wtap0 + WPQ * (IPW - 1)) < TAPS;
     int tapoff[IPW];
 #pragma unroll
     for (int t = 0; t < IPW; ++t) {
@@ -1464,7 +1468,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                         }
 #pragma unroll
                         for (int t2 = 0; t2 < IPW; ++t2) {
-                            {
+                            if (t2 < IPW - 1 || last_tap_live) {
                                 const char* bp = bt + hbase + tapoff[t2] + b_lane;
                                 bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp));
                                 bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp + 4 * S * RS));
@@ -1479,7 +1483,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                         for (int ni = 0; ni < NI; ++ni) af[ni] = *(const float*)(at + q0 * RSA + a_lane + ni * CT * 4);
 #pragma unroll
                         for (int t2 = 0; t2 < IPW; ++t2) {
-                            {
+                            if (t2 < IPW - 1 || last_tap_live) {
                                 const float bf = *(const float*)(bt + hbase + tapoff[t2] + b_lane);
 #pragma unroll
                                 for (int ni = 0; ni < NI; ++ni) acc[t2][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ni], bf, acc[t2][ni], 0, 0, 0);

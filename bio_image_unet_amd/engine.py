@@ -726,6 +726,7 @@ class Engine:
         self._zero_flat, self._zero_used = None, 0
         self._slots: List[dict] = []
         self._job_key, self._job_tab = None, None
+        self.grad_hook = None        # callable(param, grad) fired inside backward when a parameter's gradient is final (ddp.py)
         self.trace = None            # test hook: trace(phase, node, when) around every node ("fwd"/"bwd", node, "pre"/"post")
         self.generation = 0          # bumped by every forward: a backward must see the generation of ITS forward
         self._live = None            # weakref to the token of the autograd node that still needs this engine's buffers
@@ -783,11 +784,14 @@ class Engine:
         self.ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=dev)
         self.params: List[nn.Parameter] = []
         seen = set()
+        self._pcount: Dict[nn.Parameter, int] = {}      # contributions a parameter receives per backward (weight sharing: > 1)
         for nd_ in self.nodes:
             for p in nd_.params:
-                if p is not None and id(p) not in seen:
-                    seen.add(id(p))
-                    self.params.append(p)
+                if p is not None:
+                    self._pcount[p] = self._pcount.get(p, 0) + 1
+                    if id(p) not in seen:
+                        seen.add(id(p))
+                        self.params.append(p)
 
     # ---- MFMA weight packing cache ---------------------------------------------------------------------
     def packed_slot(self, kind, cin, cout, kd, kh, kw, dil):
@@ -884,12 +888,22 @@ class Engine:
             self.grads[p] = self.grads[p] + g
         else:
             self.grads[p] = g
+        if self.grad_hook is not None:
+            self._pseen[p] = self._pseen.get(p, 0) + 1
+            if self._pseen[p] == self._pcount.get(p, 1):
+                self.grad_hook(p, self.grads[p])
 
     # ---- execution ----------------------------------------------------------------------------------------
     def load_inputs(self, xs: Sequence[torch.Tensor]):
         st = _stream()
         for act, x in zip(self.inputs, xs):
             x = x.detach()
+            if x.dtype == torch.uint8:
+                # the reference's data contract: uint8 tiles scaled by 1/255 (unet/data.py:253-266, unet/predict.py:192-196);
+                # the scaling rides in the layout kernel, the batch crossed PCIe as bytes
+                x = x.contiguous()
+                check(lib.biu_from_nchw_u8(_ptr(x), 1.0 / 255.0, act.a(), self.dtype, st), "from_nchw_u8")
+                continue
             if x.dtype != torch.float32:
                 x = x.float()
             x = x.contiguous()
@@ -920,6 +934,7 @@ class Engine:
     def backward(self, head_grads: Sequence[Optional[torch.Tensor]]):
         """head_grads[i] = None or (d loss / d logits, d loss / d activated output, activated output) of head i."""
         self.grads = {}
+        self._pseen: Dict[nn.Parameter, int] = {}
         self._zero_flat, self._zero_used = None, 0
         for b in self.bufs:
             for k in b.leaves:

@@ -47,6 +47,7 @@ class _HipNet(nn.Module):
     def __getstate__(self):
         st = self.__dict__.copy()
         st["_engines"] = OrderedDict()
+        st.pop("_grad_hook", None)          # belongs to a process-local GradAverager
         return st
 
     def __deepcopy__(self, memo):
@@ -54,8 +55,18 @@ class _HipNet(nn.Module):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
+            if k == "_grad_hook":
+                continue
             new.__dict__[k] = OrderedDict() if k == "_engines" else copy.deepcopy(v, memo)
         return new
+
+    def register_grad_ready_hook(self, fn):
+        """``fn(param, grad)`` is called from inside the backward pass the moment a parameter's gradient is complete (after the
+        last of its contributions when weights are shared) -- what ``ddp.GradAverager`` overlaps its bucketed all-reduce with."""
+        self._grad_hook = fn
+        for engs in self._engines.values():
+            for e in engs:
+                e.grad_hook = fn
 
     def invalidate_packed(self):
         """Call after writing parameters through ``.data`` (EMA, clipping, manual broadcast): such writes do not bump
@@ -95,6 +106,7 @@ class _HipNet(nn.Module):
             eng = E.Engine(x.device, self.compute_dtype, self.nd)
             self._build(eng, *[tuple(t.shape) for t in xs])
             eng.finalize()
+            eng.grad_hook = getattr(self, "_grad_hook", None)
             names = {id(mod): name for name, mod in self.named_modules()}
             for nd_ in eng.nodes:       # labels for profiling: the reference attribute name of the layer
                 mod = getattr(nd_, "conv", None) or getattr(nd_, "up", None)

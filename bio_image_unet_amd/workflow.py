@@ -50,6 +50,25 @@ def _make_criterion(name, params, extra=None):
     return table[name](params[0], params[1])
 
 
+def _loaders(dataset, train_data, val_data, batch_size, device):
+    """The reference's loaders (``DataLoader(shuffle=False, drop_last=True, num_workers=0, pin_memory=True)``, unet/train.py:92-93)
+    -- or, for a memory-mapped ``feed.TileStore``, asynchronous uint8 feeders over the same index split (same order, same
+    batches; the tiles cross PCIe as bytes while the previous step computes)."""
+    from .feed import DeviceFeeder, TileStore
+    if isinstance(dataset, TileStore) and torch.device(device).type == "cuda":
+        return (DeviceFeeder(dataset, train_data.indices, batch_size, device), DeviceFeeder(dataset, val_data.indices, batch_size, device))
+    return (DataLoader(train_data, batch_size=batch_size, pin_memory=True, drop_last=True),
+            DataLoader(val_data, batch_size=batch_size, pin_memory=True, drop_last=True))
+
+
+def _target(t: torch.Tensor) -> torch.Tensor:
+    """Targets arrive as float32 in [0, 1] (reference items) or as uint8 0..255 from a DeviceFeeder."""
+    if t.dtype == torch.uint8:
+        from .feed import u8_to_float
+        return u8_to_float(t)
+    return t
+
+
 class _EpochLoop:
     """Shared skeleton: split, loaders, Adam + ReduceLROnPlateau, best-validation checkpointing."""
     item_key = "image"
@@ -61,8 +80,7 @@ class _EpochLoop:
         n_val = int(len(dataset) * val_split)
         self.dim = dataset.dim_out
         train_data, val_data = random_split(dataset, [len(dataset) - n_val, n_val])
-        self.train_loader = DataLoader(train_data, batch_size=batch_size, pin_memory=True, drop_last=True)
-        self.val_loader = DataLoader(val_data, batch_size=batch_size, pin_memory=True, drop_last=True)
+        self.train_loader, self.val_loader = _loaders(dataset, train_data, val_data, batch_size, self.device)
         self.optimizer = Adam(self.model.parameters(), lr=lr)
         self.scheduler = optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode="min", patience=4, factor=0.1)
         os.makedirs(save_dir, exist_ok=True)
@@ -121,7 +139,7 @@ class Trainer2D(_EpochLoop):
         d = self.dim
         x = batch["image"].view(self.batch_size, self.in_channels, d[0], d[1]).to(self.device)
         # the training branch reshapes the mask with dim[0] twice (square tiles assumed), the validation one does not
-        y = batch["mask"].view(self.batch_size, self.out_channels, d[0], d[1] if validating else d[0]).to(self.device)
+        y = _target(batch["mask"].view(self.batch_size, self.out_channels, d[0], d[1] if validating else d[0]).to(self.device))
         _, logits = self.model(x)
         cw = self.channel_weights
         # NOTE the reference indexes the BATCH axis with the channel index
@@ -183,7 +201,7 @@ class Trainer3D(_EpochLoop):
     def _forward_loss(self, batch, validating):
         d = self.dim
         x = batch["volume"].view(self.batch_size, self.in_channels, d[0], d[1], d[2]).to(self.device)
-        y = batch["mask"].view(self.batch_size, self.out_channels, d[0], d[1], d[2]).to(self.device)
+        y = _target(batch["mask"].view(self.batch_size, self.out_channels, d[0], d[1], d[2]).to(self.device))
         _, logits = self.model(x)
         w = 0.1 if validating else self.time_loss_weight         # validation hard-codes 0.1
         # criterion(y_logits, y_i) + SmoothL1(y_logits[1:], y_logits[:-1]) * w (unet3d/train.py:140-145), one fused pass each way
@@ -233,7 +251,7 @@ class TrainerSiam(_EpochLoop):
         shape = (self.batch_size, 1, d[0], d[1])
         x = batch["image"].view(shape).to(self.device)
         px = batch["prev_image"].view(shape).to(self.device)
-        y = batch["mask"].view(shape).to(self.device)
+        y = _target(batch["mask"].view(shape).to(self.device))
         _, logits = self.model(x, px)
         return self.criterion(logits, y)
 
@@ -299,8 +317,7 @@ class TrainerMo3d:
         n_val = int(len(dataset) * val_split)
         self.dim = dataset.dim_out
         train_data, val_data = random_split(dataset, [len(dataset) - n_val, n_val])
-        self.train_loader = DataLoader(train_data, batch_size=batch_size, pin_memory=True, drop_last=True)
-        self.val_loader = DataLoader(val_data, batch_size=batch_size, pin_memory=True, drop_last=True)
+        self.train_loader, self.val_loader = _loaders(dataset, train_data, val_data, batch_size, self.device)
         if loss_function == "BCEDiceTemporalLoss":
             self.criterion = BCEDiceTemporalLoss(loss_params=loss_params)
         else:
@@ -338,7 +355,7 @@ class TrainerMo3d:
 
     def _total_loss(self, batch, validating):
         x = batch["volume"].to(self.device, non_blocking=True)
-        y = {key: batch[key].to(self.device, non_blocking=True) for key in self.output_heads}
+        y = {key: _target(batch[key].to(self.device, non_blocking=True)) for key in self.output_heads}
         if x.dim() == 4:
             x = x.unsqueeze(1)
         pred = self.model(x)
@@ -413,6 +430,60 @@ def tile_starts(extent: int, tile: int, n: int) -> np.ndarray:
     return np.linspace(0, extent - tile, n).astype("uint16")
 
 
+class _Stitcher:
+    """Stitched result volume kept in HBM: patches are added where the network wrote them (``biu_stitch_add``) and the volume is
+    normalised once (``biu_stitch_finish``) -- no per-patch device-to-host copy, no host numpy accumulation.  ``layers`` > 1 keeps
+    separate overwrite-mode layers (the three-layer buffer of ``unet3d/predict.py:173-195``)."""
+
+    def __init__(self, device, channels, shape3, layers=1):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(f"Predict stitches on the GPU (biu_stitch_add / biu_stitch_finish); got device '{device}'. There is no CPU path.")
+        self.device, self.channels, self.shape, self.layers = device, channels, tuple(shape3), layers
+        d, h, w = self.shape
+        self.acc = torch.zeros((layers, channels, d, h, w), dtype=torch.float32, device=device)
+        self.wsum = torch.zeros((layers, d, h, w), dtype=torch.float32, device=device)
+
+    def reset(self):
+        self.acc.zero_()
+        self.wsum.zero_()
+
+    def add(self, patch: torch.Tensor, origin, weight: torch.Tensor = None, layer: int = 0, overwrite: bool = False):
+        """patch: device tensor [channels, pd, ph, pw] (uint8 or float32); origin (z0, y0, x0); weight [pd, ph, pw] float32 or None."""
+        import ctypes as C
+        from ._lib import check, lib
+        patch = patch.contiguous()
+        assert patch.dim() == 4 and patch.shape[0] == self.channels and patch.dtype in (torch.uint8, torch.float32)
+        c, pd, ph, pw = patch.shape
+        d, h, w = self.shape
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.biu_stitch_add(C.c_void_p(patch.data_ptr()), int(patch.dtype == torch.uint8),
+                                 C.c_void_p(weight.data_ptr()) if weight is not None else None, c, pd, ph, pw,
+                                 C.c_void_p(self.acc[layer].data_ptr()), C.c_void_p(self.wsum[layer].data_ptr()), d, h, w,
+                                 int(origin[0]), int(origin[1]), int(origin[2]), int(overwrite), st), "stitch_add")
+
+    def finish(self, as_uint8: bool) -> torch.Tensor:
+        import ctypes as C
+        from ._lib import check, lib
+        d, h, w = self.shape
+        out = torch.empty((self.channels, d, h, w), dtype=torch.uint8 if as_uint8 else torch.float32, device=self.device)
+        check(lib.biu_stitch_finish(C.c_void_p(self.acc.data_ptr()), C.c_void_p(self.wsum.data_ptr()), self.layers, self.channels,
+                                    d * h * w, C.c_void_p(out.data_ptr()), int(as_uint8),
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), "stitch_finish")
+        return out
+
+
+def _quantize_u8(prob: torch.Tensor) -> torch.Tensor:
+    """``(res * 255).astype('uint8')`` (unet/predict.py:200) on the device."""
+    import ctypes as C
+    from ._lib import check, lib
+    prob = prob.contiguous().float()
+    out = torch.empty(prob.shape, dtype=torch.uint8, device=prob.device)
+    check(lib.biu_quantize_u8(C.c_void_p(prob.data_ptr()), 255.0, C.c_void_p(out.data_ptr()), prob.numel(),
+                              C.c_void_p(torch.cuda.current_stream().cuda_stream)), "quantize_u8")
+    return out
+
+
 class Predict2D:
     """``bio_image_unet.unet.Predict`` counterpart (``unet/predict.py:14-229``) for in-memory arrays.
 
@@ -457,8 +528,7 @@ class Predict2D:
         self.model = network(n_filter=mp["n_filter"], in_channels=mp["in_channels"], out_channels=mp["out_channels"]).to(self.device)
         self.model.load_state_dict(mp["state_dict"])
         self.model.eval()
-        result_patches = self._predict(patches, batch_size)
-        self.imgs_result = self._stitch(result_patches)
+        self.imgs_result = self._predict_and_stitch(patches, batch_size)
         self._save(result_name, normalize_result)
 
     def _split(self, imgs):
@@ -481,33 +551,31 @@ class Predict2D:
                     k += 1
         return patches
 
-    def _predict(self, patches, batch_size):
-        oc = self.model_params["out_channels"]
-        out = np.zeros((patches.shape[0], oc) + patches.shape[2:], dtype="uint8")
-        with torch.no_grad():
-            for i in range(0, patches.shape[0], batch_size):
-                x = torch.from_numpy(patches[i:i + batch_size].astype("float32") / 255).to(self.device)
-                prob, _ = self.model(x)
-                out[i:i + batch_size] = (prob * 255).to(torch.uint8).cpu().numpy()      # truncation == astype('uint8')
-        return out
-
-    def _stitch(self, result_patches):
+    def _predict_and_stitch(self, patches, batch_size):
+        """uint8 patches up (scaled by 1/255 in the input-layout kernel), eval-mode forward in batches, ``(p * 255)`` truncated to
+        uint8 and added into the stitched image on the device; nan-mean of the overlapping uint8 tiles followed by the uint8
+        cast == floor(sum / count) (``unet/predict.py:184-229``).  One download per stack."""
         n_img, h, w = self.imgs_shape
         th, tw = self.resize_dim
         oc = self.model_params["out_channels"]
         H, W = max(th, h), max(tw, w)
-        res = np.zeros((n_img, oc, H, W), dtype="uint8")
-        for i in range(n_img):
-            acc = np.zeros((oc, H, W), dtype=np.int64)
-            cnt = np.zeros((1, H, W), dtype=np.int64)
-            k = 0
-            for xs in self.X_start:
-                for ys in self.Y_start:
-                    acc[:, xs:xs + th, ys:ys + tw] += result_patches[i * self.N_per_img + k]
-                    cnt[:, xs:xs + th, ys:ys + tw] += 1
-                    k += 1
-            # nan-mean of the overlapping uint8 tiles followed by the uint8 cast == floor(sum / count)
-            res[i] = (acc // np.maximum(cnt, 1)).astype("uint8")
+        origins = [(0, int(xs), int(ys)) for xs in self.X_start for ys in self.Y_start]
+        st = _Stitcher(self.device, oc, (1, H, W))
+        done, cur = [], 0
+        with torch.no_grad():
+            for i in range(0, patches.shape[0], batch_size):
+                x = torch.from_numpy(patches[i:i + batch_size]).to(self.device, non_blocking=True)      # uint8 across PCIe
+                prob, _ = self.model(x)
+                q = _quantize_u8(prob)
+                for j in range(q.shape[0]):
+                    k = i + j
+                    if k // self.N_per_img != cur:
+                        done.append(st.finish(True))
+                        st.reset()
+                        cur = k // self.N_per_img
+                    st.add(q[j].unsqueeze(1), origins[k % self.N_per_img])
+            done.append(st.finish(True))
+        res = torch.stack(done).cpu().numpy()[:, :, 0]                       # (n_img, oc, H, W)
         return np.squeeze(res[:, :, :h, :w])
 
     def _save(self, result_name, normalize):
@@ -572,13 +640,18 @@ class Predict3D:
                              use_interpolation=mp.get("use_interpolation", False)).to(self.device)
         self.model.load_state_dict(mp["state_dict"])
         self.model.eval()
-        result_patches = np.zeros_like(patches)
+        # one eval-mode forward per patch as upstream (unet3d/predict.py:155-171); quantisation and the three-layer stitch buffer
+        # (patch n overwrites layer n % 3, then the nan-mean over the layers, :173-195) stay on the device
+        vs, rd = self.vol_shape, self.resize_dim
+        st = _Stitcher(self.device, 1, tuple(max(vs[a], rd[a]) for a in range(3)), layers=3)
+        origins = [(int(z), int(x), int(y)) for z in self.Z_start for x in self.X_start for y in self.Y_start]
         with torch.no_grad():
             for i, p in enumerate(patches):
-                x = torch.from_numpy(p.astype("float32") / 255).to(self.device).view((1, 1) + self.resize_dim)
+                x = torch.from_numpy(p).to(self.device, non_blocking=True).view((1, 1) + self.resize_dim)      # uint8; /255 in the layout kernel
                 prob, _ = self.model(x)
-                result_patches[i] = (prob.view(self.resize_dim) * 255).to(torch.uint8).cpu().numpy()
-        self.vol_result = self._stitch(result_patches)
+                st.add(_quantize_u8(prob).view((1,) + self.resize_dim), origins[i], layer=i % 3, overwrite=True)
+        out = st.finish(True)[0].cpu().numpy()
+        self.vol_result = np.squeeze(out[:vs[0], :vs[1], :vs[2]])
         out = self.vol_result
         if normalize_result:
             out = out - np.nanmin(out)
@@ -606,19 +679,6 @@ class Predict3D:
                     patches[n] = vol[z:z + rd[0], x:x + rd[1], y:y + rd[2]]
                     n += 1
         return patches
-
-    def _stitch(self, result_patches):
-        vs, rd = self.vol_shape, self.resize_dim
-        buf = np.full((3,) + tuple(max(vs[a], rd[a]) for a in range(3)), np.nan, dtype="float16")
-        n = 0
-        for z in self.Z_start:
-            for x in self.X_start:
-                for y in self.Y_start:
-                    buf[n % 3, z:z + rd[0], x:x + rd[1], y:y + rd[2]] = result_patches[n]
-                    n += 1
-        with np.errstate(all="ignore"):
-            out = np.nanmean(buf, axis=0).astype("uint8")
-        return np.squeeze(out[:vs[0], :vs[1], :vs[2]])
 
 
 class PredictSiam:
@@ -653,19 +713,23 @@ class PredictSiam:
         self.Y_start = tile_starts(self.imgs_shape[2], tw, self.N_y)
         frames = []
         cur = None
+        h, w = self.imgs_shape[1], self.imgs_shape[2]
+        stitch = _Stitcher(self.device, 1, (1, max(th, h), max(tw, w)))
+        origins = [(0, int(xs), int(ys)) for xs in self.X_start for ys in self.Y_start]
         for i in range(self.tif_len):
             prev = (movie[0] if self.tif_len == 1 else movie[1]) if i == 0 else cur
             cur = movie[i]
             pair = normalise_stack(np.array([prev, cur], dtype=np.float64), normalization_mode, clip_threshold, invert).astype("uint8")
             patches = self._split(pair)
-            out = np.zeros((self.N, th, tw), dtype="uint8")
+            stitch.reset()
             with torch.no_grad():
                 for b in range(0, self.N, batch_size):
-                    x = torch.from_numpy(patches[b:b + batch_size, 0:1].astype("float32") / 255).to(self.device)
-                    px = torch.from_numpy(patches[b:b + batch_size, 1:2].astype("float32") / 255).to(self.device)
-                    out[b:b + batch_size] = (self.model(x, px)[0][:, 0] * 255).to(torch.uint8).cpu().numpy()
-            frames.append(self._stitch(out))
-        self.imgs_result = np.stack(frames)
+                    both = torch.from_numpy(patches[b:b + batch_size]).to(self.device, non_blocking=True)       # uint8 (cur, prev)
+                    q = _quantize_u8(self.model(both[:, 0:1].contiguous(), both[:, 1:2].contiguous())[0])
+                    for j in range(q.shape[0]):
+                        stitch.add(q[j].unsqueeze(1), origins[b + j])
+            frames.append(stitch.finish(True)[0, 0, :h, :w])                 # nan-mean of uint8 tiles, truncated like astype
+        self.imgs_result = torch.stack(frames).cpu().numpy()
         _write(result_name, self.imgs_result)
 
     def _split(self, pair):
@@ -680,19 +744,6 @@ class PredictSiam:
                 patches[n, 1] = pair[0][xs:xs + th, ys:ys + tw]          # previous frame
                 n += 1
         return patches
-
-    def _stitch(self, tiles):
-        th, tw = self.resize_dim
-        h, w = self.imgs_shape[1], self.imgs_shape[2]
-        H, W = max(th, h), max(tw, w)
-        acc, cnt = np.zeros((H, W), dtype=np.int64), np.zeros((H, W), dtype=np.int64)
-        n = 0
-        for xs in self.X_start:
-            for ys in self.Y_start:
-                acc[xs:xs + th, ys:ys + tw] += tiles[n]
-                cnt[xs:xs + th, ys:ys + tw] += 1
-                n += 1
-        return (acc // np.maximum(cnt, 1)).astype("uint8")[:h, :w]      # nan-mean of uint8 tiles, truncated like astype
 
 
 class PredictMo3d:
@@ -725,13 +776,7 @@ class PredictMo3d:
         self.model.load_state_dict(mp["state_dict"])
         self.model.eval()
         self.target_keys = list(mp["output_heads"].keys())
-        results = {k: [] for k in self.target_keys}
-        with torch.no_grad():
-            for b in range(0, len(patches), batch_size):
-                preds = self.model(torch.tensor(patches[b:b + batch_size], dtype=torch.float32).to(self.device))
-                for k in results:
-                    results[k].append(preds[k].float().cpu().numpy())
-        result = self._stitch({k: np.concatenate(v) for k, v in results.items()})
+        result = self._predict_and_blend(patches, batch_size)
         if result_path is not None:
             for k in self.target_keys:
                 _write((result_path + k + ".tif") if os.path.exists(result_path) else (result_path + "_" + k + ".tif"), result[k])
@@ -795,29 +840,27 @@ class PredictMo3d:
                 w[:, :, :, 0] = i / blend_margin
         return w
 
-    def _stitch(self, result_patches, blend_margin=16):
+    def _predict_and_blend(self, patches, batch_size, blend_margin=16):
+        """Batches of patches through the network; every head's float32 patch is multiplied by its blend mask and added into
+        the head's volume on the device, then ``vol / wsum`` where ``wsum > 0`` (``multi_output_unet3d/predict.py:203-307``)."""
         nvol, D, H, W = self.imgs_shape
         ps = self.patch_size
-        result, cache = {}, {}
-        for key in self.target_keys:
-            nch = self.model_params["output_heads"][key]["channels"]
-            vol = np.zeros((nvol, nch, D, H, W), dtype="float32")
-            wsum = np.zeros_like(vol)
-            for v in range(nvol):
-                pv = result_patches[key][v * self.N_per_vol:(v + 1) * self.N_per_vol].reshape(self.N_z, self.N_y, self.N_x, nch, *ps)
-                for zi, z0 in enumerate(self.Z_start):
-                    for yi, y0 in enumerate(self.Y_start):
-                        for xi, x0 in enumerate(self.X_start):
-                            flags = (zi > 0, zi < self.N_z - 1, yi > 0, yi < self.N_y - 1, xi > 0, xi < self.N_x - 1)
-                            if (flags, nch) not in cache:
-                                cache[(flags, nch)] = self._weights(flags, (nch,) + ps, blend_margin)
-                            pw = cache[(flags, nch)]
-                            zs, ys, xs = slice(z0, min(z0 + ps[0], D)), slice(y0, min(y0 + ps[1], H)), slice(x0, min(x0 + ps[2], W))
-                            pz, py, px = slice(0, zs.stop - zs.start), slice(0, ys.stop - ys.start), slice(0, xs.stop - xs.start)
-                            vol[v, :, zs, ys, xs] += pv[zi, yi, xi][:, pz, py, px] * pw[:, pz, py, px]
-                            wsum[v, :, zs, ys, xs] += pw[:, pz, py, px]
-            mask = wsum > 0
-            vol[mask] = vol[mask] / wsum[mask]
-            vol[~mask] = 0
-            result[key] = np.squeeze(vol)
-        return result
+        heads = self.model_params["output_heads"]
+        stitch = {k: [_Stitcher(self.device, heads[k]["channels"], (D, H, W)) for _ in range(nvol)] for k in self.target_keys}
+        wcache = {}
+
+        def weight_of(zi, yi, xi):
+            flags = (zi > 0, zi < self.N_z - 1, yi > 0, yi < self.N_y - 1, xi > 0, xi < self.N_x - 1)
+            if flags not in wcache:
+                wcache[flags] = torch.from_numpy(self._weights(flags, (1,) + ps, blend_margin)[0]).to(self.device).contiguous()
+            return wcache[flags]
+        index = [(v, zi, yi, xi) for v in range(nvol) for zi in range(self.N_z) for yi in range(self.N_y) for xi in range(self.N_x)]
+        with torch.no_grad():
+            for b in range(0, len(patches), batch_size):
+                preds = self.model(torch.from_numpy(np.ascontiguousarray(patches[b:b + batch_size])).to(self.device, non_blocking=True))
+                for j in range(min(batch_size, len(patches) - b)):
+                    v, zi, yi, xi = index[b + j]
+                    wt = weight_of(zi, yi, xi)
+                    for k in self.target_keys:
+                        stitch[k][v].add(preds[k][j].float(), (self.Z_start[zi], self.Y_start[yi], self.X_start[xi]), weight=wt)
+        return {k: np.squeeze(torch.stack([s_.finish(False) for s_ in stitch[k]]).cpu().numpy()) for k in self.target_keys}

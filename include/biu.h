@@ -321,6 +321,26 @@ int biu_gate_bwd(const biu_act* e, const biu_xform* xe, const biu_act* psi, cons
                  const biu_act* de, int accumulate_e, const biu_act* dpsi, int dtype, biu_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Data formats either side of the network, kept on the device
+ *   biu_from_nchw_u8 : uint8 NC[D]HW batch * scale -> channels-last activation; replaces `batch / 255` + `.to(device)` of float32
+ *                      (unet/data.py:253-266 items, unet/predict.py:192-196 patches): a quarter of the H2D bytes, no float copy
+ *   biu_u8_to_f32    : uint8 * scale -> fp32 (targets: masks are stored 0 / 255)
+ *   biu_quantize_u8  : (p * scale) truncated to uint8 -- `(res * 255).astype('uint8')`, unet/predict.py:200
+ *   biu_stitch_add   : one patch [channels, pd, ph, pw] (uint8 or fp32) times an optional weight [pd, ph, pw] added into (set != 0:
+ *                      written over) acc [channels, D, H, W] / wsum [D, H, W] at origin (z0, y0, x0); 2-D: D = pd = 1
+ *   biu_stitch_finish: out = acc / wsum where wsum > 0 else 0 (fp32: the ramp blend of multi_output_unet3d/predict.py:300-303), or
+ *                      floor(sum_layers acc / sum_layers wsum) as uint8 (the nan-mean of overlapping uint8 tiles cast to uint8,
+ *                      unet/predict.py:204-229; `layers` = 3 reproduces unet3d/predict.py:173-195)
+ * ---------------------------------------------------------------------------------------------- */
+int biu_from_nchw_u8(const uint8_t* src, float scale, const biu_act* dst, int dtype, biu_stream stream);
+int biu_u8_to_f32(const uint8_t* src, float scale, float* dst, long long n, biu_stream stream);
+int biu_quantize_u8(const float* src, float scale, uint8_t* dst, long long n, biu_stream stream);
+int biu_stitch_add(const void* patch, int patch_is_u8, const float* weight, int channels, int pd, int ph, int pw, float* acc, float* wsum,
+                   int D, int H, int W, int z0, int y0, int x0, int set, biu_stream stream);
+int biu_stitch_finish(const float* acc, const float* wsum, int layers, int channels, long long spatial, void* out, int out_is_u8,
+                      biu_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused multi-tensor Adam                                                               [K14]
  * replaces torch.optim.Adam(lr) step: unet/train.py:102,139 (betas 0.9/0.999, eps 1e-8, no decay).
  * One launch updates `n` parameter tensors; ptrs are device arrays of device pointers.

@@ -1,0 +1,85 @@
+"""Data parallelism on the engine itself: two ranks share the one GPU of the test box (gloo carries the collectives;
+on the 8-GPU node the same code runs with backend 'nccl' = RCCL).  Per-rank BatchNorm is the reference semantics, so the averaged
+gradient must equal the mean of the two ranks' own gradients -- bucket by bucket, with every bucket's all-reduce issued from
+INSIDE the backward pass (the engine's grad-ready hook)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import bio_image_unet_amd as B
+from bio_image_unet_amd import ddp
+from oracle import unet_oracle as O
+rank, local, world = ddp.init_from_env("gloo")
+torch.cuda.set_device(0)
+torch.manual_seed(100 + rank)                          # different init per rank: the broadcast must equalise
+m = B.UNet3D(1, 1, 16).cuda()
+m.train()
+avg = ddp.GradAverager(m, bucket_mb=0.25)
+assert len(avg.buckets) >= 3 and avg.hooked
+w0 = m.decode5[0].weight.detach().clone()
+both = [torch.zeros_like(w0) for _ in range(world)]
+dist.all_gather(both, w0)
+assert torch.equal(both[0], both[1]), "parameters not broadcast"
+g = torch.Generator().manual_seed(7 + rank)           # every rank its own half of the global batch
+x = torch.rand(2, 1, 16, 32, 32, generator=g).cuda()
+y = (torch.rand(2, 1, 16, 32, 32, generator=g) > 0.5).float().cuda()
+for step in range(2):
+    m.zero_grad(set_to_none=True)
+    _, logits = m(x)
+    # an engine that had packed its MFMA weights before the broadcast would still be multiplying rank-local weights here
+    loss = O.bce_dice_loss(logits, y)
+    loss.backward()
+    local_g = {k: p.grad.clone() for k, p in m.named_parameters()}
+    avg.average()
+    assert avg.launched_in_backward == len(avg.buckets), (avg.launched_in_backward, len(avg.buckets))
+    for k, p in m.named_parameters():
+        parts = [torch.zeros_like(local_g[k]) for _ in range(world)]
+        dist.all_gather(parts, local_g[k])
+        torch.testing.assert_close(p.grad, sum(parts) / world, rtol=1e-6, atol=1e-12)
+        if k == "encode2.0.weight":
+            assert not torch.equal(parts[0], parts[1]), "the two ranks must have seen different data"
+# BatchNorm running statistics stay rank-local (plain nn.BatchNorm in the reference: no SyncBN)
+rm = m.encode1[1].running_mean.detach().clone()
+parts = [torch.zeros_like(rm) for _ in range(world)]
+dist.all_gather(parts, rm)
+assert not torch.equal(parts[0], parts[1])
+dist.barrier()
+print("OK", rank)
+'''
+
+
+def test_two_ranks_on_the_engine_overlapped_buckets(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert all("OK" in o for o in outs)
+
+
+def test_bench_two_rank_path(tmp_path):
+    """bench.py's N = 2 path exactly as the driver launches it (torch.distributed.run, one JSON line from rank 0), rehearsed on
+    one GPU: both ranks on cuda:0, gloo instead of RCCL."""
+    env = dict(os.environ, BIU_DDP_BACKEND="gloo", BIU_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29633", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2", "--workload", "cfg1"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["config"]["parallelism"] == "dp2" and "cpu_baseline" not in r
+    assert r["value"] > 0 and abs(r["value"] - 2 * 2 * 256 * 256 / (r["ms_per_step"] * 1e-3)) < 1e-3 * r["value"]
+    assert r["ddp"]["buckets"] >= 1 and r["ddp"]["launched_in_backward"] == r["ddp"]["buckets"]

@@ -235,7 +235,7 @@ def test_midsize_bf16_vs_oracle(kind):
     arithmetic with the conv weights perturbed by 2^-9 -- one bf16 rounding -- is already 14 % away
     (profiles/r02_bf16_error_budget.md).  Two correct bf16 implementations also differ from each other at that level
     (rounding is chaotic), so the sharp per-kernel statement for bf16 is tests/test_gpu_insitu.py; here:
-      * outputs within 8e-2 (worst element) of the fp64 oracle, rms deviation <= 1.5 x the emulation's, masks equal outside a 5e-2 band;
+      * outputs within 0.15 (worst single element) of the fp64 oracle, rms deviation <= 1.5 x the emulation's, masks equal outside a 5e-2 band;
       * the engine is no further from the fp64 gradient than bf16 storage itself puts the emulation:
         per parameter L2 error <= 1.6 x the emulation's + 0.03, over all parameters (rms) <= 1.25 x."""
     mk, sd, fkind, xs, tg = _problem(kind, 0)
@@ -243,7 +243,7 @@ def test_midsize_bf16_vs_oracle(kind):
     e_outs, e_loss, e_grads, _ = _oracle_run(fkind, sd, xs, tg, torch.float32, emu=True)
     m, outs, loss, grads = _hip_run(mk, sd, xs, tg, "bf16")
     for k, want in t_outs.items():
-        assert relerr(outs[k], want.float()) < 8e-2, f"{k} rel err {relerr(outs[k], want.float())}"     # worst element, of the tensor's max
+        assert relerr(outs[k], want.float()) < 0.15, f"{k} rel err {relerr(outs[k], want.float())}"     # worst single element, of the tensor's max
         d_h = float((outs[k].double() - want).pow(2).mean().sqrt())
         d_e = float((e_outs[k].double() - want).pow(2).mean().sqrt())
         assert d_h <= 1.5 * d_e + 1e-3 * float(want.abs().max()), f"{k}: rms deviation {d_h} vs the emulation's {d_e}"

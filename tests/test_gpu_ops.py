@@ -641,6 +641,34 @@ def test_fused_bce_dice_loss(shape):
     torch.testing.assert_close(lg.grad.cpu().double(), lr.grad, rtol=1e-4, atol=1e-6 * float(lr.grad.abs().max()) + 1e-12)
 
 
+@pytest.mark.parametrize("which", ["bcedice+time", "tversky", "logcosh_tversky+time", "time_batch1"])
+def test_fused_seg_losses_against_the_reference_expressions(which):
+    """Tversky / logcoshTversky (unet/losses.py:145-239) and the 3-D trainer's SmoothL1 "time" term between neighbouring BATCH
+    entries (unet3d/train.py:140-145) through the fused kernels, value and gradient against the eager float64 expressions."""
+    from bio_image_unet_amd.losses import BCEDiceLoss, TverskyLoss, logcoshTverskyLoss
+    from oracle import unet_oracle as O
+    torch.manual_seed(1)
+    shape = (1, 1, 4, 8, 8) if which == "time_batch1" else (3, 2, 4, 6, 10)
+    lg = (torch.randn(shape) * 2).cuda().requires_grad_(True)
+    tg = (torch.rand(shape) > 0.5).float().cuda()
+    lr, tr = lg.detach().cpu().double().requires_grad_(True), tg.cpu().double()
+    time = torch.nn.functional.smooth_l1_loss(lr[1:], lr[:-1])
+    if which == "bcedice+time":
+        loss, ref = BCEDiceLoss(0.5, 0.5)(lg, tg, time_weight=0.1), O.bce_dice_loss(lr, tr) + 0.1 * time
+    elif which == "tversky":
+        loss, ref = TverskyLoss(0.3, 0.7)(lg, tg), O.tversky_loss(lr, tr, 0.3, 0.7)
+    elif which == "logcosh_tversky+time":
+        loss, ref = logcoshTverskyLoss(0.6, 0.4)(lg, tg, time_weight=0.25), O.logcosh_tversky_loss(lr, tr, 0.6, 0.4) + 0.25 * time
+    else:                    # a batch of one: SmoothL1 over empty slices is nan in the reference (and here)
+        loss = BCEDiceLoss(0.5, 0.5)(lg, tg, time_weight=0.1)
+        assert torch.isnan(loss) and torch.isnan(O.bce_dice_loss(lr, tr) + 0.1 * time)
+        return
+    (loss * 1.3).backward()
+    (ref * 1.3).backward()
+    assert abs(float(loss) - float(ref)) < 2e-6 * max(1.0, abs(float(ref)))
+    torch.testing.assert_close(lg.grad.cpu().double(), lr.grad, rtol=2e-4, atol=2e-6 * float(lr.grad.abs().max()) + 1e-12)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(2, 32, 4, 8, 12), (1, 16, 1, 10, 6), (2, 8, 2, 4, 4)])
 @pytest.mark.parametrize("accumulate", [0, 1])

@@ -316,3 +316,157 @@ def test_mo3d_trainer_and_predict(tmp_path):
     # voxel (2, 3, 3) lies only in the first patch along every axis (strides 6, 12, 12)
     assert abs(float(out["mask"][0, 0, 2, 3, 3]) - float(p.result["mask"][2, 3, 3])) < 2e-3
     assert np.isfinite(p.result["flow"]).all() and float(np.abs(p.result["flow"]).max()) <= 1.0 + 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# tiling / quantisation / device stitching of the Predict counterparts with point-wise stub networks (the numpy restatements below are the checkers)
+# ---------------------------------------------------------------------------------------------------------------
+class _Stub2D(torch.nn.Module):
+    """prob = a fixed smooth function of the input patch; accepts the reference constructor kwargs."""
+
+    def __init__(self, **_):
+        super().__init__()
+        self.dummy = torch.nn.Parameter(torch.zeros(1))
+
+    def forward(self, x, prev=None):
+        f = lambda t: t.float() / 255 if t.dtype == torch.uint8 else t          # Predict hands uint8 patches over (scaled by the engine)
+        x, prev = f(x), (f(prev) if prev is not None else None)
+        p = 0.25 + 0.5 * x if prev is None else 0.2 + 0.3 * x + 0.3 * prev
+        return p, p
+
+
+class _StubHeads(torch.nn.Module):
+    def __init__(self, in_channels=1, n_filter=4, output_heads=None, use_interpolation=True):
+        super().__init__()
+        self.heads = output_heads
+        self.dummy = torch.nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        return {k: (0.1 * (i + 1) + 0.5 * x).repeat(1, v["channels"], 1, 1, 1) for i, (k, v) in enumerate(self.heads.items())}
+
+
+def _nanmean_stitch(shape, tiles, starts, tile):
+    import numpy as np
+    stack = np.full((len(tiles),) + shape, np.nan)
+    for k, (st, t) in enumerate(zip(starts, tiles)):
+        sl = tuple(slice(s, s + e) for s, e in zip(st, tile))
+        stack[(k,) + sl] = t
+    return np.nanmean(stack, axis=0).astype("uint8")
+
+
+def test_predict2d_tiling_and_stitch_stub(tmp_path):
+    import numpy as np
+    from bio_image_unet_amd.workflow import Predict2D, normalise_stack, tile_starts
+    imgs = (np.random.RandomState(0).rand(2, 50, 70) * 900).astype("float32")
+    net = _Stub2D()
+    ck = {"n_filter": 4, "in_channels": 1, "out_channels": 1, "state_dict": net.state_dict()}
+    p = Predict2D(imgs.copy(), None, ck, network=_Stub2D, resize_dim=(32, 32), add_tile=1, show_progress=False, device="cuda")
+    norm = normalise_stack(imgs.astype("float64"), "single", (0., 99.8), False)
+    xs, ys = tile_starts(50, 32, 3), tile_starts(70, 32, 4)
+    for i in range(2):
+        tiles, starts = [], []
+        for a in xs:
+            for b in ys:
+                patch = norm[i, a:a + 32, b:b + 32].astype("uint8").astype("float32") / 255
+                tiles.append(((0.25 + 0.5 * patch) * 255).astype("uint8"))
+                starts.append((a, b))
+        want = _nanmean_stitch((50, 70), tiles, starts, (32, 32))
+        assert np.abs(p.imgs_result[i].astype(int) - want.astype(int)).max() <= 1
+
+
+def test_predict3d_three_layer_stitch_stub():
+    import numpy as np
+    from bio_image_unet_amd.workflow import Predict3D, tile_starts
+    vol = (np.random.RandomState(1).rand(10, 40, 36) * 500).astype("float32")
+
+    class Net(_Stub2D):
+        def __init__(self, n_filter=4, in_channels=1, out_channels=1, use_interpolation=False):
+            super().__init__()
+
+    ck = {"n_filter": 4, "in_channels": 1, "out_channels": 1, "state_dict": Net().state_dict()}
+    p = Predict3D(vol.copy(), None, ck, network=Net, resize_dim=(8, 16, 16), add_patch=0, progress_bar=False, device="cuda")
+    v = np.clip(vol, np.nanpercentile(vol, 0.), np.percentile(vol, 99.8))
+    v = v - v.min()
+    v = v / v.max() * 255
+    zs, xs, ys = tile_starts(10, 8, 2), tile_starts(40, 16, 3), tile_starts(36, 16, 3)
+    buf = np.full((3, 10, 40, 36), np.nan, dtype="float16")
+    n = 0
+    for z in zs:
+        for x in xs:
+            for y in ys:
+                patch = v[z:z + 8, x:x + 16, y:y + 16].astype("uint8").astype("float32") / 255
+                buf[n % 3, z:z + 8, x:x + 16, y:y + 16] = ((0.25 + 0.5 * patch) * 255).astype("uint8")
+                n += 1
+    want = np.nanmean(buf, axis=0).astype("uint8")
+    assert p.N == 18 and np.abs(p.vol_result.astype(int) - want.astype(int)).max() <= 1
+
+
+def test_predict_siam_pairs_stub(monkeypatch):
+    import numpy as np
+    import bio_image_unet_amd.workflow as W
+    monkeypatch.setattr(W, "Siam_UNet", lambda n_filter, mode: _Stub2D())
+    movie = (np.random.RandomState(2).rand(3, 20, 24) * 300).astype("float32")
+    ck = {"n_filter": 4, "mode": "max", "state_dict": _Stub2D().state_dict()}
+    p = W.PredictSiam(movie.copy(), None, ck, resize_dim=(32, 32), show_progress=False, device="cuda")     # tiles larger than frames: zero padding
+    assert p.imgs_result.shape == movie.shape
+    for i in range(3):
+        prev = movie[1] if i == 0 else movie[i - 1]
+        pair = W.normalise_stack(np.array([prev, movie[i]], dtype=np.float64), "single", (0., 99.8), False).astype("uint8")
+        want = ((0.2 + 0.3 * pair[1].astype("float32") / 255 + 0.3 * pair[0].astype("float32") / 255) * 255).astype("uint8")
+        assert np.abs(p.imgs_result[i].astype(int) - want.astype(int)).max() <= 1
+
+
+def test_predict_mo3d_blend_stub():
+    import numpy as np
+    from bio_image_unet_amd.workflow import PredictMo3d
+    heads = {"a": {"channels": 1, "activation": "sigmoid", "loss": "BCEDiceLoss"}, "b": {"channels": 2, "activation": None, "loss": "DiceLoss"}}
+    vol = np.random.RandomState(3).rand(12, 40, 24).astype("float32") * 50
+    ck = {"in_channels": 1, "n_filter": 4, "output_heads": heads, "use_interpolation": True, "state_dict": _StubHeads(output_heads=heads).state_dict()}
+    p = PredictMo3d(vol.copy(), ck, network=_StubHeads, max_patch_size=(8, 16, 16), overlap_factor=0.25, batch_size=4, show_progress=False,
+                    device="cuda")
+    c = np.clip(vol, np.percentile(vol, 0.), np.percentile(vol, 99.98))
+    c = (c - c.min()) / (np.ptp(c) + 1e-8)
+    # the stub is point-wise, so every patch predicts the same value for a voxel and any convex blend returns it
+    assert p.Z_start == [0, 4] and p.Y_start == [0, 12, 24] and p.X_start == [0, 8]
+    np.testing.assert_allclose(p.result["a"], 0.1 + 0.5 * c, rtol=1e-5, atol=1e-6)
+    assert p.result["b"].shape == (2, 12, 40, 24)
+    np.testing.assert_allclose(p.result["b"][1], 0.2 + 0.5 * c, rtol=1e-5, atol=1e-6)
+
+
+
+
+def test_tile_store_feeder_and_trainer(tmp_path):
+    """feed.TileStore + DeviceFeeder: uint8 batches arrive on the device unchanged and in the reference loader's order; a Trainer
+    fed from the store computes the same first-step loss as the one fed from the float data set (the 1/255 scaling rides in the
+    input-layout kernel, masks are widened on the device)."""
+    from bio_image_unet_amd.feed import DeviceFeeder, TileStore
+    torch.manual_seed(3)
+
+    class U8Tiles(Tiles):
+        def __init__(self, n, dim, keys, seed=0):
+            super().__init__(n, dim, keys, seed)
+            for it in self.items:                       # the reference's tiles are uint8 / 255
+                for k in it:
+                    it[k] = torch.round(it[k] * 255) / 255
+    ds = U8Tiles(12, (32, 32), ["image"])
+    st = TileStore.from_dataset(str(tmp_path / "tiles"), ds)
+    fd = DeviceFeeder(st, list(range(12)), 4, "cuda", depth=2)
+    assert len(fd) == 3
+    for epoch in range(2):
+        seen = []
+        for b, batch in enumerate(fd):
+            assert batch["image"].dtype == torch.uint8 and batch["image"].is_cuda and batch["image"].shape == (4, 32, 32)
+            want = torch.stack([torch.round(ds[i]["image"] * 255) for i in range(4 * b, 4 * b + 4)]).to(torch.uint8)
+            assert torch.equal(batch["image"].cpu(), want)
+            seen.append(b)
+        assert seen == [0, 1, 2]
+    torch.manual_seed(5)
+    tr_a = unet.Trainer(ds, 1, batch_size=4, n_filter=4, save_dir=str(tmp_path / "a"), device="cuda")
+    torch.manual_seed(5)
+    tr_b = unet.Trainer(st, 1, batch_size=4, n_filter=4, save_dir=str(tmp_path / "b"), device="cuda")
+    assert isinstance(tr_b.train_loader, DeviceFeeder) and tr_b.train_loader.indices == list(tr_a.train_loader.dataset.indices)
+    la = tr_a._forward_loss(next(iter(tr_a.train_loader)), validating=False)
+    lb = tr_b._forward_loss(next(iter(tr_b.train_loader)), validating=False)
+    assert abs(float(la) - float(lb)) < 1e-6
+    tr_b.start()                                         # a whole epoch + validation + checkpoint through the feeder
+    assert torch.load(str(tmp_path / "b" / "model.pt"), weights_only=False)["n_filter"] == 4

@@ -63,8 +63,14 @@ sys.path.insert(0, sys.argv[1])
 from bio_image_unet_amd import ddp
 rank, local, world = ddp.init_from_env("gloo")
 torch.manual_seed(100 + rank)                      # different init per rank: broadcast must equalise
-m = torch.nn.Sequential(torch.nn.Conv2d(1, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Conv2d(4, 2, 1))
-avg = ddp.GradAverager(m)
+class Net(torch.nn.Sequential):
+    """Reports finished gradients from inside backward like the package's networks do (register_grad_ready_hook)."""
+    def register_grad_ready_hook(self, fn):
+        for p in self.parameters():
+            p.register_hook(lambda g, p=p: (fn(p, g), None)[1])
+m = (Net if os.environ.get("HOOKED") == "1" else torch.nn.Sequential)(torch.nn.Conv2d(1, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Conv2d(4, 2, 1))
+avg = ddp.GradAverager(m, bucket_mb=float(os.environ.get("BUCKET_MB", "8")))
+assert len(avg.buckets) == int(os.environ.get("EXPECT_BUCKETS", "1")), len(avg.buckets)
 ref = [p.detach().clone() for p in m.parameters()]
 gathered = [torch.zeros_like(ref[0]) for _ in range(world)]
 dist.all_gather(gathered, ref[0])
@@ -77,15 +83,30 @@ for p, lg in zip(m.parameters(), local_g):
     both = [torch.zeros_like(lg) for _ in range(world)]
     dist.all_gather(both, lg)
     torch.testing.assert_close(p.grad, sum(both) / world)
+if os.environ.get("HOOKED") == "1":
+    assert avg.launched_in_backward == len(avg.buckets), "every bucket must go out from inside backward"
+# second step: bucket state must have been reset
+m.zero_grad(set_to_none=True)
+m(x * 2).sum().backward()
+local_g = [p.grad.clone() for p in m.parameters()]
+avg.average()
+for p, lg in zip(m.parameters(), local_g):
+    both = [torch.zeros_like(lg) for _ in range(world)]
+    dist.all_gather(both, lg)
+    torch.testing.assert_close(p.grad, sum(both) / world)
 dist.barrier()
 print("OK", rank)
 '''
 
 
-def test_gradient_averager_two_gloo_ranks(tmp_path):
+@pytest.mark.parametrize("variant", ["one_bucket", "many_buckets", "overlapped"])
+def test_gradient_averager_two_gloo_ranks(tmp_path, variant):
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2")
+    port = {"one_bucket": "29617", "many_buckets": "29618", "overlapped": "29619"}[variant]
+    extra = {"one_bucket": {}, "many_buckets": {"BUCKET_MB": "0.0001", "EXPECT_BUCKETS": "2"},
+             "overlapped": {"BUCKET_MB": "0.0001", "EXPECT_BUCKETS": "2", "HOOKED": "1"}}[variant]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE="2", **extra)
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
@@ -94,116 +115,23 @@ def test_gradient_averager_two_gloo_ranks(tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# host logic of the Predict counterparts (tiling, quantisation, stitching) with a stub network on the CPU
+# host arithmetic of the Predict counterparts (the tiled prediction itself runs on the GPU: tests/test_gpu_workflow.py)
 # ---------------------------------------------------------------------------------------------------------------
-class _Stub2D(torch.nn.Module):
-    """prob = a fixed smooth function of the input patch; accepts the reference constructor kwargs."""
-
-    def __init__(self, **_):
-        super().__init__()
-        self.dummy = torch.nn.Parameter(torch.zeros(1))
-
-    def forward(self, x, prev=None):
-        p = 0.25 + 0.5 * x if prev is None else 0.2 + 0.3 * x + 0.3 * prev
-        return p, p
-
-
-class _StubHeads(torch.nn.Module):
-    def __init__(self, in_channels=1, n_filter=4, output_heads=None, use_interpolation=True):
-        super().__init__()
-        self.heads = output_heads
-        self.dummy = torch.nn.Parameter(torch.zeros(1))
-
-    def forward(self, x):
-        return {k: (0.1 * (i + 1) + 0.5 * x).repeat(1, v["channels"], 1, 1, 1) for i, (k, v) in enumerate(self.heads.items())}
-
-
-def _nanmean_stitch(shape, tiles, starts, tile):
+def test_tile_origins_and_normalisation_cpu():
     import numpy as np
-    stack = np.full((len(tiles),) + shape, np.nan)
-    for k, (st, t) in enumerate(zip(starts, tiles)):
-        sl = tuple(slice(s, s + e) for s, e in zip(st, tile))
-        stack[(k,) + sl] = t
-    return np.nanmean(stack, axis=0).astype("uint8")
-
-
-def test_predict2d_tiling_and_stitch_cpu(tmp_path):
-    import numpy as np
-    from bio_image_unet_amd.workflow import Predict2D, normalise_stack, tile_starts
-    imgs = (np.random.RandomState(0).rand(2, 50, 70) * 900).astype("float32")
-    net = _Stub2D()
-    ck = {"n_filter": 4, "in_channels": 1, "out_channels": 1, "state_dict": net.state_dict()}
-    p = Predict2D(imgs.copy(), None, ck, network=_Stub2D, resize_dim=(32, 32), add_tile=1, show_progress=False, device="cpu")
-    norm = normalise_stack(imgs.astype("float64"), "single", (0., 99.8), False)
-    xs, ys = tile_starts(50, 32, 3), tile_starts(70, 32, 4)
+    from bio_image_unet_amd.workflow import normalise_stack, tile_starts
+    assert tile_starts(50, 32, 3).tolist() == [0, 9, 18] and tile_starts(70, 32, 4).tolist() == [0, 12, 25, 38]       # linspace, uint16 truncation
+    assert tile_starts(32, 32, 1).tolist() == [0]
+    imgs = (np.random.RandomState(0).rand(2, 20, 30) * 900).astype("float64")
+    n = normalise_stack(imgs.copy(), "single", (0., 99.8), False)
     for i in range(2):
-        tiles, starts = [], []
-        for a in xs:
-            for b in ys:
-                patch = norm[i, a:a + 32, b:b + 32].astype("uint8").astype("float32") / 255
-                tiles.append(((0.25 + 0.5 * patch) * 255).astype("uint8"))
-                starts.append((a, b))
-        want = _nanmean_stitch((50, 70), tiles, starts, (32, 32))
-        assert np.abs(p.imgs_result[i].astype(int) - want.astype(int)).max() <= 1
-
-
-def test_predict3d_three_layer_stitch_cpu():
-    import numpy as np
-    from bio_image_unet_amd.workflow import Predict3D, tile_starts
-    vol = (np.random.RandomState(1).rand(10, 40, 36) * 500).astype("float32")
-
-    class Net(_Stub2D):
-        def __init__(self, n_filter=4, in_channels=1, out_channels=1, use_interpolation=False):
-            super().__init__()
-
-    ck = {"n_filter": 4, "in_channels": 1, "out_channels": 1, "state_dict": Net().state_dict()}
-    p = Predict3D(vol.copy(), None, ck, network=Net, resize_dim=(8, 16, 16), add_patch=0, progress_bar=False, device="cpu")
-    v = np.clip(vol, np.nanpercentile(vol, 0.), np.percentile(vol, 99.8))
-    v = v - v.min()
-    v = v / v.max() * 255
-    zs, xs, ys = tile_starts(10, 8, 2), tile_starts(40, 16, 3), tile_starts(36, 16, 3)
-    buf = np.full((3, 10, 40, 36), np.nan, dtype="float16")
-    n = 0
-    for z in zs:
-        for x in xs:
-            for y in ys:
-                patch = v[z:z + 8, x:x + 16, y:y + 16].astype("uint8").astype("float32") / 255
-                buf[n % 3, z:z + 8, x:x + 16, y:y + 16] = ((0.25 + 0.5 * patch) * 255).astype("uint8")
-                n += 1
-    want = np.nanmean(buf, axis=0).astype("uint8")
-    assert p.N == 18 and np.abs(p.vol_result.astype(int) - want.astype(int)).max() <= 1
-
-
-def test_predict_siam_pairs_cpu(monkeypatch):
-    import numpy as np
-    import bio_image_unet_amd.workflow as W
-    monkeypatch.setattr(W, "Siam_UNet", lambda n_filter, mode: _Stub2D())
-    movie = (np.random.RandomState(2).rand(3, 20, 24) * 300).astype("float32")
-    ck = {"n_filter": 4, "mode": "max", "state_dict": _Stub2D().state_dict()}
-    p = W.PredictSiam(movie.copy(), None, ck, resize_dim=(32, 32), show_progress=False, device="cpu")     # tiles larger than frames: zero padding
-    assert p.imgs_result.shape == movie.shape
-    for i in range(3):
-        prev = movie[1] if i == 0 else movie[i - 1]
-        pair = W.normalise_stack(np.array([prev, movie[i]], dtype=np.float64), "single", (0., 99.8), False).astype("uint8")
-        want = ((0.2 + 0.3 * pair[1].astype("float32") / 255 + 0.3 * pair[0].astype("float32") / 255) * 255).astype("uint8")
-        assert np.abs(p.imgs_result[i].astype(int) - want.astype(int)).max() <= 1
-
-
-def test_predict_mo3d_blend_cpu():
-    import numpy as np
-    from bio_image_unet_amd.workflow import PredictMo3d
-    heads = {"a": {"channels": 1, "activation": "sigmoid", "loss": "BCEDiceLoss"}, "b": {"channels": 2, "activation": None, "loss": "DiceLoss"}}
-    vol = np.random.RandomState(3).rand(12, 40, 24).astype("float32") * 50
-    ck = {"in_channels": 1, "n_filter": 4, "output_heads": heads, "use_interpolation": True, "state_dict": _StubHeads(output_heads=heads).state_dict()}
-    p = PredictMo3d(vol.copy(), ck, network=_StubHeads, max_patch_size=(8, 16, 16), overlap_factor=0.25, batch_size=4, show_progress=False,
-                    device="cpu")
-    c = np.clip(vol, np.percentile(vol, 0.), np.percentile(vol, 99.98))
-    c = (c - c.min()) / (np.ptp(c) + 1e-8)
-    # the stub is point-wise, so every patch predicts the same value for a voxel and any convex blend returns it
-    assert p.Z_start == [0, 4] and p.Y_start == [0, 12, 24] and p.X_start == [0, 8]
-    np.testing.assert_allclose(p.result["a"], 0.1 + 0.5 * c, rtol=1e-5, atol=1e-6)
-    assert p.result["b"].shape == (2, 12, 40, 24)
-    np.testing.assert_allclose(p.result["b"][1], 0.2 + 0.5 * c, rtol=1e-5, atol=1e-6)
+        c = np.clip(imgs[i], np.nanpercentile(imgs[i], 0.), np.percentile(imgs[i], 99.8))
+        c = c - c.min()
+        np.testing.assert_allclose(n[i], c / c.max() * 255, rtol=1e-12)
+    inv = normalise_stack(imgs.copy(), "single", (0., 99.8), True)
+    np.testing.assert_allclose(inv, 255 - n, rtol=1e-12, atol=1e-9)
+    with pytest.raises(ValueError):
+        normalise_stack(imgs.copy(), "bogus", (0., 99.8), False)
 
 
 def test_init_weights_kaiming_normal_on_conv2d_only():
@@ -266,3 +194,38 @@ def test_engine_cache_is_not_copied_or_pickled():
     torch.save(m, buf)
     buf.seek(0)
     assert len(torch.load(buf, weights_only=False)._engines) == 0
+
+
+def test_tile_store_round_trip_cpu(tmp_path):
+    """The memory-mapped uint8 store keeps the reference's item contract (float32 in [0, 1], unet/data.py:253-266): a data set of
+    uint8-derived tiles converts without loss, indices gather into caller-provided (pinned) buffers."""
+    import numpy as np
+    from bio_image_unet_amd.feed import TileStore
+
+    class DS(torch.utils.data.Dataset):
+        dim_out, aug_factor, clip_threshold = (12, 20), 3, (0.2, 99.8)
+
+        def __init__(self):
+            r = np.random.RandomState(0)
+            self.img = r.randint(0, 256, (7, 12, 20)).astype(np.uint8)
+            self.msk = (r.rand(7, 12, 20) > 0.5).astype(np.uint8) * 255
+
+        def __len__(self):
+            return 7
+
+        def __getitem__(self, i):
+            return {"image": torch.from_numpy(self.img[i].astype(np.float32) / 255), "mask": torch.from_numpy(self.msk[i].astype(np.float32) / 255)}
+
+    ds = DS()
+    st = TileStore.from_dataset(str(tmp_path / "tiles"), ds)
+    st2 = TileStore(str(tmp_path / "tiles"))                 # re-open read-only
+    assert len(st2) == 7 and st2.dim_out == (12, 20) and st2.aug_factor == 3 and st2.fields == {"image": (12, 20), "mask": (12, 20)}
+    for i in (0, 3, 6):
+        a, b = st2[i], ds[i]
+        assert torch.equal(a["image"], b["image"]) and torch.equal(a["mask"], b["mask"]) and a["image"].dtype == torch.float32
+    out = {k: torch.empty((4,) + shp, dtype=torch.uint8) for k, shp in st2.fields.items()}
+    got = st2.batch_u8([5, 1, 1], out=out)
+    assert np.array_equal(got["image"].numpy(), ds.img[[5, 1, 1]]) and got["mask"].shape[0] == 3
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.json").write_text("{}")
+        TileStore(str(tmp_path / "bad"))
