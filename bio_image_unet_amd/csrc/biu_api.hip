@@ -137,6 +137,16 @@ extern "C" int biu_convt_bwd_data_bnred(const biu_act* dy, const float* w, const
     BIU_REQUIRE(scale && shift && mean && invstd && partial && nblk, BIU_ERR_SHAPE, "convt_bwd_data_bnred: null pointer");
     const size_t es = dsize(dtype);
     const bool yok = ((uintptr_t)y_up->p % 16) == 0 && ((size_t)y_up->pitch * es) % 16 == 0;
+    if (packed && yok && !disabled("convt_dgrad") && !disabled("dgrad_bnred") && biu_mfma_convt_ok(1, dx, dy, kd, dtype) &&
+        biu_convt_all_ok(dx, dy, kd, dtype)) {
+        const int nb = biu_convt_all_dgrad_rows(dx, dy, kd);           // one partial row per persistent block
+        if ((size_t)nb * dx->c * 2 <= partial_floats) {
+            BnRedFuse red{y_up, scale, shift, slope, mean, invstd};
+            int rc = biu_convt_all_dgrad(dy, packed, kd, dx, 0, (hipStream_t)stream, partial, &red);
+            if (rc == BIU_OK) *nblk = nb;
+            return rc;
+        }
+    }
     if (packed && yok && !disabled("convt_dgrad") && !disabled("dgrad_bnred") && biu_mfma_convt_ok(1, dx, dy, kd, dtype)) {
         const int nb = biu_mfma_convt_dgrad_bricks(dx, kd);
         if ((size_t)nb * dx->c * 2 <= partial_floats) {
@@ -266,16 +276,20 @@ extern "C" int biu_convt_fwd(const biu_act* x, const biu_xform* xf, const float*
                              int kd, const biu_act* y, int dtype, biu_stream stream) {
     BIU_REQUIRE(valid_act(x) && valid_act(y) && w && biu_convt_shapes_ok(x, y, kd), BIU_ERR_SHAPE,
                 "convt_fwd: output must be 2x the input extent (kd=%d)", kd);
-    if (packed && !disabled("convt_fwd") && biu_mfma_convt_ok(0, x, y, kd, dtype))
+    if (packed && !disabled("convt_fwd") && biu_mfma_convt_ok(0, x, y, kd, dtype)) {
+        if (biu_convt_all_ok(x, y, kd, dtype)) return biu_convt_all_fwd(x, xf, packed, bias, kd, y, (hipStream_t)stream);     // all parities from one tile
         return biu_mfma_convt_fwd(x, xf, packed, bias, kd, y, dtype, (hipStream_t)stream);
+    }
     return biu_convt_fwd_direct(x, xf, w, bias, kd, y, dtype, (hipStream_t)stream);
 }
 extern "C" int biu_convt_bwd_data(const biu_act* dy, const float* w, const void* packed, int kd, const biu_act* dx,
                                   int accumulate, int dtype, biu_stream stream) {
     BIU_REQUIRE(valid_act(dx) && valid_act(dy) && w && biu_convt_shapes_ok(dx, dy, kd), BIU_ERR_SHAPE,
                 "convt_bwd_data: dy must be 2x the dx extent (kd=%d)", kd);
-    if (packed && !disabled("convt_dgrad") && biu_mfma_convt_ok(1, dx, dy, kd, dtype))
+    if (packed && !disabled("convt_dgrad") && biu_mfma_convt_ok(1, dx, dy, kd, dtype)) {
+        if (biu_convt_all_ok(dx, dy, kd, dtype)) return biu_convt_all_dgrad(dy, packed, kd, dx, accumulate, (hipStream_t)stream);
         return biu_mfma_convt_dgrad(dy, packed, kd, dx, accumulate, dtype, (hipStream_t)stream);
+    }
     return biu_convt_bwd_data_direct(dy, w, kd, dx, accumulate, dtype, (hipStream_t)stream);
 }
 extern "C" size_t biu_convt_bwd_weight_workspace(int cin, int cout, int kd, int dtype) {

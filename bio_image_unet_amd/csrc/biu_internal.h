@@ -89,3 +89,10 @@ int biu_maxpool_bwd_bnred_rv(const biu_act* x, const biu_xform* xf, const biu_ac
                              const float* mean, const float* invstd, float* partial, size_t partial_floats, int* nblk, int dtype,
                              hipStream_t st);
 int biu_nearest_rv(int mode, const biu_act* src, const biu_xform* xf, const biu_act* dst, int pd, int accumulate, int dtype, hipStream_t st);
+
+// biu_convt.hip: bf16 ConvTranspose k2 s2 forward / data gradient with all parities from one resident tile
+bool biu_convt_all_ok(const biu_act* lo, const biu_act* hi, int kd, int dtype);
+int biu_convt_all_fwd(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, const biu_act* y, hipStream_t st);
+int biu_convt_all_dgrad_rows(const biu_act* dx, const biu_act* dy, int kd);
+int biu_convt_all_dgrad(const biu_act* dy, const void* packed, int kd, const biu_act* dx, int accumulate, hipStream_t st,
+                        float* bn_partial = nullptr, const BnRedFuse* red = nullptr);

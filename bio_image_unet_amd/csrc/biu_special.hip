@@ -4,6 +4,7 @@
 //   * per-channel two-term reductions (BatchNorm statistics, BatchNorm backward sums, channel sums) with 16-byte
 //     loads and deterministic per-block partials
 #include "biu_internal.h"
+#include <stdlib.h>
 
 #define TPB 256
 
@@ -157,14 +158,14 @@ __global__ __launch_bounds__(TPB) void k_conv_c1_fwd4(DAct x, DXf xf, const floa
     for (int i = threadIdx.x; i < COUT; i += TPB) ws[TAPS * COUT + i] = bias ? bias[co0 + i] : 0.f;
     __syncthreads();
     const float s = xf.scale ? xf.scale[0] : 1.f, b = xf.shift ? xf.shift[0] : 0.f, sl = xf.slope ? xf.slope[0] : 1.f;
-    const int W4 = y.w / 4;
-    const i64 total = (i64)y.n * y.d * y.h * W4;
-    for (i64 gidx = (i64)blockIdx.x * TPB + threadIdx.x; gidx < total; gidx += (i64)gridDim.x * TPB) {
-        i64 t = gidx;
+    const unsigned W4 = (unsigned)y.w / 4u;          // 32-bit index arithmetic (nvox < 2^31, checked on the host)
+    const unsigned total = (unsigned)y.n * (unsigned)y.d * (unsigned)y.h * W4;
+    for (unsigned gidx = blockIdx.x * (unsigned)TPB + threadIdx.x; gidx < total; gidx += gridDim.x * (unsigned)TPB) {
+        unsigned t = gidx;
         const int w0 = (int)(t % W4) * 4; t /= W4;
-        const int ph = (int)(t % y.h); t /= y.h;
-        const int pdd = (int)(t % y.d);
-        const int pn = (int)(t / y.d);
+        const int ph = (int)(t % (unsigned)y.h); t /= (unsigned)y.h;
+        const int pdd = (int)(t % (unsigned)y.d);
+        const int pn = (int)(t / (unsigned)y.d);
         float acc[4][COUT];
 #pragma unroll
         for (int vx = 0; vx < 4; ++vx)
@@ -178,13 +179,13 @@ __global__ __launch_bounds__(TPB) void k_conv_c1_fwd4(DAct x, DXf xf, const floa
                 const int ih = ph + bb - 1;
                 const bool rowok = id >= 0 && id < x.d && ih >= 0 && ih < x.h;
                 float xr[6];
-                const i64 rowbase = (((i64)pn * x.d + id) * x.h + ih) * x.w;
+                const unsigned rowbase = (((unsigned)pn * (unsigned)x.d + (unsigned)id) * (unsigned)x.h + (unsigned)ih) * (unsigned)x.w;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
                     const int iw = w0 - 1 + k;
                     // branch-free: a clamped address and a select keep the six loads of a row in flight together
                     const bool ok = rowok && iw >= 0 && iw < x.w;
-                    const float tt = fmaf(s, to_f(((const T*)x.p)[ok ? (rowbase + iw) * x.pitch : 0]), b);
+                    const float tt = fmaf(s, to_f(((const T*)x.p)[ok ? (i64)(rowbase + (unsigned)iw) * x.pitch : 0]), b);
                     xr[k] = ok ? (tt > 0.f ? tt : sl * tt) : 0.f;
                 }
 #pragma unroll
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(TPB) void k_conv_c1_fwd4(DAct x, DXf xf, const floa
                 }
             }
         }
-        const i64 v0 = (((i64)pn * y.d + pdd) * y.h + ph) * y.w + w0;
+        const i64 v0 = (i64)((((unsigned)pn * (unsigned)y.d + pdd) * (unsigned)y.h + ph) * (unsigned)y.w + w0);
         constexpr int G = 16 / sizeof(T);
 #pragma unroll
         for (int vx = 0; vx < 4; ++vx) {
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(TPB) void k_conv_c1_fwd4(DAct x, DXf xf, const floa
 
 // weight gradient, 4 voxels per lane: wave q owns taps [q*TPW, ...); acc[t][co] += sum_vx x[vx + tap] * dy[vx][co]
 template <typename T, int COUT, int KD, int TPW>
-__global__ __launch_bounds__(256) void k_conv_c1_wgrad4(DAct x, DXf xf, DAct dy, int co0, float* __restrict__ partial) {
+__global__ __launch_bounds__(64 * ((KD * 9 + TPW - 1) / TPW)) void k_conv_c1_wgrad4(DAct x, DXf xf, DAct dy, int co0, float* __restrict__ partial) {
     constexpr int TAPS = KD * 9;
     constexpr int G = 16 / sizeof(T);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -234,15 +235,17 @@ __global__ __launch_bounds__(256) void k_conv_c1_wgrad4(DAct x, DXf xf, DAct dy,
 #pragma unroll
         for (int c = 0; c < COUT; ++c) acc[t][c] = 0.f;
     const float s = xf.scale ? xf.scale[0] : 1.f, b = xf.shift ? xf.shift[0] : 0.f, sl = xf.slope ? xf.slope[0] : 1.f;
-    const int W4 = dy.w / 4;
-    const i64 total = (i64)dy.n * dy.d * dy.h * W4;
-    for (i64 gidx = (i64)blockIdx.x * 64 + lane; gidx < total; gidx += (i64)gridDim.x * 64) {
-        i64 tt_ = gidx;
+    // 32-bit index arithmetic throughout (the host checks nvox < 2^31): the 64-bit divisions of a linear voxel index cost as
+    // many VALU instructions per iteration as the 448 FMAs they fed
+    const unsigned W4 = (unsigned)dy.w / 4u;
+    const unsigned total = (unsigned)dy.n * (unsigned)dy.d * (unsigned)dy.h * W4;
+    for (unsigned gidx = blockIdx.x * 64u + lane; gidx < total; gidx += gridDim.x * 64u) {
+        unsigned tt_ = gidx;
         const int w0 = (int)(tt_ % W4) * 4; tt_ /= W4;
-        const int ph = (int)(tt_ % dy.h); tt_ /= dy.h;
-        const int pdd = (int)(tt_ % dy.d);
-        const int pn = (int)(tt_ / dy.d);
-        const i64 v0 = (((i64)pn * dy.d + pdd) * dy.h + ph) * dy.w + w0;
+        const int ph = (int)(tt_ % (unsigned)dy.h); tt_ /= (unsigned)dy.h;
+        const int pdd = (int)(tt_ % (unsigned)dy.d);
+        const int pn = (int)(tt_ / (unsigned)dy.d);
+        const i64 v0 = (i64)((((unsigned)pn * (unsigned)dy.d + pdd) * (unsigned)dy.h + ph) * (unsigned)dy.w + w0);
         float g[4][COUT];
 #pragma unroll
         for (int vx = 0; vx < 4; ++vx) {
@@ -261,12 +264,12 @@ __global__ __launch_bounds__(256) void k_conv_c1_wgrad4(DAct x, DXf xf, DAct dy,
                 const int a = tap / 9, bb = (tap / 3) % 3, c = tap % 3;
                 const int id = pdd + a - KD / 2, ih = ph + bb - 1;
                 const bool rowok = id >= 0 && id < x.d && ih >= 0 && ih < x.h;
-                const i64 rowbase = (((i64)pn * x.d + id) * x.h + ih) * x.w;
+                const unsigned rowbase = (((unsigned)pn * (unsigned)x.d + (unsigned)id) * (unsigned)x.h + (unsigned)ih) * (unsigned)x.w;
 #pragma unroll
                 for (int vx = 0; vx < 4; ++vx) {
                     const int iw = w0 + vx + c - 1;
                     const bool ok = rowok && iw >= 0 && iw < x.w;          // branch-free (loads stay in flight together)
-                    const float q = fmaf(s, to_f(((const T*)x.p)[ok ? (rowbase + iw) * x.pitch : 0]), b);
+                    const float q = fmaf(s, to_f(((const T*)x.p)[ok ? (i64)(rowbase + (unsigned)iw) * x.pitch : 0]), b);
                     const float xv = ok ? (q > 0.f ? q : sl * q) : 0.f;
 #pragma unroll
                     for (int co = 0; co < COUT; ++co) acc[t][co] = fmaf(xv, g[vx][co], acc[t][co]);
@@ -290,6 +293,7 @@ __global__ __launch_bounds__(256) void k_conv_c1_wgrad4(DAct x, DXf xf, DAct dy,
 static bool c1_ok(const biu_act* x, const biu_act* y, int kd, int kh, int kw, int dil, int dtype) {
     if (x->c != 1 || dil != 1 || kh != 3 || kw != 3 || (kd != 1 && kd != 3)) return false;
     if (y->c % 8 != 0 || y->c < 8) return false;
+    if (nvox(y) >= (1LL << 31) || nvox(x) >= (1LL << 31)) return false;          // 32-bit voxel indices in the 4-voxel kernels
     const size_t es = dsize(dtype);
     return ((uintptr_t)y->p % 16) == 0 && ((size_t)y->pitch * es) % 16 == 0;
 }
@@ -338,7 +342,9 @@ static int c1_wgrad_t(const biu_act* x, const biu_xform* xf, const biu_act* dy, 
             hipLaunchKernelGGL((k_conv_c1_wgrad<T, 32, KD, TPW>), dim3(nblk), dim3(64 * ((TAPS + TPW - 1) / TPW)), 0, st, dact(x), dxf(xf), dact(dy), co0, (float*)ws);
         } else if (rem >= 16) {
             constexpr int TPW = 7; chunk = 16;
-            if (dy->w % 4 == 0) hipLaunchKernelGGL((k_conv_c1_wgrad4<T, 16, KD, TPW>), dim3(nblk), dim3(64 * ((TAPS + TPW - 1) / TPW)), 0, st, dact(x), dxf(xf), dact(dy), co0, (float*)ws);
+            static const bool tpw4 = [] { const char* e = getenv("BIU_C1_TPW"); return e && e[0] == '4'; }();       // experiment switch
+            if (dy->w % 4 == 0 && tpw4) hipLaunchKernelGGL((k_conv_c1_wgrad4<T, 16, KD, 4>), dim3(nblk), dim3(64 * ((TAPS + 3) / 4)), 0, st, dact(x), dxf(xf), dact(dy), co0, (float*)ws);
+            else if (dy->w % 4 == 0) hipLaunchKernelGGL((k_conv_c1_wgrad4<T, 16, KD, TPW>), dim3(nblk), dim3(64 * ((TAPS + TPW - 1) / TPW)), 0, st, dact(x), dxf(xf), dact(dy), co0, (float*)ws);
             else hipLaunchKernelGGL((k_conv_c1_wgrad<T, 16, KD, TPW>), dim3(nblk), dim3(64 * ((TAPS + TPW - 1) / TPW)), 0, st, dact(x), dxf(xf), dact(dy), co0, (float*)ws);
         } else {
             constexpr int TPW = 9; chunk = 8;

@@ -109,6 +109,8 @@ class DeviceFeeder:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError(f"DeviceFeeder copies to a GPU; got device '{device}'")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.drop_last, self.depth = drop_last, max(2, depth)
         self.copy_stream = torch.cuda.Stream(device=self.device)
         mk = lambda shp, pin: (torch.empty((batch_size,) + shp, dtype=torch.uint8).pin_memory() if pin
@@ -131,6 +133,12 @@ class DeviceFeeder:
             slot["free"] = None
 
         def producer():
+            try:
+                produce()
+            except BaseException as e:                       # surface a failure of the feeder thread in the training thread
+                filled.put(e)
+
+        def produce():
             # gather (page cache -> pinned memory) and enqueue the asynchronous upload; never blocks the training thread
             torch.cuda.set_device(self.device)
             for bi, idx in enumerate(batches):
@@ -158,6 +166,8 @@ class DeviceFeeder:
                 item = filled.get()
                 if item is None:
                     break
+                if isinstance(item, BaseException):
+                    raise RuntimeError("DeviceFeeder: the feeder thread failed") from item
                 bi, nb = item
                 slot = self.slots[bi % self.depth]
                 torch.cuda.current_stream(self.device).wait_event(slot["ready"])     # device-side wait: the host does not block

@@ -58,24 +58,26 @@ print("OK", rank)
 '''
 
 
+@pytest.mark.timeout(300)
 def test_two_ranks_on_the_engine_overlapped_buckets(tmp_path):
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=600)[0] for p in procs]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert all("OK" in o for o in outs)
 
 
+@pytest.mark.timeout(400)
 def test_bench_two_rank_path(tmp_path):
     """bench.py's N = 2 path exactly as the driver launches it (torch.distributed.run, one JSON line from rank 0), rehearsed on
     one GPU: both ranks on cuda:0, gloo instead of RCCL."""
     env = dict(os.environ, BIU_DDP_BACKEND="gloo", BIU_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29633", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2", "--workload", "cfg1"]
-    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=360)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
