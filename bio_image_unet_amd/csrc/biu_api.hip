@@ -54,6 +54,14 @@ extern "C" int biu_conv_fwd_stats(const biu_act* x, const biu_xform* xf, const f
                 "conv_fwd: x/y extents differ or unsupported kernel %dx%dx%d dil %d", kd, kh, kw, dilation);
     BIU_REQUIRE(w && bn_partial && bn_nblk, BIU_ERR_SHAPE, "conv_fwd_stats: null pointer");
     *bn_nblk = 0;
+    if (!disabled("c1") && !disabled("fused_stats") && biu_c1m_ok(x, y, kd, kh, kw, dilation, dtype)) {
+        const int nb = biu_c1m_fwd_rows(y, kd);                    // first layer on the matrix cores, statistics from its epilogue
+        if ((size_t)nb * y->c * 2 <= bn_partial_floats) {
+            int rc = biu_c1m_fwd(x, xf, w, bias, kd, y, bn_partial, (hipStream_t)stream);
+            if (rc == BIU_OK) *bn_nblk = nb;
+            return rc;
+        }
+    }
     if (packed && !disabled("conv_fwd") && !disabled("fused_stats") && biu_mfma_conv_ok(x, y, kd, kh, kw, dilation, dtype)) {
         const int nb = biu_mfma_conv_stat_rows(y, kd);           // one partial row per workgroup column
         if ((size_t)nb * y->c * 2 <= bn_partial_floats) {
@@ -79,6 +87,8 @@ extern "C" int biu_conv_fwd(const biu_act* x, const biu_xform* xf, const float* 
     BIU_REQUIRE(conv_args_ok(x, y, kd, kh, kw, dilation), BIU_ERR_SHAPE,
                 "conv_fwd: x/y extents differ or unsupported kernel %dx%dx%d dil %d", kd, kh, kw, dilation);
     BIU_REQUIRE(w, BIU_ERR_SHAPE, "conv_fwd: null weight");
+    if (!disabled("c1") && biu_c1m_ok(x, y, kd, kh, kw, dilation, dtype))
+        return biu_c1m_fwd(x, xf, w, bias, kd, y, nullptr, (hipStream_t)stream);
     if (!disabled("c1") && biu_c1_conv_ok(x, y, kd, kh, kw, dilation, dtype))
         return biu_c1_conv_fwd(x, xf, w, bias, kd, y, dtype, (hipStream_t)stream);
     if (packed && !disabled("conv_fwd") && biu_mfma_conv_ok(x, y, kd, kh, kw, dilation, dtype))
@@ -163,7 +173,10 @@ extern "C" int biu_convt_bwd_data_bnred(const biu_act* dy, const float* w, const
 }
 
 extern "C" size_t biu_conv_bwd_weight_workspace(int cin, int cout, int kd, int kh, int kw, int dtype) {
-    if (cin == 1 && kh == 3 && kw == 3) return biu_c1_wgrad_workspace(cout, kd);
+    if (cin == 1 && kh == 3 && kw == 3) {
+        const size_t a = biu_c1_wgrad_workspace(cout, kd), b = biu_c1m_wgrad_workspace(cout, kd);
+        return a > b ? a : b;
+    }
     return biu_mfma_wgrad_workspace(cin, cout, kd, kh, kw, dtype);
 }
 
@@ -172,6 +185,11 @@ extern "C" int biu_conv_bwd_weight(const biu_act* x, const biu_xform* xf, const 
                                    biu_stream stream) {
     BIU_REQUIRE(conv_args_ok(x, dy, kd, kh, kw, dilation), BIU_ERR_SHAPE, "conv_bwd_weight: x/dy extents differ");
     BIU_REQUIRE(dw, BIU_ERR_SHAPE, "conv_bwd_weight: null dw");
+    if (!disabled("c1") && biu_c1m_ok(x, dy, kd, kh, kw, dilation, dtype) && ws && ws_bytes >= biu_c1m_wgrad_workspace(dy->c, kd)) {
+        int rc = biu_c1m_wgrad(x, xf, dy, nullptr, kd, dw, ws, ws_bytes, (hipStream_t)stream);
+        if (rc == BIU_OK && dbias) rc = biu_chan_sum(dy, dbias, dtype, (hipStream_t)stream);
+        return rc;
+    }
     if (!disabled("c1") && biu_c1_conv_ok(x, dy, kd, kh, kw, dilation, dtype) && ws && ws_bytes >= biu_c1_wgrad_workspace(dy->c, kd)) {
         int rc = biu_c1_conv_wgrad(x, xf, dy, kd, dw, ws, ws_bytes, dtype, (hipStream_t)stream);
         if (rc == BIU_OK && dbias) rc = biu_chan_sum(dy, dbias, dtype, (hipStream_t)stream);
@@ -198,6 +216,12 @@ extern "C" int biu_conv_bwd_weight_bn(const biu_act* x, const biu_xform* xf, con
     const size_t es = dsize(dtype);
     const bool yok = ((uintptr_t)y->p % 16) == 0 && ((size_t)y->pitch * es) % 16 == 0 &&
                      (i64)y->d * y->h * y->w * y->pitch * (i64)es < (1LL << 32) - 65536;
+    if (!disabled("c1") && !disabled("wgrad_bn") && yok && biu_c1m_ok(x, da, kd, kh, kw, dilation, dtype) && ws &&
+        ws_bytes >= biu_c1m_wgrad_workspace(da->c, kd)) {
+        // first layer: BatchNorm backward in the dy staging of the im2col weight gradient (da -> dy written back in the same pass)
+        BnBwdFuse bn{y, scale, shift, slope, coefA, coefB, coefC};
+        return biu_c1m_wgrad(x, xf, da, &bn, kd, dw, ws, ws_bytes, (hipStream_t)stream);
+    }
     if (!disabled("conv_wgrad") && !disabled("wgrad_bn") && yok && biu_mfma_wgrad_ok(x, da, kd, kh, kw, dilation, dtype)) {
         BIU_REQUIRE(ws && ws_bytes >= biu_mfma_wgrad_workspace(x->c, da->c, kd, kh, kw, dtype), BIU_ERR_WORKSPACE,
                     "conv_bwd_weight_bn: workspace too small");

@@ -740,6 +740,14 @@ static bool conv_nw4() {
     return v == 1;
 }
 
+// experiment switch: BIU_CONV_CK4=1 stages single-tile 3-D layers in 32-channel chunks (64 bytes of every voxel row per pass) on
+// 4x8x16 bricks: half as many passes over the 128-byte rows of a 64-channel source (see profiles/r02_cfg4_mfma_busy.md: FETCH_SIZE)
+static bool conv_ck4() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("BIU_CONV_CK4"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 // (a 4-tile weight slab no longer fits the double buffer next to the activation tile: two tiles is the widest block)
 static inline int pick_nt(int ntiles) { return (ntiles % 2 == 0) ? 2 : 1; }
 
@@ -760,6 +768,8 @@ static int launch_conv(const ConvArgs& a, int kd, hipStream_t st) {
     const int nt = pick_nt(ntiles);
     const bool wide = (a.GW % 32 == 0);
     if (kd == 3) {
+        if (nt == 1 && conv_ck4() && !a.red_mode && a.Cin % 32 == 0 && (!a.x1 || a.csplit % 32 == 0))
+            return launch_cfg<T, 3, 3, 1, 4, 8, 16, 1, 4>(a, ntiles, 1, st);
         if (nt == 1 && conv_nw4()) return launch_cfg<T, 3, 3, 1, 4, 8, 16, 1, 2, 4>(a, ntiles, 1, st);
         if (nt == 1) return wide ? launch_cfg<T, 3, 3, 1, 4, 8, 32, 1, 2>(a, ntiles, 1, st) : launch_cfg<T, 3, 3, 1, 4, 16, 16, 1, 2>(a, ntiles, 1, st);
         return launch_cfg<T, 3, 3, 1, 4, 8, 16, 2, 2>(a, ntiles, 1, st);

@@ -342,6 +342,10 @@ int launch(const CtArgs& a, int ntb, int grid_x, size_t lds_bytes, hipStream_t s
 bool shapes_ok(const biu_act* lo, const biu_act* hi, int kd, int dtype) {
     if (dtype != BIU_BF16 || (kd != 1 && kd != 2)) return false;
     if (lo->c % 32 || hi->c % 32 || lo->c < 32 || hi->c < 32 || lo->c > 256 || hi->c > 256) return false;
+    // measured (cfg4, r02): 64 -> 64 channels at 64^3 -> 128^3 runs 0.41 -> 0.33 ms forward and 0.68 -> 0.41 ms data gradient against the
+    // per-parity launches of k_conv_pipe; at 128 / 256 channels the weight slab (128 KB) leaves one 4-wave block per CU and the
+    // small coarse tensors no longer hide it (up2 0.15 -> 0.16, 0.16 -> 0.21 ms): those stay on k_conv_pipe
+    if (lo->c > 64 || hi->c > 64) return false;
     if ((uintptr_t)lo->p % 16 || (uintptr_t)hi->p % 16 || (lo->pitch * 2) % 16 || (hi->pitch * 2) % 16) return false;
     if (nvox(hi) >= (1LL << 31)) return false;
     return true;

@@ -96,3 +96,11 @@ int biu_convt_all_fwd(const biu_act* x, const biu_xform* xf, const void* packed,
 int biu_convt_all_dgrad_rows(const biu_act* dx, const biu_act* dy, int kd);
 int biu_convt_all_dgrad(const biu_act* dy, const void* packed, int kd, const biu_act* dx, int accumulate, hipStream_t st,
                         float* bn_partial = nullptr, const BnRedFuse* red = nullptr);
+
+// biu_c1.hip: bf16 first layer (Cin = 1) on the matrix cores through an im2col image in LDS
+bool biu_c1m_ok(const biu_act* x, const biu_act* y, int kd, int kh, int kw, int dil, int dtype);
+int biu_c1m_fwd_rows(const biu_act* y, int kd);
+int biu_c1m_fwd(const biu_act* x, const biu_xform* xf, const float* w, const float* bias, int kd, const biu_act* y, float* bn_partial, hipStream_t st);
+size_t biu_c1m_wgrad_workspace(int cout, int kd);
+int biu_c1m_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* da, const BnBwdFuse* bn, int kd, float* dw, void* ws, size_t ws_bytes,
+                  hipStream_t st);

@@ -195,6 +195,8 @@ def emu_input(x):
 def mfma_layer(cin: int, cout: int, dilation: int = 1, ksize: int = 3) -> bool:
     """Which conv / ConvTranspose layers run on the MFMA kernels in bf16 mode (csrc/biu_conv_mfma.hip: chan_ok); 1x1 convs
     (attention gates) and dilated ones take the any-shape kernels, which multiply unrounded fp32 operands."""
+    if cin == 1 and dilation == 1 and ksize == 3 and cout >= 16 and cout % 16 == 0:
+        return True                             # first layer: im2col MFMA kernels (csrc/biu_c1.hip), weights packed as bf16
     return dilation == 1 and ksize != 1 and cin >= 16 and cin % 16 == 0 and cout >= 16 and cout % 8 == 0
 
 

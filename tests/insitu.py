@@ -128,6 +128,8 @@ class InSitu:
 
     # ---- helpers ---------------------------------------------------------------------------------------------------
     def _mfma(self, cin, cout, dil=1, k=3):
+        if cin == 1 and self.bf16 and dil == 1 and k == 3 and cout >= 16 and cout % 16 == 0:
+            return True                     # first layer through the im2col MFMA kernels (csrc/biu_c1.hip): bf16 weights
         return dil == 1 and k != 1 and cin >= 16 and cin % (16 if self.bf16 else 8) == 0 and cout >= 16 and cout % 8 == 0
 
     def _conv(self, x, w, b, dil, transposed=False):

@@ -33,57 +33,53 @@ class Tiles(torch.utils.data.Dataset):
         return self.items[i]
 
 
+def _engine_decisions(model):
+    """LeakyReLU / max-pool / max-join decisions of the model's last forward (tests/insitu.py): the oracle step below is taken on
+    the same branch of the piecewise-linear network, so its Adam update is comparable entry by entry."""
+    from tests import insitu
+    return insitu.extract_decisions(list(model._engines.values())[-1][-1])
+
+
 def test_trainer2d_one_step_matches_oracle(tmp_path):
     torch.manual_seed(0)
     ds = Tiles(8, (32, 32), ["image"])
     tr = unet.Trainer(ds, 1, batch_size=2, n_filter=8, in_channels=1, out_channels=1, save_dir=str(tmp_path), device="cuda")
     sd0 = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
     batch = next(iter(tr.train_loader))
+    # product side
+    loss = tr._forward_loss(batch, validating=False)
+    tr.optimizer.zero_grad()
+    loss.backward()
+    q = _engine_decisions(tr.model)
+    tr.optimizer.step()
+    torch.cuda.synchronize()
     # oracle side: same weights, same batch, the reference's loss expression, torch Adam
     osd = O.clone_state(sd0, requires_grad=True)
     x = batch["image"].view(2, 1, 32, 32)
     y = batch["mask"].view(2, 1, 32, 32)
-    _, ol = O.unet2d_forward(osd, x, training=True)
+    with O.forced_decisions(q):
+        _, ol = O.unet2d_forward(osd, x, training=True)
     oloss = O.trainer2d_loss(ol, y, 1)
-    params = [v for v in osd.values() if v.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-3)
+    opt = torch.optim.Adam([v for v in osd.values() if v.requires_grad], lr=1e-3)
     oloss.backward()
     opt.step()
-    # product side
-    loss = tr._forward_loss(batch, validating=False)
     assert abs(float(loss) - float(oloss)) < 1e-4
-    tr.optimizer.zero_grad()
-    loss.backward()
-    tr.optimizer.step()
-    torch.cuda.synchronize()
-    new = tr.model.state_dict()
-    worst = 0.0
-    for k, v in osd.items():
-        # conv biases in front of a BatchNorm have an exactly-zero gradient here and rounding noise (~1e-9) in the
-        # reference, which Adam's first step turns into a random +-lr walk of a parameter the network is invariant to
-        is_dead_bias = k.endswith(".0.bias") and not k.startswith("final")
-        if v.requires_grad and not is_dead_bias:
-            # Adam's first step moves every weight by ~lr*sign(g): compare the *update*
-            du_ref = v.detach() - sd0[k]
-            du = new[k].cpu() - sd0[k]
-            big = du_ref.abs() > 0.5e-3          # entries whose gradient is well away from zero
-            if big.any():
-                worst = max(worst, float((du - du_ref)[big].abs().max()))
-    assert worst < 2e-4, worst
+    _adam_update_matches(tr.model.state_dict(), osd, sd0)
 
 
 def _adam_update_matches(new, osd, sd0, tol=2e-4):
     """After one Adam step every weight moved by lr * g / (|g| + eps) ~ lr * sign(g): compare the UPDATES of the entries whose
-    oracle gradient is well away from zero -- above 5 % of the tensor's largest: an entry with |g| ~ eps moves by a
-    rounding-dependent fraction of lr in the reference too, and a LeakyReLU / max decision within fp32 rounding of its boundary
-    moves small entries by up to ~1e-2 of the largest in ANY fp32 implementation (tests/test_gpu_models.py); conv biases in
-    front of a BatchNorm have true gradient 0: a random +-lr walk there, exact 0 here."""
+    oracle gradient is well away from zero (an entry with |g| ~ eps moves by a rounding-dependent fraction of lr in the
+    reference too).  The oracle step is taken on the engine's branch of the LeakyReLU / max decisions (forced_decisions): at these
+    tiny extents (4 x 4 bottleneck maps) one decision within fp32 rounding of its boundary flips the SIGN of weight-gradient
+    entries of 8 % of the tensor's largest.  Conv biases in front of a BatchNorm have true gradient 0: a random +-lr walk in the
+    reference, exact 0 here."""
     worst, where = 0.0, ""
     for k, v in osd.items():
         is_dead_bias = k.endswith(".0.bias") and not k.startswith("final")
         if v.requires_grad and not is_dead_bias and v.grad is not None:
             du_ref, du = v.detach() - sd0[k], new[k].cpu() - sd0[k]
-            big = v.grad.abs() > 5e-2 * float(v.grad.abs().max())
+            big = v.grad.abs() > 1e-3 * float(v.grad.abs().max())
             if big.any():
                 e = (du - du_ref).abs() * big
                 if float(e.max()) > worst:
@@ -100,19 +96,21 @@ def test_trainer3d_one_step_matches_oracle(tmp_path):
     tr = unet3d.Trainer(ds, 1, batch_size=2, n_filter=8, save_dir=str(tmp_path), time_loss_weight=0.1, device="cuda")
     sd0 = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
     batch = next(iter(tr.train_loader))
+    loss = tr._forward_loss(batch, validating=False)
+    tr.optimizer.zero_grad()
+    loss.backward()
+    q = _engine_decisions(tr.model)
+    tr.optimizer.step()
+    torch.cuda.synchronize()
     osd = O.clone_state(sd0, requires_grad=True)
     x, y = batch["volume"].view(2, 1, 8, 16, 16), batch["mask"].view(2, 1, 8, 16, 16)
-    _, ol = O.unet3d_forward(osd, x, training=True)
+    with O.forced_decisions(q):
+        _, ol = O.unet3d_forward(osd, x, training=True)
     oloss = O.trainer3d_loss(ol, y, 0.1)
     opt = torch.optim.Adam([v for v in osd.values() if v.requires_grad], lr=1e-3)
     oloss.backward()
     opt.step()
-    loss = tr._forward_loss(batch, validating=False)
     assert abs(float(loss) - float(oloss)) < 1e-4
-    tr.optimizer.zero_grad()
-    loss.backward()
-    tr.optimizer.step()
-    torch.cuda.synchronize()
     _adam_update_matches(tr.model.state_dict(), osd, sd0)
     # validation hard-codes the time weight 0.1 whatever the trainer was given (unet3d/train.py:163-169)
     tr.time_loss_weight = 0.7
@@ -132,19 +130,21 @@ def test_trainer_siam_one_step_matches_oracle(tmp_path, mode):
     assert type(tr.criterion).__name__ == "BCEDiceLossSiam" and siam.BCEDiceLoss is type(tr.criterion)
     sd0 = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
     batch = next(iter(tr.train_loader))
+    loss = tr._forward_loss(batch, validating=False)
+    tr.optimizer.zero_grad()
+    loss.backward()
+    q = _engine_decisions(tr.model)
+    tr.optimizer.step()
+    torch.cuda.synchronize()
     osd = O.clone_state(sd0, requires_grad=True)
     x, px, y = (batch[k].view(2, 1, 32, 32) for k in ("image", "prev_image", "mask"))
-    _, ol = O.siam_forward(osd, x, px, mode=mode, training=True)
+    with O.forced_decisions(q):
+        _, ol = O.siam_forward(osd, x, px, mode=mode, training=True)
     oloss = O.siam_bce_dice_loss(ol, y, 1.0, 1.0)
     opt = torch.optim.Adam([v for v in osd.values() if v.requires_grad], lr=1e-3)
     oloss.backward()
     opt.step()
-    loss = tr._forward_loss(batch, validating=False)
     assert abs(float(loss) - float(oloss)) < 1e-4
-    tr.optimizer.zero_grad()
-    loss.backward()
-    tr.optimizer.step()
-    torch.cuda.synchronize()
     _adam_update_matches(tr.model.state_dict(), osd, sd0)
     # BatchNorm buffers of the weight-shared encoder were updated twice (x, then prev_x)
     assert int(tr.model.state_dict()["encode1.1.num_batches_tracked"]) == 2
@@ -466,9 +466,9 @@ def test_tile_store_feeder_and_trainer(tmp_path):
             seen.append(b)
         assert seen == [0, 1, 2]
     torch.manual_seed(5)
-    tr_a = unet.Trainer(ds, 1, batch_size=4, n_filter=4, save_dir=str(tmp_path / "a"), device="cuda")
+    tr_a = unet.Trainer(ds, 1, batch_size=2, n_filter=4, save_dir=str(tmp_path / "a"), device="cuda")
     torch.manual_seed(5)
-    tr_b = unet.Trainer(st, 1, batch_size=4, n_filter=4, save_dir=str(tmp_path / "b"), device="cuda")
+    tr_b = unet.Trainer(st, 1, batch_size=2, n_filter=4, save_dir=str(tmp_path / "b"), device="cuda")
     assert isinstance(tr_b.train_loader, DeviceFeeder) and tr_b.train_loader.indices == list(tr_a.train_loader.dataset.indices)
     la = tr_a._forward_loss(next(iter(tr_a.train_loader)), validating=False)
     lb = tr_b._forward_loss(next(iter(tr_b.train_loader)), validating=False)
