@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbiu_hip.so")
+LIB_PATH = os.environ.get("BIU_LIB_PATH") or os.path.join(_HERE, "libbiu_hip.so")     # override: A/B builds of tools/build_variant.sh
 
 BIU_F32, BIU_BF16 = 0, 1
 BN_MAX_PARTIALS = 1024

@@ -16,6 +16,7 @@
 //
 // fp32 uses v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains), bf16 uses v_mfma_f32_32x32x16_bf16 (fp32 accumulate).
 #include "biu_internal.h"
+#include <type_traits>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -135,7 +136,19 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base_unifo
 #ifndef BIU_CONV_ILV
 #define BIU_CONV_ILV 1
 #endif
-constexpr size_t conv_lds_budget(int nw) { return nw == 8 ? 150 * 1024 : 72 * 1024; }
+// Prefetch placement: the next item's n global loads go out in the first BIU_PF_SPAN-th of the ng MFMA slices (1 = spread over all
+// of them, 2 = over the first half, ...): pf_lo(g, n, ng) is the first piece slice g issues.
+#ifndef BIU_PF_SPAN
+#define BIU_PF_SPAN 1
+#endif
+constexpr int pf_lo(int g, int n, int ng) {
+    const int span = (ng + BIU_PF_SPAN - 1) / BIU_PF_SPAN;
+    return g >= span ? n : (g * n) / span;
+}
+#ifndef BIU_PRIO_ALT
+#define BIU_PRIO_ALT 0      // measured 1-3 % slower on cfg4 (profiles/r02_experiments.md); kept as a build switch
+#endif
+constexpr size_t conv_lds_budget(int nw) { return nw == 8 ? 142 * 1024 : 70 * 1024; }
 
 template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP, bool RED, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
@@ -151,6 +164,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     constexpr int TILES = TD * TH * TW / 32;
     static_assert(TILES % NWAVE == 0, "brick must give a multiple of NW voxel tiles");
     constexpr int MT = TILES / NWAVE;
+#ifndef BIU_CONV_RH
+#define BIU_CONV_RH 1
+#endif
+    constexpr bool RH = BIU_CONV_RH && TW == 32 && S == 1 && KHW == 3 && MT >= 2 && TH % MT == 0;   // row-stacked fragment reuse
     constexpr int TAPS = KD * KHW * KHW;
     constexpr int SPC = CKP / 2;
     constexpr int NSTEP = TAPS * SPC;
@@ -170,21 +187,28 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     uint4* lact = lds;                       // [CKP][PSV]
     uint4* lw = lds + CKP * PSV;             // [NWB][NSTEP][NT][64]
     float* lxf = (float*)(lw + NWB * WN);    // [3][Cin] transform vectors (if any)
-    float* lred = lxf + 3 * a.Cin;           // [NT*32][2] BatchNorm partial sums of the current brick
-    float* lbias = lred + NT * 32 * 2;       // [NT*32] bias of this block's output channels (zero when there is none)
+    float* lred = lxf + 3 * a.Cin;           // [NWAVE][NT*32][2] per-wave partial sums of the epilogue reduction
+    float* lbias = lred + NWAVE * NT * 32 * 2;   // [NT*32] bias of this block's output channels (zero when there is none)
+    float* lrs = lbias + NT * 32;            // [3][NT*32] RED: scale / shift / slope of the upstream block's transform
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hf = lane >> 5;
+    const int wpar = __builtin_amdgcn_readfirstlane(tid >> 8) & 1;      // which of the two waves of its SIMD this is (waves w, w + 4)
     const bool has_xf = a.xs != nullptr || a.xs1 != nullptr;
     const size_t esz = sizeof(T);
     const int nchunks = a.Cin / CK;
     const int nbricks = a.N * a.nbd * a.nbh * a.nbw;
     const int p_mine = tid % CKP;
 
-    if (tid < NT * 32 * 2) lred[tid] = 0.f;
     if (tid < NT * 32) {
         const int co = blockIdx.y * NT * 32 + tid;
         lbias[tid] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+        if constexpr (RED) {
+            const bool okc = co < a.Cout && a.red_scale != nullptr;
+            lrs[tid] = okc ? a.red_scale[co] : 0.f;
+            lrs[NT * 32 + tid] = okc ? a.red_shift[co] : 0.f;
+            lrs[2 * NT * 32 + tid] = (okc && a.red_slope) ? a.red_slope[co] : 1.f;
+        }
     }
     if (has_xf) {
         for (int i = tid; i < a.Cin; i += NTHR) {      // logical channel order; a source without a transform reads as identity
@@ -357,48 +381,54 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     unsigned long long dsum_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t0c_ = tprev_, t0r_ = __builtin_amdgcn_s_memrealtime();
 #endif
-    // Epilogue partial sums.  BatchNorm statistics (forward kernels) stay in registers across ALL bricks of this block and
-    // are reduced once after the loop -- one partial row per block; the cross-lane reduction costs ~7 k cycles, too much to
-    // pay per brick.  The data-gradient kernels (RED) have no registers for that and reduce per brick.
+    // Epilogue partial sums.  After the MFMAs a lane holds 16 of the 32 channels of ONE voxel per channel tile (rows (e & 3) +
+    // 8 (e >> 2) + 4 hf of D), i.e. NP 16-byte pieces of CPP channels once the bf16 halves are exchanged (see the epilogue).  Its
+    // per-channel sums live in s1/s2[nt][piece][e].  Forward kernels keep them in registers across ALL bricks of the block and
+    // reduce once after the loop (one partial row per block); the data-gradient kernels (RED) reduce every brick, piece by piece.
     constexpr int CPP = 16 / (int)sizeof(T);     // channels per 16-byte piece: 8 (bf16) / 4 (fp32)
-    constexpr int NHB = 8 / CPP;                 // 64-byte channel blocks per 32-channel tile: 1 / 2
+    constexpr int NP = 16 / CPP;                 // pieces per lane and channel tile: 2 / 4
+    constexpr int PSTEP = 32 / NP;               // channel distance between a lane's pieces: 16 / 8
     constexpr bool ACCB = !RED;
     const bool want_stats = a.bn_partial != nullptr;
-    float s1[NT][NHB][CPP], s2[NT][NHB][CPP];
+    float s1[ACCB ? NT : 1][ACCB ? NP : 1][CPP], s2[ACCB ? NT : 1][ACCB ? NP : 1][CPP];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < (ACCB ? NT : 1); ++nt)
 #pragma unroll
-        for (int hb = 0; hb < NHB; ++hb)
+        for (int p = 0; p < (ACCB ? NP : 1); ++p)
 #pragma unroll
-            for (int e = 0; e < CPP; ++e) s1[nt][hb][e] = s2[nt][hb][e] = 0.f;
-    auto reduce_stats = [&](int row) {
-        // lanes with the same (lane & 3) hold the same channels.  Inside a row of 16 lanes two DPP rotate-adds (VALU, no LDS
-        // traffic) give every lane its class sum; lanes 0-3 of the four rows then add into LDS (4-way same-address), which
-        // also merges the 8 waves.  lred is zero on entry: zeroed at kernel start and by the readers below.
+            for (int e = 0; e < CPP; ++e) s1[nt][p][e] = s2[nt][p][e] = 0.f;
+    // the 32 lanes of a half-wave hold the same channels: four DPP rotate-adds sum each row of 16 lanes, row_bcast:15 adds the
+    // even rows into the odd ones (VALU only), lanes 16 / 48 park the half-wave sums in LDS -- lred[wave][channel][2], plain
+    // stores, no atomics -- and flush_stats adds the NWAVE rows after a barrier.  (channel = nt * 32 + p * PSTEP + hf * CPP + e)
+    auto reduce_piece = [&](float (&u_)[CPP], float (&v_)[CPP], int nt, int p) {
+        float* slot = lred + ((size_t)(wave * (NT * 32) + nt * 32 + p * PSTEP + hf * CPP)) * 2;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int hb = 0; hb < NHB; ++hb)
-#pragma unroll
-                for (int e = 0; e < CPP; ++e) {
-                    float u = s1[nt][hb][e], v = s2[nt][hb][e];
-                    u += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x124, 0xf, 0xf, false));   // row_ror:4
-                    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));
-                    u += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x128, 0xf, 0xf, false));   // row_ror:8
-                    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
-                    if ((lane & 12) == 0) {
-                        const int cc = nt * 32 + hb * (4 * CPP) + (lane & 3) * CPP + e;
-                        atomicAdd(&lred[cc * 2 + 0], u);
-                        atomicAdd(&lred[cc * 2 + 1], v);
-                    }
-                    s1[nt][hb][e] = s2[nt][hb][e] = 0.f;
-                }
+        for (int e = 0; e < CPP; ++e) {
+            float u = u_[e], v = v_[e];
+            u += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x128, 0xf, 0xf, false));   // row_ror:8
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+            u += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x124, 0xf, 0xf, false));   // row_ror:4
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));
+            u += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x122, 0xf, 0xf, false));   // row_ror:2
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));
+            u += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x121, 0xf, 0xf, false));   // row_ror:1
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));
+            u += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));
+            if ((lane & 31) == 16) *(float2*)(slot + 2 * e) = make_float2(u, v);
+            u_[e] = v_[e] = 0.f;
+        }
+    };
+    auto flush_stats = [&](int row) {
         __syncthreads();
         if (tid < NT * 32) {
             const int co = blockIdx.y * NT * 32 + tid;
-            const float l0 = lred[tid * 2 + 0], l1 = lred[tid * 2 + 1];
-            lred[tid * 2 + 0] = 0.f;          // ready for the next brick: the item loop's barriers order this before its adds
-            lred[tid * 2 + 1] = 0.f;
+            float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < NWAVE; ++w2) {
+                const float2 t = *(const float2*)(lred + ((size_t)w2 * (NT * 32) + tid) * 2);
+                l0 += t.x; l1 += t.y;
+            }
             if (co < a.Cout) {
                 float* dstp = a.bn_partial + ((size_t)row * a.Cout + co) * 2;
                 dstp[0] = l0;
@@ -453,6 +483,32 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
                 }
             }
         };
+        // Row-stacked variant (RH): a wave's MT voxel tiles are MT consecutive rows of 32 voxels, so the fragment tile mt needs for
+        // tap row tb is the row (mt + tb) of the halo tile: MT + 2 fragment reads serve 3 * MT MFMAs per (ta, tc) -- 0.5 KiB of LDS
+        // activation traffic per MFMA instead of 1 KiB, which at NT = 1 is what bounded the kernel (LDS: 128 B/clk per CU against
+        // 4 SIMDs * 1.25 KiB per 32-cycle MFMA).
+        auto window_h = [&](int ta, int tc) {
+#pragma unroll
+            for (int sidx = 0; sidx < SPC; ++sidx) {
+                uint4 rows[MT + 2];
+                const uint4* lap = lact + hvb[0] + 2 * sidx * PSV + ta * HH * HW + tc;
+#pragma unroll
+                for (int j = 0; j < MT + 2; ++j) rows[j] = lap[j * HW];
+#pragma unroll
+                for (int tb = 0; tb < KHW; ++tb) {
+                    uint4 wf[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) wf[nt] = lwc[(((((ta * KHW + tb) * KHW + tc) * SPC) + sidx) * NT + nt) * 64];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) F::mma(wf[nt], rows[mt + tb], acc[nt][mt]);
+                }
+            }
+        };
+        auto tapgroup = [&](int g0, int g1) {
+            if constexpr (RH) window_h(g0, g1); else window(g0, g1);
+        };
         if constexpr (BIU_CONV_ILV) {
             // ---- MFMA phase with the next item's global loads spread over its (kd, kh) tap groups: the address
             //      unit takes the pieces one by one while the matrix cores run, instead of in a burst in front of them.
@@ -461,15 +517,19 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
             issue_prep(have_next ? nbrick : brick, nch, have_next);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
+                // the two waves of a SIMD (w, w + 4) take turns at the higher issue priority, tap group by tap group: with a fixed
+                // order the older wave runs ahead and the younger one finishes its MFMAs alone, at a single wave's rate
+                if constexpr (BIU_PRIO_ALT) { if (((g & 1) ^ wpar) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #pragma unroll
-                for (int j = (g * NPA) / NG; j < ((g + 1) * NPA) / NG; ++j) issue_piece(j);
+                for (int j = pf_lo(g, NPA, NG); j < pf_lo(g + 1, NPA, NG); ++j) issue_piece(j);
                 if constexpr (!W1) {
 #pragma unroll
-                    for (int j = (g * NPW) / NG; j < ((g + 1) * NPW) / NG; ++j) issue_wpiece(nch, have_next, j);
+                    for (int j = pf_lo(g, NPW, NG); j < pf_lo(g + 1, NPW, NG); ++j) issue_wpiece(nch, have_next, j);
                 }
-                window(g / KHW, g % KHW);
+                tapgroup(g / KHW, g % KHW);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (BIU_PRIO_ALT) __builtin_amdgcn_s_setprio(0);
             DIAG_STAMP(1);
         } else {
             issue(have_next ? nbrick : brick, nch, have_next);
@@ -480,107 +540,111 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
 #pragma unroll 1
             for (int ta = 0; ta < KD; ++ta) {
 #pragma unroll 1
-                for (int tb = 0; tb < KHW; ++tb) window(ta, tb);
+                for (int tb = 0; tb < KHW; ++tb) tapgroup(ta, tb);
             }
         }
 
         DIAG_STAMP(2);
         // ---- brick finished: epilogue ----------------------------------------------------------------------------------
         if (ch == nchunks - 1) {
-            // Every wave is done with the activation tile after this barrier, so its LDS doubles as the staging area:
-            // a wave turns its MFMA result (lane = voxel, registers = channels) into rows of 64 B of channels per
-            // voxel, 16 voxels at a time, and reads them back as 16-byte pieces -- the global stores (and the loads of
-            // the accumulate / BatchNorm-backward operands) are then 64 contiguous bytes per voxel instead of 8.
-            __syncthreads();
+            // No LDS staging: a lane holds, for ITS voxel, channel groups 8 g + 4 hf .. + 3 (g = 0..3) of each tile.  fp32: every
+            // group is a 16-byte piece already.  bf16: a group is 8 bytes; v_permlane32_swap exchanges the upper half-wave's group
+            // 2p with the lower one's group 2p+1, after which lanes 0-31 hold channels 16 p .. + 7 and lanes 32-63 channels
+            // 16 p + 8 .. + 15 of their voxel: one 16-byte store per lane and pair (cdna_hip_programming.md T21).
             const Org o = origin(brick);
-            constexpr int QPB = 4 / NHB;                 // accumulator quads per block
-            constexpr int ROWB = 80;                     // staged row: 64 B + 16 B pad (spreads the rows over the banks)
-            char* stg = (char*)lact + wave * (16 * ROWB);
+            int vo[MT];                                  // output voxel index of this lane's voxel in tile mt, -1 outside the tensor
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int q = (wave * MT + mt) * 32 + r;
+                const int lw_ = q % TW;
+                const int t = q / TW;
+                const int lh = t % TH;
+                const int ld = t / TH;
+                const int gd = o.d0 + ld, gh = o.h0 + lh, gw = o.w0 + lw_;
+                const int od = gd * a.osd + ((a.osd == 2) ? (int)(blockIdx.z >> 2) : 0);
+                const int oh = gh * a.osh + ((a.osh == 2) ? (int)((blockIdx.z >> 1) & 1) : 0);
+                const int ow = gw * a.osw + ((a.osw == 2) ? (int)(blockIdx.z & 1) : 0);
+                vo[mt] = (gd < a.GD && gh < a.GH && gw < a.GW) ? ((o.n * a.OD + od) * a.OH + oh) * a.OW + ow : -1;
+            }
             // destination of this block's channel tile (the second tensor of a split output when the tile lies beyond osplit)
             const bool o1 = a.y1 && (int)(blockIdx.y * NT * 32) >= a.osplit;
             char* ybase = o1 ? a.y1 : a.y;
             const int ypitch_o = o1 ? a.ypitch1 : a.ypitch;
             const int coff = o1 ? a.osplit : 0;
             const int accum_o = o1 ? a.accumulate1 : a.accumulate;
-            const int prow = lane >> 2, pcol = lane & 3; // read-back: lane -> (voxel row, piece)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-                for (int hb = 0; hb < NHB; ++hb) {
-                    const int cl = (blockIdx.y * NT + nt) * 32 + hb * (4 * CPP) + pcol * CPP;   // this lane's channels
+                for (int p = 0; p < NP; ++p) {
+                    const int cl = (blockIdx.y * NT + nt) * 32 + p * PSTEP + hf * CPP;      // this lane's channels of piece p
                     const bool c_ok = cl < a.Cout;
-                    float rsc[CPP], rsh[CPP], rsl[CPP];
+                    float rsc[CPP], rsh[CPP], rsl[CPP], t1[CPP], t2[CPP];
                     if constexpr (RED) {
 #pragma unroll
                         for (int e = 0; e < CPP; ++e) {
-                            rsc[e] = c_ok ? a.red_scale[cl + e] : 0.f;
-                            rsh[e] = c_ok ? a.red_shift[cl + e] : 0.f;
-                            rsl[e] = (c_ok && a.red_slope) ? a.red_slope[cl + e] : 1.f;
+                            const int ci = nt * 32 + p * PSTEP + hf * CPP + e;
+                            rsc[e] = lrs[ci]; rsh[e] = lrs[NT * 32 + ci]; rsl[e] = lrs[2 * NT * 32 + ci];
+                            t1[e] = t2[e] = 0.f;
                         }
                     }
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
+                        uint4 piece;
+                        if constexpr (sizeof(T) == 2) {
+                            Pack<T, 4> g0, g1;
 #pragma unroll
-                        for (int vh = 0; vh < 2; ++vh) {
-                            if ((r >> 4) == vh) {
+                            for (int i = 0; i < 4; ++i) { g0.v[i] = (T)acc[nt][mt][8 * p + i]; g1.v[i] = (T)acc[nt][mt][8 * p + 4 + i]; }
+                            uint2 ua = __builtin_bit_cast(uint2, g0), ub = __builtin_bit_cast(uint2, g1);
+                            const auto sx = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+                            const auto sy = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+                            piece = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                        } else {
+                            piece = make_uint4(__float_as_uint(acc[nt][mt][4 * p]), __float_as_uint(acc[nt][mt][4 * p + 1]),
+                                               __float_as_uint(acc[nt][mt][4 * p + 2]), __float_as_uint(acc[nt][mt][4 * p + 3]));
+                        }
+                        if (!(c_ok && vo[mt] >= 0)) continue;
+                        const size_t vox = (size_t)vo[mt];
+                        uint4* dst = (uint4*)((T*)ybase + vox * ypitch_o + (cl - coff));
+                        float f[CPP];
+                        if (accum_o) {
+                            float g[CPP];
+                            F::unpack(piece, f);
+                            F::unpack(*dst, g);
 #pragma unroll
-                                for (int j = 0; j < QPB; ++j) {
-                                    Pack<T, 4> pk;
+                            for (int e = 0; e < CPP; ++e) f[e] += g[e];
+                            piece = F::pack(f);
+                        }
+                        *dst = piece;
+                        if (want_stats) {
+                            F::unpack(piece, f);          // statistics of the values as stored
+                            if constexpr (!RED) {
 #pragma unroll
-                                    for (int i = 0; i < 4; ++i) pk.v[i] = (T)acc[nt][mt][4 * (hb * QPB + j) + i];
-                                    *(Pack<T, 4>*)(stg + (r & 15) * ROWB + (8 * j + 4 * hf) * (int)sizeof(T)) = pk;
+                                for (int e = 0; e < CPP; ++e) {
+                                    s1[nt][p][e] += f[e];
+                                    s2[nt][p][e] = fmaf(f[e], f[e], s2[nt][p][e]);
                                 }
-                            }
-                            asm volatile("" ::: "memory");       // same wave: LDS executes in order, only the compiler must not reorder
-                            uint4 piece = *(const uint4*)(stg + prow * ROWB + pcol * 16);
-                            asm volatile("" ::: "memory");
-                            const int q = (wave * MT + mt) * 32 + 16 * vh + prow;
-                            const int lw_ = q % TW;
-                            const int t = q / TW;
-                            const int lh = t % TH;
-                            const int ld = t / TH;
-                            const int gd = o.d0 + ld, gh = o.h0 + lh, gw = o.w0 + lw_;
-                            if (!(c_ok && gd < a.GD && gh < a.GH && gw < a.GW)) continue;
-                            const int od = gd * a.osd + ((a.osd == 2) ? (int)(blockIdx.z >> 2) : 0);
-                            const int oh = gh * a.osh + ((a.osh == 2) ? (int)((blockIdx.z >> 1) & 1) : 0);
-                            const int ow = gw * a.osw + ((a.osw == 2) ? (int)(blockIdx.z & 1) : 0);
-                            const size_t vox = ((size_t)(o.n * a.OD + od) * a.OH + oh) * a.OW + ow;
-                            uint4* dst = (uint4*)((T*)ybase + vox * ypitch_o + (cl - coff));
-                            float f[CPP];
-                            if (accum_o) {
-                                float g[CPP];
-                                F::unpack(piece, f);
-                                F::unpack(*dst, g);
+                            } else {
+                                float yv[CPP];
+                                F::unpack(*(const uint4*)((const T*)a.red_y + vox * a.red_ypitch + cl), yv);
 #pragma unroll
-                                for (int e = 0; e < CPP; ++e) f[e] += g[e];
-                                piece = F::pack(f);
-                            }
-                            *dst = piece;
-                            if (want_stats) {
-                                F::unpack(piece, f);          // statistics of the values as stored
-                                if constexpr (!RED) {
-#pragma unroll
-                                    for (int e = 0; e < CPP; ++e) {
-                                        s1[nt][hb][e] += f[e];
-                                        s2[nt][hb][e] = fmaf(f[e], f[e], s2[nt][hb][e]);
-                                    }
-                                } else {
-                                    float yv[CPP];
-                                    F::unpack(*(const uint4*)((const T*)a.red_y + vox * a.red_ypitch + cl), yv);
-#pragma unroll
-                                    for (int e = 0; e < CPP; ++e) {
-                                        const float tt = fmaf(rsc[e], yv[e], rsh[e]);
-                                        const float dz = f[e] * (tt > 0.f ? 1.f : rsl[e]);
-                                        s1[nt][hb][e] += dz;
-                                        s2[nt][hb][e] = fmaf(dz, yv[e], s2[nt][hb][e]);     // raw; centred when the partial is written
-                                    }
+                                for (int e = 0; e < CPP; ++e) {
+                                    const float tt = fmaf(rsc[e], yv[e], rsh[e]);
+                                    const float dz = f[e] * (tt > 0.f ? 1.f : rsl[e]);
+                                    t1[e] += dz;
+                                    t2[e] = fmaf(dz, yv[e], t2[e]);     // raw; centred when the partial is written
                                 }
                             }
                         }
                     }
+                    if constexpr (RED) {
+                        if (want_stats) reduce_piece(t1, t2, nt, p);
+                    }
                 }
             }
-            if (want_stats && !ACCB) reduce_stats(brick);
+            if constexpr (RED) {
+                if (want_stats) flush_stats(brick);
+            }
+
         }
         DIAG_STAMP(3);
 #ifdef BIU_DIAG
@@ -602,7 +666,15 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
         DIAG_STAMP(6);
         brick = nbrick; ch = nch; k = nk;
     }
-    if (want_stats && ACCB) reduce_stats((int)blockIdx.x);
+    if constexpr (ACCB) {
+        if (want_stats) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) reduce_piece(s1[nt][p], s2[nt][p], nt, p);
+            flush_stats((int)blockIdx.x);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -698,7 +770,7 @@ static int launch_cfg_r(const ConvArgs& a0, int ntiles, int nz, hipStream_t st) 
     constexpr int PSV = cpad_planes(HV, CKP);
     constexpr int WN = KD * KHW * KHW * (CKP / 2) * NT * 64;
     constexpr int NWB = ((size_t)(CKP * PSV + 2 * WN) * 16 <= conv_lds_budget(NW)) ? 2 : 1;        // must mirror k_conv_pipe::W2
-    const size_t lds_bytes = (size_t)(CKP * PSV + NWB * WN) * 16 + (size_t)3 * a.Cin * sizeof(float) + (size_t)NT * 32 * 3 * sizeof(float);
+    const size_t lds_bytes = (size_t)(CKP * PSV + NWB * WN) * 16 + (size_t)3 * a.Cin * sizeof(float) + (size_t)NT * 32 * (2 * NW + 4) * sizeof(float);
     if (lds_bytes > (size_t)(NW == 8 ? 160 : 80) * 1024) return biu_fail(BIU_ERR_UNSUPPORTED, "conv_pipe: %zu bytes of LDS (Cin=%d)", lds_bytes, a.Cin);
     a.nbd = (a.GD + TD - 1) / TD;
     a.nbh = (a.GH + TH - 1) / TH;
@@ -1245,10 +1317,6 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     // w / KSPLIT + WPQ * t, t < IPW -- every wave runs the same branch-free loop over ITS k-groups with IPW MFMAs per A
     // fragment; a tap index past the last one multiplies into an accumulator nobody flushes.
     const int wq = wave % KSPLIT, wtap0 = wave / KSPLIT;
-    // TAPS is rarely a multiple of the tap slots (27 taps on 8 x 4 slots, 9 on 2 x 5): the waves whose last slot has no tap
-    // skip its LDS reads and MFMA (wave-uniform scalar branch) instead of multiplying into an accumulator nobody flushes --
-    // the SIMD they share with a full wave issues 7 MFMAs per k-group instead of 8
-    const bool last_tap_live = (wtap0 + WPQ * (IPW - 1)) < TAPS;
     int tapoff[IPW];
 #pragma unroll
     for (int t = 0; t < IPW; ++t) {
@@ -1449,60 +1517,66 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
             static_assert(NKG % KSPLIT == 0 && KPW % NG == 0, "k-groups must split evenly into slices");
             constexpr int KPG = KPW / NG;
             WSTAMP(0);
+            using FragR = typename std::conditional<sizeof(T) == 2, bf16x8, float>::type;
+            FragR fa[2][NI], fb[2][IPW];
+            auto load_frags = [&](int kg, FragR (&af)[NI], FragR (&bfr)[IPW]) {
+                const int q0 = kg * KUNIT;
+                const int lw0 = q0 % TW;
+                const int t = q0 / TW;
+                const int lh = t % TH;
+                const int ld = t / TH;
+                const int hbase = ((ld * SD * HH + lh * S) * HW + lw0 * S) * RS;
+                if constexpr (sizeof(T) == 2) {
+                    typedef bf16x4 __attribute__((address_space(3))) * lp;
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const char* ap = at + q0 * RSA + a_lane + ni * CT * 2;
+                        bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap));
+                        bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap + 4 * RSA));
+                        af[ni] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+#pragma unroll
+                    for (int t2 = 0; t2 < IPW; ++t2) {
+                        const char* bp = bt + hbase + tapoff[t2] + b_lane;
+                        bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp));
+                        bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp + 4 * S * RS));
+                        bfr[t2] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                } else {
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) af[ni] = *(const float*)(at + q0 * RSA + a_lane + ni * CT * 4);
+#pragma unroll
+                    for (int t2 = 0; t2 < IPW; ++t2) bfr[t2] = *(const float*)(bt + hbase + tapoff[t2] + b_lane);
+                }
+            };
+            load_frags(wq * KPW, fa[0], fb[0]);
             issue_prep(have_next ? nbrick : brick, have_next);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
+                if constexpr (BIU_PRIO_ALT) { if (((g & 1) ^ ((wave >> 2) & 1)) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }     // see k_conv_pipe
 #pragma unroll
-                for (int j = (g * NA) / NG; j < ((g + 1) * NA) / NG; ++j) issue_a(j);
+                for (int j = pf_lo(g, NA, NG); j < pf_lo(g + 1, NA, NG); ++j) issue_a(j);
 #pragma unroll
-                for (int j = (g * NB) / NG; j < ((g + 1) * NB) / NG; ++j) issue_b(j);
-                // fp32 steps are tiny (one ds_read_b32 per 64-cycle MFMA): unroll deeper so the LDS reads run ahead
-#pragma unroll(sizeof(T) == 2 ? 2 : (IPW > 5 ? 2 : 4))
+                for (int j = pf_lo(g, NB, NG); j < pf_lo(g + 1, NB, NG); ++j) issue_b(j);
+                // Fragment reads run one k-group ahead of the MFMAs, in a second register set (the loops are fully unrolled, so the
+                // set is picked at compile time): left to itself the compiler re-used one register quad for every B fragment and
+                // put an lgkmcnt(0) in front of each MFMA, i.e. the full LDS latency per MFMA.  Every wave multiplies all IPW tap
+                // slots -- a slot past the last tap lands in an accumulator nobody flushes -- so the loop body has no branch.
+#pragma unroll
                 for (int kk = 0; kk < KPG; ++kk) {
-                    const int kg = wq * KPW + g * KPG + kk;
-                    const int q0 = kg * KUNIT;
-                    const int lw0 = q0 % TW;
-                    const int t = q0 / TW;
-                    const int lh = t % TH;
-                    const int ld = t / TH;
-                    const int hbase = ((ld * SD * HH + lh * S) * HW + lw0 * S) * RS;
-                    if constexpr (sizeof(T) == 2) {
-                        typedef bf16x4 __attribute__((address_space(3))) * lp;
-                        bf16x8 af[NI];
+                    const int idx = g * KPG + kk;
+                    if (idx + 1 < KPW) load_frags(wq * KPW + idx + 1, fa[(idx + 1) & 1], fb[(idx + 1) & 1]);
+#pragma unroll
+                    for (int t2 = 0; t2 < IPW; ++t2)
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni) {
-                            const char* ap = at + q0 * RSA + a_lane + ni * CT * 2;
-                            bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap));
-                            bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap + 4 * RSA));
-                            af[ni] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                            if constexpr (sizeof(T) == 2) acc[t2][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[idx & 1][ni], fb[idx & 1][t2], acc[t2][ni], 0, 0, 0);
+                            else acc[t2][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[idx & 1][ni], fb[idx & 1][t2], acc[t2][ni], 0, 0, 0);
                         }
-#pragma unroll
-                        for (int t2 = 0; t2 < IPW; ++t2) {
-                            if (t2 < IPW - 1 || last_tap_live) {
-                                const char* bp = bt + hbase + tapoff[t2] + b_lane;
-                                bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp));
-                                bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp + 4 * S * RS));
-                                bf16x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                                for (int ni = 0; ni < NI; ++ni) acc[t2][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ni], bf, acc[t2][ni], 0, 0, 0);
-                            }
-                        }
-                    } else {
-                        float af[NI];
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) af[ni] = *(const float*)(at + q0 * RSA + a_lane + ni * CT * 4);
-#pragma unroll
-                        for (int t2 = 0; t2 < IPW; ++t2) {
-                            if (t2 < IPW - 1 || last_tap_live) {
-                                const float bf = *(const float*)(bt + hbase + tapoff[t2] + b_lane);
-#pragma unroll
-                                for (int ni = 0; ni < NI; ++ni) acc[t2][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ni], bf, acc[t2][ni], 0, 0, 0);
-                            }
-                        }
-                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (BIU_PRIO_ALT) __builtin_amdgcn_s_setprio(0);
             WSTAMP(1);
 #ifdef BIU_DIAG
             dsum_[7] += 1;

@@ -38,7 +38,11 @@ def main():
         y = torch.empty(n, d, h, w, cout, device="cuda", dtype=tdt)
         dy = torch.randn(n, d, h, w, cout, device="cuda").to(tdt)
         dx = torch.empty_like(x)
+        if os.environ.get("BENCH_ZERO") == "1":          # power probe: all-zero operands toggle no datapath bits
+            x.zero_(); dy.zero_()
         wt = torch.randn((cout, cin) + (3,) * nd, device="cuda") * 0.05
+        if os.environ.get("BENCH_ZERO") == "1":
+            wt.zero_()
         bias = torch.randn(cout, device="cuda")
         xs, xb, xl = torch.ones(cin, device="cuda"), torch.zeros(cin, device="cuda"), torch.full((cin,), 0.1, device="cuda")
         xf = biu_xform(xs.data_ptr(), xb.data_ptr(), xl.data_ptr())

@@ -3,7 +3,7 @@ import ctypes as C, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bio_image_unet_amd._lib import biu_act, biu_xform, SIGNATURES
-lib = C.CDLL(os.path.join(ROOT, "tools", "libbiu_diag.so"))
+lib = C.CDLL(os.path.join(ROOT, "tools", "variants", "libbiu_diag.so"))
 for name, (res, args) in SIGNATURES.items():
     getattr(lib, name).restype = res; getattr(lib, name).argtypes = args
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
