@@ -63,7 +63,7 @@ extern "C" int biu_conv_fwd_stats(const biu_act* x, const biu_xform* xf, const f
         }
     }
     if (packed && !disabled("conv_fwd") && !disabled("fused_stats") && biu_mfma_conv_ok(x, y, kd, kh, kw, dilation, dtype)) {
-        const int nb = biu_mfma_conv_stat_rows(y, kd);           // one partial row per workgroup column
+        const int nb = biu_mfma_conv_stat_rows(y, kd, x, dtype);           // one partial row per workgroup column
         if ((size_t)nb * y->c * 2 <= bn_partial_floats) {
             int rc = biu_mfma_conv(x, xf, packed, bias, kd, kh, kw, y, 0, bn_partial, dtype, (hipStream_t)stream);
             if (rc == BIU_OK) *bn_nblk = nb;
@@ -125,7 +125,7 @@ extern "C" int biu_conv_bwd_data_bnred(const biu_act* dy, const float* w, const 
     const size_t es = dsize(dtype);
     const bool yok = ((uintptr_t)y_up->p % 16) == 0 && ((size_t)y_up->pitch * es) % 16 == 0;
     if (packed && yok && !disabled("conv_dgrad") && !disabled("dgrad_bnred") && biu_mfma_conv_ok(dy, dx, kd, kh, kw, dilation, dtype)) {
-        const int nb = biu_mfma_conv_bricks(dx, kd);
+        const int nb = biu_mfma_conv_bricks(dx, kd, dy, dtype);
         if ((size_t)nb * dx->c * 2 <= partial_floats) {
             BnRedFuse red{y_up, scale, shift, slope, mean, invstd};
             int rc = biu_mfma_conv(dy, nullptr, packed, nullptr, kd, kh, kw, dx, 0, partial, dtype, (hipStream_t)stream, &red);

@@ -17,6 +17,8 @@
 // fp32 uses v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains), bf16 uses v_mfma_f32_32x32x16_bf16 (fp32 accumulate).
 #include "biu_internal.h"
 #include <type_traits>
+#include <cstring>
+#include <cstdlib>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -677,6 +679,340 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     }
 }
 
+// ===============================================================================================================
+// 16-output-channel variant (bf16): v_mfma_f32_16x16x32_bf16, so a 16-channel layer (decode6 forward, the data gradient
+// of encode2 in UNet3D(n_filter=16..32)) does not multiply 16 rows of zeros on a 32-row tile.
+//
+//   D[cout 0..15][voxel 0..15] += A[cout][k 0..31] * B[k][voxel]       one MFMA = one tap, 32 input channels, 16 voxels
+//
+// Lane l = (n = l & 15, q = l >> 4): A = W[cout n][k = 8q..8q+7], B = in[voxel n][channel piece q], D rows 4q..4q+3 of column n.
+// The LDS image is the one k_conv_pipe uses -- planes of 16-byte pieces [piece][halo voxel], 4 planes = 32 channels per
+// chunk -- so a B fragment is lact[q * PSV + voxel].  A wave owns R consecutive rows of 16 voxels (brick TD x TH x 16): per
+// (kd tap, kw tap) it reads R + 2 row fragments and 3 weight fragments for 3 R MFMAs (the fragment of tile row j and kh tap b is
+// row j + b).  Staging, prefetch, weight DMA, brick walk and the epilogue reductions follow k_conv_pipe.
+// ===============================================================================================================
+typedef float floatx4m __attribute__((ext_vector_type(4)));
+
+template <int KD, int TD, int TH, bool RED>
+__global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
+    using T = bf16_t;
+    using F = Frag<T>;
+    constexpr int TW = 16, NTHR = 512, NWAVE = 8, PE = 8, CKP = 4, CK = 32;
+    constexpr int PD = (KD == 3) ? 1 : 0;
+    constexpr int HD = TD + KD - 1, HH = TH + 2, HW = TW + 2, HV = HD * HH * HW;
+    constexpr int PSV = (HV + 15) & ~15;              // plane stride = 0 (mod 16 pieces): the four planes of a read hit disjoint banks
+    constexpr int R = TD * TH / NWAVE;                // 16-voxel rows per wave
+    static_assert(TH % R == 0 && R >= 2 && (TD * TH) % NWAVE == 0, "rows of a wave must stay inside one plane");
+    constexpr int TAPS = KD * 9;
+    constexpr int NPA = (HV * CKP + NTHR - 1) / NTHR;
+    constexpr int WN = TAPS * 64;                     // weight fragments (16 B) per chunk
+    constexpr int NPW = (WN + NTHR - 1) / NTHR;
+    constexpr int NG = KD * 3;                        // MFMA groups per item: (kd tap, kw tap)
+
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+    uint4* lact = lds;                       // [CKP][PSV]
+    uint4* lw = lds + CKP * PSV;             // [2][TAPS][64]
+    float* lxf = (float*)(lw + 2 * WN);      // [3][Cin]
+    float* lred = lxf + 3 * a.Cin;           // [NWAVE][16][2]
+    float* lbias = lred + NWAVE * 16 * 2;    // [16]
+    float* lrs = lbias + 16;                 // [3][16]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n16 = lane & 15, q4 = lane >> 4;
+    const bool has_xf = a.xs != nullptr;
+    const int nchunks = a.Cin / CK;
+    const int nbricks = a.N * a.nbd * a.nbh * a.nbw;
+    const int p_mine = tid % CKP;
+
+    if (tid < 16) {
+        lbias[tid] = (a.bias && tid < a.Cout) ? a.bias[tid] : 0.f;
+        if constexpr (RED) {
+            const bool okc = tid < a.Cout && a.red_scale != nullptr;
+            lrs[tid] = okc ? a.red_scale[tid] : 0.f;
+            lrs[16 + tid] = okc ? a.red_shift[tid] : 0.f;
+            lrs[32 + tid] = (okc && a.red_slope) ? a.red_slope[tid] : 1.f;
+        }
+    }
+    if (has_xf) {
+        for (int i = tid; i < a.Cin; i += NTHR) {
+            lxf[i] = a.xs[i];
+            lxf[a.Cin + i] = a.xb[i];
+            lxf[2 * a.Cin + i] = a.xl[i];
+        }
+    }
+    const int G = gridDim.x;
+    auto brick_of = [&](int k) -> int {
+        if ((G & 7) == 0) return k * G + (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);
+        return k * G + (int)blockIdx.x;
+    };
+    struct Org { int n, d0, h0, w0; };
+    auto origin = [&](int brick) -> Org {
+        int b = brick;
+        Org o;
+        o.w0 = (b % a.nbw) * TW; b /= a.nbw;
+        o.h0 = (b % a.nbh) * TH; b /= a.nbh;
+        o.d0 = (b % a.nbd) * TD;
+        o.n = b / a.nbd;
+        return o;
+    };
+    // this wave's rows: flattened (d, h) rows wave * R .. + R - 1 of the brick
+    const int ld_w = (wave * R) / TH, lh_w = (wave * R) % TH;
+    const int hvb = q4 * PSV + (ld_w * HH + lh_w) * HW + n16;      // fragment address of row 0, tap (0, 0, 0)
+
+    floatx4m acc[R];
+    uint4 pa[NPA];
+    int wcur = 0;
+    constexpr unsigned GBITS = (1u << 9) | (1u << 19) | (1u << 29);
+    unsigned xs_[NPA], lvox[NPA];
+    const unsigned cpb = (unsigned)(p_mine * PE * 2);
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+        const int i = tid + NTHR * j;
+        const int hv = i / CKP;
+        const int hw = hv % HW;
+        const int t = hv / HW;
+        const int hh = t % HH;
+        const int hd = t / HH;
+        xs_[j] = (hv < HV) ? (unsigned)(hd | (hh << 10) | (hw << 20)) : 511u;
+        lvox[j] = (unsigned)((hd * a.IH + hh) * a.IW + hw);
+    }
+    auto issue_wpiece = [&](int ch, bool live, int j) {
+        const int q = tid + NTHR * j;
+        if (q < WN && live) {                          // wave-uniform: WN is a multiple of 64
+            const uint4* src = a.wpk + (size_t)ch * WN + q;
+            uint4* dstw = lw + (wcur ^ 1) * WN + (q - lane);
+            const unsigned lbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)dstw));
+            glds16(src, lbase);
+        }
+    };
+    unsigned inb_mask = 0, c_lo = 0, c_hi = 0, rowb = 0;
+    int brb = 0;
+    __amdgpu_buffer_rsrc_t rs;
+    auto issue_prep = [&](int brick, int ch, bool live) {
+        const Org o = origin(brick);
+        const int gd0 = o.d0 - PD, gh0 = o.h0 - 1, gw0 = o.w0 - 1;
+        const int lod = max(0, -gd0), loh = max(0, -gh0), low = max(0, -gw0);
+        const int hid = min(HD - 1, a.ID - 1 - gd0), hih = min(HH - 1, a.IH - 1 - gh0), hiw = min(HW - 1, a.IW - 1 - gw0);
+        c_lo = GBITS - (unsigned)(lod | (loh << 10) | (low << 20));
+        c_hi = GBITS + (unsigned)(hid | (hih << 10) | (hiw << 20));
+        rowb = (unsigned)(a.xpitch * 2);
+        brb = (int)(unsigned)((long long)((gd0 * a.IH + gh0) * a.IW + gw0) * rowb + (long long)ch * CK * 2);
+        const size_t sample_bytes = (size_t)a.ID * a.IH * a.IW * rowb;
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (size_t)o.n * sample_bytes), 0, live ? (int)(unsigned)sample_bytes : 0, 0x00020000);
+        inb_mask = 0;
+    };
+    auto issue_piece = [&](int j) {
+        const unsigned in_lo = xs_[j] + c_lo, in_hi = c_hi - xs_[j];
+        const bool ok = ((in_lo & in_hi) & GBITS) == GBITS;
+        const int off = ok ? (int)(__umul24(lvox[j], rowb) + cpb + (unsigned)brb) : -1;
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+        pa[j] = make_uint4(v[0], v[1], v[2], v[3]);
+        inb_mask |= ok ? (1u << j) : 0u;
+    };
+    auto commit = [&](int ch) {
+        float sc[PE], sh[PE], sl[PE];
+        if (has_xf) {
+            const int c0 = ch * CK + p_mine * PE;
+#pragma unroll
+            for (int e = 0; e < PE; ++e) { sc[e] = lxf[c0 + e]; sh[e] = lxf[a.Cin + c0 + e]; sl[e] = lxf[2 * a.Cin + c0 + e]; }
+        }
+#pragma unroll
+        for (int j = 0; j < NPA; ++j) {
+            const int i = tid + NTHR * j;
+            if (i < HV * CKP) {
+                uint4 v = pa[j];
+                if (has_xf && ((inb_mask >> j) & 1u)) {
+                    float f[PE];
+                    F::unpack(v, f);
+#pragma unroll
+                    for (int e = 0; e < PE; ++e) {
+                        const float t = fmaf(sc[e], f[e], sh[e]);
+                        f[e] = fmaxf(t, sl[e] * t);
+                    }
+                    v = F::pack(f);
+                }
+                lact[p_mine * PSV + i / CKP] = v;
+            }
+        }
+    };
+    // per-channel sums: a lane holds channels 4 q4 .. + 3 of its voxel; the 16 lanes of a DPP row share them
+    const bool want_stats = a.bn_partial != nullptr;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    auto reduce4 = [&](float (&u_)[4], float (&v_)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float u = u_[e], v = v_[e];
+            u += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x128, 0xf, 0xf, false));
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+            u += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x124, 0xf, 0xf, false));
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));
+            u += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x122, 0xf, 0xf, false));
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));
+            u += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x121, 0xf, 0xf, false));
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));
+            if (n16 == 0) *(float2*)(lred + ((wave * 16) + 4 * q4 + e) * 2) = make_float2(u, v);
+            u_[e] = v_[e] = 0.f;
+        }
+    };
+    auto flush_stats = [&](int row) {
+        __syncthreads();
+        if (tid < 16) {
+            float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < NWAVE; ++w2) {
+                const float2 t = *(const float2*)(lred + (w2 * 16 + tid) * 2);
+                l0 += t.x; l1 += t.y;
+            }
+            if (tid < a.Cout) {
+                float* dstp = a.bn_partial + ((size_t)row * a.Cout + tid) * 2;
+                dstp[0] = l0;
+                if constexpr (RED) dstp[1] = a.red_invstd[tid] * (l1 - a.red_mean[tid] * l0);
+                else dstp[1] = l1;
+            }
+        }
+    };
+
+    int k = 0;
+    int brick = brick_of(0);
+    if (brick >= nbricks) return;
+    int ch = 0;
+    issue_prep(brick, 0, true);
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) issue_piece(j);
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) issue_wpiece(0, true, j);
+    __syncthreads();                         // lxf visible
+    commit(0);
+    wcur ^= 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    while (true) {
+        if (ch == 0) {
+#pragma unroll
+            for (int mt = 0; mt < R; ++mt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[mt][e] = lbias[4 * q4 + e];
+        }
+        int nbrick = brick, nch = ch + 1, nk = k;
+        if (nch == nchunks) { nch = 0; nk = k + 1; nbrick = brick_of(nk); }
+        const bool have_next = nbrick < nbricks;
+        const uint4* lwc = lw + wcur * WN + lane;
+        issue_prep(have_next ? nbrick : brick, nch, have_next);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int ta = g / 3, tc = g % 3;
+#pragma unroll
+            for (int j = pf_lo(g, NPA, NG); j < pf_lo(g + 1, NPA, NG); ++j) issue_piece(j);
+#pragma unroll
+            for (int j = pf_lo(g, NPW, NG); j < pf_lo(g + 1, NPW, NG); ++j) issue_wpiece(nch, have_next, j);
+            uint4 rows[R + 2];
+            const uint4* lap = lact + hvb + ta * HH * HW + tc;
+#pragma unroll
+            for (int j = 0; j < R + 2; ++j) rows[j] = lap[j * HW];
+#pragma unroll
+            for (int tb = 0; tb < 3; ++tb) {
+                const uint4 wf = lwc[((ta * 3 + tb) * 3 + tc) * 64];
+#pragma unroll
+                for (int mt = 0; mt < R; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, rows[mt + tb]), acc[mt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ch == nchunks - 1) {
+            // epilogue: lane = (voxel n16 of row mt, channels 4 q4 .. + 3): 8-byte stores, 16 voxels x 32 B contiguous per wave-store
+            const Org o = origin(brick);
+            const bool c_ok = 4 * q4 < a.Cout;
+            float rsc[4], rsh[4], rsl[4], t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (RED) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { rsc[e] = lrs[4 * q4 + e]; rsh[e] = lrs[16 + 4 * q4 + e]; rsl[e] = lrs[32 + 4 * q4 + e]; }
+            }
+#pragma unroll
+            for (int mt = 0; mt < R; ++mt) {
+                const int gd = o.d0 + ld_w, gh = o.h0 + lh_w + mt, gw = o.w0 + n16;
+                if (!(c_ok && gd < a.GD && gh < a.GH && gw < a.GW)) continue;
+                const size_t vox = ((size_t)(o.n * a.OD + gd) * a.OH + gh) * a.OW + gw;
+                Pack<T, 4> pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk.v[e] = (T)acc[mt][e];
+                uint2 piece = __builtin_bit_cast(uint2, pk);
+                uint2* dst = (uint2*)((T*)a.y + vox * a.ypitch + 4 * q4);
+                float f[4];
+                if (a.accumulate) {
+                    const uint2 old = *dst;
+                    f[0] = __uint_as_float(piece.x << 16) + __uint_as_float(old.x << 16);
+                    f[1] = __uint_as_float(piece.x & 0xffff0000u) + __uint_as_float(old.x & 0xffff0000u);
+                    f[2] = __uint_as_float(piece.y << 16) + __uint_as_float(old.y << 16);
+                    f[3] = __uint_as_float(piece.y & 0xffff0000u) + __uint_as_float(old.y & 0xffff0000u);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk.v[e] = (T)f[e];
+                    piece = __builtin_bit_cast(uint2, pk);
+                }
+                *dst = piece;
+                if (want_stats) {
+                    f[0] = __uint_as_float(piece.x << 16); f[1] = __uint_as_float(piece.x & 0xffff0000u);      // values as stored
+                    f[2] = __uint_as_float(piece.y << 16); f[3] = __uint_as_float(piece.y & 0xffff0000u);
+                    if constexpr (!RED) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { s1[e] += f[e]; s2[e] = fmaf(f[e], f[e], s2[e]); }
+                    } else {
+                        const uint2 yr = *(const uint2*)((const T*)a.red_y + vox * a.red_ypitch + 4 * q4);
+                        const float yv[4] = {__uint_as_float(yr.x << 16), __uint_as_float(yr.x & 0xffff0000u), __uint_as_float(yr.y << 16),
+                                             __uint_as_float(yr.y & 0xffff0000u)};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float tt = fmaf(rsc[e], yv[e], rsh[e]);
+                            const float dz = f[e] * (tt > 0.f ? 1.f : rsl[e]);
+                            t1[e] += dz;
+                            t2[e] = fmaf(dz, yv[e], t2[e]);
+                        }
+                    }
+                }
+            }
+            if constexpr (RED) {
+                if (want_stats) { reduce4(t1, t2); flush_stats(brick); }
+            }
+        }
+        if (!have_next) break;
+        __syncthreads();                     // everyone is done reading the tile
+        commit(nch);
+        wcur ^= 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // weight DMA landed
+        __syncthreads();
+        brick = nbrick; ch = nch; k = nk;
+    }
+    if constexpr (!RED) {
+        if (want_stats) { reduce4(s1, s2); flush_stats((int)blockIdx.x); }
+    }
+}
+
+// packed weights of the 16-channel variant: out[kstep32][tap][lane]; lane (n = l & 15, q = l >> 4) holds W[row n][k = 32 ks + 8 q + e]
+__global__ void k_pack_weights16(const float* __restrict__ w, int cin, int cout, int taps, int kind, int Kc, int Nc, uint4* __restrict__ out) {
+    using F = Frag<bf16_t>;
+    const int nKS = Kc / 32;
+    const size_t total = (size_t)nKS * taps * 64;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx % 64);
+        size_t t = idx / 64;
+        const int tap = (int)(t % taps);
+        const int ks = (int)(t / taps);
+        const int i = lane & 15;
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = ks * 32 + (lane >> 4) * 8 + e;
+            float v = 0.f;
+            if (i < Nc && k < Kc) {
+                if (kind == 0) v = w[((size_t)i * cin + k) * taps + tap];                 // W[co=i][ci=k][tap]
+                else v = w[((size_t)k * cin + i) * taps + (taps - 1 - tap)];              // W[co=k][ci=i][flipped tap]
+            }
+            f[e] = v;
+        }
+        out[idx] = F::pack(f);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // weight packing: out[ntile][kstep][tap][lane] (16 B each); lane (r, h) holds W[i = 32*ntile + r][k = KS*kstep + PE*h + e]
 // ---------------------------------------------------------------------------------------------------------------
@@ -716,13 +1052,26 @@ static inline i64 sample_bytes(const biu_act* t, size_t es) { return (i64)t->d *
 
 static bool chan_ok(int K, int Nn, int dtype) { return K >= 16 && K % ks_of(dtype) == 0 && Nn >= 16 && Nn % 8 == 0; }
 
+// 16-channel variant (k_conv16_pipe): eligible by channels alone, so the packed buffer carries its fragment image behind the regular one
+static bool m16_disabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("BIU_DISABLE"); v = (e && strstr(e, "m16")) ? 1 : 0; }
+    return v == 1;
+}
+static bool m16_chan_ok(int K, int Nn, int dtype) { return dtype == BIU_BF16 && Nn == 16 && K >= 32 && K % 32 == 0; }
+static size_t regular_packed_bytes(int K, int Nn, int taps, int dtype) {
+    const size_t ntiles = (Nn + 31) / 32, nKS = K / ks_of(dtype);
+    return ntiles * nKS * (size_t)taps * 1024;
+}
+
 size_t biu_mfma_packed_bytes(int kind, int cin, int cout, int kd, int kh, int kw, int dilation, int dtype) {
     if (dilation != 1 || kh != 3 || kw != 3 || (kd != 1 && kd != 3)) return 0;
     if (dtype != BIU_BF16 && dtype != BIU_F32) return 0;
     const int K = kind == 0 ? cin : cout, Nn = kind == 0 ? cout : cin;
     if (!chan_ok(K, Nn, dtype)) return 0;
-    const size_t ntiles = (Nn + 31) / 32, nKS = K / ks_of(dtype);
-    return ntiles * nKS * (size_t)(kd * 9) * 1024;
+    size_t b = regular_packed_bytes(K, Nn, kd * 9, dtype);
+    if (m16_chan_ok(K, Nn, dtype)) b += (size_t)(K / 32) * (kd * 9) * 1024;
+    return b;
 }
 
 int biu_mfma_pack(int kind, const float* w, int cin, int cout, int kd, int kh, int kw, int dtype, void* packed, hipStream_t st) {
@@ -732,6 +1081,12 @@ int biu_mfma_pack(int kind, const float* w, int cin, int cout, int kd, int kh, i
     BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_weights<T>, dim3(grid_for((i64)total, 256, 4096)), dim3(256), 0, st, w, cin,
                                                  cout, taps, kind, K, Nn, nKS, ntiles, (uint4*)packed));
     BIU_CHECK_LAUNCH("pack_weights");
+    if (m16_chan_ok(K, Nn, dtype)) {
+        const size_t total16 = (size_t)(K / 32) * taps * 64;
+        hipLaunchKernelGGL(k_pack_weights16, dim3(grid_for((i64)total16, 256, 4096)), dim3(256), 0, st, w, cin, cout, taps, kind, K, Nn,
+                           (uint4*)((char*)packed + regular_packed_bytes(K, Nn, taps, dtype)));
+        BIU_CHECK_LAUNCH("pack_weights16");
+    }
     return BIU_OK;
 }
 
@@ -857,23 +1212,70 @@ int biu_mfma_convt_dgrad_bricks(const biu_act* dx, int kd) {
     return dx->n * ((dx->d + td - 1) / td) * ((dx->h + th - 1) / th) * ((dx->w + tw - 1) / tw);
 }
 
-// number of bricks of a 3x3(x3) launch writing y (= BatchNorm-backward partial rows of the data-gradient kernels)
-int biu_mfma_conv_bricks(const biu_act* y, int kd) {
-    const int ntiles = (y->c + 31) / 32;
-    const BrickDim b = conv3_brick(kd, pick_nt(ntiles), y->w % 32 == 0);
+// the 16-channel kernel takes a launch when the channels fit, the tensors are plain (no concatenation) and it is not switched off
+static bool m16_ok(const biu_act* x, const biu_act* y, int dtype) {
+    return x && !m16_disabled() && m16_chan_ok(x->c, y->c, dtype);
+}
+static BrickDim m16_brick(int kd) { return kd == 3 ? BrickDim{4, 8, 16} : BrickDim{1, 32, 16}; }
+static int bricks_of(const biu_act* y, BrickDim b) {
     return y->n * ((y->d + b.td - 1) / b.td) * ((y->h + b.th - 1) / b.th) * ((y->w + b.tw - 1) / b.tw);
 }
+
+// number of bricks of a 3x3(x3) launch writing y (= BatchNorm-backward partial rows of the data-gradient kernels).  x (the tensor the
+// launch reads) and dtype select the kernel; without them the count is an upper bound over the kernels that could run (buffer sizing).
+int biu_mfma_conv_bricks(const biu_act* y, int kd, const biu_act* x, int dtype) {
+    const int ntiles = (y->c + 31) / 32;
+    const int reg = bricks_of(y, conv3_brick(kd, pick_nt(ntiles), y->w % 32 == 0));
+    if (x) return m16_ok(x, y, dtype) ? bricks_of(y, m16_brick(kd)) : reg;
+    const int m16 = (y->c == 16) ? bricks_of(y, m16_brick(kd)) : 0;
+    return reg > m16 ? reg : m16;
+}
 // number of workgroup columns of that launch (= BatchNorm statistics partial rows of the forward kernels: one per block);
-// must mirror launch_cfg_r's grid computation
-int biu_mfma_conv_stat_rows(const biu_act* y, int kd) {
+// must mirror launch_cfg_r's / launch_conv16's grid computation
+int biu_mfma_conv_stat_rows(const biu_act* y, int kd, const biu_act* x, int dtype) {
+    if (m16_ok(x, y, dtype)) {
+        int g = num_cus() & ~7;
+        if (g < 8) g = 8;
+        const int nbricks = bricks_of(y, m16_brick(kd));
+        return g > nbricks ? nbricks : g;
+    }
     const int ntiles = (y->c + 31) / 32;
     const int nt = pick_nt(ntiles);
     const bool nw4 = conv_nw4() && nt == 1;
     int g = (nw4 ? 2 : 1) * num_cus() / (ntiles / nt);
     g &= ~7;
     if (g < 8) g = 8;
-    const int nbricks = biu_mfma_conv_bricks(y, kd);
+    const int nbricks = biu_mfma_conv_bricks(y, kd, x ? x : y, x ? dtype : -1);
     return g > nbricks ? nbricks : g;
+}
+
+template <int KD, int TD, int TH>
+static int launch_conv16(ConvArgs a, hipStream_t st) {
+    constexpr int HV = (TD + KD - 1) * (TH + 2) * 18;
+    constexpr int PSV = (HV + 15) & ~15;
+    constexpr int WN = KD * 9 * 64;
+    const size_t lds_bytes = (size_t)(4 * PSV + 2 * WN) * 16 + (size_t)3 * a.Cin * sizeof(float) + (size_t)(8 * 16 * 2 + 16 + 48) * sizeof(float);
+    if (lds_bytes > (size_t)160 * 1024) return biu_fail(BIU_ERR_UNSUPPORTED, "conv16_pipe: %zu bytes of LDS (Cin=%d)", lds_bytes, a.Cin);
+    a.nbd = (a.GD + TD - 1) / TD;
+    a.nbh = (a.GH + TH - 1) / TH;
+    a.nbw = (a.GW + 15) / 16;
+    const int nbricks = a.N * a.nbd * a.nbh * a.nbw;
+    int g = num_cus() & ~7;
+    if (g < 8) g = 8;
+    if (g > nbricks) g = nbricks;
+    auto launch = [&](auto kern) -> int {
+        static size_t attr_set = 0;
+        if (attr_set < lds_bytes) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+                return biu_fail(BIU_ERR_LAUNCH, "conv16_pipe: cannot reserve %zu bytes of LDS", lds_bytes);
+            attr_set = lds_bytes;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(512), lds_bytes, st, a);
+        BIU_CHECK_LAUNCH("conv16_pipe");
+        return BIU_OK;
+    };
+    if (a.red_mode) return launch(k_conv16_pipe<KD, TD, TH, true>);
+    return launch(k_conv16_pipe<KD, TD, TH, false>);
 }
 
 static void clear_cat(ConvArgs& a) {
@@ -948,6 +1350,10 @@ int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, con
 #else
     a.diag = nullptr;
 #endif
+    if (!(cat && (cat->x1 || cat->y1)) && m16_ok(x, y, dtype)) {
+        a.wpk = (const uint4*)((const char*)packed + regular_packed_bytes(x->c, y->c, kd * 9, dtype));
+        return kd == 3 ? launch_conv16<3, 4, 8>(a, st) : launch_conv16<1, 1, 32>(a, st);
+    }
     if (dtype == BIU_BF16) return launch_conv<bf16_t>(a, kd, st);
     return launch_conv<float>(a, kd, st);
 }
@@ -1042,6 +1448,26 @@ __global__ void k_pack_batch(const biu_pack_job* __restrict__ jobs) {
             f[e] = v;
         }
         out[idx] = F::pack(f);
+    }
+    // the 16-channel kernel's fragment image follows the regular one (biu_mfma_packed_bytes / k_pack_weights16)
+    if constexpr (sizeof(T) == 2) {
+        if (!j.transposed && Nc == 16 && Kc >= 32 && Kc % 32 == 0) {
+            uint4* __restrict__ out16 = out + total;
+            const size_t total16 = (size_t)(Kc / 32) * taps * 64;
+            for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total16; idx += (size_t)gridDim.x * blockDim.x) {
+                const int lane = (int)(idx % 64);
+                const size_t t = idx / 64;
+                const int tap = (int)(t % taps), ks = (int)(t / taps);
+                const int i = lane & 15;
+                float f[PE];
+#pragma unroll
+                for (int e = 0; e < PE; ++e) {
+                    const int k = ks * 32 + (lane >> 4) * 8 + e;
+                    f[e] = kind == 0 ? w[((size_t)i * cin + k) * taps + tap] : w[((size_t)k * cin + i) * taps + (taps - 1 - tap)];
+                }
+                out16[idx] = F::pack(f);
+            }
+        }
     }
 }
 int biu_mfma_pack_batch(const biu_pack_job* jobs_device, int n, int dtype, hipStream_t st) {

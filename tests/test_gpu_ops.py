@@ -320,6 +320,10 @@ MFMA_CASES = [
     (2, 1, 64, 64, (24, 40)),
     (2, 1, 128, 128, (16, 16)),
     (2, 1, 32, 96, (20, 12)),
+    # 16 output channels (forward) / 16 input channels (data gradient): the 16x16x32 MFMA kernel on bf16
+    (3, 1, 64, 16, (5, 9, 20)),
+    (2, 1, 64, 16, (20, 28)),
+    (2, 2, 16, 64, (33, 17)),
 ]
 
 
@@ -863,3 +867,36 @@ def test_conv_cat_forms_match_concat_buffer(case, dtype):
     dyr2 = dab.get(squeeze2d=(nd == 2))                                              # the dy the kernel stored is what it multiplied
     (gw2,) = torch.autograd.grad(conv_ref(xa.detach(), wq, None, 1), wq, dyr2)
     torch.testing.assert_close(dwb.cpu(), gw2, **tl(gw2, 2.0))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pack_batch_equals_the_single_packers(dtype):
+    """biu_pack_batch (what a training step uses to refresh every packed weight in one launch) must write exactly the bytes of
+    biu_conv_pack / biu_convt_pack -- including the 16-channel kernel's fragment image that follows the regular one."""
+    from bio_image_unet_amd._lib import biu_pack_job
+    code = DT[dtype][1]
+    jobs = [(0, 0, 32, 16, 3), (0, 1, 16, 32, 3), (0, 0, 64, 16, 1), (0, 1, 16, 64, 1), (0, 0, 48, 32, 3), (0, 1, 32, 96, 1),
+            (1, 0, 32, 16, 2), (1, 1, 64, 32, 1)]                       # (transposed, kind, cin, cout, kd)
+    arr = (biu_pack_job * len(jobs))()
+    keep, single = [], []
+    for j, (tr, kind, cin, cout, kd) in zip(arr, jobs):
+        if tr:
+            w = rnd(cin, cout, *([2] * (3 if kd == 2 else 2)), seed=cin + cout).cuda()
+            nb = lib.biu_convt_packed_bytes(kind, cin, cout, kd, code)
+        else:
+            w = rnd(cout, cin, *([3] * (3 if kd == 3 else 2)), seed=cin + cout).cuda()
+            nb = lib.biu_conv_packed_bytes(kind, cin, cout, kd, 3, 3, 1, code)
+        assert nb > 0
+        a, b = torch.zeros(nb, dtype=torch.uint8, device="cuda"), torch.full((nb,), 0xAB, dtype=torch.uint8, device="cuda")
+        if tr:
+            check(lib.biu_convt_pack(kind, ptr(w), cin, cout, kd, code, ptr(a), stream()), "convt_pack")
+        else:
+            check(lib.biu_conv_pack(kind, ptr(w), cin, cout, kd, 3, 3, code, ptr(a), stream()), "conv_pack")
+        j.w, j.packed = w.data_ptr(), b.data_ptr()
+        j.transposed, j.kind, j.cin, j.cout, j.kd, j.kh, j.kw, j.reserved = tr, kind, cin, cout, kd, (2 if tr else 3), (2 if tr else 3), 0
+        keep.append(w); single.append((a, b))
+    tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+    check(lib.biu_pack_batch(ptr(tab), len(jobs), code, stream()), "pack_batch")
+    torch.cuda.synchronize()
+    for (a, b), job in zip(single, jobs):
+        assert torch.equal(a, b), f"batched packing differs from the single packer for job {job}"
