@@ -62,7 +62,9 @@ extern "C" int biu_conv_fwd_stats(const biu_act* x, const biu_xform* xf, const f
             return rc;
         }
     }
-    if (packed && !disabled("conv_fwd") && !disabled("fused_stats") && biu_mfma_conv_ok(x, y, kd, kh, kw, dilation, dtype)) {
+    // (a launch split over the input channels cannot take its statistics from the epilogue: plain conv, then biu_bn_stats)
+    if (packed && !disabled("conv_fwd") && !disabled("fused_stats") && biu_mfma_conv_ok(x, y, kd, kh, kw, dilation, dtype) &&
+        biu_mfma_conv_ksplit(x->c, y, kd, dtype) == 1) {
         const int nb = biu_mfma_conv_stat_rows(y, kd, x, dtype);           // one partial row per workgroup column
         if ((size_t)nb * y->c * 2 <= bn_partial_floats) {
             int rc = biu_mfma_conv(x, xf, packed, bias, kd, kh, kw, y, 0, bn_partial, dtype, (hipStream_t)stream);
@@ -124,7 +126,8 @@ extern "C" int biu_conv_bwd_data_bnred(const biu_act* dy, const float* w, const 
     BIU_REQUIRE(w && scale && shift && mean && invstd && partial && nblk, BIU_ERR_SHAPE, "conv_bwd_data_bnred: null pointer");
     const size_t es = dsize(dtype);
     const bool yok = ((uintptr_t)y_up->p % 16) == 0 && ((size_t)y_up->pitch * es) % 16 == 0;
-    if (packed && yok && !disabled("conv_dgrad") && !disabled("dgrad_bnred") && biu_mfma_conv_ok(dy, dx, kd, kh, kw, dilation, dtype)) {
+    if (packed && yok && !disabled("conv_dgrad") && !disabled("dgrad_bnred") && biu_mfma_conv_ok(dy, dx, kd, kh, kw, dilation, dtype) &&
+        biu_mfma_conv_ksplit(dy->c, dx, kd, dtype) == 1) {
         const int nb = biu_mfma_conv_bricks(dx, kd, dy, dtype);
         if ((size_t)nb * dx->c * 2 <= partial_floats) {
             BnRedFuse red{y_up, scale, shift, slope, mean, invstd};
@@ -248,6 +251,13 @@ extern "C" int biu_conv_fwd_cat(const biu_act* x0, const biu_xform* xf0, const b
     BIU_REQUIRE(biu_conv_cat_ok(x0, x1, y, kd, kh, kw, dilation, dtype) && w && packed, BIU_ERR_UNSUPPORTED,
                 "conv_fwd_cat: shapes not served by the two-source kernels (ask biu_conv_cat_ok)");
     ConvCat cat{x1, xf1, nullptr, 0};
+    if (bn_partial && biu_mfma_conv_ksplit(x0->c + x1->c, y, kd, dtype) > 1) {       // split launch: statistics in a pass of their own
+        BIU_REQUIRE(bn_nblk, BIU_ERR_SHAPE, "conv_fwd_cat: null bn_nblk");
+        int rc = biu_mfma_conv(x0, xf0, packed, bias, kd, kh, kw, y, 0, nullptr, dtype, (hipStream_t)stream, nullptr, &cat);
+        if (rc != BIU_OK) return rc;
+        BIU_REQUIRE(bn_partial_floats >= (size_t)BIU_BN_MAX_PARTIALS * y->c * 2, BIU_ERR_WORKSPACE, "conv_fwd_cat: partial buffer too small");
+        return biu_bn_stats(y, bn_partial, bn_nblk, dtype, stream);
+    }
     if (bn_partial) {
         BIU_REQUIRE(bn_nblk, BIU_ERR_SHAPE, "conv_fwd_cat: null bn_nblk");
         const int nb = biu_mfma_conv_stat_rows(y, kd);

@@ -92,6 +92,12 @@ struct ConvArgs {
     const float* xs1; const float* xb1; const float* xl1;
     char* y1; int ypitch1; int osplit; int accumulate1;
     const float* red_scale; const float* red_shift; const float* red_slope; const float* red_mean; const float* red_invstd;
+    // split over the input channels (fp32 only): blockIdx.z = split index takes the chunks [z, z+1) * nchunks / ksplit and writes its partial
+    // result (split 0 carries the bias) to slice z of a workspace laid out like y (y/y1 point at slice 0, slices y_zstride/y1_zstride bytes
+    // apart); k_split_reduce then sums the slices into the real output.  For launches whose bricks x channel tiles would fill only a few
+    // CUs (the 16 x 16 images of a U-Net bottleneck).
+    int ksplit;
+    size_t y_zstride, y1_zstride;
 };
 
 #ifdef BIU_DIAG
@@ -199,12 +205,15 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     const bool has_xf = a.xs != nullptr || a.xs1 != nullptr;
     const size_t esz = sizeof(T);
     const int nchunks = a.Cin / CK;
+    const int ksz = (a.ksplit > 1) ? (int)blockIdx.z : 0;
+    const int c_begin = (a.ksplit > 1) ? (ksz * nchunks) / a.ksplit : 0;
+    const int c_end = (a.ksplit > 1) ? ((ksz + 1) * nchunks) / a.ksplit : nchunks;
     const int nbricks = a.N * a.nbd * a.nbh * a.nbw;
     const int p_mine = tid % CKP;
 
     if (tid < NT * 32) {
         const int co = blockIdx.y * NT * 32 + tid;
-        lbias[tid] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+        lbias[tid] = (a.bias && co < a.Cout && (a.ksplit <= 1 || blockIdx.z == 0)) ? a.bias[co] : 0.f;
         if constexpr (RED) {
             const bool okc = co < a.Cout && a.red_scale != nullptr;
             lrs[tid] = okc ? a.red_scale[co] : 0.f;
@@ -442,16 +451,16 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     int k = 0;
     int brick = brick_of(0);
     if (brick >= nbricks) return;            // uniform per block
-    int ch = 0;
-    issue(brick, 0, true);
-    if constexpr (W1) issue_w(0, true);
+    int ch = c_begin;
+    issue(brick, c_begin, true);
+    if constexpr (W1) issue_w(c_begin, true);
     __syncthreads();                         // lxf visible
-    commit(0);
+    commit(c_begin);
     if constexpr (WGLDS) { if constexpr (W2) wcur ^= 1; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     __syncthreads();
 
     while (true) {
-        if (ch == 0) {
+        if (ch == c_begin) {
             // accumulators start at the bias (lane holds channels 8*qq + 4*hf + i of each 32-channel tile)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -464,7 +473,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
         }
         // next item
         int nbrick = brick, nch = ch + 1, nk = k;
-        if (nch == nchunks) { nch = 0; nk = k + 1; nbrick = brick_of(nk); }
+        if (nch == c_end) { nch = c_begin; nk = k + 1; nbrick = brick_of(nk); }
         const bool have_next = nbrick < nbricks;
         DIAG_STAMP(0);
         const uint4* lwc = lw + (W2 ? wcur * WN : 0) + lane;
@@ -548,7 +557,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
 
         DIAG_STAMP(2);
         // ---- brick finished: epilogue ----------------------------------------------------------------------------------
-        if (ch == nchunks - 1) {
+        if (ch == c_end - 1) {
             // No LDS staging: a lane holds, for ITS voxel, channel groups 8 g + 4 hf .. + 3 (g = 0..3) of each tile.  fp32: every
             // group is a 16-byte piece already.  bf16: a group is 8 bytes; v_permlane32_swap exchanges the upper half-wave's group
             // 2p with the lower one's group 2p+1, after which lanes 0-31 hold channels 16 p .. + 7 and lanes 32-63 channels
@@ -570,7 +579,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
             }
             // destination of this block's channel tile (the second tensor of a split output when the tile lies beyond osplit)
             const bool o1 = a.y1 && (int)(blockIdx.y * NT * 32) >= a.osplit;
-            char* ybase = o1 ? a.y1 : a.y;
+            char* ybase = (o1 ? a.y1 : a.y) + (a.ksplit > 1 ? (size_t)blockIdx.z * (o1 ? a.y1_zstride : a.y_zstride) : (size_t)0);
             const int ypitch_o = o1 ? a.ypitch1 : a.ypitch;
             const int coff = o1 ? a.osplit : 0;
             const int accum_o = o1 ? a.accumulate1 : a.accumulate;
@@ -1189,21 +1198,47 @@ static BrickDim conv3_brick(int kd, int nt, bool wide) {
     return wide ? BrickDim{1, 16, 32} : BrickDim{1, 32, 16};
 }
 
+// Input-channel split of a 3x3(x3) fp32 launch (ConvArgs::ksplit): when bricks x channel tiles fill under half of the CUs and every
+// split still has >= 4 chunks of 8 channels.  1 = no split.  BIU_DISABLE=ksplit switches it off.
+int biu_mfma_conv_ksplit(int cin, const biu_act* y, int kd, int dtype) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("BIU_DISABLE"); off = (e && strstr(e, "ksplit")) ? 1 : 0; }
+    if (off || dtype != BIU_F32 || (kd != 1 && kd != 3)) return 1;
+    const int ntiles = (y->c + 31) / 32, nt = pick_nt(ntiles);
+    const BrickDim b = conv3_brick(kd, nt, y->w % 32 == 0);
+    const long blocks = (long)y->n * ((y->d + b.td - 1) / b.td) * ((y->h + b.th - 1) / b.th) * ((y->w + b.tw - 1) / b.tw) * (ntiles / nt);
+    const int nchunks = cin / 8;
+    int ks = 1;
+    while (blocks * ks * 2 <= num_cus() && nchunks / (ks * 2) >= 4 && ks < 32) ks *= 2;
+    return ks;
+}
+// y[v][c] = (accumulate ? y[v][c] : 0) + sum_z ws[z][v][c]   (ws slices share y's pitch)
+__global__ void k_split_reduce(const float* __restrict__ ws, size_t zstride_f, int ks, float* __restrict__ y, long nvoxels, int c, int pitch, int accumulate) {
+    const long total = nvoxels * c;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const size_t o = (size_t)(i / c) * pitch + (size_t)(i % c);
+        float v = accumulate ? y[o] : 0.f;
+        for (int z = 0; z < ks; ++z) v += ws[z * zstride_f + o];
+        y[o] = v;
+    }
+}
+
 template <typename T>
 static int launch_conv(const ConvArgs& a, int kd, hipStream_t st) {
     const int ntiles = (a.Cout + 31) / 32;
     const int nt = pick_nt(ntiles);
     const bool wide = (a.GW % 32 == 0);
+    const int nz = a.ksplit > 1 ? a.ksplit : 1;
     if (kd == 3) {
         if (nt == 1 && conv_ck4() && !a.red_mode && a.Cin % 32 == 0 && (!a.x1 || a.csplit % 32 == 0))
-            return launch_cfg<T, 3, 3, 1, 4, 8, 16, 1, 4>(a, ntiles, 1, st);
-        if (nt == 1 && conv_nw4()) return launch_cfg<T, 3, 3, 1, 4, 8, 16, 1, 2, 4>(a, ntiles, 1, st);
-        if (nt == 1) return wide ? launch_cfg<T, 3, 3, 1, 4, 8, 32, 1, 2>(a, ntiles, 1, st) : launch_cfg<T, 3, 3, 1, 4, 16, 16, 1, 2>(a, ntiles, 1, st);
-        return launch_cfg<T, 3, 3, 1, 4, 8, 16, 2, 2>(a, ntiles, 1, st);
+            return launch_cfg<T, 3, 3, 1, 4, 8, 16, 1, 4>(a, ntiles, nz, st);
+        if (nt == 1 && conv_nw4()) return launch_cfg<T, 3, 3, 1, 4, 8, 16, 1, 2, 4>(a, ntiles, nz, st);
+        if (nt == 1) return wide ? launch_cfg<T, 3, 3, 1, 4, 8, 32, 1, 2>(a, ntiles, nz, st) : launch_cfg<T, 3, 3, 1, 4, 16, 16, 1, 2>(a, ntiles, nz, st);
+        return launch_cfg<T, 3, 3, 1, 4, 8, 16, 2, 2>(a, ntiles, nz, st);
     }
-    if (nt == 1 && conv_nw4()) return wide ? launch_cfg<T, 1, 3, 1, 1, 16, 32, 1, 2, 4>(a, ntiles, 1, st) : launch_cfg<T, 1, 3, 1, 1, 32, 16, 1, 2, 4>(a, ntiles, 1, st);
-    if (nt == 1) return wide ? launch_cfg<T, 1, 3, 1, 1, 32, 32, 1, 2>(a, ntiles, 1, st) : launch_cfg<T, 1, 3, 1, 1, 64, 16, 1, 2>(a, ntiles, 1, st);
-    return wide ? launch_cfg<T, 1, 3, 1, 1, 16, 32, 2, 2>(a, ntiles, 1, st) : launch_cfg<T, 1, 3, 1, 1, 32, 16, 2, 2>(a, ntiles, 1, st);
+    if (nt == 1 && conv_nw4()) return wide ? launch_cfg<T, 1, 3, 1, 1, 16, 32, 1, 2, 4>(a, ntiles, nz, st) : launch_cfg<T, 1, 3, 1, 1, 32, 16, 1, 2, 4>(a, ntiles, nz, st);
+    if (nt == 1) return wide ? launch_cfg<T, 1, 3, 1, 1, 32, 32, 1, 2>(a, ntiles, nz, st) : launch_cfg<T, 1, 3, 1, 1, 64, 16, 1, 2>(a, ntiles, nz, st);
+    return wide ? launch_cfg<T, 1, 3, 1, 1, 16, 32, 2, 2>(a, ntiles, nz, st) : launch_cfg<T, 1, 3, 1, 1, 32, 16, 2, 2>(a, ntiles, nz, st);
 }
 
 // number of bricks of a ConvTranspose data-gradient launch on the coarse tensor dx
@@ -1279,6 +1314,7 @@ static int launch_conv16(ConvArgs a, hipStream_t st) {
 }
 
 static void clear_cat(ConvArgs& a) {
+    a.ksplit = 1; a.y_zstride = a.y1_zstride = 0;
     a.x1 = nullptr; a.xpitch1 = 0; a.csplit = 0;
     a.xs1 = a.xb1 = a.xl1 = nullptr;
     a.y1 = nullptr; a.ypitch1 = 0; a.osplit = 0; a.accumulate1 = 0;
@@ -1350,6 +1386,50 @@ int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, con
 #else
     a.diag = nullptr;
 #endif
+    a.ksplit = 1;
+    a.y_zstride = a.y1_zstride = 0;
+    if (!bn_partial && !red) {
+        biu_act yall = *y;
+        yall.c = a.Cout;
+        const int ks = biu_mfma_conv_ksplit(a.Cin, &yall, kd, dtype);
+        if (ks > 1) {
+            // stream-ordered scratch for the partial results: slices laid out like y (and y1), summed into the outputs afterwards
+            const biu_act* y1t = (cat && cat->y1) ? cat->y1 : nullptr;
+            const size_t sl0 = (size_t)nvox(y) * y->pitch * sizeof(float), sl1 = y1t ? (size_t)nvox(y1t) * y1t->pitch * sizeof(float) : 0;
+            char* ws = nullptr;
+            static bool pool_kept = false;               // keep freed scratch in the device's default pool across synchronisations
+            if (!pool_kept) {
+                int dev = 0;
+                hipMemPool_t pool;
+                if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+                    uint64_t keep = UINT64_MAX;
+                    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+                }
+                (void)hipGetLastError();
+                pool_kept = true;
+            }
+            if (hipMallocAsync((void**)&ws, (size_t)ks * (sl0 + sl1), st) != hipSuccess) { (void)hipGetLastError(); ws = nullptr; }
+            if (ws) {
+                ConvArgs b = a;
+                b.ksplit = ks;
+                b.y = ws; b.y_zstride = sl0; b.accumulate = 0;
+                if (y1t) { b.y1 = ws + (size_t)ks * sl0; b.y1_zstride = sl1; b.accumulate1 = 0; }
+                rc = launch_conv<float>(b, kd, st);
+                if (rc == BIU_OK) {
+                    hipLaunchKernelGGL(k_split_reduce, dim3(grid_for((i64)nvox(y) * y->c, 256, 2048)), dim3(256), 0, st, (const float*)ws, sl0 / sizeof(float),
+                                       ks, (float*)y->p, (long)nvox(y), y->c, y->pitch, accumulate);
+                    if (y1t)
+                        hipLaunchKernelGGL(k_split_reduce, dim3(grid_for((i64)nvox(y1t) * y1t->c, 256, 2048)), dim3(256), 0, st,
+                                           (const float*)(ws + (size_t)ks * sl0), sl1 / sizeof(float), ks, (float*)y1t->p, (long)nvox(y1t), y1t->c,
+                                           y1t->pitch, cat->accumulate1);
+                }
+                (void)hipFreeAsync(ws, st);
+                if (rc != BIU_OK) return rc;
+                BIU_CHECK_LAUNCH("split_reduce");
+                return BIU_OK;
+            }
+        }
+    }
     if (!(cat && (cat->x1 || cat->y1)) && m16_ok(x, y, dtype)) {
         a.wpk = (const uint4*)((const char*)packed + regular_packed_bytes(x->c, y->c, kd * 9, dtype));
         return kd == 3 ? launch_conv16<3, 4, 8>(a, st) : launch_conv16<1, 1, 32>(a, st);
