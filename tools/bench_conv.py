@@ -31,6 +31,7 @@ def main():
     tdt, code = (torch.bfloat16, 1) if dt == "bf16" else (torch.float32, 0)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: C.c_void_p(t.data_ptr())
+    keep = []
     for name, nd, n, cin, cout, sp in LAYERS[cfg]:
         if only and only != name:
             continue
@@ -75,6 +76,22 @@ def main():
             "wg_bn": lambda: lib.biu_conv_bwd_weight_bn(C.byref(ax), C.byref(xf), C.byref(ady), C.byref(ay), P(kvec[0]), P(kvec[1]), P(kvec[2]),
                                                         P(kvec[3]), P(kvec[4]), P(kvec[5]), kd, 3, 3, 1, P(dw), P(ws), ws.numel(), code, st),
         }
+        # two-source forms (what the decoder's first conv runs): x = concat(x0 | x1) held in two dense tensors, split 2:1 like up(2F) | skip(F)
+        c0 = (2 * cin // 3) // 32 * 32
+        if cin % 96 == 0 and c0 > 0 and lib.biu_conv_cat_ok is not None:
+            x0 = x[..., :c0].contiguous()
+            x1 = x[..., c0:].contiguous()
+            ax0 = biu_act(x0.data_ptr(), n, d, h, w, c0, c0)
+            ax1 = biu_act(x1.data_ptr(), n, d, h, w, cin - c0, cin - c0)
+            xs0 = biu_xform(xs.data_ptr(), xb.data_ptr(), xl.data_ptr())
+            xs1 = biu_xform(xs[c0:].data_ptr(), xb[c0:].data_ptr(), xl[c0:].data_ptr())
+            if lib.biu_conv_cat_ok(C.byref(ax0), C.byref(ax1), C.byref(ay), kd, 3, 3, 1, code):
+                keep.extend([x0, x1])
+                calls["fwd_cat"] = lambda: lib.biu_conv_fwd_cat(C.byref(ax0), C.byref(xs0), C.byref(ax1), C.byref(xs1), P(wt), P(pk0), P(bias), kd, 3, 3, 1,
+                                                                 C.byref(ay), P(stat), stat.numel(), C.byref(nblk), code, st)
+                calls["wg_cat"] = lambda: lib.biu_conv_bwd_weight_cat(C.byref(ax0), C.byref(xs0), C.byref(ax1), C.byref(xs1), C.byref(ady), C.byref(ay),
+                                                                      P(kvec[0]), P(kvec[1]), P(kvec[2]), P(kvec[3]), P(kvec[4]), P(kvec[5]), kd, 3, 3, 1,
+                                                                      P(dw), P(ws), ws.numel(), code, st)
         legs = os.environ.get("BENCH_LEGS")
         if legs:
             calls = {k: v for k, v in calls.items() if k in legs.split(",")}
