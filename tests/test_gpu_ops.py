@@ -900,3 +900,46 @@ def test_pack_batch_equals_the_single_packers(dtype):
     torch.cuda.synchronize()
     for (a, b), job in zip(single, jobs):
         assert torch.equal(a, b), f"batched packing differs from the single packer for job {job}"
+
+
+@pytest.mark.parametrize("path", ["bn_stats", "conv_fwd_stats"])
+def test_batchnorm_statistics_with_a_large_offset(path):
+    """|mean| >> std: the variance comes from (sum y, sum y^2) partials (fp32 per block, merged in fp64), i.e. E[y^2] - mean^2 with
+    cancellation.  At mean = 60, std = 1 (offset^2 / var = 3600) the batch variance must still be within 1 % and the mean within 1e-5
+    relative -- through the separate statistics pass and through the conv epilogue's fused statistics (where a large conv bias is
+    what produces such an offset)."""
+    n, c, d, h, w = 2, 32, 8, 16, 32
+    nvox = n * d * h * w
+    rm_d, rv_d = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    g_d, b_d = torch.ones(c, device="cuda"), torch.zeros(c, device="cuda")
+    scale, shift, mean, invstd = (torch.empty(c, device="cuda") for _ in range(4))
+    nblk = C.c_int(0)
+    if path == "bn_stats":
+        y = rnd(n, c, d, h, w, seed=1) + 60.0
+        yd = Dev(y, dtype="f32")
+        partial = torch.empty(1024 * c * 2, device="cuda")
+        check(lib.biu_bn_stats(yd.a(), ptr(partial), C.byref(nblk), 0, stream()), "bn_stats")
+        yref = yd.ref()
+    else:
+        cin = 16
+        x = rnd(n, cin, d, h, w, seed=2)
+        wt = rnd(c, cin, 3, 3, 3, seed=3) * (1.0 / (cin * 27) ** 0.5)
+        bias = torch.full((c,), 60.0)
+        xd, yd = Dev(x, dtype="f32"), Dev(shape=(n, c, d, h, w), dtype="f32")
+        wd, bd = wt.cuda(), bias.cuda()
+        nbytes = lib.biu_conv_packed_bytes(0, cin, c, 3, 3, 3, 1, 0)
+        pk = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        check(lib.biu_conv_pack(0, ptr(wd), cin, c, 3, 3, 3, 0, ptr(pk), stream()), "conv_pack")
+        nfl = lib.biu_conv_fwd_stats_floats(yd.a(), 3)
+        partial = torch.empty(nfl, device="cuda")
+        check(lib.biu_conv_fwd_stats(xd.a(), None, ptr(wd), ptr(pk), ptr(bd), 3, 3, 3, 1, yd.a(), ptr(partial), nfl, C.byref(nblk), 0, stream()),
+              "conv_fwd_stats")
+        yref = yd.get()
+    check(lib.biu_bn_finalize(ptr(partial), nblk.value, c, float(nvox), ptr(g_d), ptr(b_d), ptr(rm_d), ptr(rv_d), 0.1, 1e-5,
+                              ptr(scale), ptr(shift), ptr(mean), ptr(invstd), stream()), "bn_finalize")
+    y64 = yref.double()
+    m_ref = y64.mean(dim=(0, 2, 3, 4))
+    v_ref = y64.var(dim=(0, 2, 3, 4), unbiased=False)
+    torch.testing.assert_close(mean.cpu().double(), m_ref, rtol=1e-5, atol=0)
+    var = 1.0 / invstd.cpu().double() ** 2 - 1e-5
+    torch.testing.assert_close(var, v_ref, rtol=1e-2, atol=0)
