@@ -51,18 +51,18 @@ __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
 }
 __device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
 
-template <int KD> struct Geo {
-    static constexpr int TD = (KD == 3) ? 2 : 1, TH = (KD == 3) ? 8 : 16, TW = 32;
-    static constexpr int BV = TD * TH * TW;                      // 512 voxels per brick
+template <int KD, int HALF = 0> struct Geo {                      // HALF: 256-voxel bricks (the weight gradient runs three 256-thread blocks per CU)
+    static constexpr int TD = (KD == 3) ? (HALF ? 1 : 2) : 1, TH = (KD == 3) ? 8 : (HALF ? 8 : 16), TW = 32;
+    static constexpr int BV = TD * TH * TW;                      // 512 (256) voxels per brick
     static constexpr int HD = TD + KD - 1, HH = TH + 2, HW = TW + 2;
     static constexpr int HV = HD * HH * HW;
     static constexpr int TAPS = KD * 9;
 };
 
 // halo tile of T(x) (zero outside the volume) -> lx ; then the im2col image xp[v][32] (taps beyond TAPS are zero)
-template <int KD, int NTHR>
+template <int KD, int NTHR, int HALF = 0>
 __device__ __forceinline__ void stage_xp(const C1Args& a, int n, int d0, int h0, int w0, unsigned short* lx, char* lxp) {
-    using G = Geo<KD>;
+    using G = Geo<KD, HALF>;
     const int tid = threadIdx.x;
     const bool has_xf = a.xs != nullptr;
     const float xs = has_xf ? a.xs[0] : 1.f, xb = has_xf ? a.xb[0] : 0.f, xl = has_xf ? a.xl[0] : 1.f;
@@ -200,9 +200,12 @@ __global__ __launch_bounds__(256) void k_c1_fwd_mfma(C1Args a) {
 // ---------------------------------------------------------------------------------------------------------------------
 // weight gradient (optionally with the BatchNorm + LeakyReLU backward of the block's own output fused into the dy staging)
 // ---------------------------------------------------------------------------------------------------------------------
+// A streaming kernel (4 MFMAs per wave and brick): three 256-thread blocks per CU keep other bricks' loads in flight while one block
+// stages or multiplies.
 template <int KD>
-__global__ __launch_bounds__(512) void k_c1_wgrad_mfma(C1Args a) {
-    using G = Geo<KD>;
+__global__ __launch_bounds__(256, 3) void k_c1_wgrad_mfma(C1Args a) {
+    using G = Geo<KD, 1>;
+    constexpr int NTHR = 256, NWV = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lxp = smem;                                            // [BV][ROWB]  xp[v][tap]
     char* ldy = smem + G::BV * ROWB;                             // [BV][ROWB]  dy[v][co] (32 columns, zero beyond cout)
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(512) void k_c1_wgrad_mfma(C1Args a) {
     const bool fused = a.yraw != nullptr;
     const int ppv = a.cout / 8;                                  // 16-byte pieces per voxel (2 or 4)
     // this thread's channel piece is the same for every piece it stages: hoist the BatchNorm-backward vectors
-    const int mypiece = tid % 4;                                 // (i = tid + 512 k in the staging loop: i % 4 is constant)
+    const int mypiece = tid % 4;                                 // (i = tid + NTHR k in the staging loop: i % 4 is constant)
     float ks[8], kh[8], kl[8], ka[8], kb[8], kc[8];
     if (fused && mypiece < ppv) {
 #pragma unroll
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(512) void k_c1_wgrad_mfma(C1Args a) {
             ka[e] = a.bn_cA[c]; kb[e] = a.bn_cB[c]; kc[e] = a.bn_cC[c];
         }
     }
-    for (int i = tid; i < 32 * 32; i += 512) lacc[i] = 0.f;
+    for (int i = tid; i < 32 * 32; i += NTHR) lacc[i] = 0.f;
     floatx16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(512) void k_c1_wgrad_mfma(C1Args a) {
         const int d0 = (b % a.nbd) * G::TD;
         const int n = b / a.nbd;
         // dy tile (+ fused BatchNorm backward, + write-back), zero rows for voxels outside the volume
-        for (int i = tid; i < G::BV * 4; i += 512) {
+        for (int i = tid; i < G::BV * 4; i += NTHR) {
             const int v = i / 4, pc = i % 4;
             uint4 out = make_uint4(0, 0, 0, 0);
             if (pc < ppv) {
@@ -263,9 +266,9 @@ __global__ __launch_bounds__(512) void k_c1_wgrad_mfma(C1Args a) {
             }
             *(uint4*)(ldy + v * ROWB + pc * 16) = out;
         }
-        stage_xp<KD, 512>(a, n, d0, h0, w0, lx, lxp);             // (its barriers also publish the dy tile)
+        stage_xp<KD, NTHR, 1>(a, n, d0, h0, w0, lx, lxp);             // (its barriers also publish the dy tile)
         typedef bf16x4 __attribute__((address_space(3))) * lp;
-        for (int ksx = wave; ksx < G::BV / 16; ksx += 8) {
+        for (int ksx = wave; ksx < G::BV / 16; ksx += NWV) {
             const char* ap = lxp + ksx * 16 * ROWB + tr_lane;
             const char* bp = ldy + ksx * 16 * ROWB + tr_lane;
             const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap));
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(512) void k_c1_wgrad_mfma(C1Args a) {
         for (int e = 0; e < 16; ++e) atomicAdd(&lacc[((e & 3) + 8 * (e >> 2) + 4 * hf) * 32 + j], acc[e]);
     }
     __syncthreads();
-    for (int i = tid; i < G::TAPS * a.cout; i += 512) {
+    for (int i = tid; i < G::TAPS * a.cout; i += NTHR) {
         const int tap = i / a.cout, co = i % a.cout;
         a.partial[(size_t)blockIdx.x * (G::TAPS * a.cout) + i] = lacc[tap * 32 + co];
     }
@@ -316,8 +319,8 @@ int cus() {
     return n;
 }
 
-template <int KD> void bricks_of(C1Args& a) {
-    using G = Geo<KD>;
+template <int KD, int HALF = 0> void bricks_of(C1Args& a) {
+    using G = Geo<KD, HALF>;
     a.nbd = (a.D + G::TD - 1) / G::TD; a.nbh = (a.H + G::TH - 1) / G::TH; a.nbw = (a.W + G::TW - 1) / G::TW;
     a.nbricks = a.N * a.nbd * a.nbh * a.nbw;
 }
@@ -366,7 +369,7 @@ int biu_c1m_fwd(const biu_act* x, const biu_xform* xf, const float* w, const flo
     return BIU_OK;
 }
 
-size_t biu_c1m_wgrad_workspace(int cout, int kd) { return (size_t)cus() * kd * 9 * 32 * sizeof(float); }
+size_t biu_c1m_wgrad_workspace(int cout, int kd) { return (size_t)3 * cus() * kd * 9 * 32 * sizeof(float); }
 
 int biu_c1m_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* da, const BnBwdFuse* bn, int kd, float* dw, void* ws, size_t ws_bytes,
                   hipStream_t st) {
@@ -383,23 +386,16 @@ int biu_c1m_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* da, cons
         a.bn_scale = bn->scale; a.bn_shift = bn->shift; a.bn_slope = bn->slope; a.bn_cA = bn->cA; a.bn_cB = bn->cB; a.bn_cC = bn->cC;
     }
     const int taps = kd * 9;
-    if (kd == 3) bricks_of<3>(a); else bricks_of<1>(a);
-    int grid = cus();
+    if (kd == 3) bricks_of<3, 1>(a); else bricks_of<1, 1>(a);
+    int grid = 3 * cus();
     if (grid > a.nbricks) grid = a.nbricks;
-    const size_t hv = kd == 3 ? (size_t)Geo<3>::HV : (size_t)Geo<1>::HV;
-    const size_t lds = (size_t)2 * 512 * ROWB + ((hv * 2 + 15) & ~(size_t)15) + 32 * 32 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_c1_wgrad_mfma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_c1_wgrad_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) != hipSuccess)
-            return biu_fail(BIU_ERR_LAUNCH, "c1_wgrad_mfma: cannot reserve LDS");
-        attr_set = true;
-    }
+    const size_t hv = kd == 3 ? (size_t)Geo<3, 1>::HV : (size_t)Geo<1, 1>::HV;
+    const size_t lds = (size_t)2 * 256 * ROWB + ((hv * 2 + 15) & ~(size_t)15) + 32 * 32 * sizeof(float);
     for (int co0 = 0; co0 < da->c;) {
         const int chunk = (da->c - co0) >= 32 ? 32 : 16;
         a.co0 = co0; a.cout = chunk;
-        if (kd == 3) hipLaunchKernelGGL(k_c1_wgrad_mfma<3>, dim3(grid), dim3(512), lds, st, a);
-        else hipLaunchKernelGGL(k_c1_wgrad_mfma<1>, dim3(grid), dim3(512), lds, st, a);
+        if (kd == 3) hipLaunchKernelGGL(k_c1_wgrad_mfma<3>, dim3(grid), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL(k_c1_wgrad_mfma<1>, dim3(grid), dim3(256), lds, st, a);
         BIU_CHECK_LAUNCH("c1_wgrad_mfma");
         hipLaunchKernelGGL(k_c1m_finalize, dim3(taps * chunk), dim3(256), 0, st, (const float*)ws, grid, taps, chunk, co0, dw);
         BIU_CHECK_LAUNCH("c1_wgrad_mfma_finalize");
