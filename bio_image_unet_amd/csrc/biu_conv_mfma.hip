@@ -1823,6 +1823,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     // w / KSPLIT + WPQ * t, t < IPW -- every wave runs the same branch-free loop over ITS k-groups with IPW MFMAs per A
     // fragment; a tap index past the last one multiplies into an accumulator nobody flushes.
     const int wq = wave % KSPLIT, wtap0 = wave / KSPLIT;
+    const bool last_tap_live = (wtap0 + WPQ * (IPW - 1)) < TAPS;      // wave-uniform (wave comes from readfirstlane)
     int tapoff[IPW];
 #pragma unroll
     for (int t = 0; t < IPW; ++t) {
@@ -2025,7 +2026,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
             WSTAMP(0);
             using FragR = typename std::conditional<sizeof(T) == 2, bf16x8, float>::type;
             FragR fa[2][NI], fb[2][IPW];
-            auto load_frags = [&](int kg, FragR (&af)[NI], FragR (&bfr)[IPW]) {
+            auto load_frags = [&](auto ntap_c, int kg, FragR (&af)[NI], FragR (&bfr)[IPW]) {
+                constexpr int NTAP = decltype(ntap_c)::value;
                 const int q0 = kg * KUNIT;
                 const int lw0 = q0 % TW;
                 const int t = q0 / TW;
@@ -2042,7 +2044,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                         af[ni] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
                     }
 #pragma unroll
-                    for (int t2 = 0; t2 < IPW; ++t2) {
+                    for (int t2 = 0; t2 < NTAP; ++t2) {
                         const char* bp = bt + hbase + tapoff[t2] + b_lane;
                         bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp));
                         bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp + 4 * S * RS));
@@ -2052,11 +2054,13 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) af[ni] = *(const float*)(at + q0 * RSA + a_lane + ni * CT * 4);
 #pragma unroll
-                    for (int t2 = 0; t2 < IPW; ++t2) bfr[t2] = *(const float*)(bt + hbase + tapoff[t2] + b_lane);
+                    for (int t2 = 0; t2 < NTAP; ++t2) bfr[t2] = *(const float*)(bt + hbase + tapoff[t2] + b_lane);
                 }
             };
-            load_frags(wq * KPW, fa[0], fb[0]);
             issue_prep(have_next ? nbrick : brick, have_next);
+            auto mfma_phase = [&](auto ntap_c) {
+            constexpr int NTAP = decltype(ntap_c)::value;
+            load_frags(ntap_c, wq * KPW, fa[0], fb[0]);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 if constexpr (BIU_PRIO_ALT) { if (((g & 1) ^ ((wave >> 2) & 1)) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }     // see k_conv_pipe
@@ -2066,14 +2070,15 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                 for (int j = pf_lo(g, NB, NG); j < pf_lo(g + 1, NB, NG); ++j) issue_b(j);
                 // Fragment reads run one k-group ahead of the MFMAs, in a second register set (the loops are fully unrolled, so the
                 // set is picked at compile time): left to itself the compiler re-used one register quad for every B fragment and
-                // put an lgkmcnt(0) in front of each MFMA, i.e. the full LDS latency per MFMA.  Every wave multiplies all IPW tap
-                // slots -- a slot past the last tap lands in an accumulator nobody flushes -- so the loop body has no branch.
+                // put an lgkmcnt(0) in front of each MFMA, i.e. the full LDS latency per MFMA.  The loop body has no branch: the
+                // whole phase exists twice, for waves whose last tap slot holds a tap and for those where it does not (27 taps
+                // on 8 x 4 slots leave 5 empty: their reads and MFMAs are energy the power-limited kernel does not have).
 #pragma unroll
                 for (int kk = 0; kk < KPG; ++kk) {
                     const int idx = g * KPG + kk;
-                    if (idx + 1 < KPW) load_frags(wq * KPW + idx + 1, fa[(idx + 1) & 1], fb[(idx + 1) & 1]);
+                    if (idx + 1 < KPW) load_frags(ntap_c, wq * KPW + idx + 1, fa[(idx + 1) & 1], fb[(idx + 1) & 1]);
 #pragma unroll
-                    for (int t2 = 0; t2 < IPW; ++t2)
+                    for (int t2 = 0; t2 < NTAP; ++t2)
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni) {
                             if constexpr (sizeof(T) == 2) acc[t2][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[idx & 1][ni], fb[idx & 1][t2], acc[t2][ni], 0, 0, 0);
@@ -2081,6 +2086,15 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                         }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            };
+            // (a second copy of the phase only where it removes >= 1/8 of the slots: 27 taps on 32; the 2-D kernels' 9 on 10 stay branch-free)
+            constexpr bool TWO_PHASES = IPW > 1 && (IPW * WPQ - TAPS) * 8 >= IPW * WPQ;
+            if constexpr (TWO_PHASES) {
+                if (!last_tap_live) mfma_phase(std::integral_constant<int, (IPW > 1 ? IPW - 1 : 1)>{});
+                else mfma_phase(std::integral_constant<int, IPW>{});
+            } else {
+                mfma_phase(std::integral_constant<int, IPW>{});
             }
             if constexpr (BIU_PRIO_ALT) __builtin_amdgcn_s_setprio(0);
             WSTAMP(1);
