@@ -153,6 +153,9 @@ constexpr int pf_lo(int g, int n, int ng) {
     const int span = (ng + BIU_PF_SPAN - 1) / BIU_PF_SPAN;
     return g >= span ? n : (g * n) / span;
 }
+#ifndef BIU_WGRAD_RR
+#define BIU_WGRAD_RR 1
+#endif
 #ifndef BIU_PRIO_ALT
 #define BIU_PRIO_ALT 0      // measured 1-3 % slower on cfg4 (profiles/r02_experiments.md); kept as a build switch
 #endif
@@ -1824,10 +1827,19 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     // fragment; a tap index past the last one multiplies into an accumulator nobody flushes.
     const int wq = wave % KSPLIT, wtap0 = wave / KSPLIT;
     const bool last_tap_live = (wtap0 + WPQ * (IPW - 1)) < TAPS;      // wave-uniform (wave comes from readfirstlane)
-    int tapoff[IPW];
+    // Row-reuse variant (RR; 3x3x3, bf16, bricks of 16-voxel rows): wave w < 8 owns the three kh taps of ONE (kd, kw) pair -- pair
+    // w / 3, w % 3 -- so the B fragment of (row r, kh tap b) is the fragment of (row r + 1, tap b - 1): walking the rows of a
+    // plane it reads ONE new fragment per row instead of three.  The ninth pair (2, 2) has no wave of its own: its three taps are
+    // the fourth slot of waves 0, 1, 2 (read per row like before).  2 + 2 (+ 2) transposed reads per row instead of 2 + 6 (+ 2):
+    // the weight gradient's MFMAs are fed from LDS with little reuse, and LDS traffic is energy the power-limited kernel pays for.
+    constexpr bool RR = BIU_WGRAD_RR && sizeof(T) == 2 && KD == 3 && KHW == 3 && S == 1 && KSPLIT == 1 && NI == 1 && TW == 16 && IPW == 4 && WPQ == 8;
+    int tapoff[IPW], tapid[IPW];
 #pragma unroll
     for (int t = 0; t < IPW; ++t) {
-        const int tap = (wtap0 + WPQ * t) % TAPS;
+        int tap = wtap0 + WPQ * t;
+        if constexpr (RR) tap = (t < 3) ? ((wave / 3) * 3 + t) * 3 + (wave % 3) : (wave < 3 ? (2 * 3 + wave) * 3 + 2 : TAPS);
+        tapid[t] = tap;
+        tap %= TAPS;
         const int ta = tap / (KHW * KHW), tb = (tap / KHW) % KHW, tc = tap % KHW;
         tapoff[t] = ((ta * HH + tb) * HW + tc) * RS;
     }
@@ -2088,9 +2100,57 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             };
+            // row-reuse phase (RR): rows r = 0 .. TD*TH-1 of the brick in order, fragment ring of 4 halo rows, A / extra-tap
+            // fragments and the ring's new row read one row ahead; a plane's first three rows are read after the previous row's MFMAs
+            auto rr_phase = [&](auto has_x_c) {
+                constexpr bool HAS_X = decltype(has_x_c)::value;
+                constexpr int NROW = TD * TH;
+                static_assert(!RR || NROW == KPW, "one k-group per 16-voxel row");
+                typedef bf16x4 __attribute__((address_space(3))) * lp;
+                auto rd = [&](const char* p_, int step) -> bf16x8 {
+                    const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p_));
+                    const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p_ + 4 * step));
+                    return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                };
+                const char* bbase = bt + tapoff[0] + b_lane;          // tap (kd, kh = 0, kw) of this wave's pair
+                const char* xbase = bt + tapoff[IPW - 1] + b_lane;    // the extra tap (waves 0-2)
+                const char* abase = at + a_lane;
+                bf16x8 ring[4], fxx[2], faa[2];
+                faa[0] = rd(abase, RSA);
+                if constexpr (HAS_X) fxx[0] = rd(xbase, RS);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) ring[j] = rd(bbase + j * HW * RS, RS);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                    for (int j = pf_lo(g, NA, NG); j < pf_lo(g + 1, NA, NG); ++j) issue_a(j);
+#pragma unroll
+                    for (int j = pf_lo(g, NB, NG); j < pf_lo(g + 1, NB, NG); ++j) issue_b(j);
+#pragma unroll
+                    for (int kk = 0; kk < KPG; ++kk) {
+                        const int r = g * KPG + kk, lh = r % TH;
+                        const int r1 = r + 1, ld1 = r1 / TH, lh1 = r1 % TH;
+                        if (r1 < NROW) {
+                            faa[r1 & 1] = rd(abase + r1 * 16 * RSA, RSA);
+                            if constexpr (HAS_X) fxx[r1 & 1] = rd(xbase + ((ld1 * HH + lh1) * HW) * RS, RS);
+                            if (lh1 != 0) ring[(lh1 + 2) & 3] = rd(bbase + ((ld1 * HH + lh1 + 2) * HW) * RS, RS);
+                        }
+#pragma unroll
+                        for (int tb = 0; tb < 3; ++tb) acc[tb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faa[r & 1], ring[(lh + tb) & 3], acc[tb][0], 0, 0, 0);
+                        if constexpr (HAS_X) acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faa[r & 1], fxx[r & 1], acc[3][0], 0, 0, 0);
+                        if (r1 < NROW && lh1 == 0) {
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) ring[j] = rd(bbase + ((ld1 * HH + j) * HW) * RS, RS);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
             // (a second copy of the phase only where it removes >= 1/8 of the slots: 27 taps on 32; the 2-D kernels' 9 on 10 stay branch-free)
             constexpr bool TWO_PHASES = IPW > 1 && (IPW * WPQ - TAPS) * 8 >= IPW * WPQ;
-            if constexpr (TWO_PHASES) {
+            if constexpr (RR) {
+                if (wave < 3) rr_phase(std::true_type{}); else rr_phase(std::false_type{});
+            } else if constexpr (TWO_PHASES) {
                 if (!last_tap_live) mfma_phase(std::integral_constant<int, (IPW > 1 ? IPW - 1 : 1)>{});
                 else mfma_phase(std::integral_constant<int, IPW>{});
             } else {
@@ -2124,7 +2184,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     if (jj < a.CB) {
 #pragma unroll
         for (int t2 = 0; t2 < IPW; ++t2) {
-            const int tap = wtap0 + WPQ * t2;
+            const int tap = tapid[t2];
             if (tap < TAPS) {
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
