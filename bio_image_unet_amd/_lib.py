@@ -8,6 +8,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- FIRST: the library must bind to the HIP runtime torch ships (loaded before torch, /opt/rocm's copy comes in as a
+#                 second runtime and every call of ours then fails with 'no ROCm-capable device is detected')
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BIU_LIB_PATH") or os.path.join(_HERE, "libbiu_hip.so")     # override: A/B builds of tools/build_variant.sh
 
