@@ -1710,6 +1710,9 @@ struct WgradArgs {
     int ypitch;
     const float* bn_scale; const float* bn_shift; const float* bn_slope;
     const float* bn_cA; const float* bn_cB; const float* bn_cC;
+    // ConvTranspose launches (S == 2: the tapped tile holds every fine voxel of the brick exactly once): per-channel sums of the tapped
+    // operand (= d bias), accumulated while its pieces are committed to LDS, by the blocks of the first plain-operand tile; zeroed by the host
+    float* dbias_out;
 };
 
 template <typename T, int PE>
@@ -1856,6 +1859,11 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
 
     uint4 pa[NA], pb[NB], pyv[NA];
     unsigned amask = 0, bmask = 0;
+    constexpr bool DBIAS = (S == 2);                                // ConvTranspose weight gradient: d bias rides in the B-tile commit
+    const bool dbias_on = DBIAS && a.dbias_out != nullptr && it == 0 && bpiece_ok;
+    float bsum[DBIAS ? PE : 1];
+#pragma unroll
+    for (int e = 0; e < (DBIAS ? PE : 1); ++e) bsum[e] = 0.f;
     // Per-thread piece coordinates, packed in 10-bit fields (d | h << 10 | w << 20); 511 marks a piece this thread does
     // not have.  Per brick: a guard-bit range test, two 24-bit multiply-adds for the offset, one buffer load whose
     // descriptor range check returns zeros for the pieces outside the volume (same scheme as k_conv_pipe).
@@ -1998,6 +2006,14 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
             const int i = tid + NTHR * j;
             if (i < HV * PPV) {
                 uint4 v = pb[j];
+                if constexpr (DBIAS) {
+                    if (dbias_on && ((bmask >> j) & 1u)) {
+                        float f[PE];
+                        F::unpack(v, f);
+#pragma unroll
+                        for (int e = 0; e < PE; ++e) bsum[e] += f[e];
+                    }
+                }
                 if (b_xf && ((bmask >> j) & 1u)) v = apply_xf16<T, PE>(v, sc, sh, sl);
                 ((uint4*)bt)[i] = v;
             }
@@ -2178,6 +2194,20 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         }
     }
 
+    if constexpr (DBIAS) {
+        if (a.dbias_out != nullptr && it == 0) {                     // block-uniform
+            __syncthreads();                                        // every wave is done with the tiles: bt's first floats become the sum
+            float* lsum = (float*)bt;
+            if (tid < CT) lsum[tid] = 0.f;
+            __syncthreads();
+            if (dbias_on) {
+#pragma unroll
+                for (int e = 0; e < PE; ++e) atomicAdd(&lsum[piece * PE + e], bsum[e]);
+            }
+            __syncthreads();
+            if (tid < CT && jt * CT + tid < a.CB) atomicAdd(a.dbias_out + jt * CT + tid, lsum[tid]);
+        }
+    }
     // ---- flush once per block ------------------------------------------------------------------------------------------
     const int jj = jt * CT + (lane & 31);
     const int hf = lane >> 5;
@@ -2318,6 +2348,7 @@ int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int
     }
     a.pa = (const char*)dy->p;  a.apitch = dy->pitch;  a.CA = dy->c;      // plain operand: dy  (rows i = co)
     a.pb = (const char*)x->p;   a.bpitch = x->pitch;   a.CB = x->c;       // tapped operand: x (cols j = ci)
+    a.dbias_out = nullptr;
     a.pb1 = nullptr; a.bpitch1 = 0; a.bsplit = 0; a.bs1_ = a.bb1_ = a.bl1_ = nullptr;
     if (x1) {                                                              // x = concat(x, x1)
         a.pb1 = (const char*)x1->p; a.bpitch1 = x1->pitch; a.bsplit = x->c; a.CB = x->c + x1->c;
@@ -2363,6 +2394,8 @@ int biu_mfma_convt_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* d
     const size_t need = wgrad_acc_bytes(a.CA, a.CB, taps);
     BIU_REQUIRE(ws_bytes >= need + (dbias ? biu_chan_sum_workspace(dy->c) : 0), BIU_ERR_WORKSPACE, "convt_wgrad_mfma: workspace %zu too small", ws_bytes);
     if (hipMemsetAsync(ws, 0, need, st) != hipSuccess) return biu_fail(BIU_ERR_LAUNCH, "convt_wgrad_mfma: memset failed");
+    a.dbias_out = dbias;                                   // d bias = channel sums of dy, taken while the kernel stages dy (no second pass)
+    if (dbias && hipMemsetAsync(dbias, 0, (size_t)dy->c * sizeof(float), st) != hipSuccess) return biu_fail(BIU_ERR_LAUNCH, "convt_wgrad_mfma: memset failed");
     // two 32-wide tiles of x's channels per block when x has them: the fine-grid dy is then read half as often
     const bool wide = a.CA > 32;
     if (dtype == BIU_BF16) {
@@ -2376,6 +2409,5 @@ int biu_mfma_convt_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* d
     hipLaunchKernelGGL(k_wgrad_finalize, dim3(grid_for((i64)a.CA * a.CB * taps, 256, 2048)), dim3(256), 0, st, (const float*)ws,
                        a.CA, a.CB, taps, dw);
     BIU_CHECK_LAUNCH("convt_wgrad_finalize");
-    if (dbias) return biu_chan_sum_vec(dy, dbias, (char*)ws + need, dtype, st);
     return BIU_OK;
 }

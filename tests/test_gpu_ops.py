@@ -449,6 +449,12 @@ def test_convtranspose_mfma(case, dtype):
     check(lib.biu_convt_bwd_weight(xd.a(), xf.x(), gd.a(), kd, ptr(dw), ptr(db), ptr(ws), ws.numel(), code, stream()), "convt_bwd_weight(mfma)")
     t3 = dict(rtol=1e-3, atol=2e-4 * float(wq.grad.abs().max())) if dtype == "f32" else dict(rtol=1e-2, atol=1e-2 * float(wq.grad.abs().max()))
     torch.testing.assert_close(dw.cpu(), wq.grad, **t3)
+    # d bias = channel sums of dy, accumulated by the weight-gradient kernel while it stages dy (no second pass over the fine tensor)
+    dbr = gr.sum(dim=[0] + list(range(2, gr.dim())))
+    torch.testing.assert_close(db.cpu(), dbr, rtol=1e-3, atol=1e-3 * float(gr.abs().sum() ** 0.5))
+    db.fill_(float("nan"))                           # a second call must not depend on what the buffer held
+    check(lib.biu_convt_bwd_weight(xd.a(), xf.x(), gd.a(), kd, ptr(dw), ptr(db), ptr(ws), ws.numel(), code, stream()), "convt_bwd_weight(mfma) again")
+    torch.testing.assert_close(db.cpu(), dbr, rtol=1e-3, atol=1e-3 * float(gr.abs().sum() ** 0.5))
 
 
 # ---------------------------------------------------------------------------------------------------------------
