@@ -1215,6 +1215,32 @@ int biu_mfma_conv_ksplit(int cin, const biu_act* y, int kd, int dtype) {
     while (blocks * ks * 2 <= num_cus() && nchunks / (ks * 2) >= 4 && ks < 32) ks *= 2;
     return ks;
 }
+// Scratch for the input-channel split: one buffer per (device, stream), grown on demand and kept (a hipMallocAsync / hipFreeAsync pair
+// per call cost the host ~30 us, and the small layers that split are host-bound).  Calls on one stream are ordered, so a buffer is never
+// in use by two launches at once; growing synchronises that stream before the old buffer is released.
+static char* split_scratch(size_t bytes, hipStream_t st) {
+    struct Slot { int dev; hipStream_t st; char* p; size_t cap; };
+    static Slot slots[16];
+    static int nslots = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    Slot* s = nullptr;
+    for (int i = 0; i < nslots; ++i)
+        if (slots[i].dev == dev && slots[i].st == st) { s = &slots[i]; break; }
+    if (!s) {
+        if (nslots == 16) return nullptr;                   // more streams than slots: the caller falls back to the unsplit launch
+        s = &slots[nslots++];
+        *s = Slot{dev, st, nullptr, 0};
+    }
+    if (s->cap < bytes) {
+        if (s->p) { (void)hipStreamSynchronize(st); (void)hipFree(s->p); s->p = nullptr; s->cap = 0; }
+        size_t cap = bytes < ((size_t)32 << 20) ? ((size_t)32 << 20) : bytes + bytes / 4;
+        if (hipMalloc((void**)&s->p, cap) != hipSuccess) { (void)hipGetLastError(); s->p = nullptr; return nullptr; }
+        s->cap = cap;
+    }
+    return s->p;
+}
+
 // y[v][c] = (accumulate ? y[v][c] : 0) + sum_z ws[z][v][c]   (ws slices share y's pitch)
 __global__ void k_split_reduce(const float* __restrict__ ws, size_t zstride_f, int ks, float* __restrict__ y, long nvoxels, int c, int pitch, int accumulate) {
     const long total = nvoxels * c;
@@ -1396,22 +1422,10 @@ int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, con
         yall.c = a.Cout;
         const int ks = biu_mfma_conv_ksplit(a.Cin, &yall, kd, dtype);
         if (ks > 1) {
-            // stream-ordered scratch for the partial results: slices laid out like y (and y1), summed into the outputs afterwards
+            // scratch for the partial results: slices laid out like y (and y1), summed into the outputs afterwards
             const biu_act* y1t = (cat && cat->y1) ? cat->y1 : nullptr;
             const size_t sl0 = (size_t)nvox(y) * y->pitch * sizeof(float), sl1 = y1t ? (size_t)nvox(y1t) * y1t->pitch * sizeof(float) : 0;
-            char* ws = nullptr;
-            static bool pool_kept = false;               // keep freed scratch in the device's default pool across synchronisations
-            if (!pool_kept) {
-                int dev = 0;
-                hipMemPool_t pool;
-                if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-                    uint64_t keep = UINT64_MAX;
-                    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-                }
-                (void)hipGetLastError();
-                pool_kept = true;
-            }
-            if (hipMallocAsync((void**)&ws, (size_t)ks * (sl0 + sl1), st) != hipSuccess) { (void)hipGetLastError(); ws = nullptr; }
+            char* ws = split_scratch((size_t)ks * (sl0 + sl1), st);
             if (ws) {
                 ConvArgs b = a;
                 b.ksplit = ks;
@@ -1426,7 +1440,6 @@ int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, con
                                            (const float*)(ws + (size_t)ks * sl0), sl1 / sizeof(float), ks, (float*)y1t->p, (long)nvox(y1t), y1t->c,
                                            y1t->pitch, cat->accumulate1);
                 }
-                (void)hipFreeAsync(ws, st);
                 if (rc != BIU_OK) return rc;
                 BIU_CHECK_LAUNCH("split_reduce");
                 return BIU_OK;

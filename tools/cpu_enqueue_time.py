@@ -1,8 +1,8 @@
 import sys, time, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-wl = bench.WORKLOADS["cfg4"]
-model, step, fwd, nvox = bench.make_step(wl, torch.device("cuda", 0))
+wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cfg4"]
+model, step, fwd, nvox, _avg = bench.make_step(wl, torch.device("cuda", 0))
 for _ in range(3): step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
