@@ -813,14 +813,28 @@ __global__ void k_adam(int n, float* const* params, const float* const* grads, f
     float* mm = m[t];
     float* vv = v[t];
     const i64 cnt = numel[t];
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (i64)gridDim.x * blockDim.x) {
-        float gr = g[i] * gscale;
-        float m1 = b1 * mm[i] + (1.f - b1) * gr;       // torch: exp_avg.lerp_(grad, 1 - beta1)
-        float v1 = b2 * vv[i] + (1.f - b2) * gr * gr;
-        mm[i] = m1;
-        vv[i] = v1;
-        float denom = sqrtf(v1) / bc2_sqrt + eps;
-        p[i] = p[i] - (lr / bc1) * (m1 / denom);
+    const float step_lr = lr / bc1;
+    auto upd = [&](float pv, float gv, float& m1, float& v1) -> float {
+        const float gr = gv * gscale;
+        m1 = b1 * m1 + (1.f - b1) * gr;                // torch: exp_avg.lerp_(grad, 1 - beta1)
+        v1 = b2 * v1 + (1.f - b2) * gr * gr;
+        const float denom = sqrtf(v1) / bc2_sqrt + eps;
+        return pv - step_lr * (m1 / denom);
+    };
+    // 16-byte accesses when the four arrays allow it (torch allocations are 256-byte aligned; views inside a flat bucket may not be)
+    const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)mm | (uintptr_t)vv) & 15) == 0;
+    const i64 nv = vec ? cnt / 4 : 0;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (i64)gridDim.x * blockDim.x) {
+        float4 pv = ((float4*)p)[i], mv = ((float4*)mm)[i], vq = ((float4*)vv)[i];
+        const float4 gv = ((const float4*)g)[i];
+        pv.x = upd(pv.x, gv.x, mv.x, vq.x); pv.y = upd(pv.y, gv.y, mv.y, vq.y);
+        pv.z = upd(pv.z, gv.z, mv.z, vq.z); pv.w = upd(pv.w, gv.w, mv.w, vq.w);
+        ((float4*)mm)[i] = mv; ((float4*)vv)[i] = vq; ((float4*)p)[i] = pv;
+    }
+    for (i64 i = nv * 4 + (i64)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (i64)gridDim.x * blockDim.x) {
+        float m1 = mm[i], v1 = vv[i];
+        p[i] = upd(p[i], g[i], m1, v1);
+        mm[i] = m1; vv[i] = v1;
     }
 }
 
@@ -1255,7 +1269,7 @@ extern "C" int biu_adam_step(int n, float* const* params, const float* const* gr
     BIU_REQUIRE(n > 0 && params && grads && exp_avg && exp_avg_sq && numel && step >= 1, BIU_ERR_SHAPE, "adam_step: bad arguments");
     float bc1 = 1.f - powf(beta1, (float)step);
     float bc2 = 1.f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(k_adam, dim3(64, n), dim3(TPB), 0, (hipStream_t)stream, n, params, grads, exp_avg, exp_avg_sq, numel,
+    hipLaunchKernelGGL(k_adam, dim3(128, n), dim3(TPB), 0, (hipStream_t)stream, n, params, grads, exp_avg, exp_avg_sq, numel,
                        lr, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale);
     BIU_CHECK_LAUNCH("adam_step");
     return BIU_OK;
