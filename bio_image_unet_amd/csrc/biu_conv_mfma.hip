@@ -214,6 +214,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     const int nbricks = a.N * a.nbd * a.nbh * a.nbw;
     const int p_mine = tid % CKP;
 
+    for (int i = tid; i < NWAVE * NT * 32 * 2; i += NTHR) lred[i] = 0.f;
     if (tid < NT * 32) {
         const int co = blockIdx.y * NT * 32 + tid;
         lbias[tid] = (a.bias && co < a.Cout && (a.ksplit <= 1 || blockIdx.z == 0)) ? a.bias[co] : 0.f;
@@ -412,8 +413,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < CPP; ++e) s1[nt][p][e] = s2[nt][p][e] = 0.f;
     // the 32 lanes of a half-wave hold the same channels: four DPP rotate-adds sum each row of 16 lanes, row_bcast:15 adds the
-    // even rows into the odd ones (VALU only), lanes 16 / 48 park the half-wave sums in LDS -- lred[wave][channel][2], plain
-    // stores, no atomics -- and flush_stats adds the NWAVE rows after a barrier.  (channel = nt * 32 + p * PSTEP + hf * CPP + e)
+    // even rows into the odd ones (VALU only), lanes 16 / 48 add the half-wave sums into the wave's OWN LDS slots -- lred[wave][channel][2],
+    // zeroed at kernel start, no atomics, no barrier -- and flush_stats adds the NWAVE rows ONCE, after the block's last brick: one
+    // partial row per block for the forward statistics and for the data-gradient sums alike.  (channel = nt * 32 + p * PSTEP + hf * CPP + e)
     auto reduce_piece = [&](float (&u_)[CPP], float (&v_)[CPP], int nt, int p) {
         float* slot = lred + ((size_t)(wave * (NT * 32) + nt * 32 + p * PSTEP + hf * CPP)) * 2;
 #pragma unroll
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
             v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));
             u += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
             v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));
-            if ((lane & 31) == 16) *(float2*)(slot + 2 * e) = make_float2(u, v);
+            if ((lane & 31) == 16) { float2 o = *(float2*)(slot + 2 * e); o.x += u; o.y += v; *(float2*)(slot + 2 * e) = o; }   // this wave's own slot
             u_[e] = v_[e] = 0.f;
         }
     };
@@ -655,9 +657,6 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
                     }
                 }
             }
-            if constexpr (RED) {
-                if (want_stats) flush_stats(brick);
-            }
 
         }
         DIAG_STAMP(3);
@@ -680,14 +679,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
         DIAG_STAMP(6);
         brick = nbrick; ch = nch; k = nk;
     }
-    if constexpr (ACCB) {
-        if (want_stats) {
+    if (want_stats) {
+        if constexpr (ACCB) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int p = 0; p < NP; ++p) reduce_piece(s1[nt][p], s2[nt][p], nt, p);
-            flush_stats((int)blockIdx.x);
         }
+        flush_stats((int)blockIdx.x);
     }
 }
 
@@ -736,6 +735,7 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
     const int nbricks = a.N * a.nbd * a.nbh * a.nbw;
     const int p_mine = tid % CKP;
 
+    if (tid < NWAVE * 16 * 2) lred[tid] = 0.f;
     if (tid < 16) {
         lbias[tid] = (a.bias && tid < a.Cout) ? a.bias[tid] : 0.f;
         if constexpr (RED) {
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
             v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));
             u += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x121, 0xf, 0xf, false));
             v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));
-            if (n16 == 0) *(float2*)(lred + ((wave * 16) + 4 * q4 + e) * 2) = make_float2(u, v);
+            if (n16 == 0) { float2* sl_ = (float2*)(lred + ((wave * 16) + 4 * q4 + e) * 2); float2 o = *sl_; o.x += u; o.y += v; *sl_ = o; }
             u_[e] = v_[e] = 0.f;
         }
     };
@@ -983,7 +983,7 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
                 }
             }
             if constexpr (RED) {
-                if (want_stats) { reduce4(t1, t2); flush_stats(brick); }
+                if (want_stats) reduce4(t1, t2);
             }
         }
         if (!have_next) break;
@@ -995,8 +995,9 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
         brick = nbrick; ch = nch; k = nk;
     }
     if constexpr (!RED) {
-        if (want_stats) { reduce4(s1, s2); flush_stats((int)blockIdx.x); }
+        if (want_stats) reduce4(s1, s2);
     }
+    if (want_stats) flush_stats((int)blockIdx.x);
 }
 
 // packed weights of the 16-channel variant: out[kstep32][tap][lane]; lane (n = l & 15, q = l >> 4) holds W[row n][k = 32 ks + 8 q + e]
@@ -1274,6 +1275,16 @@ static int launch_conv(const ConvArgs& a, int kd, hipStream_t st) {
 int biu_mfma_convt_dgrad_bricks(const biu_act* dx, int kd) {
     const int td = (kd == 2) ? 2 : 1, th = (kd == 2) ? 8 : 16, tw = 16;
     return dx->n * ((dx->d + td - 1) / td) * ((dx->h + th - 1) / th) * ((dx->w + tw - 1) / tw);
+}
+
+// partial rows its fused BatchNorm-backward sums occupy: one per workgroup column (must mirror launch_cfg_r's grid computation)
+int biu_mfma_convt_dgrad_rows(const biu_act* dx, int kd) {
+    const int ntiles = (dx->c + 31) / 32, gy = ntiles / pick_nt(ntiles);
+    int g = num_cus() / gy;
+    g &= ~7;
+    if (g < 8) g = 8;
+    const int nbricks = biu_mfma_convt_dgrad_bricks(dx, kd);
+    return g > nbricks ? nbricks : g;
 }
 
 // the 16-channel kernel takes a launch when the channels fit, the tensors are plain (no concatenation) and it is not switched off
