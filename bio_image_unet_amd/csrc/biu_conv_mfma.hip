@@ -156,9 +156,6 @@ constexpr int pf_lo(int g, int n, int ng) {
 #ifndef BIU_WGRAD_RR
 #define BIU_WGRAD_RR 1
 #endif
-#ifndef BIU_PRIO_ALT
-#define BIU_PRIO_ALT 0      // measured 1-3 % slower on cfg4 (profiles/r02_experiments.md); kept as a build switch
-#endif
 constexpr size_t conv_lds_budget(int nw) { return nw == 8 ? 142 * 1024 : 70 * 1024; }
 
 template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP, bool RED, int NW>
@@ -204,7 +201,6 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hf = lane >> 5;
-    const int wpar = __builtin_amdgcn_readfirstlane(tid >> 8) & 1;      // which of the two waves of its SIMD this is (waves w, w + 4)
     const bool has_xf = a.xs != nullptr || a.xs1 != nullptr;
     const size_t esz = sizeof(T);
     const int nchunks = a.Cin / CK;
@@ -533,9 +529,6 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
             issue_prep(have_next ? nbrick : brick, nch, have_next);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                // the two waves of a SIMD (w, w + 4) take turns at the higher issue priority, tap group by tap group: with a fixed
-                // order the older wave runs ahead and the younger one finishes its MFMAs alone, at a single wave's rate
-                if constexpr (BIU_PRIO_ALT) { if (((g & 1) ^ wpar) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #pragma unroll
                 for (int j = pf_lo(g, NPA, NG); j < pf_lo(g + 1, NPA, NG); ++j) issue_piece(j);
                 if constexpr (!W1) {
@@ -545,7 +538,6 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
                 tapgroup(g / KHW, g % KHW);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (BIU_PRIO_ALT) __builtin_amdgcn_s_setprio(0);
             DIAG_STAMP(1);
         } else {
             issue(have_next ? nbrick : brick, nch, have_next);
@@ -1180,14 +1172,6 @@ static bool conv_nw4() {
     return v == 1;
 }
 
-// experiment switch: BIU_CONV_CK4=1 stages single-tile 3-D layers in 32-channel chunks (64 bytes of every voxel row per pass) on
-// 4x8x16 bricks: half as many passes over the 128-byte rows of a 64-channel source (see profiles/r02_cfg4_mfma_busy.md: FETCH_SIZE)
-static bool conv_ck4() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("BIU_CONV_CK4"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
-
 // (a 4-tile weight slab no longer fits the double buffer next to the activation tile: two tiles is the widest block)
 static inline int pick_nt(int ntiles) { return (ntiles % 2 == 0) ? 2 : 1; }
 
@@ -1260,8 +1244,6 @@ static int launch_conv(const ConvArgs& a, int kd, hipStream_t st) {
     const bool wide = (a.GW % 32 == 0);
     const int nz = a.ksplit > 1 ? a.ksplit : 1;
     if (kd == 3) {
-        if (nt == 1 && conv_ck4() && !a.red_mode && a.Cin % 32 == 0 && (!a.x1 || a.csplit % 32 == 0))
-            return launch_cfg<T, 3, 3, 1, 4, 8, 16, 1, 4>(a, ntiles, nz, st);
         if (nt == 1 && conv_nw4()) return launch_cfg<T, 3, 3, 1, 4, 8, 16, 1, 2, 4>(a, ntiles, nz, st);
         if (nt == 1) return wide ? launch_cfg<T, 3, 3, 1, 4, 8, 32, 1, 2>(a, ntiles, nz, st) : launch_cfg<T, 3, 3, 1, 4, 16, 16, 1, 2>(a, ntiles, nz, st);
         return launch_cfg<T, 3, 3, 1, 4, 8, 16, 2, 2>(a, ntiles, nz, st);
@@ -2115,7 +2097,6 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
             load_frags(ntap_c, wq * KPW, fa[0], fb[0]);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                if constexpr (BIU_PRIO_ALT) { if (((g & 1) ^ ((wave >> 2) & 1)) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }     // see k_conv_pipe
 #pragma unroll
                 for (int j = pf_lo(g, NA, NG); j < pf_lo(g + 1, NA, NG); ++j) issue_a(j);
 #pragma unroll
@@ -2196,7 +2177,6 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
             } else {
                 mfma_phase(std::integral_constant<int, IPW>{});
             }
-            if constexpr (BIU_PRIO_ALT) __builtin_amdgcn_s_setprio(0);
             WSTAMP(1);
 #ifdef BIU_DIAG
             dsum_[7] += 1;
