@@ -355,7 +355,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     // commit pa / pw to LDS (producer transform + zero padding applied here)
     auto commit = [&](int ch) {
         float sc[PE], sh[PE], sl[PE];
-        if (has_xf) {
+        // a chunk lies in ONE source tensor; when that source has no transform (the up-sampled half of a decoder concat) the pieces
+        // go to LDS as they are -- no unpack / fma / max / pack for two thirds of decode5's chunks
+        const bool xf_here = has_xf && ((a.x1 && ch * CK >= a.csplit) ? (a.xs1 != nullptr) : (a.xs != nullptr));
+        if (xf_here) {
             const int c0 = ch * CK + p_mine * PE;
 #pragma unroll
             for (int e = 0; e < PE; ++e) { sc[e] = lxf[c0 + e]; sh[e] = lxf[a.Cin + c0 + e]; sl[e] = lxf[2 * a.Cin + c0 + e]; }
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
             const int i = tid + NTHR * j;
             if (i < HV * CKP) {
                 uint4 v = pa[j];
-                if (has_xf && ((inb_mask >> j) & 1u)) {
+                if (xf_here && ((inb_mask >> j) & 1u)) {
                     float f[PE];
                     F::unpack(v, f);
 #pragma unroll
