@@ -1168,12 +1168,6 @@ static int launch_cfg(const ConvArgs& a, int ntiles, int nz, hipStream_t st) {
     return launch_cfg_r<T, KD, KHW, S, TD, TH, TW, NT, CKP, false, NW>(a, ntiles, nz, st);
 }
 
-// experiment switch: BIU_CONV_NW4=1 runs single-tile (NT = 1) 3x3(x3) layers as two 256-thread blocks per CU
-static bool conv_nw4() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("BIU_CONV_NW4"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
 
 // (a 4-tile weight slab no longer fits the double buffer next to the activation tile: two tiles is the widest block)
 static inline int pick_nt(int ntiles) { return (ntiles % 2 == 0) ? 2 : 1; }
@@ -1182,10 +1176,10 @@ static inline int pick_nt(int ntiles) { return (ntiles % 2 == 0) ? 2 : 1; }
 struct BrickDim { int td, th, tw; };
 static BrickDim conv3_brick(int kd, int nt, bool wide) {
     if (kd == 3) {
-        if (nt == 1) return conv_nw4() ? BrickDim{4, 8, 16} : (wide ? BrickDim{4, 8, 32} : BrickDim{4, 16, 16});
+        if (nt == 1) return wide ? BrickDim{4, 8, 32} : BrickDim{4, 16, 16};
         return BrickDim{4, 8, 16};
     }
-    if (nt == 1) return conv_nw4() ? (wide ? BrickDim{1, 16, 32} : BrickDim{1, 32, 16}) : (wide ? BrickDim{1, 32, 32} : BrickDim{1, 64, 16});
+    if (nt == 1) return wide ? BrickDim{1, 32, 32} : BrickDim{1, 64, 16};
     return wide ? BrickDim{1, 16, 32} : BrickDim{1, 32, 16};
 }
 
@@ -1247,11 +1241,9 @@ static int launch_conv(const ConvArgs& a, int kd, hipStream_t st) {
     const bool wide = (a.GW % 32 == 0);
     const int nz = a.ksplit > 1 ? a.ksplit : 1;
     if (kd == 3) {
-        if (nt == 1 && conv_nw4()) return launch_cfg<T, 3, 3, 1, 4, 8, 16, 1, 2, 4>(a, ntiles, nz, st);
         if (nt == 1) return wide ? launch_cfg<T, 3, 3, 1, 4, 8, 32, 1, 2>(a, ntiles, nz, st) : launch_cfg<T, 3, 3, 1, 4, 16, 16, 1, 2>(a, ntiles, nz, st);
         return launch_cfg<T, 3, 3, 1, 4, 8, 16, 2, 2>(a, ntiles, nz, st);
     }
-    if (nt == 1 && conv_nw4()) return wide ? launch_cfg<T, 1, 3, 1, 1, 16, 32, 1, 2, 4>(a, ntiles, nz, st) : launch_cfg<T, 1, 3, 1, 1, 32, 16, 1, 2, 4>(a, ntiles, nz, st);
     if (nt == 1) return wide ? launch_cfg<T, 1, 3, 1, 1, 32, 32, 1, 2>(a, ntiles, nz, st) : launch_cfg<T, 1, 3, 1, 1, 64, 16, 1, 2>(a, ntiles, nz, st);
     return wide ? launch_cfg<T, 1, 3, 1, 1, 16, 32, 2, 2>(a, ntiles, nz, st) : launch_cfg<T, 1, 3, 1, 1, 32, 16, 2, 2>(a, ntiles, nz, st);
 }
@@ -1301,8 +1293,7 @@ int biu_mfma_conv_stat_rows(const biu_act* y, int kd, const biu_act* x, int dtyp
     }
     const int ntiles = (y->c + 31) / 32;
     const int nt = pick_nt(ntiles);
-    const bool nw4 = conv_nw4() && nt == 1;
-    int g = (nw4 ? 2 : 1) * num_cus() / (ntiles / nt);
+    int g = num_cus() / (ntiles / nt);
     g &= ~7;
     if (g < 8) g = 8;
     const int nbricks = biu_mfma_conv_bricks(y, kd, x ? x : y, x ? dtype : -1);
