@@ -18,6 +18,7 @@
 #include "biu_internal.h"
 #include <type_traits>
 #include <cstring>
+#include <mutex>
 #include <cstdlib>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -1204,6 +1205,8 @@ static char* split_scratch(size_t bytes, hipStream_t st) {
     struct Slot { int dev; hipStream_t st; char* p; size_t cap; };
     static Slot slots[16];
     static int nslots = 0;
+    static std::mutex mu;                                   // the table, not the buffers: a buffer belongs to one stream
+    std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     Slot* s = nullptr;
