@@ -11,6 +11,14 @@
 struct Vox4 { int n, d, h, w; };
 __device__ __forceinline__ Vox4 unvox4(i64 v, int D, int H, int W) {
     Vox4 r;
+    if ((unsigned long long)v < (1ull << 32)) {      // the common case: three 32-bit divisions instead of three 64-bit ones (~4x fewer instructions)
+        unsigned u = (unsigned)v;
+        r.w = (int)(u % (unsigned)W); u /= (unsigned)W;
+        r.h = (int)(u % (unsigned)H); u /= (unsigned)H;
+        r.d = (int)(u % (unsigned)D); u /= (unsigned)D;
+        r.n = (int)u;
+        return r;
+    }
     r.w = (int)(v % W); v /= W;
     r.h = (int)(v % H); v /= H;
     r.d = (int)(v % D); v /= D;
