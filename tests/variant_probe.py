@@ -1,0 +1,31 @@
+"""Helper of test_gpu_variants: one train-mode forward/backward of a small network, parameter gradients dumped to a file.
+Run as a subprocess so that BIU_DISABLE (read once per process by the library) can differ between runs."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bio_image_unet_amd as B  # noqa: E402
+from oracle import unet_oracle as O  # noqa: E402
+
+which, out = sys.argv[1], sys.argv[2]
+torch.manual_seed(0)
+g = torch.Generator().manual_seed(5)
+if which == "unet3d_bf16":            # UNet3D(n_filter=32): decode6 forward and encode2 data gradient take the 16-row MFMA kernel
+    m = B.UNet3D(1, 1, 32).cuda()
+    m.load_state_dict(O.init_unet3d(1, 1, 32, seed=7))
+    m.set_compute_dtype(torch.bfloat16)
+    shape = (2, 1, 16, 32, 32)
+else:                                 # Unet(n_filter=32) fp32, 2 x 64 x 64: the 8x8 / 4x4 layers split over their input channels
+    m = B.Unet(1, 1, 32).cuda()
+    m.load_state_dict(O.init_unet2d(1, 1, 32, seed=3))
+    shape = (2, 1, 64, 64)
+m.train()
+x = torch.rand(*shape, generator=g).cuda()
+y = (torch.rand(*shape, generator=g) > 0.5).float().cuda()
+outs = m(x)
+loss = O.bce_dice_loss(outs[1], y)
+loss.backward()
+torch.save({"loss": float(loss.detach()), "logits": outs[1].detach().cpu(), **{k: p.grad.cpu() for k, p in m.named_parameters()}}, out)
