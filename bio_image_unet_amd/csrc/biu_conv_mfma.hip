@@ -1744,7 +1744,7 @@ constexpr bool wgrad_tab_in_lds(size_t tile_bytes, int pieces) { return tile_byt
 
 // NI = 32-wide tiles of the plain operand's channels a block owns (its A tile is NI * 32 channels wide): with NI = 2 the tapped
 // operand -- the large fine-grid tensor of a ConvTranspose weight gradient -- is read half as often.
-template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int KSPLIT, int NI>
+template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int KSPLIT, int NI, bool RR16 = false>
 __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     using F = Frag<T>;
     constexpr int NTHR = 512, NWAVE = 8;
@@ -1850,11 +1850,26 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         tapoff[t] = ((ta * HH + tb) * HW + tc) * RS;
     }
 
-    int a_lane, b_lane;
+    // rr16 (RR kernels, tapped operand with 16 channels -- encode2 of UNet3D(n_filter = 32)): a 32-wide B tile would be half zeros.
+    // Instead the upper 16 columns read the same 16 channels at a second (kd, kw) pair: unit u < 3 = pairs (0, u) | (1, u), units
+    // 3-5 = pair (2, u - 3) alone (upper columns duplicate the lower ones and are not flushed).  18 MFMA slots per row instead of 27.
+    constexpr bool rr16 = RR && RR16;                              // (the launcher picks this instantiation when the tapped operand has 16 channels)
+    int u16_unit = 0, u16_r0 = 0, u16_boff = 0, u16_delta = 0;
+    bool u16_half = false;
+    if (rr16) {
+        u16_unit = (wave == 6) ? 0 : (wave == 7) ? 1 : wave;
+        u16_half = (wave < 2 || wave > 5);
+        u16_r0 = (wave > 5) ? (TD * TH / 2) : 0;
+        const int kdA = (u16_unit < 3) ? 0 : 2, kwA = (u16_unit < 3) ? u16_unit : u16_unit - 3;
+        u16_boff = ((kdA * HH) * HW + kwA) * RS;
+        u16_delta = (u16_unit < 3) ? HH * HW * RS : 0;
+    }
+    int a_lane, b_lane, b_lane16 = 0;
     if constexpr (sizeof(T) == 2) {
         const int g = lane >> 4, li = lane & 15, qrow = li >> 2, p = li & 3, cg = g & 1, h = g >> 1;
         a_lane = (8 * h + qrow) * RSA + (16 * cg + 4 * p) * 2;
         b_lane = (8 * h + qrow) * S * RS + (16 * cg + 4 * p) * 2;
+        b_lane16 = (8 * h + qrow) * S * RS + (4 * p) * 2 + (cg ? u16_delta : 0);
     } else {
         a_lane = (lane >> 5) * RSA + (lane & 31) * 4;
         b_lane = (lane >> 5) * S * RS + (lane & 31) * 4;
@@ -2120,19 +2135,18 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
             };
             // row-reuse phase (RR): rows r = 0 .. TD*TH-1 of the brick in order, fragment ring of 4 halo rows, A / extra-tap
             // fragments and the ring's new row read one row ahead; a plane's first three rows are read after the previous row's MFMAs
-            auto rr_phase = [&](auto has_x_c) {
+            auto rr_phase = [&](auto has_x_c, auto nrow_c, const char* bbase, const char* abase) {
                 constexpr bool HAS_X = decltype(has_x_c)::value;
-                constexpr int NROW = TD * TH;
-                static_assert(!RR || NROW == KPW, "one k-group per 16-voxel row");
+                constexpr int NROW = decltype(nrow_c)::value;           // rows this wave walks: the whole brick, or half of it (rr16)
+                constexpr int KPG = NROW / NG;
+                static_assert(!RR || (TD * TH == KPW && NROW % NG == 0 && NROW % TH == 0), "one k-group per 16-voxel row");
                 typedef bf16x4 __attribute__((address_space(3))) * lp;
                 auto rd = [&](const char* p_, int step) -> bf16x8 {
                     const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p_));
                     const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p_ + 4 * step));
                     return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
                 };
-                const char* bbase = bt + tapoff[0] + b_lane;          // tap (kd, kh = 0, kw) of this wave's pair
                 const char* xbase = bt + tapoff[IPW - 1] + b_lane;    // the extra tap (waves 0-2)
-                const char* abase = at + a_lane;
                 bf16x8 ring[4], fxx[2], faa[2];
                 faa[0] = rd(abase, RSA);
                 if constexpr (HAS_X) fxx[0] = rd(xbase, RS);
@@ -2167,7 +2181,19 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
             // (a second copy of the phase only where it removes >= 1/8 of the slots: 27 taps on 32; the 2-D kernels' 9 on 10 stay branch-free)
             constexpr bool TWO_PHASES = IPW > 1 && (IPW * WPQ - TAPS) * 8 >= IPW * WPQ;
             if constexpr (RR) {
-                if (wave < 3) rr_phase(std::true_type{}); else rr_phase(std::false_type{});
+                using Full = std::integral_constant<int, TD * TH>;
+                using Half = std::integral_constant<int, TD * TH / 2>;
+                if (rr16) {
+                    // 16-channel tapped operand: columns 0-15 / 16-31 of the B fragment are the SAME 16 channels at two (kd, kw) pairs
+                    // (u16_* below); waves 0, 1, 6, 7 walk half of the brick's rows, 2-5 all of them: 144 MFMAs per SIMD and brick
+                    const char* bb = bt + u16_boff + b_lane16 + (u16_r0 / TH) * (HH * HW * RS);
+                    const char* ab = at + a_lane + u16_r0 * 16 * RSA;
+                    if (u16_half) rr_phase(std::false_type{}, Half{}, bb, ab); else rr_phase(std::false_type{}, Full{}, bb, ab);
+                } else if (wave < 3) {
+                    rr_phase(std::true_type{}, Full{}, bt + tapoff[0] + b_lane, at + a_lane);
+                } else {
+                    rr_phase(std::false_type{}, Full{}, bt + tapoff[0] + b_lane, at + a_lane);
+                }
             } else if constexpr (TWO_PHASES) {
                 if (!last_tap_live) mfma_phase(std::integral_constant<int, (IPW > 1 ? IPW - 1 : 1)>{});
                 else mfma_phase(std::integral_constant<int, IPW>{});
@@ -2210,8 +2236,25 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         }
     }
     // ---- flush once per block ------------------------------------------------------------------------------------------
-    const int jj = jt * CT + (lane & 31);
     const int hf = lane >> 5;
+    if (rr16) {
+        // column j of an accumulator: channel j & 15 of pair A (j < 16) or pair B (j >= 16, double units only)
+        const int ch = lane & 15, up = (lane >> 4) & 1;
+        const int kd = (u16_unit < 3) ? up : 2, kw = (u16_unit < 3) ? u16_unit : u16_unit - 3;
+        if (!(up && u16_unit >= 3)) {
+#pragma unroll
+            for (int tb = 0; tb < 3; ++tb) {
+                const int tap = (kd * 3 + tb) * 3 + kw;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ii = it * CTA + (e & 3) + 8 * (e >> 2) + 4 * hf;
+                    if (ii < a.CA) atomicAdd(a.ws + ((size_t)tap * a.CA + ii) * a.CB + ch, acc[tb][0][e]);
+                }
+            }
+        }
+        return;
+    }
+    const int jj = jt * CT + (lane & 31);
     if (jj < a.CB) {
 #pragma unroll
         for (int t2 = 0; t2 < IPW; ++t2) {
@@ -2273,7 +2316,7 @@ bool biu_mfma_convt_wgrad_ok(const biu_act* x, const biu_act* dy, int kd, int dt
     return (kd == 1 || kd == 2) && wgrad_chan_ok(x->c, dy->c) && wgrad_ptrs_ok(x, dy, dtype);
 }
 
-template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int KSPLIT, int NI = 1>
+template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int KSPLIT, int NI = 1, bool RR16 = false>
 static int launch_wgrad(WgradArgs a, hipStream_t st) {
     constexpr int SD = (KD == 1) ? 1 : S;
     constexpr int HV = ((TD - 1) * SD + KD) * ((TH - 1) * S + KHW) * ((TW - 1) * S + KHW);
@@ -2289,7 +2332,7 @@ static int launch_wgrad(WgradArgs a, hipStream_t st) {
     const int nit = (a.CA + 32 * NI - 1) / (32 * NI);
     a.njt = (a.CB + 31) / 32;
     a.bricks_per_block = 0;
-    auto kern = k_wgrad_pipe<T, KD, KHW, S, TD, TH, TW, KSPLIT, NI>;
+    auto kern = k_wgrad_pipe<T, KD, KHW, S, TD, TH, TW, KSPLIT, NI, RR16>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
@@ -2366,7 +2409,10 @@ int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int
     const size_t need = wgrad_acc_bytes(a.CA, a.CB, taps);
     BIU_REQUIRE(ws_bytes >= need + (dbias ? biu_chan_sum_workspace(dy->c) : 0), BIU_ERR_WORKSPACE, "wgrad_mfma: workspace %zu too small", ws_bytes);
     if (hipMemsetAsync(ws, 0, need, st) != hipSuccess) return biu_fail(BIU_ERR_LAUNCH, "wgrad_mfma: memset failed");
-    if (dtype == BIU_BF16) rc = (kd == 3) ? launch_wgrad<bf16_t, 3, 3, 1, 4, 8, 16, 1>(a, st) : launch_wgrad<bf16_t, 1, 3, 1, 1, 16, 32, 4>(a, st);
+    static int rr16_off = -1;
+    if (rr16_off < 0) { const char* e = getenv("BIU_DISABLE"); rr16_off = (e && strstr(e, "rr16")) ? 1 : 0; }
+    if (dtype == BIU_BF16 && kd == 3 && a.CB == 16 && !x1 && !rr16_off) rc = launch_wgrad<bf16_t, 3, 3, 1, 4, 8, 16, 1, 1, true>(a, st);   // paired taps
+    else if (dtype == BIU_BF16) rc = (kd == 3) ? launch_wgrad<bf16_t, 3, 3, 1, 4, 8, 16, 1>(a, st) : launch_wgrad<bf16_t, 1, 3, 1, 1, 16, 32, 4>(a, st);
     else rc = (kd == 3) ? launch_wgrad<float, 3, 3, 1, 4, 4, 16, 1>(a, st) : launch_wgrad<float, 1, 3, 1, 1, 16, 16, 4>(a, st);
     if (rc != BIU_OK) return rc;
     hipLaunchKernelGGL(k_wgrad_finalize, dim3(grid_for((i64)a.CA * a.CB * taps, 256, 2048)), dim3(256), 0, st, (const float*)ws,

@@ -1,5 +1,5 @@
 """The kernel variants a launch can take must agree with the kernels they replace: the 16-row MFMA kernel (BIU_DISABLE=m16 falls back to
-the 32-row one) and the input-channel split of small fp32 launches (BIU_DISABLE=ksplit).  The switches are read once per process, so
+the 32-row one), the paired-tap weight gradient of a 16-channel input (BIU_DISABLE=rr16) and the input-channel split of small fp32 launches (BIU_DISABLE=ksplit).  The switches are read once per process, so
 each side runs in its own subprocess (tests/variant_probe.py)."""
 import os
 import subprocess
@@ -29,7 +29,7 @@ def _run(which, disable, tmp_path):
     ("unet2d_f32", "ksplit", 1e-5, 2e-2),
     # bf16: two correct bf16 kernels differ by output rounding; discrete LeakyReLU / max-pool decisions then move gradients by ~1 %
     #  -- a wrong tap or tile would move them by tens of percent
-    ("unet3d_bf16", "m16", 2e-2, 6e-2),
+    ("unet3d_bf16", "m16,rr16", 2e-2, 6e-2),
 ])
 def test_variant_matches_the_kernel_it_replaces(which, disable, tol_out, tol_grad, tmp_path):
     on, off = _run(which, None, tmp_path), _run(which, disable, tmp_path)
