@@ -233,39 +233,63 @@ __global__ __launch_bounds__(256, 3) void k_c1_wgrad_mfma(C1Args a) {
     const int g = lane >> 4, li = lane & 15, qrow = li >> 2, p = li & 3, cg = g & 1, h = g >> 1;
     const int tr_lane = (8 * h + qrow) * ROWB + (16 * cg + 4 * p) * 2;
 
-    for (int brick = blockIdx.x; brick < a.nbricks; brick += gridDim.x) {
+    // The (da, y) pieces of the NEXT brick are requested before this brick's im2col staging and MFMAs (the loop has nothing else to hide
+    // their latency behind); a thread's pieces: voxels tid / 4 + 64 k, channel piece tid % 4.
+    constexpr int NPC = G::BV * 4 / NTHR;
+    uint4 pda[NPC], pyr[NPC];
+    size_t pvox[NPC];
+    unsigned pmask = 0;
+    auto origin = [&](int brick, int& n, int& d0, int& h0, int& w0) {
         int b = brick;
-        const int w0 = (b % a.nbw) * G::TW; b /= a.nbw;
-        const int h0 = (b % a.nbh) * G::TH; b /= a.nbh;
-        const int d0 = (b % a.nbd) * G::TD;
-        const int n = b / a.nbd;
-        // dy tile (+ fused BatchNorm backward, + write-back), zero rows for voxels outside the volume
-        for (int i = tid; i < G::BV * 4; i += NTHR) {
-            const int v = i / 4, pc = i % 4;
-            uint4 out = make_uint4(0, 0, 0, 0);
-            if (pc < ppv) {
-                const int lw = v % G::TW, t = v / G::TW;
-                const int gd = d0 + t / G::TH, gh = h0 + t % G::TH, gw = w0 + lw;
-                if (gd < a.D && gh < a.H && gw < a.W) {
-                    const size_t vox = (((size_t)n * a.D + gd) * a.H + gh) * a.W + gw;
-                    uint4* gp = (uint4*)(a.y + (vox * a.ypitch + a.co0 + pc * 8) * 2);
-                    out = *gp;
-                    if (fused) {
-                        float gg[8], yy[8];
-                        unpack8(out, gg);
-                        unpack8(*(const uint4*)(a.yraw + (vox * a.yrawpitch + a.co0 + pc * 8) * 2), yy);
+        w0 = (b % a.nbw) * G::TW; b /= a.nbw;
+        h0 = (b % a.nbh) * G::TH; b /= a.nbh;
+        d0 = (b % a.nbd) * G::TD;
+        n = b / a.nbd;
+    };
+    auto request = [&](int brick) {
+        int n, d0, h0, w0;
+        origin(brick, n, d0, h0, w0);
+        pmask = 0;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float dz = gg[e] * (fmaf(ks[e], yy[e], kh[e]) > 0.f ? 1.f : kl[e]);
-                            gg[e] = fmaf(ka[e], dz, fmaf(kb[e], yy[e], kc[e]));
-                        }
-                        out = make_uint4(pack2(gg[0], gg[1]), pack2(gg[2], gg[3]), pack2(gg[4], gg[5]), pack2(gg[6], gg[7]));
-                        *gp = out;                                  // dy replaces da
-                    }
-                }
+        for (int k = 0; k < NPC; ++k) {
+            const int v = (tid + NTHR * k) / 4;
+            const int lw = v % G::TW, t = v / G::TW;
+            const int gd = d0 + t / G::TH, gh = h0 + t % G::TH, gw = w0 + lw;
+            pda[k] = make_uint4(0, 0, 0, 0);
+            pyr[k] = make_uint4(0, 0, 0, 0);
+            if (mypiece < ppv && gd < a.D && gh < a.H && gw < a.W) {
+                const size_t vox = (((size_t)n * a.D + gd) * a.H + gh) * a.W + gw;
+                pvox[k] = vox;
+                pda[k] = *(const uint4*)(a.y + (vox * a.ypitch + a.co0 + mypiece * 8) * 2);
+                if (fused) pyr[k] = *(const uint4*)(a.yraw + (vox * a.yrawpitch + a.co0 + mypiece * 8) * 2);
+                pmask |= 1u << k;
             }
-            *(uint4*)(ldy + v * ROWB + pc * 16) = out;
         }
+    };
+    if ((int)blockIdx.x < a.nbricks) request(blockIdx.x);
+    for (int brick = blockIdx.x; brick < a.nbricks; brick += gridDim.x) {
+        int n, d0, h0, w0;
+        origin(brick, n, d0, h0, w0);
+        // dy tile (+ fused BatchNorm backward, + write-back), zero rows for voxels outside the volume
+#pragma unroll
+        for (int k = 0; k < NPC; ++k) {
+            const int v = (tid + NTHR * k) / 4;
+            uint4 out = pda[k];
+            if (fused && ((pmask >> k) & 1u)) {
+                float gg[8], yy[8];
+                unpack8(out, gg);
+                unpack8(pyr[k], yy);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float dz = gg[e] * (fmaf(ks[e], yy[e], kh[e]) > 0.f ? 1.f : kl[e]);
+                    gg[e] = fmaf(ka[e], dz, fmaf(kb[e], yy[e], kc[e]));
+                }
+                out = make_uint4(pack2(gg[0], gg[1]), pack2(gg[2], gg[3]), pack2(gg[4], gg[5]), pack2(gg[6], gg[7]));
+                *(uint4*)(a.y + (pvox[k] * a.ypitch + a.co0 + mypiece * 8) * 2) = out;          // dy replaces da
+            }
+            *(uint4*)(ldy + v * ROWB + mypiece * 16) = out;
+        }
+        if (brick + (int)gridDim.x < a.nbricks) request(brick + gridDim.x);
         stage_xp<KD, NTHR, 1>(a, n, d0, h0, w0, lx, lxp);             // (its barriers also publish the dy tile)
         typedef bf16x4 __attribute__((address_space(3))) * lp;
         for (int ksx = wave; ksx < G::BV / 16; ksx += NWV) {
