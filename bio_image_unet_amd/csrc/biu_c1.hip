@@ -59,28 +59,48 @@ template <int KD, int HALF = 0> struct Geo {                      // HALF: 256-v
     static constexpr int TAPS = KD * 9;
 };
 
-// halo tile of T(x) (zero outside the volume) -> lx ; then the im2col image xp[v][32] (taps beyond TAPS are zero)
+// halo tile of T(x) (zero outside the volume): xp_request loads this thread's halo voxels of a brick into registers (issued a brick ahead,
+// so their latency hides behind the previous brick's work), xp_commit writes them to lx and builds the im2col image xp[v][32] (taps
+// beyond TAPS are zero)
 template <int KD, int NTHR, int HALF = 0>
-__device__ __forceinline__ void stage_xp(const C1Args& a, int n, int d0, int h0, int w0, unsigned short* lx, char* lxp) {
+struct XpRegs { unsigned short v[(Geo<KD, HALF>::HV + NTHR - 1) / NTHR]; unsigned inside; };   // inside: bit k = voxel k lies in the volume
+
+template <int KD, int NTHR, int HALF = 0>
+__device__ __forceinline__ void xp_request(const C1Args& a, int n, int d0, int h0, int w0, XpRegs<KD, NTHR, HALF>& xr) {
     using G = Geo<KD, HALF>;
+    constexpr int NX = (G::HV + NTHR - 1) / NTHR;
     const int tid = threadIdx.x;
-    const bool has_xf = a.xs != nullptr;
-    const float xs = has_xf ? a.xs[0] : 1.f, xb = has_xf ? a.xb[0] : 0.f, xl = has_xf ? a.xl[0] : 1.f;
-    for (int i = tid; i < G::HV; i += NTHR) {
+    xr.inside = 0;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        const int i = tid + NTHR * k;
         const int hw = i % G::HW, t = i / G::HW;
         const int hh = t % G::HH, hd = t / G::HH;
         const int gd = d0 + hd - (KD == 3 ? 1 : 0), gh = h0 + hh - 1, gw = w0 + hw - 1;
-        const bool ok = gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-        unsigned short v = 0;
-        if (ok) {
-            v = *(const unsigned short*)(a.x + ((size_t)(((size_t)n * a.D + gd) * a.H + gh) * a.W + gw) * a.xpitch * 2);
-            if (has_xf) {
+        const bool ok = i < G::HV && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+        xr.v[k] = ok ? *(const unsigned short*)(a.x + ((size_t)(((size_t)n * a.D + gd) * a.H + gh) * a.W + gw) * a.xpitch * 2) : (unsigned short)0;
+        xr.inside |= ok ? (1u << k) : 0u;
+    }
+}
+template <int KD, int NTHR, int HALF = 0>
+__device__ __forceinline__ void xp_commit(const C1Args& a, const XpRegs<KD, NTHR, HALF>& xr, unsigned short* lx, char* lxp) {
+    using G = Geo<KD, HALF>;
+    constexpr int NX = (G::HV + NTHR - 1) / NTHR;
+    const int tid = threadIdx.x;
+    const bool has_xf = a.xs != nullptr;
+    const float xs = has_xf ? a.xs[0] : 1.f, xb = has_xf ? a.xb[0] : 0.f, xl = has_xf ? a.xl[0] : 1.f;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        const int i = tid + NTHR * k;
+        if (i < G::HV) {
+            unsigned short v = xr.v[k];
+            if (has_xf && ((xr.inside >> k) & 1u)) {                 // padding stays zero: it is applied after the transform
                 const float tt = fmaf(xs, bf2f(v), xb);
                 const float o = tt > 0.f ? tt : xl * tt;
                 v = (unsigned short)(pack2(o, 0.f) & 0xffffu);
             }
+            lx[i] = v;
         }
-        lx[i] = v;
     }
     __syncthreads();
     for (int v = tid; v < G::BV; v += NTHR) {
@@ -138,13 +158,20 @@ __global__ __launch_bounds__(256) void k_c1_fwd_mfma(C1Args a) {
         for (int e = 0; e < 8; ++e) s1[q][e] = s2[q][e] = 0.f;
     __syncthreads();
 
-    for (int brick = blockIdx.x; brick < a.nbricks; brick += gridDim.x) {
+    auto origin_of = [&](int brick, int& n, int& d0, int& h0, int& w0) {
         int b = brick;
-        const int w0 = (b % a.nbw) * G::TW; b /= a.nbw;
-        const int h0 = (b % a.nbh) * G::TH; b /= a.nbh;
-        const int d0 = (b % a.nbd) * G::TD;
-        const int n = b / a.nbd;
-        stage_xp<KD, 256>(a, n, d0, h0, w0, lx, lxp);
+        w0 = (b % a.nbw) * G::TW; b /= a.nbw;
+        h0 = (b % a.nbh) * G::TH; b /= a.nbh;
+        d0 = (b % a.nbd) * G::TD;
+        n = b / a.nbd;
+    };
+    XpRegs<KD, 256> xr;
+    if ((int)blockIdx.x < a.nbricks) { int n, d0, h0, w0; origin_of(blockIdx.x, n, d0, h0, w0); xp_request<KD, 256>(a, n, d0, h0, w0, xr); }
+    for (int brick = blockIdx.x; brick < a.nbricks; brick += gridDim.x) {
+        int n, d0, h0, w0;
+        origin_of(brick, n, d0, h0, w0);
+        xp_commit<KD, 256>(a, xr, lx, lxp);
+        if (brick + (int)gridDim.x < a.nbricks) { int n2, d2, h2, w2; origin_of(brick + gridDim.x, n2, d2, h2, w2); xp_request<KD, 256>(a, n2, d2, h2, w2, xr); }
         for (int tile = wave; tile < G::BV / 32; tile += 4) {
             const int v = tile * 32 + r;
             floatx16 acc;
@@ -266,7 +293,13 @@ __global__ __launch_bounds__(256, 3) void k_c1_wgrad_mfma(C1Args a) {
             }
         }
     };
-    if ((int)blockIdx.x < a.nbricks) request(blockIdx.x);
+    XpRegs<KD, NTHR, 1> xr;
+    if ((int)blockIdx.x < a.nbricks) {
+        request(blockIdx.x);
+        int n0, d00, h00, w00;
+        origin(blockIdx.x, n0, d00, h00, w00);
+        xp_request<KD, NTHR, 1>(a, n0, d00, h00, w00, xr);
+    }
     for (int brick = blockIdx.x; brick < a.nbricks; brick += gridDim.x) {
         int n, d0, h0, w0;
         origin(brick, n, d0, h0, w0);
@@ -289,8 +322,13 @@ __global__ __launch_bounds__(256, 3) void k_c1_wgrad_mfma(C1Args a) {
             }
             *(uint4*)(ldy + v * ROWB + mypiece * 16) = out;
         }
-        if (brick + (int)gridDim.x < a.nbricks) request(brick + gridDim.x);
-        stage_xp<KD, NTHR, 1>(a, n, d0, h0, w0, lx, lxp);             // (its barriers also publish the dy tile)
+        xp_commit<KD, NTHR, 1>(a, xr, lx, lxp);                         // (its barriers also publish the dy tile)
+        if (brick + (int)gridDim.x < a.nbricks) {
+            request(brick + gridDim.x);
+            int n2, d2, h2, w2;
+            origin(brick + gridDim.x, n2, d2, h2, w2);
+            xp_request<KD, NTHR, 1>(a, n2, d2, h2, w2, xr);
+        }
         typedef bf16x4 __attribute__((address_space(3))) * lp;
         for (int ksx = wave; ksx < G::BV / 16; ksx += NWV) {
             const char* ap = lxp + ksx * 16 * ROWB + tr_lane;
