@@ -208,6 +208,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     const int ksz = (a.ksplit > 1) ? (int)blockIdx.z : 0;
     const int c_begin = (a.ksplit > 1) ? (ksz * nchunks) / a.ksplit : 0;
     const int c_end = (a.ksplit > 1) ? ((ksz + 1) * nchunks) / a.ksplit : nchunks;
+    const bool w_static = WGLDS && (c_end - c_begin == 1);        // one chunk per brick: the weight slab in LDS never changes after the first item
     const int nbricks = a.N * a.nbd * a.nbh * a.nbw;
     const int p_mine = tid % CKP;
 
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
                 for (int j = pf_lo(g, NPA, NG); j < pf_lo(g + 1, NPA, NG); ++j) issue_piece(j);
                 if constexpr (!W1) {
 #pragma unroll
-                    for (int j = pf_lo(g, NPW, NG); j < pf_lo(g + 1, NPW, NG); ++j) issue_wpiece(nch, have_next, j);
+                    for (int j = pf_lo(g, NPW, NG); j < pf_lo(g + 1, NPW, NG); ++j) issue_wpiece(nch, have_next && !w_static, j);
                 }
                 tapgroup(g / KHW, g % KHW);
                 __builtin_amdgcn_sched_barrier(0);
@@ -667,9 +668,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
         if (!have_next) break;
         __syncthreads();                     // everyone is done reading the tile
         DIAG_STAMP(4);
-        if constexpr (W1) issue_w(nch, true);                // the slab is free now; the copy flies while the tile is committed
+        if constexpr (W1) { if (!w_static) issue_w(nch, true); }   // the slab is free now; the copy flies while the tile is committed
         commit(nch);
-        if constexpr (WGLDS) { if constexpr (W2) wcur ^= 1; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // weight DMA landed
+        if constexpr (WGLDS) { if constexpr (W2) { if (!w_static) wcur ^= 1; } asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // weight DMA landed
         DIAG_STAMP(5);
         __syncthreads();
         DIAG_STAMP(6);
@@ -913,7 +914,7 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
 #pragma unroll
             for (int j = pf_lo(g, NPA, NG); j < pf_lo(g + 1, NPA, NG); ++j) issue_piece(j);
 #pragma unroll
-            for (int j = pf_lo(g, NPW, NG); j < pf_lo(g + 1, NPW, NG); ++j) issue_wpiece(nch, have_next, j);
+            for (int j = pf_lo(g, NPW, NG); j < pf_lo(g + 1, NPW, NG); ++j) issue_wpiece(nch, have_next && nchunks > 1, j);
             uint4 rows[R + 2];
             const uint4* lap = lact + hvb + ta * HH * HW + tc;
 #pragma unroll
@@ -985,7 +986,7 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
         if (!have_next) break;
         __syncthreads();                     // everyone is done reading the tile
         commit(nch);
-        wcur ^= 1;
+        if (nchunks > 1) wcur ^= 1;                           // (one chunk per brick: the slab loaded for the first item stays)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // weight DMA landed
         __syncthreads();
         brick = nbrick; ch = nch; k = nk;
