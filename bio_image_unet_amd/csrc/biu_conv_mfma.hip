@@ -154,6 +154,12 @@ constexpr int pf_lo(int g, int n, int ng) {
     const int span = (ng + BIU_PF_SPAN - 1) / BIU_PF_SPAN;
     return g >= span ? n : (g * n) / span;
 }
+#ifndef BIU_TAIL_BRANCH
+#define BIU_TAIL_BRANCH 1
+#endif
+#ifndef BIU_TWO_PHASE_DIV
+#define BIU_TWO_PHASE_DIV 8
+#endif
 #ifndef BIU_WGRAD_RR
 #define BIU_WGRAD_RR 1
 #endif
@@ -2073,6 +2079,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
             WSTAMP(0);
             using FragR = typename std::conditional<sizeof(T) == 2, bf16x8, float>::type;
             FragR fa[2][NI], fb[2][IPW];
+            // 2-D fp32 kernels: 9 taps on 2 x 5 slots leave one empty; a second copy of the phase spills there, a wave-uniform branch around
+            // the last slot's reads and 64-cycle MFMA does not (cfg2 weight gradients 96 -> 104-112 TFLOP/s)
+            constexpr bool TWO_PHASES_ = IPW > 1 && (IPW * WPQ - TAPS) * BIU_TWO_PHASE_DIV >= IPW * WPQ;
+            constexpr bool TAIL_BRANCH = BIU_TAIL_BRANCH && sizeof(T) == 4 && !TWO_PHASES_ && IPW > 1 && IPW * WPQ > TAPS;   // (bf16 2-D: measured neutral)
             auto load_frags = [&](auto ntap_c, int kg, FragR (&af)[NI], FragR (&bfr)[IPW]) {
                 constexpr int NTAP = decltype(ntap_c)::value;
                 const int q0 = kg * KUNIT;
@@ -2092,6 +2102,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                     }
 #pragma unroll
                     for (int t2 = 0; t2 < NTAP; ++t2) {
+                        if (TAIL_BRANCH && t2 == IPW - 1 && !last_tap_live) continue;        // wave-uniform: this wave's last slot holds no tap
                         const char* bp = bt + hbase + tapoff[t2] + b_lane;
                         bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp));
                         bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp + 4 * S * RS));
@@ -2101,7 +2112,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) af[ni] = *(const float*)(at + q0 * RSA + a_lane + ni * CT * 4);
 #pragma unroll
-                    for (int t2 = 0; t2 < NTAP; ++t2) bfr[t2] = *(const float*)(bt + hbase + tapoff[t2] + b_lane);
+                    for (int t2 = 0; t2 < NTAP; ++t2) { if (TAIL_BRANCH && t2 == IPW - 1 && !last_tap_live) continue; bfr[t2] = *(const float*)(bt + hbase + tapoff[t2] + b_lane); }
                 }
             };
             issue_prep(have_next ? nbrick : brick, have_next);
@@ -2127,6 +2138,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                     for (int t2 = 0; t2 < NTAP; ++t2)
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni) {
+                            if (TAIL_BRANCH && t2 == IPW - 1 && !last_tap_live) continue;
                             if constexpr (sizeof(T) == 2) acc[t2][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[idx & 1][ni], fb[idx & 1][t2], acc[t2][ni], 0, 0, 0);
                             else acc[t2][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[idx & 1][ni], fb[idx & 1][t2], acc[t2][ni], 0, 0, 0);
                         }
@@ -2180,7 +2192,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                 }
             };
             // (a second copy of the phase only where it removes >= 1/8 of the slots: 27 taps on 32; the 2-D kernels' 9 on 10 stay branch-free)
-            constexpr bool TWO_PHASES = IPW > 1 && (IPW * WPQ - TAPS) * 8 >= IPW * WPQ;
+            constexpr bool TWO_PHASES = IPW > 1 && (IPW * WPQ - TAPS) * BIU_TWO_PHASE_DIV >= IPW * WPQ;
             if constexpr (RR) {
                 using Full = std::integral_constant<int, TD * TH>;
                 using Half = std::integral_constant<int, TD * TH / 2>;
