@@ -61,6 +61,21 @@ template <> struct Frag<float> {
     }
 };
 
+// T(v) = max(t, slope * t), t = scale * v + shift on PE values: the affine part and the slope product as packed fp32 pairs
+// (v_pk_fma_f32 / v_pk_mul_f32: half the VALU instructions of the scalar form; there is no packed max)
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+template <int PE>
+__device__ __forceinline__ void lrelu_affine(float (&f)[PE], const float* sc, const float* sh, const float* sl) {
+#pragma unroll
+    for (int e = 0; e < PE; e += 2) {
+        const floatx2 v = {f[e], f[e + 1]}, s = {sc[e], sc[e + 1]}, b = {sh[e], sh[e + 1]}, l = {sl[e], sl[e + 1]};
+        const floatx2 t = __builtin_elementwise_fma(s, v, b);
+        const floatx2 u = l * t;
+        f[e] = fmaxf(t[0], u[0]);
+        f[e + 1] = fmaxf(t[1], u[1]);
+    }
+}
+
 struct ConvArgs {
     const char* x;
     char* y;
@@ -379,11 +394,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
                 if (xf_here && ((inb_mask >> j) & 1u)) {
                     float f[PE];
                     F::unpack(v, f);
-#pragma unroll
-                    for (int e = 0; e < PE; ++e) {
-                        const float t = fmaf(sc[e], f[e], sh[e]);
-                        f[e] = fmaxf(t, sl[e] * t);
-                    }
+                    lrelu_affine<PE>(f, sc, sh, sl);
                     v = F::pack(f);
                 }
                 lact[p_mine * PSV + i / CKP] = v;
@@ -839,11 +850,7 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
                 if (has_xf && ((inb_mask >> j) & 1u)) {
                     float f[PE];
                     F::unpack(v, f);
-#pragma unroll
-                    for (int e = 0; e < PE; ++e) {
-                        const float t = fmaf(sc[e], f[e], sh[e]);
-                        f[e] = fmaxf(t, sl[e] * t);
-                    }
+                    lrelu_affine<PE>(f, sc, sh, sl);
                     v = F::pack(f);
                 }
                 lact[p_mine * PSV + i / CKP] = v;
@@ -887,6 +894,11 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
         }
     };
 
+#ifdef BIU_DIAG
+    unsigned long long tprev_ = __builtin_readcyclecounter();
+    unsigned long long dsum_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t0c_ = tprev_, t0r_ = __builtin_amdgcn_s_memrealtime();
+#endif
     int k = 0;
     int brick = brick_of(0);
     if (brick >= nbricks) return;
@@ -912,6 +924,7 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
         int nbrick = brick, nch = ch + 1, nk = k;
         if (nch == nchunks) { nch = 0; nk = k + 1; nbrick = brick_of(nk); }
         const bool have_next = nbrick < nbricks;
+        DIAG_STAMP(0);
         const uint4* lwc = lw + wcur * WN + lane;
         issue_prep(have_next ? nbrick : brick, nch, have_next);
 #pragma unroll
@@ -934,6 +947,8 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        DIAG_STAMP(1);
+        DIAG_STAMP(2);
         if (ch == nchunks - 1) {
             // epilogue: lane = (voxel n16 of row mt, channels 4 q4 .. + 3): 8-byte stores, 16 voxels x 32 B contiguous per wave-store
             const Org o = origin(brick);
@@ -989,12 +1004,24 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
                 if (want_stats) reduce4(t1, t2);
             }
         }
+        DIAG_STAMP(3);
+#ifdef BIU_DIAG
+        dsum_[7] += 1;
+        if (!have_next && a.diag && tid == 0) {
+            for (int q_ = 0; q_ < 8; ++q_) atomicAdd(a.diag + q_, dsum_[q_]);
+            atomicAdd(a.diag + 8, __builtin_readcyclecounter() - t0c_);
+            atomicAdd(a.diag + 9, __builtin_amdgcn_s_memrealtime() - t0r_);
+        }
+#endif
         if (!have_next) break;
         __syncthreads();                     // everyone is done reading the tile
+        DIAG_STAMP(4);
         commit(nch);
         if (nchunks > 1) wcur ^= 1;                           // (one chunk per brick: the slab loaded for the first item stays)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // weight DMA landed
+        DIAG_STAMP(5);
         __syncthreads();
+        DIAG_STAMP(6);
         brick = nbrick; ch = nch; k = nk;
     }
     if constexpr (!RED) {
@@ -1730,11 +1757,7 @@ __device__ __forceinline__ uint4 apply_xf16(uint4 v, const float* sc, const floa
     using F = Frag<T>;
     float f[PE];
     F::unpack(v, f);
-#pragma unroll
-    for (int e = 0; e < PE; ++e) {
-        const float tt = fmaf(sc[e], f[e], sh[e]);
-        f[e] = fmaxf(tt, sl[e] * tt);
-    }
+    lrelu_affine<PE>(f, sc, sh, sl);
     return F::pack(f);
 }
 
