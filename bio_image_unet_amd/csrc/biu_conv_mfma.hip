@@ -786,6 +786,7 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
     const int hvb = q4 * PSV + (ld_w * HH + lh_w) * HW + n16;      // fragment address of row 0, tap (0, 0, 0)
 
     floatx4m acc[R];
+    uint2 yrp[RED ? R : 1];
     uint4 pa[NPA];
     int wcur = 0;
     constexpr unsigned GBITS = (1u << 9) | (1u << 19) | (1u << 29);
@@ -930,6 +931,20 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int ta = g / 3, tc = g % 3;
+            if constexpr (RED) {
+                // the upstream block's raw output at this lane's voxels, needed by the epilogue's BatchNorm-backward sums: requested at
+                // the start of the brick's last MFMA phase instead of inside the epilogue (a global round trip per brick otherwise)
+                if (g == 0 && ch == nchunks - 1 && want_stats) {
+                    const Org o = origin(brick);
+#pragma unroll
+                    for (int mt = 0; mt < R; ++mt) {
+                        const int gd = o.d0 + ld_w, gh = o.h0 + lh_w + mt, gw = o.w0 + n16;
+                        const bool ok = 4 * q4 < a.Cout && gd < a.GD && gh < a.GH && gw < a.GW;
+                        const size_t vox = ((size_t)(o.n * a.OD + gd) * a.OH + gh) * a.OW + gw;
+                        yrp[mt] = ok ? *(const uint2*)((const T*)a.red_y + vox * a.red_ypitch + 4 * q4) : make_uint2(0, 0);
+                    }
+                }
+            }
 #pragma unroll
             for (int j = pf_lo(g, NPA, NG); j < pf_lo(g + 1, NPA, NG); ++j) issue_piece(j);
 #pragma unroll
@@ -987,7 +1002,7 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { s1[e] += f[e]; s2[e] = fmaf(f[e], f[e], s2[e]); }
                     } else {
-                        const uint2 yr = *(const uint2*)((const T*)a.red_y + vox * a.red_ypitch + 4 * q4);
+                        const uint2 yr = yrp[mt];
                         const float yv[4] = {__uint_as_float(yr.x << 16), __uint_as_float(yr.x & 0xffff0000u), __uint_as_float(yr.y << 16),
                                              __uint_as_float(yr.y & 0xffff0000u)};
 #pragma unroll
