@@ -617,8 +617,20 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
                             t1[e] = t2[e] = 0.f;
                         }
                     }
+                    // RED: the upstream block's raw output at this lane's MT voxels -- all MT loads of the piece in flight together
+                    // (inside the loop below they were MT serial round trips per piece, NT * NP * MT per brick)
+                    constexpr int YB = (MT > 2) ? 2 : MT;           // loads per batch (MT = 4: two batches of two -- all four spill)
+                    uint4 yq[RED ? YB : 1];
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
+                        if constexpr (RED) {
+                            if (want_stats && mt % YB == 0) {
+#pragma unroll
+                                for (int m2 = 0; m2 < YB; ++m2)
+                                    yq[m2] = (c_ok && vo[mt + m2] >= 0) ? *(const uint4*)((const T*)a.red_y + (size_t)vo[mt + m2] * a.red_ypitch + cl)
+                                                                        : make_uint4(0, 0, 0, 0);
+                            }
+                        }
                         uint4 piece;
                         if constexpr (sizeof(T) == 2) {
                             Pack<T, 4> g0, g1;
@@ -655,7 +667,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
                                 }
                             } else {
                                 float yv[CPP];
-                                F::unpack(*(const uint4*)((const T*)a.red_y + vox * a.red_ypitch + cl), yv);
+                                F::unpack(yq[mt % YB], yv);
 #pragma unroll
                                 for (int e = 0; e < CPP; ++e) {
                                     const float tt = fmaf(rsc[e], yv[e], rsh[e]);
