@@ -123,7 +123,14 @@ __global__ __launch_bounds__(NTHR) void k_convt_all(CtArgs a) {
         if (tid < NTB * 32) {
             const int co = nt0 * 32 + tid;
             lbias[tid] = (!DGRAD && a.bias && co < a.Chi) ? a.bias[co] : 0.f;
-            if (RED) { lred[2 * tid] = 0.f; lred[2 * tid + 1] = 0.f; }
+            if (RED) {
+                lred[2 * tid] = 0.f; lred[2 * tid + 1] = 0.f;
+                // the upstream block's transform vectors, read from LDS in the epilogue (lxf is free in the data-gradient kernels)
+                const bool okc = co < a.Clo;
+                lxf[tid] = okc ? a.red_scale[co] : 0.f;
+                lxf[NTB * 32 + tid] = okc ? a.red_shift[co] : 0.f;
+                lxf[2 * NTB * 32 + tid] = (okc && a.red_slope) ? a.red_slope[co] : 1.f;
+            }
         }
     }
     __syncthreads();
@@ -208,6 +215,16 @@ __global__ __launch_bounds__(NTHR) void k_convt_all(CtArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
             uint4 bcur[MAXKS], bnxt[MAXKS];
+            uint4 yq[RED ? NTB : 1][2];                          // RED: the upstream block's raw output at this lane's voxel, requested before
+            if constexpr (RED) {                                 // the eight parities are multiplied (it was a round trip per piece in the epilogue)
+#pragma unroll
+                for (int nt = 0; nt < NTB; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int ci = (nt0 + nt) * 32 + 16 * q + 8 * hf;
+                        yq[nt][q] = (vok && ci < a.Clo) ? *(const uint4*)(a.red_y + ((size_t)vc * a.red_ypitch + ci) * 2) : make_uint4(0, 0, 0, 0);
+                    }
+            }
             {
                 const char* row = a.hi + fine_row(0) * 2;
 #pragma unroll
@@ -255,11 +272,12 @@ __global__ __launch_bounds__(NTHR) void k_convt_all(CtArgs a) {
                     if constexpr (RED) {
                         float f[8], yv[8];
                         unpack8(piece, f);                              // sums of the values as stored
-                        unpack8(*(const uint4*)(a.red_y + ((size_t)vc * a.red_ypitch + ci) * 2), yv);
+                        unpack8(yq[nt][q], yv);
+                        const int cl = nt * 32 + 16 * q + 8 * hf;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            const float tt = fmaf(a.red_scale[ci + e], yv[e], a.red_shift[ci + e]);
-                            const float dz = f[e] * (tt > 0.f ? 1.f : (a.red_slope ? a.red_slope[ci + e] : 1.f));
+                            const float tt = fmaf(lxf[cl + e], yv[e], lxf[NTB * 32 + cl + e]);
+                            const float dz = f[e] * (tt > 0.f ? 1.f : lxf[2 * NTB * 32 + cl + e]);
                             s1[nt][q][e] += dz;
                             s2[nt][q][e] = fmaf(dz, yv[e], s2[nt][q][e]);
                         }
