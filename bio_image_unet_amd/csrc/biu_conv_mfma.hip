@@ -1188,6 +1188,16 @@ static int num_cus() {
     return n;
 }
 
+// Blocks per column of a persistent launch with `cols` columns (channel tiles x splits): a multiple of 8 keeps the block id's XCD equal
+// to blockIdx.x mod 8 (halo neighbours of the brick walk share an L2), but rounding 85 down to 80 leaves 6 % of the CUs without a
+// block -- the exact quotient wins when the rounding would idle more than 1/32 of the chip (the walk then falls back to plain order).
+static int grid_per_column(int budget, int cols) {
+    const int exact = budget / cols, r8 = exact & ~7;
+    int g = ((exact - r8) * cols * 32 > budget) ? exact : r8;
+    if (g < 8) g = 8;
+    return g;
+}
+
 template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP, bool RED, int NW>
 static int launch_cfg_r(const ConvArgs& a0, int ntiles, int nz, hipStream_t st) {
     ConvArgs a = a0;
@@ -1202,9 +1212,7 @@ static int launch_cfg_r(const ConvArgs& a0, int ntiles, int nz, hipStream_t st) 
     a.nbw = (a.GW + TW - 1) / TW;
     const int nbricks = a.N * a.nbd * a.nbh * a.nbw;
     const int gy = ntiles / NT;
-    int g = (NW == 8 ? 1 : 2) * num_cus() / (gy * nz);
-    g &= ~7;
-    if (g < 8) g = 8;
+    int g = grid_per_column((NW == 8 ? 1 : 2) * num_cus(), gy * nz);
     if (g > nbricks) g = nbricks;
     dim3 grid((unsigned)g, (unsigned)gy, (unsigned)nz);
     auto kern = k_conv_pipe<T, KD, KHW, S, TD, TH, TW, NT, CKP, RED, NW>;
@@ -1321,9 +1329,7 @@ int biu_mfma_convt_dgrad_bricks(const biu_act* dx, int kd) {
 // partial rows its fused BatchNorm-backward sums occupy: one per workgroup column (must mirror launch_cfg_r's grid computation)
 int biu_mfma_convt_dgrad_rows(const biu_act* dx, int kd) {
     const int ntiles = (dx->c + 31) / 32, gy = ntiles / pick_nt(ntiles);
-    int g = num_cus() / gy;
-    g &= ~7;
-    if (g < 8) g = 8;
+    int g = grid_per_column(num_cus(), gy);
     const int nbricks = biu_mfma_convt_dgrad_bricks(dx, kd);
     return g > nbricks ? nbricks : g;
 }
@@ -1357,9 +1363,7 @@ int biu_mfma_conv_stat_rows(const biu_act* y, int kd, const biu_act* x, int dtyp
     }
     const int ntiles = (y->c + 31) / 32;
     const int nt = pick_nt(ntiles);
-    int g = num_cus() / (ntiles / nt);
-    g &= ~7;
-    if (g < 8) g = 8;
+    int g = grid_per_column(num_cus(), ntiles / nt);
     const int nbricks = biu_mfma_conv_bricks(y, kd, x ? x : y, x ? dtype : -1);
     return g > nbricks ? nbricks : g;
 }
@@ -2413,7 +2417,7 @@ static int launch_wgrad(WgradArgs a, hipStream_t st) {
         b.jt_begin = jt_begin; b.jt_count = jt_count; b.write_back = write_back;
         const int pairs = nit * jt_count;
         int g = num_cus() / pairs;                        // persistent: about one block per CU in total
-        if (g >= 16) g &= ~7;                             // multiple of 8: linear block id mod 8 (the XCD) == blockIdx.x mod 8
+        if (g >= 16) g = grid_per_column(num_cus(), pairs);   // multiple of 8 (linear block id mod 8 == blockIdx.x mod 8) unless that idles > 3 % of the CUs
         if (g < 1) g = 1;
         if (g > b.nbricks) g = b.nbricks;
         hipLaunchKernelGGL(kern, dim3(g, pairs), dim3(512), lds_bytes, st, b);
