@@ -27,6 +27,8 @@ import torch  # noqa: E402
 
 HBM_PEAK = 8.0e12            # B/s   (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
 MFMA_PEAK = {"bf16": 2.5e15, "f32": 157.3e12}
+# --fp32-products bf16x3 (opt-in, fp32 workloads only): the 2-D 3x3 kernels multiply fp32 tensors as three bf16 MFMAs per product with
+# fp32 accumulation; the ceiling of those launches is a third of the bf16 peak.
 
 HEADS5 = {"seg": {"channels": 1, "activation": "sigmoid"}, "flow": {"channels": 2, "activation": None},
           "dist": {"channels": 1, "activation": "sigmoid"}}
@@ -193,6 +195,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp32-products", default="exact", choices=["exact", "bf16x3"], help="fp32 workloads: how the 3x3 kernels multiply (default: fp32 MFMA)")
     ap.add_argument("--breakdown", default=None, help="write the per-launch time table of one profiled step to this file")
     args = ap.parse_args()
 
@@ -206,6 +209,9 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     wl = WORKLOADS[args.workload]
+    if args.fp32_products != "exact":
+        import bio_image_unet_amd
+        bio_image_unet_amd.set_fp32_products(args.fp32_products)
     model, step, fwd, nvox, avg = make_step(wl, device)
 
     def barrier():
@@ -267,10 +273,12 @@ def main():
     dom_launch_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in watched) / max(len(watched), 1)
     fl, by = call_cost(eng, *dom_key)
     dt_name = wl["dtype"]
+    x3 = dt_name == "f32" and wl["model"] in ("Unet", "Siam_UNet") and args.fp32_products == "bf16x3"
+    mfma_peak = MFMA_PEAK["bf16"] / 3 if x3 else MFMA_PEAK[dt_name]
     ai = fl / by if by else 0.0
-    ridge = MFMA_PEAK[dt_name] / HBM_PEAK
+    ridge = mfma_peak / HBM_PEAK
     if fl > 0 and ai >= ridge * 0.5:
-        roof = {"bound": "mfma", "achieved": fl / (dom_launch_ms * 1e-3) / 1e12, "peak": MFMA_PEAK[dt_name] / 1e12, "unit": "TFLOP/s"}
+        roof = {"bound": "mfma", "achieved": fl / (dom_launch_ms * 1e-3) / 1e12, "peak": mfma_peak / 1e12, "unit": "TFLOP/s"}
     else:
         roof = {"bound": "hbm", "achieved": by / (dom_launch_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
@@ -298,10 +306,14 @@ def main():
                                "train step = forward + reference loss + backward + Adam", "parallelism": f"dp{world}"},
         "fwd_only": {"value": nvox / (fwd_ms * 1e-3) * world, "unit": "voxels/s", "ms": fwd_ms},
         "step_roofline": {"hbm_frac_algorithmic": vps_gpu * per_vox[1] / HBM_PEAK, "algorithmic_GBps": vps_gpu * per_vox[1] / 1e9,
-                          "algorithmic_TFLOPps": vps_gpu * per_vox[0] / 1e12, "mfma_frac": vps_gpu * per_vox[0] / MFMA_PEAK[dt_name],
+                          "algorithmic_TFLOPps": vps_gpu * per_vox[0] / 1e12, "mfma_frac": vps_gpu * per_vox[0] / mfma_peak,
                           "kernel_time_ms_one_step": total_kernel_ms},
         "roofline": roof,
     }
+    if x3:
+        out["arithmetic"] = ("fp32 tensors and accumulators; the products of the 3x3 convolutions (forward, data and weight gradient) are bf16x3: "
+                             "operands split hi + lo in bf16, hi*hi + hi*lo + lo*hi on the bf16 MFMA, <= 2^-15 relative per product; "
+                             "roofline peak = bf16 dense peak / 3")
     if world > 1:           # gradient all-reduce: decoder -> encoder buckets, issued from inside backward (bio_image_unet_amd/ddp.py)
         out["ddp"] = {"buckets": len(avg.buckets), "launched_in_backward": avg.launched_in_backward,
                       "bucket_mbytes": [round(b.flat.numel() * 4 / 2 ** 20, 2) for b in avg.buckets]}

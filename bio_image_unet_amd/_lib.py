@@ -48,6 +48,7 @@ _Z = C.c_size_t
 SIGNATURES = {
     "biu_last_error": (C.c_char_p, []),
     "biu_version": (_I, []),
+    "biu_set_fp32_products": (_I, [_I]),
     "biu_conv_packed_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "biu_conv_pack": (_I, [_I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "biu_pack_batch": (_I, [_P, _I, _I, _P]),

@@ -61,6 +61,27 @@ template <> struct Frag<float> {
     }
 };
 
+// fp32 tensors multiplied on the bf16 matrix pipe ("bf16x3"): every operand value v is split into hi = bf16(v) and lo = bf16(v - hi)
+// (round to nearest even; v - hi is exact in fp32), and a product is taken as hi*hi' + hi*lo' + lo*hi' with fp32 accumulation -- the
+// dropped lo*lo' term and the rounding of lo are each <= 2^-16 of |v v'|.  Three 32x32x16 bf16 MFMAs (96 cycles) cover the 16 reduction
+// channels that take eight 32x32x2 fp32 MFMAs (512 cycles).  Global memory stays fp32 on both sides; the split happens while staging.
+struct f32x3_t { float v; };
+template <> struct Frag<f32x3_t> : Frag<float> {};
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_bf16x3(const float (&f)[4], uint2& hi, uint2& lo) {
+    bf16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = (__bf16)f[e];
+        l[e] = (__bf16)(f[e] - (float)h[e]);
+    }
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
+}
+__device__ __forceinline__ void mma_bf16(const uint4& a, const uint4& b, floatx16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 // T(v) = max(t, slope * t), t = scale * v + shift on PE values: the affine part and the slope product as packed fp32 pairs
 // (v_pk_fma_f32 / v_pk_mul_f32: half the VALU instructions of the scalar form; there is no packed max)
 typedef float floatx2 __attribute__((ext_vector_type(2)));
@@ -184,6 +205,8 @@ template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, in
 __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     using F = Frag<T>;
     constexpr int NTHR = NW * 64, NWAVE = NW;         // NW = 8: one block per CU; NW = 4: two (half the LDS each)
+    constexpr bool X3 = std::is_same<T, f32x3_t>::value;     // fp32 tensors, bf16x3 products: a chunk is 16 channels = planes [hi|lo][hf] of 8 bf16
+    static_assert(!X3 || CKP == 4, "bf16x3 chunks are 16 channels (4 fp32 pieces)");
     constexpr int PE = F::PE;
     constexpr int PD = (KD == 3) ? 1 : 0;
     constexpr int PHW = (KHW == 3) ? 1 : 0;
@@ -386,6 +409,25 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < PE; ++e) { sc[e] = lxf[c0 + e]; sh[e] = lxf[a.Cin + c0 + e]; sl[e] = lxf[2 * a.Cin + c0 + e]; }
         }
+        if constexpr (X3) {
+            // piece p = 4 channels 4p .. 4p+3 of the chunk; lane half hf = p & 1 multiplies pieces hf and hf + 2 as ONE 8-element fragment:
+            // plane (hi: hf, lo: 2 + hf), slot of the voxel, 8-byte half p >> 1
+            uint2* l2 = (uint2*)lact;
+#pragma unroll
+            for (int j = 0; j < NPA; ++j) {
+                const int i = tid + NTHR * j;
+                if (i < HV * CKP) {
+                    float f[4];
+                    F::unpack(pa[j], f);
+                    if (xf_here && ((inb_mask >> j) & 1u)) lrelu_affine<4>(f, sc, sh, sl);
+                    uint2 hi, lo;
+                    split_bf16x3(f, hi, lo);
+                    const int slot = ((p_mine & 1) * PSV + i / CKP) * 2 + (p_mine >> 1);
+                    l2[slot] = hi;
+                    l2[slot + 4 * PSV] = lo;
+                }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < NPA; ++j) {
             const int i = tid + NTHR * j;
@@ -399,6 +441,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
                 }
                 lact[p_mine * PSV + i / CKP] = v;
             }
+        }
         }
         if constexpr (!WGLDS) {
 #pragma unroll
@@ -503,6 +546,23 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
         auto window = [&](int ta, int tb) {
             const uint4* lwp = lwc + ((ta * KHW + tb) * KHW) * (SPC * NT * 64);
             const uint4* lap = lact + (ta * HH + tb) * HW;
+            if constexpr (X3) {
+#pragma unroll
+                for (int tc = 0; tc < KHW; ++tc) {
+                    uint4 wh[NT], wl[NT], bh[MT], bl[MT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) { wh[nt] = lwp[(tc * 2 * NT + nt) * 64]; wl[nt] = lwp[((tc * 2 + 1) * NT + nt) * 64]; }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) { bh[mt] = lap[hvb[mt] + tc]; bl[mt] = lap[hvb[mt] + 2 * PSV + tc]; }
+#pragma unroll
+                    for (int term = 0; term < 3; ++term)        // small terms first; MT * NT independent accumulators between dependent MFMAs
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) mma_bf16(term == 0 ? wl[nt] : wh[nt], term == 1 ? bl[mt] : bh[mt], acc[nt][mt]);
+                }
+                return;
+            }
 #pragma unroll
             for (int st2 = 0; st2 < KHW * SPC; ++st2) {
                 const int tc = st2 / SPC, sidx = st2 % SPC;
@@ -522,6 +582,28 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
         // activation traffic per MFMA instead of 1 KiB, which at NT = 1 is what bounded the kernel (LDS: 128 B/clk per CU against
         // 4 SIMDs * 1.25 KiB per 32-cycle MFMA).
         auto window_h = [&](int ta, int tc) {
+            if constexpr (X3) {
+                uint4 rh[MT + 2], rl[MT + 2];
+                const uint4* lap = lact + hvb[0] + ta * HH * HW + tc;
+#pragma unroll
+                for (int j = 0; j < MT + 2; ++j) { rh[j] = lap[j * HW]; rl[j] = lap[2 * PSV + j * HW]; }
+#pragma unroll
+                for (int tb = 0; tb < KHW; ++tb) {
+                    uint4 wh[NT], wl[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        wh[nt] = lwc[((((ta * KHW + tb) * KHW + tc) * 2) * NT + nt) * 64];
+                        wl[nt] = lwc[((((ta * KHW + tb) * KHW + tc) * 2 + 1) * NT + nt) * 64];
+                    }
+#pragma unroll
+                    for (int term = 0; term < 3; ++term)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) mma_bf16(term == 0 ? wl[nt] : wh[nt], term == 1 ? rl[mt + tb] : rh[mt + tb], acc[nt][mt]);
+                }
+                return;
+            }
 #pragma unroll
             for (int sidx = 0; sidx < SPC; ++sidx) {
                 uint4 rows[MT + 2];
@@ -1086,9 +1168,22 @@ __global__ void k_pack_weights16(const float* __restrict__ w, int cin, int cout,
 // ---------------------------------------------------------------------------------------------------------------
 // weight packing: out[ntile][kstep][tap][lane] (16 B each); lane (r, h) holds W[i = 32*ntile + r][k = KS*kstep + PE*h + e]
 // ---------------------------------------------------------------------------------------------------------------
+// bf16x3 image of an fp32 weight fragment (k_conv_pipe<f32x3_t>): the k-steps 2s and 2s+1 of a lane hold the hi halves and the lo halves
+// of its 8 weights k = 8 (2s + (u >> 2)) + 4 hf + (u & 3), u = 0..7 -- the order the kernel stages the activations in
+template <typename Load>
+__device__ __forceinline__ uint4 x3_weight_piece(int ks, int hf, Load&& wload) {
+    float f0[4], f1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f0[e] = wload((ks & ~1) * 8 + hf * 4 + e); f1[e] = wload((ks | 1) * 8 + hf * 4 + e); }
+    uint2 h0, l0, h1, l1;
+    split_bf16x3(f0, h0, l0);
+    split_bf16x3(f1, h1, l1);
+    return (ks & 1) ? make_uint4(l0.x, l0.y, l1.x, l1.y) : make_uint4(h0.x, h0.y, h1.x, h1.y);
+}
+
 template <typename T>
 __global__ void k_pack_weights(const float* __restrict__ w, int cin, int cout, int taps, int kind, int Kc, int Nc,
-                               int nKS, int ntiles, uint4* __restrict__ out) {
+                               int nKS, int ntiles, uint4* __restrict__ out, int x3) {
     using F = Frag<T>;
     constexpr int PE = F::PE;
     const size_t total = (size_t)ntiles * nKS * taps * 64;
@@ -1099,6 +1194,15 @@ __global__ void k_pack_weights(const float* __restrict__ w, int cin, int cout, i
         const int ks = (int)(t % nKS);
         const int nt = (int)(t / nKS);
         const int i = nt * 32 + (lane & 31);
+        if constexpr (sizeof(T) == 4) {
+            if (x3) {
+                out[idx] = x3_weight_piece(ks, lane >> 5, [&](int k) -> float {
+                    if (i >= Nc || k >= Kc) return 0.f;
+                    return kind == 0 ? w[((size_t)i * cin + k) * taps + tap] : w[((size_t)k * cin + i) * taps + (taps - 1 - tap)];
+                });
+                continue;
+            }
+        }
         float f[PE];
 #pragma unroll
         for (int e = 0; e < PE; ++e) {
@@ -1128,6 +1232,27 @@ static bool m16_disabled() {
     if (v < 0) { const char* e = getenv("BIU_DISABLE"); v = (e && strstr(e, "m16")) ? 1 : 0; }
     return v == 1;
 }
+// Opt-in (biu_set_fp32_products(1), or BIU_FP32_PRODUCTS=bf16x3 in the environment): the fp32 2-D 3x3 convolutions -- forward, data gradient
+// (reduction channels in chunks of 16) and weight gradient -- run as bf16x3 products; the packed weights of such a layer carry the (hi, lo)
+// image (x3_weight_piece).  The mode is fixed by its first use in the process: packed images of one mode must never meet launches of the other.
+static int g_x3_mode = -1;           // -1: not decided yet
+static bool g_x3_used = false;
+static std::mutex g_x3_mu;
+static bool x3_disabled() {
+    std::lock_guard<std::mutex> lock(g_x3_mu);
+    if (g_x3_mode < 0) { const char* e = getenv("BIU_FP32_PRODUCTS"); g_x3_mode = (e && strstr(e, "bf16x3")) ? 1 : 0; }
+    g_x3_used = true;
+    return g_x3_mode != 1;
+}
+int biu_mfma_set_fp32_products(int mode) {
+    std::lock_guard<std::mutex> lock(g_x3_mu);
+    if (mode != 0 && mode != 1) return biu_fail(BIU_ERR_UNSUPPORTED, "set_fp32_products: mode %d (0 = exact fp32 MFMA, 1 = bf16x3)", mode);
+    if (g_x3_used && g_x3_mode != mode)
+        return biu_fail(BIU_ERR_UNSUPPORTED, "set_fp32_products: fp32 kernels already ran in the other mode (set it before the first forward)");
+    g_x3_mode = mode;
+    return BIU_OK;
+}
+static bool x3_ok(int K, int kd, int dtype) { return dtype == BIU_F32 && kd == 1 && K >= 16 && K % 16 == 0 && !x3_disabled(); }
 static bool m16_chan_ok(int K, int Nn, int dtype) { return dtype == BIU_BF16 && Nn == 16 && K >= 32 && K % 32 == 0; }
 static size_t regular_packed_bytes(int K, int Nn, int taps, int dtype) {
     const size_t ntiles = (Nn + 31) / 32, nKS = K / ks_of(dtype);
@@ -1149,7 +1274,7 @@ int biu_mfma_pack(int kind, const float* w, int cin, int cout, int kd, int kh, i
     const int taps = kd * kh * kw, ntiles = (Nn + 31) / 32, nKS = K / ks_of(dtype);
     const size_t total = (size_t)ntiles * nKS * taps * 64;
     BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_weights<T>, dim3(grid_for((i64)total, 256, 4096)), dim3(256), 0, st, w, cin,
-                                                 cout, taps, kind, K, Nn, nKS, ntiles, (uint4*)packed));
+                                                 cout, taps, kind, K, Nn, nKS, ntiles, (uint4*)packed, x3_ok(K, kd, dtype) ? 1 : 0));
     BIU_CHECK_LAUNCH("pack_weights");
     if (m16_chan_ok(K, Nn, dtype)) {
         const size_t total16 = (size_t)(K / 32) * taps * 64;
@@ -1262,7 +1387,7 @@ int biu_mfma_conv_ksplit(int cin, const biu_act* y, int kd, int dtype) {
     const int ntiles = (y->c + 31) / 32, nt = pick_nt(ntiles);
     const BrickDim b = conv3_brick(kd, nt, y->w % 32 == 0);
     const long blocks = (long)y->n * ((y->d + b.td - 1) / b.td) * ((y->h + b.th - 1) / b.th) * ((y->w + b.tw - 1) / b.tw) * (ntiles / nt);
-    const int nchunks = cin / 8;
+    const int nchunks = x3_ok(cin, kd, dtype) ? cin / 16 : cin / 8;
     int ks = 1;
     while (blocks * ks * 2 <= num_cus() && nchunks / (ks * 2) >= 4 && ks < 32) ks *= 2;
     return ks;
@@ -1318,6 +1443,16 @@ static int launch_conv(const ConvArgs& a, int kd, hipStream_t st) {
     }
     if (nt == 1) return wide ? launch_cfg<T, 1, 3, 1, 1, 32, 32, 1, 2>(a, ntiles, nz, st) : launch_cfg<T, 1, 3, 1, 1, 64, 16, 1, 2>(a, ntiles, nz, st);
     return wide ? launch_cfg<T, 1, 3, 1, 1, 16, 32, 2, 2>(a, ntiles, nz, st) : launch_cfg<T, 1, 3, 1, 1, 32, 16, 2, 2>(a, ntiles, nz, st);
+}
+
+// fp32 2-D 3x3 as bf16x3 products (x3_ok): the bricks of launch_conv<float>, 16-channel chunks
+static int launch_conv_x3(const ConvArgs& a, hipStream_t st) {
+    const int ntiles = (a.Cout + 31) / 32;
+    const int nt = pick_nt(ntiles);
+    const bool wide = (a.GW % 32 == 0);
+    const int nz = a.ksplit > 1 ? a.ksplit : 1;
+    if (nt == 1) return wide ? launch_cfg<f32x3_t, 1, 3, 1, 1, 32, 32, 1, 4>(a, ntiles, nz, st) : launch_cfg<f32x3_t, 1, 3, 1, 1, 64, 16, 1, 4>(a, ntiles, nz, st);
+    return wide ? launch_cfg<f32x3_t, 1, 3, 1, 1, 16, 32, 2, 4>(a, ntiles, nz, st) : launch_cfg<f32x3_t, 1, 3, 1, 1, 32, 16, 2, 4>(a, ntiles, nz, st);
 }
 
 // number of bricks of a ConvTranspose data-gradient launch on the coarse tensor dx
@@ -1486,7 +1621,7 @@ int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, con
                 b.ksplit = ks;
                 b.y = ws; b.y_zstride = sl0; b.accumulate = 0;
                 if (y1t) { b.y1 = ws + (size_t)ks * sl0; b.y1_zstride = sl1; b.accumulate1 = 0; }
-                rc = launch_conv<float>(b, kd, st);
+                rc = x3_ok(b.Cin, kd, dtype) ? launch_conv_x3(b, st) : launch_conv<float>(b, kd, st);
                 if (rc == BIU_OK) {
                     hipLaunchKernelGGL(k_split_reduce, dim3(grid_for((i64)nvox(y) * y->c, 256, 2048)), dim3(256), 0, st, (const float*)ws, sl0 / sizeof(float),
                                        ks, (float*)y->p, (long)nvox(y), y->c, y->pitch, accumulate);
@@ -1506,6 +1641,7 @@ int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, con
         return kd == 3 ? launch_conv16<3, 4, 8>(a, st) : launch_conv16<1, 1, 32>(a, st);
     }
     if (dtype == BIU_BF16) return launch_conv<bf16_t>(a, kd, st);
+    if (x3_ok(a.Cin, kd, dtype)) return launch_conv_x3(a, st);
     return launch_conv<float>(a, kd, st);
 }
 
@@ -1569,7 +1705,7 @@ int biu_mfma_convt_pack(int kind, const float* w, int cin, int cout, int kd, int
 // from the step's critical path.
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void k_pack_batch(const biu_pack_job* __restrict__ jobs) {
+__global__ void k_pack_batch(const biu_pack_job* __restrict__ jobs, int x3_on) {
     using F = Frag<T>;
     constexpr int PE = F::PE;
     const biu_pack_job j = jobs[blockIdx.y];
@@ -1587,6 +1723,15 @@ __global__ void k_pack_batch(const biu_pack_job* __restrict__ jobs) {
         if (j.transposed && kind == 0) { ks = (int)(t % nKS); t /= nKS; nt = (int)(t % ntiles); tap = (int)(t / ntiles); }
         else { tap = (int)(t % taps); t /= taps; ks = (int)(t % nKS); nt = (int)(t / nKS); }
         const int i = nt * 32 + (lane & 31);
+        if constexpr (sizeof(T) == 4) {
+            if (x3_on && !j.transposed && j.kd == 1 && Kc % 16 == 0) {        // == x3_ok(): the bf16x3 image of a 2-D 3x3 layer
+                out[idx] = x3_weight_piece(ks, lane >> 5, [&](int k) -> float {
+                    if (i >= Nc || k >= Kc) return 0.f;
+                    return kind == 0 ? w[((size_t)i * cin + k) * taps + tap] : w[((size_t)k * cin + i) * taps + (taps - 1 - tap)];
+                });
+                continue;
+            }
+        }
         float f[PE];
 #pragma unroll
         for (int e = 0; e < PE; ++e) {
@@ -1623,7 +1768,7 @@ __global__ void k_pack_batch(const biu_pack_job* __restrict__ jobs) {
 }
 int biu_mfma_pack_batch(const biu_pack_job* jobs_device, int n, int dtype, hipStream_t st) {
     if (n <= 0) return BIU_OK;
-    BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_batch<T>, dim3(64, n), dim3(256), 0, st, jobs_device));
+    BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_batch<T>, dim3(64, n), dim3(256), 0, st, jobs_device, (dtype == BIU_F32 && !x3_disabled()) ? 1 : 0));
     BIU_CHECK_LAUNCH("pack_batch");
     return BIU_OK;
 }
@@ -1812,7 +1957,13 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     constexpr int PE = F::PE;
     constexpr int CT = 32;
     constexpr int PPV = CT / PE;
-    constexpr int CTA = CT * NI, PPVA = CTA / PE, RSA = CTA * (int)sizeof(T);
+    // X3 (T = f32x3_t): fp32 tensors, bf16x3 products -- the LDS tiles are TWO bf16 tiles each (hi plane, lo plane: split_bf16x3 while
+    // committing), read through the bf16 kernels' transposing fragment reads; three MFMAs per (A, B) fragment pair
+    constexpr bool X3 = std::is_same<T, f32x3_t>::value;
+    constexpr bool BFM = sizeof(T) == 2 || X3;            // bf16 fragments (32x32x16) out of LDS
+    constexpr int LES = BFM ? 2 : 4;                       // bytes per element of an LDS tile
+    constexpr int NPL = X3 ? 2 : 1;                        // planes per tile
+    constexpr int CTA = CT * NI, PPVA = CTA / PE, RSA = CTA * LES;
     constexpr int PD = (KD == 3) ? 1 : 0;
     constexpr int PHW = (KHW == 3) ? 1 : 0;
     constexpr int SD = (KD == 1) ? 1 : S;
@@ -1823,21 +1974,21 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     constexpr int WPQ = NWAVE / KSPLIT;                    // waves per K split
     constexpr int IPW = (TAPS + WPQ - 1) / WPQ;            // taps per wave
     static_assert(NWAVE % KSPLIT == 0, "K split must divide the wave count");
-    constexpr int RS = CT * (int)sizeof(T);
+    constexpr int RS = CT * LES;
     constexpr int NA = (BV * PPVA + NTHR - 1) / NTHR;
     constexpr int NB = (HV * PPV + NTHR - 1) / NTHR;
-    constexpr int KUNIT = (sizeof(T) == 2) ? 16 : 2;       // voxels per MFMA k-step
+    constexpr int KUNIT = BFM ? 16 : 2;                    // voxels per MFMA k-step
     constexpr int NKG = BV / KUNIT;
     static_assert(TW % 16 == 0 && NKG % KSPLIT == 0, "brick / split mismatch");
 
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-    char* at = (char*)lds;                           // [BV][CT]
-    char* bt = at + BV * RSA;                        // [HV][CT]
-    float* lxf = (float*)(bt + HV * RS);             // [3][CTA] transform of A, [3][CT] transform of B, [6][CT] BN-bwd (NI == 1)
+    char* at = (char*)lds;                           // [NPL][BV][CT]
+    char* bt = at + NPL * BV * RSA;                  // [NPL][HV][CT]
+    float* lxf = (float*)(bt + NPL * HV * RS);       // [3][CTA] transform of A, [3][CT] transform of B, [6][CT] BN-bwd (NI == 1)
     constexpr int LA = 0, LB = 3 * CTA, LBN = 3 * CTA + 3 * CT;
     // packed piece coordinates of every thread (brick-invariant): in LDS [NA + NB][NTHR] when they fit next to the tiles
     // (the big-tile kernels have no registers to spare), else in registers
-    constexpr bool TAB_LDS = wgrad_tab_in_lds((size_t)HV * RS + (size_t)BV * RSA, NA + NB);
+    constexpr bool TAB_LDS = wgrad_tab_in_lds((size_t)NPL * ((size_t)HV * RS + (size_t)BV * RSA), NA + NB);
     unsigned* ltab = (unsigned*)(lxf + LBN + 6 * CT);
     unsigned xa_[TAB_LDS ? 1 : NA], xb_[TAB_LDS ? 1 : NB];
 
@@ -1926,7 +2077,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         u16_delta = (u16_unit < 3) ? HH * HW * RS : 0;
     }
     int a_lane, b_lane, b_lane16 = 0;
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (BFM) {
         const int g = lane >> 4, li = lane & 15, qrow = li >> 2, p = li & 3, cg = g & 1, h = g >> 1;
         a_lane = (8 * h + qrow) * RSA + (16 * cg + 4 * p) * 2;
         b_lane = (8 * h + qrow) * S * RS + (16 * cg + 4 * p) * 2;
@@ -2073,7 +2224,16 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
             if (i < BV * PPVA) {
                 uint4 v = pa[j];
                 if (a_xf && ((amask >> j) & 1u)) v = apply_xf16<T, PE>(v, sc, sh, sl);
-                ((uint4*)at)[i] = v;
+                if constexpr (X3) {
+                    float f[4];
+                    F::unpack(v, f);
+                    uint2 hi, lo;
+                    split_bf16x3(f, hi, lo);
+                    ((uint2*)at)[i] = hi;
+                    ((uint2*)(at + BV * RSA))[i] = lo;
+                } else {
+                    ((uint4*)at)[i] = v;
+                }
             }
         }
         if (b_xf) {
@@ -2094,7 +2254,16 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                     }
                 }
                 if (b_xf && ((bmask >> j) & 1u)) v = apply_xf16<T, PE>(v, sc, sh, sl);
-                ((uint4*)bt)[i] = v;
+                if constexpr (X3) {
+                    float f[4];
+                    F::unpack(v, f);
+                    uint2 hi, lo;
+                    split_bf16x3(f, hi, lo);
+                    ((uint2*)bt)[i] = hi;
+                    ((uint2*)(bt + HV * RS))[i] = lo;
+                } else {
+                    ((uint4*)bt)[i] = v;
+                }
             }
         }
     };
@@ -2131,13 +2300,13 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
             static_assert(NKG % KSPLIT == 0 && KPW % NG == 0, "k-groups must split evenly into slices");
             constexpr int KPG = KPW / NG;
             WSTAMP(0);
-            using FragR = typename std::conditional<sizeof(T) == 2, bf16x8, float>::type;
-            FragR fa[2][NI], fb[2][IPW];
+            using FragR = typename std::conditional<BFM, bf16x8, float>::type;
+            FragR fa[2][NI * NPL], fb[2][IPW * NPL];                  // X3: [.. * 2 + plane], plane 0 = hi
             // 2-D fp32 kernels: 9 taps on 2 x 5 slots leave one empty; a second copy of the phase spills there, a wave-uniform branch around
             // the last slot's reads and 64-cycle MFMA does not (cfg2 weight gradients 96 -> 104-112 TFLOP/s)
             constexpr bool TWO_PHASES_ = IPW > 1 && (IPW * WPQ - TAPS) * BIU_TWO_PHASE_DIV >= IPW * WPQ;
             constexpr bool TAIL_BRANCH = BIU_TAIL_BRANCH && sizeof(T) == 4 && !TWO_PHASES_ && IPW > 1 && IPW * WPQ > TAPS;   // (bf16 2-D: measured neutral)
-            auto load_frags = [&](auto ntap_c, int kg, FragR (&af)[NI], FragR (&bfr)[IPW]) {
+            auto load_frags = [&](auto ntap_c, int kg, FragR (&af)[NI * NPL], FragR (&bfr)[IPW * NPL]) {
                 constexpr int NTAP = decltype(ntap_c)::value;
                 const int q0 = kg * KUNIT;
                 const int lw0 = q0 % TW;
@@ -2145,22 +2314,27 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                 const int lh = t % TH;
                 const int ld = t / TH;
                 const int hbase = ((ld * SD * HH + lh * S) * HW + lw0 * S) * RS;
-                if constexpr (sizeof(T) == 2) {
+                if constexpr (BFM) {
                     typedef bf16x4 __attribute__((address_space(3))) * lp;
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        const char* ap = at + q0 * RSA + a_lane + ni * CT * 2;
-                        bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap));
-                        bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap + 4 * RSA));
-                        af[ni] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    }
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int pl = 0; pl < NPL; ++pl) {
+                            const char* ap = at + pl * (BV * RSA) + q0 * RSA + a_lane + ni * CT * 2;
+                            bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap));
+                            bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap + 4 * RSA));
+                            af[ni * NPL + pl] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
 #pragma unroll
                     for (int t2 = 0; t2 < NTAP; ++t2) {
                         if (TAIL_BRANCH && t2 == IPW - 1 && !last_tap_live) continue;        // wave-uniform: this wave's last slot holds no tap
-                        const char* bp = bt + hbase + tapoff[t2] + b_lane;
-                        bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp));
-                        bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp + 4 * S * RS));
-                        bfr[t2] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                        for (int pl = 0; pl < NPL; ++pl) {
+                            const char* bp = bt + pl * (HV * RS) + hbase + tapoff[t2] + b_lane;
+                            bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp));
+                            bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp + 4 * S * RS));
+                            bfr[t2 * NPL + pl] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
                     }
                 } else {
 #pragma unroll
@@ -2188,6 +2362,19 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                 for (int kk = 0; kk < KPG; ++kk) {
                     const int idx = g * KPG + kk;
                     if (idx + 1 < KPW) load_frags(ntap_c, wq * KPW + idx + 1, fa[(idx + 1) & 1], fb[(idx + 1) & 1]);
+                    if constexpr (X3) {
+                        // lo * hi, hi * lo, hi * hi: term-major, so IPW * NI independent accumulators separate the dependent MFMAs
+#pragma unroll
+                        for (int term = 0; term < 3; ++term)
+#pragma unroll
+                            for (int t2 = 0; t2 < NTAP; ++t2)
+#pragma unroll
+                                for (int ni = 0; ni < NI; ++ni) {
+                                    if (TAIL_BRANCH && t2 == IPW - 1 && !last_tap_live) continue;
+                                    acc[t2][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[idx & 1][ni * 2 + (term == 0 ? 1 : 0)], fb[idx & 1][t2 * 2 + (term == 1 ? 1 : 0)],
+                                                                                         acc[t2][ni], 0, 0, 0);
+                                }
+                    } else {
 #pragma unroll
                     for (int t2 = 0; t2 < NTAP; ++t2)
 #pragma unroll
@@ -2196,6 +2383,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                             if constexpr (sizeof(T) == 2) acc[t2][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[idx & 1][ni], fb[idx & 1][t2], acc[t2][ni], 0, 0, 0);
                             else acc[t2][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[idx & 1][ni], fb[idx & 1][t2], acc[t2][ni], 0, 0, 0);
                         }
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -2480,6 +2668,7 @@ int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int
     if (rr16_off < 0) { const char* e = getenv("BIU_DISABLE"); rr16_off = (e && strstr(e, "rr16")) ? 1 : 0; }
     if (dtype == BIU_BF16 && kd == 3 && a.CB == 16 && !x1 && !rr16_off) rc = launch_wgrad<bf16_t, 3, 3, 1, 4, 8, 16, 1, 1, true>(a, st);   // paired taps
     else if (dtype == BIU_BF16) rc = (kd == 3) ? launch_wgrad<bf16_t, 3, 3, 1, 4, 8, 16, 1>(a, st) : launch_wgrad<bf16_t, 1, 3, 1, 1, 16, 32, 4>(a, st);
+    else if (kd == 1 && !x3_disabled()) rc = launch_wgrad<f32x3_t, 1, 3, 1, 1, 16, 16, 4>(a, st);        // fp32 tensors, bf16x3 products
     else rc = (kd == 3) ? launch_wgrad<float, 3, 3, 1, 4, 4, 16, 1>(a, st) : launch_wgrad<float, 1, 3, 1, 1, 16, 16, 4>(a, st);
     if (rc != BIU_OK) return rc;
     hipLaunchKernelGGL(k_wgrad_finalize, dim3(grid_for((i64)a.CA * a.CB * taps, 256, 2048)), dim3(256), 0, st, (const float*)ws,

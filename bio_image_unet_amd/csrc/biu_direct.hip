@@ -19,6 +19,7 @@ int biu_fail(int code, const char* fmt, ...) {
 
 extern "C" const char* biu_last_error(void) { return biu_errbuf; }
 extern "C" int biu_version(void) { return 100; }
+extern "C" int biu_set_fp32_products(int mode) { return biu_mfma_set_fp32_products(mode); }
 
 #define TPB 256
 

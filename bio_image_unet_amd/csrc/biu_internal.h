@@ -38,6 +38,7 @@ int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, con
 int biu_mfma_convt_dgrad_bricks(const biu_act* dx, int kd);
 int biu_mfma_convt_dgrad_rows(const biu_act* dx, int kd);
 int biu_mfma_pack_batch(const biu_pack_job* jobs_device, int n, int dtype, hipStream_t st);
+int biu_mfma_set_fp32_products(int mode);
 int biu_mfma_conv_ksplit(int cin, const biu_act* y, int kd, int dtype);
 int biu_mfma_conv_stat_rows(const biu_act* y, int kd, const biu_act* x = nullptr, int dtype = -1);
 int biu_mfma_conv_bricks(const biu_act* y, int kd, const biu_act* x = nullptr, int dtype = -1);

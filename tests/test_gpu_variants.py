@@ -1,5 +1,6 @@
 """The kernel variants a launch can take must agree with the kernels they replace: the 16-row MFMA kernel (BIU_DISABLE=m16 falls back to
-the 32-row one), the paired-tap weight gradient of a 16-channel input (BIU_DISABLE=rr16) and the input-channel split of small fp32 launches (BIU_DISABLE=ksplit).  The switches are read once per process, so
+the 32-row one), the paired-tap weight gradient of a 16-channel input (BIU_DISABLE=rr16), the input-channel split of small fp32 launches (BIU_DISABLE=ksplit) and the opt-in bf16x3 products of the fp32 2-D kernels
+(BIU_FP32_PRODUCTS=bf16x3) against the exact fp32 MFMA.  The switches are read once per process, so
 each side runs in its own subprocess (tests/variant_probe.py)."""
 import os
 import subprocess
@@ -16,7 +17,10 @@ def _run(which, disable, tmp_path):
     out = str(tmp_path / f"{which}_{disable or 'on'}.pt")
     env = dict(os.environ)
     env.pop("BIU_DISABLE", None)
-    if disable:
+    env.pop("BIU_FP32_PRODUCTS", None)
+    if disable and disable.startswith("+"):          # an opt-in mode: the "off" side of the comparison switches it ON
+        env["BIU_FP32_PRODUCTS"] = disable[1:]
+    elif disable:
         env["BIU_DISABLE"] = disable
     subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_probe.py"), which, out], check=True, env=env, timeout=300)
     return torch.load(out)
@@ -27,6 +31,9 @@ def _run(which, disable, tmp_path):
     # fp32: the split only re-associates the sum over input channels: outputs agree to 1e-5; a re-association flips a few LeakyReLU /
     # max-pool decisions, which moves single BatchNorm gradients by up to ~1e-2 even between two exact fp32 runs
     ("unet2d_f32", "ksplit", 1e-5, 2e-2),
+    # opt-in: fp32 tensors multiplied as bf16x3 products (three bf16 MFMAs, <= 2^-15 per product) against the exact fp32 MFMA: 18 conv layers
+    # deep the logits stay within 3e-4 (north-star tolerance for fp32: 1e-3); gradients as above
+    ("unet2d_f32", "+bf16x3", 3e-4, 2e-2),
     # bf16: two correct bf16 kernels differ by output rounding; discrete LeakyReLU / max-pool decisions then move gradients by ~1 %
     #  -- a wrong tap or tile would move them by tens of percent
     ("unet3d_bf16", "m16,rr16", 2e-2, 6e-2),
@@ -44,3 +51,15 @@ def test_variant_matches_the_kernel_it_replaces(which, disable, tol_out, tol_gra
         if r > worst[1]:
             worst = (k, r)
     assert worst[1] <= tol_grad, f"gradient of {worst[0]} differs by {worst[1]:.3e} between the variants"
+
+
+@pytest.mark.timeout(600)
+def test_fp32_op_tests_hold_with_bf16x3_products():
+    """Every fp32 op test of tests/test_gpu_ops.py (MFMA convolutions, data / weight gradients, two-source and BatchNorm-fused forms,
+    compared with torch fp32 at rtol 1e-4) once more with the opt-in bf16x3 products -- one child process, the mode is process-wide."""
+    env = dict(os.environ)
+    env.pop("BIU_DISABLE", None)
+    env["BIU_FP32_PRODUCTS"] = "bf16x3"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_ops.py"), "-q", "-x", "-k", "f32", "-p", "no:cacheprovider"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=550)
+    assert r.returncode == 0, r.stdout[-3000:]
