@@ -1652,7 +1652,7 @@ int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, con
 // packed weights (biu_mfma_pack_convt): kind 0 -> [a][ntile(co)][kstep(ci)][lane], kind 1 -> [ntile(ci)][kstep(co)][tap a][lane]
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void k_pack_convt(const float* __restrict__ w, int cin, int cout, int taps, int kind, uint4* __restrict__ out) {
+__global__ void k_pack_convt(const float* __restrict__ w, int cin, int cout, int taps, int kind, uint4* __restrict__ out, int x3) {
     using F = Frag<T>;
     constexpr int PE = F::PE;
     const int Kc = kind == 0 ? cin : cout, Nc = kind == 0 ? cout : cin;
@@ -1665,6 +1665,15 @@ __global__ void k_pack_convt(const float* __restrict__ w, int cin, int cout, int
         if (kind == 0) { ks = (int)(t % nKS); t /= nKS; nt = (int)(t % ntiles); tap = (int)(t / ntiles); }
         else { tap = (int)(t % taps); t /= taps; ks = (int)(t % nKS); nt = (int)(t / nKS); }
         const int i = nt * 32 + (lane & 31);
+        if constexpr (sizeof(T) == 4) {
+            if (x3) {
+                out[idx] = x3_weight_piece(ks, lane >> 5, [&](int k) -> float {
+                    if (i >= Nc || k >= Kc) return 0.f;
+                    return kind == 0 ? w[((size_t)k * cout + i) * taps + tap] : w[((size_t)i * cout + k) * taps + tap];
+                });
+                continue;
+            }
+        }
         float f[PE];
 #pragma unroll
         for (int e = 0; e < PE; ++e) {
@@ -1694,7 +1703,7 @@ int biu_mfma_convt_pack(int kind, const float* w, int cin, int cout, int kd, int
     const size_t total = biu_mfma_convt_packed_bytes(kind, cin, cout, kd, dtype) / 16;
     BIU_REQUIRE(total > 0, BIU_ERR_UNSUPPORTED, "convt_pack: shape is served by the direct kernels");
     BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_convt<T>, dim3(grid_for((i64)total, 256, 4096)), dim3(256), 0, st, w, cin, cout,
-                                                 kd * 4, kind, (uint4*)packed));
+                                                 kd * 4, kind, (uint4*)packed, x3_ok(kind == 0 ? cin : cout, kd, dtype) ? 1 : 0));
     BIU_CHECK_LAUNCH("pack_convt");
     return BIU_OK;
 }
@@ -1724,9 +1733,10 @@ __global__ void k_pack_batch(const biu_pack_job* __restrict__ jobs, int x3_on) {
         else { tap = (int)(t % taps); t /= taps; ks = (int)(t % nKS); nt = (int)(t / nKS); }
         const int i = nt * 32 + (lane & 31);
         if constexpr (sizeof(T) == 4) {
-            if (x3_on && !j.transposed && j.kd == 1 && Kc % 16 == 0) {        // == x3_ok(): the bf16x3 image of a 2-D 3x3 layer
+            if (x3_on && j.kd == 1 && Kc % 16 == 0) {        // == x3_ok(): the bf16x3 image of a 2-D layer (3x3 conv or ConvTranspose k2)
                 out[idx] = x3_weight_piece(ks, lane >> 5, [&](int k) -> float {
                     if (i >= Nc || k >= Kc) return 0.f;
+                    if (j.transposed) return kind == 0 ? w[((size_t)k * cout + i) * taps + tap] : w[((size_t)i * cout + k) * taps + tap];
                     return kind == 0 ? w[((size_t)i * cin + k) * taps + tap] : w[((size_t)k * cin + i) * taps + (taps - 1 - tap)];
                 });
                 continue;
@@ -1845,6 +1855,10 @@ int biu_mfma_convt_fwd(const biu_act* x, const biu_xform* xf, const void* packed
     a.diag = nullptr;
     a.nbd = a.nbh = a.nbw = 0;
     if (dtype == BIU_BF16) return launch_convt_fwd<bf16_t>(a, kd, st);
+    if (x3_ok(a.Cin, kd, dtype)) {       // 2-D, fp32 tensors, bf16x3 products: 16-channel chunks
+        const int ntiles = (a.Cout + 31) / 32;
+        return pick_nt(ntiles) == 1 ? launch_cfg<f32x3_t, 1, 1, 1, 1, 32, 16, 1, 4>(a, ntiles, 4, st) : launch_cfg<f32x3_t, 1, 1, 1, 1, 32, 16, 2, 4>(a, ntiles, 4, st);
+    }
     return launch_convt_fwd<float>(a, kd, st);
 }
 
@@ -1876,6 +1890,10 @@ int biu_mfma_convt_dgrad(const biu_act* dy, const void* packed, int kd, const bi
     a.diag = nullptr;
     a.nbd = a.nbh = a.nbw = 0;
     if (dtype == BIU_BF16) return launch_convt_dgrad<bf16_t>(a, kd, st);
+    if (x3_ok(a.Cin, kd, dtype)) {
+        const int ntiles = (a.Cout + 31) / 32;
+        return pick_nt(ntiles) == 1 ? launch_cfg<f32x3_t, 1, 2, 2, 1, 16, 16, 1, 4>(a, ntiles, 1, st) : launch_cfg<f32x3_t, 1, 2, 2, 1, 16, 16, 2, 4>(a, ntiles, 1, st);
+    }
     return launch_convt_dgrad<float>(a, kd, st);
 }
 
@@ -2705,7 +2723,8 @@ int biu_mfma_convt_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* d
         if (wide) rc = (kd == 2) ? launch_wgrad<bf16_t, 2, 2, 2, 2, 4, 16, 2, 2>(a, st) : launch_wgrad<bf16_t, 1, 2, 2, 1, 8, 16, 4, 2>(a, st);
         else rc = (kd == 2) ? launch_wgrad<bf16_t, 2, 2, 2, 2, 4, 16, 2>(a, st) : launch_wgrad<bf16_t, 1, 2, 2, 1, 8, 16, 4>(a, st);
     } else {
-        if (wide && kd == 1) rc = launch_wgrad<float, 1, 2, 2, 1, 8, 16, 4, 2>(a, st);      // (the fp32 3-D tiles leave no LDS for a second A tile)
+        if (kd == 1 && !x3_disabled()) rc = wide ? launch_wgrad<f32x3_t, 1, 2, 2, 1, 8, 16, 4, 2>(a, st) : launch_wgrad<f32x3_t, 1, 2, 2, 1, 8, 16, 4>(a, st);
+        else if (wide && kd == 1) rc = launch_wgrad<float, 1, 2, 2, 1, 8, 16, 4, 2>(a, st);      // (the fp32 3-D tiles leave no LDS for a second A tile)
         else rc = (kd == 2) ? launch_wgrad<float, 2, 2, 2, 2, 4, 16, 2>(a, st) : launch_wgrad<float, 1, 2, 2, 1, 8, 16, 4>(a, st);
     }
     if (rc != BIU_OK) return rc;
