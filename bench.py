@@ -43,8 +43,9 @@ WORKLOADS = {
 }
 
 
-def make_step(wl, device):
-    """Returns (model, step_fn, fwd_fn, voxels_per_step). The loss expressions are the reference trainers' own."""
+def make_step(wl, device, graph=False):
+    """Returns (model, step_fn, fwd_fn, voxels_per_step). The loss expressions are the reference trainers' own.
+    graph=True: the same step captured once in a hipGraph and replayed (bio_image_unet_amd/graph.py; single process)."""
     import bio_image_unet_amd as B
     from bio_image_unet_amd.losses import BCEDiceLoss
     from bio_image_unet_amd.optim import Adam
@@ -95,6 +96,17 @@ def make_step(wl, device):
         avg.average()
         opt.step()
         return loss
+
+    if graph:
+        from bio_image_unet_amd.graph import GraphedTrainStep
+        clip = (lambda: torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)) if wl["model"] == "MultiOutputUnet3D" else None
+        ins = [x, px] if px is not None else [x]
+        gstep = GraphedTrainStep(model, lambda outs: loss_of(outs), opt, ins, [], after_backward=clip)
+        eager_step = step
+
+        def step():                                  # noqa: F811
+            return gstep(ins, [])
+        step.eager = eager_step
 
     nvox = 1
     for s in (shape[0],) + tuple(shape[2:]):
@@ -195,6 +207,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N = 1 only)")
     ap.add_argument("--fp32-products", default="exact", choices=["exact", "bf16x3"], help="fp32 workloads: how the 3x3 kernels multiply (default: fp32 MFMA)")
     ap.add_argument("--breakdown", default=None, help="write the per-launch time table of one profiled step to this file")
     args = ap.parse_args()
@@ -212,7 +225,7 @@ def main():
     if args.fp32_products != "exact":
         import bio_image_unet_amd
         bio_image_unet_amd.set_fp32_products(args.fp32_products)
-    model, step, fwd, nvox, avg = make_step(wl, device)
+    model, step, fwd, nvox, avg = make_step(wl, device, graph=args.graph and world == 1)
 
     def barrier():
         if world > 1:
@@ -223,7 +236,7 @@ def main():
     for _ in range(max(args.warmup - 1, 0)):
         step()
     lib.prof = []
-    step()
+    getattr(step, "eager", step)()              # (a replayed graph makes no C-ABI calls: the profiled step is the eager one)
     torch.cuda.synchronize()
     prof, lib.prof = lib.prof, None
     eng = list(model._engines.values())[-1][-1]
@@ -248,6 +261,10 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    if hasattr(step, "eager"):                  # graph mode: the dominant launch is timed in eager steps after the timed region
+        for _ in range(3):
+            step.eager()
+        torch.cuda.synchronize()
     watched, lib.watch = lib.watched, None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -310,6 +327,8 @@ def main():
                           "kernel_time_ms_one_step": total_kernel_ms},
         "roofline": roof,
     }
+    if hasattr(step, "eager"):
+        out["graph"] = "step replayed from one captured hipGraph; roofline.launch_ms from eager steps after the timed region"
     if x3:
         out["arithmetic"] = ("fp32 tensors and accumulators; the products of the 3x3 convolutions (forward, data and weight gradient) are bf16x3: "
                              "operands split hi + lo in bf16, hi*hi + hi*lo + lo*hi on the bf16 MFMA, <= 2^-15 relative per product; "

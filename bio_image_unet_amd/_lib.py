@@ -116,6 +116,8 @@ SIGNATURES = {
     "biu_stitch_finish": (_I, [_P, _P, _I, _I, C.c_longlong, _P, _I, _P]),
     "biu_to_nchw": (_I, [_A, _X, _P, _I, _P]),
     "biu_adam_step": (_I, [_I, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _F, _P]),
+    "biu_adam_set_hyper": (_I, [_P, _F, _F, _F, _F, _I, _F, _P]),
+    "biu_adam_step_hyper": (_I, [_I, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 

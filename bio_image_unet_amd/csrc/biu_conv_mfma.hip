@@ -2557,6 +2557,20 @@ __global__ void k_wgrad_finalize(const float* __restrict__ ws, int rows, int col
     }
 }
 
+// zero-fill by a kernel of our own: a hipMemsetAsync captured in a hipGraph (bio_image_unet_amd/graph.py) was seen to lose its order against
+// the kernels around it when eager work ran between two replays -- weight gradients accumulated onto stale workspace contents
+__global__ void k_zero_f32(float* __restrict__ p, size_t n, float* __restrict__ q, int nq) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.f;
+    if (q && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < nq; i += blockDim.x) q[i] = 0.f;
+}
+static int zero_ws(void* ws, size_t bytes, float* extra, int nextra, hipStream_t st) {
+    const size_t n = bytes / sizeof(float);
+    hipLaunchKernelGGL(k_zero_f32, dim3(grid_for((i64)n, 256, 1024)), dim3(256), 0, st, (float*)ws, n, extra, nextra);
+    if (hipGetLastError() != hipSuccess) return biu_fail(BIU_ERR_LAUNCH, "wgrad: zero-fill launch failed");
+    return BIU_OK;
+}
+
 static bool wgrad_chan_ok(int cin, int cout) { return cin >= 16 && cin % 8 == 0 && cout >= 16 && cout % 8 == 0; }
 
 static size_t wgrad_acc_bytes(int cin, int cout, int taps) { return (((size_t)cin * cout * taps * sizeof(float)) + 255) & ~(size_t)255; }
@@ -2681,7 +2695,7 @@ int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int
     const int taps = kd * 9;
     const size_t need = wgrad_acc_bytes(a.CA, a.CB, taps);
     BIU_REQUIRE(ws_bytes >= need + (dbias ? biu_chan_sum_workspace(dy->c) : 0), BIU_ERR_WORKSPACE, "wgrad_mfma: workspace %zu too small", ws_bytes);
-    if (hipMemsetAsync(ws, 0, need, st) != hipSuccess) return biu_fail(BIU_ERR_LAUNCH, "wgrad_mfma: memset failed");
+    if (int zr = zero_ws(ws, need, nullptr, 0, st)) return zr;
     static int rr16_off = -1;
     if (rr16_off < 0) { const char* e = getenv("BIU_DISABLE"); rr16_off = (e && strstr(e, "rr16")) ? 1 : 0; }
     if (dtype == BIU_BF16 && kd == 3 && a.CB == 16 && !x1 && !rr16_off) rc = launch_wgrad<bf16_t, 3, 3, 1, 4, 8, 16, 1, 1, true>(a, st);   // paired taps
@@ -2714,9 +2728,8 @@ int biu_mfma_convt_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* d
     const int taps = kd * 4;
     const size_t need = wgrad_acc_bytes(a.CA, a.CB, taps);
     BIU_REQUIRE(ws_bytes >= need + (dbias ? biu_chan_sum_workspace(dy->c) : 0), BIU_ERR_WORKSPACE, "convt_wgrad_mfma: workspace %zu too small", ws_bytes);
-    if (hipMemsetAsync(ws, 0, need, st) != hipSuccess) return biu_fail(BIU_ERR_LAUNCH, "convt_wgrad_mfma: memset failed");
     a.dbias_out = dbias;                                   // d bias = channel sums of dy, taken while the kernel stages dy (no second pass)
-    if (dbias && hipMemsetAsync(dbias, 0, (size_t)dy->c * sizeof(float), st) != hipSuccess) return biu_fail(BIU_ERR_LAUNCH, "convt_wgrad_mfma: memset failed");
+    if (int zr = zero_ws(ws, need, dbias, dbias ? dy->c : 0, st)) return zr;
     // two 32-wide tiles of x's channels per block when x has them: the fine-grid dy is then read half as often
     const bool wide = a.CA > 32;
     if (dtype == BIU_BF16) {

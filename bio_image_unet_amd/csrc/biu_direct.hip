@@ -804,11 +804,20 @@ __global__ void k_to_nchw(DAct src, DXf xf, float* __restrict__ dst) {
 // =====================================================================================================
 // fused multi-tensor Adam
 // =====================================================================================================
+// hyper == nullptr: the step's scalars come by value.  Otherwise they are read from device memory -- {lr, beta1, beta2, eps, grad_scale,
+// step} as six floats, written by biu_adam_set_hyper -- so that the launch can sit in a captured hipGraph and still follow the
+// learning-rate schedule and the bias correction of the step it is replayed for.
 __global__ void k_adam(int n, float* const* params, const float* const* grads, float* const* m, float* const* v,
                        const int64_t* numel, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt,
-                       float gscale) {
+                       float gscale, const float* __restrict__ hyper) {
     int t = blockIdx.y;
     if (t >= n) return;
+    if (hyper) {
+        lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; gscale = hyper[4];
+        const float step = hyper[5];
+        bc1 = 1.f - powf(b1, step);
+        bc2_sqrt = sqrtf(1.f - powf(b2, step));
+    }
     float* p = params[t];
     const float* g = grads[t];
     float* mm = m[t];
@@ -1271,7 +1280,27 @@ extern "C" int biu_adam_step(int n, float* const* params, const float* const* gr
     float bc1 = 1.f - powf(beta1, (float)step);
     float bc2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(k_adam, dim3(128, n), dim3(TPB), 0, (hipStream_t)stream, n, params, grads, exp_avg, exp_avg_sq, numel,
-                       lr, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale);
+                       lr, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale, (const float*)nullptr);
     BIU_CHECK_LAUNCH("adam_step");
+    return BIU_OK;
+}
+
+__global__ void k_adam_set_hyper(float* hyper, float lr, float b1, float b2, float eps, float gscale, float step) {
+    hyper[0] = lr; hyper[1] = b1; hyper[2] = b2; hyper[3] = eps; hyper[4] = gscale; hyper[5] = step;
+}
+
+extern "C" int biu_adam_set_hyper(float* hyper, float lr, float beta1, float beta2, float eps, int step, float grad_scale, biu_stream stream) {
+    BIU_REQUIRE(hyper && step >= 1, BIU_ERR_SHAPE, "adam_set_hyper: bad arguments");
+    hipLaunchKernelGGL(k_adam_set_hyper, dim3(1), dim3(1), 0, (hipStream_t)stream, hyper, lr, beta1, beta2, eps, grad_scale, (float)step);
+    BIU_CHECK_LAUNCH("adam_set_hyper");
+    return BIU_OK;
+}
+
+extern "C" int biu_adam_step_hyper(int n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                                   const int64_t* numel, const float* hyper, biu_stream stream) {
+    BIU_REQUIRE(n > 0 && params && grads && exp_avg && exp_avg_sq && numel && hyper, BIU_ERR_SHAPE, "adam_step_hyper: bad arguments");
+    hipLaunchKernelGGL(k_adam, dim3(128, n), dim3(TPB), 0, (hipStream_t)stream, n, params, grads, exp_avg, exp_avg_sq, numel,
+                       0.f, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, hyper);
+    BIU_CHECK_LAUNCH("adam_step_hyper");
     return BIU_OK;
 }

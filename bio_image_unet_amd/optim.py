@@ -51,10 +51,63 @@ class Adam(torch.optim.Optimizer):
             self._tables[gi] = t
         return t
 
+    # ---- a step inside a captured hipGraph (bio_image_unet_amd/graph.py) -------------------------------------------------------
+    def prepare_for_capture(self):
+        """Allocates what a captured step needs BEFORE the capture starts (pinned and device memory cannot be allocated inside one):
+        per group the scalars {lr, beta1, beta2, eps, grad_scale, step} in device memory and a pinned / device pair for the table of
+        gradient pointers."""
+        for gi, group in enumerate(self.param_groups):
+            t = self._group_tables(gi, group)
+            if "hyper" not in t:
+                n, dev = len(t["ps"]), t["ps"][0].device
+                t["hyper"] = torch.zeros(6, dtype=torch.float32, device=dev)
+                t["gcap_host"] = torch.empty(n, dtype=torch.int64).pin_memory()
+                t["gcap_dev"] = torch.empty(n, dtype=torch.int64, device=dev)
+
+    def refresh_hyper(self, grad_scale: float = 1.0):
+        """In front of every replay of a captured step: advance the step count and hand the step's scalars (current learning rate
+        included) to the captured Adam launch.  One tiny kernel, arguments by value -- no host buffer the GPU could read late."""
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for gi, group in enumerate(self.param_groups):
+            t = self._group_tables(gi, group)
+            step = int(self.state[t["ps"][0]]["step"]) + 1
+            for p in t["ps"]:
+                self.state[p]["step"] = step
+            b1, b2 = group["betas"]
+            check(lib.biu_adam_set_hyper(C.c_void_p(t["hyper"].data_ptr()), float(group["lr"]), b1, b2, group["eps"], step, float(grad_scale), st),
+                  "adam_set_hyper")
+
+    def _captured_step(self, st):
+        for gi, group in enumerate(self.param_groups):
+            t = self._group_tables(gi, group)
+            if "hyper" not in t:
+                raise RuntimeError("Adam.step() inside a graph capture needs prepare_for_capture() before the capture starts")
+            ps = t["ps"]
+            for p in ps:
+                assert p.grad is not None and p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
+            # the gradients of a captured backward live in the graph's private pool at fixed addresses; the captured launch only refers to
+            # the table, finish_capture() fills it once the capture has ended (no copy node in the graph: a captured hipMemsetAsync was
+            # seen to lose its order against the kernels around it, and a copy node is the same kind of thing)
+            t["gcap_host"].copy_(torch.tensor([p.grad.data_ptr() for p in ps], dtype=torch.int64))
+            check(lib.biu_adam_step_hyper(len(ps), C.c_void_p(t["p"].data_ptr()), C.c_void_p(t["gcap_dev"].data_ptr()),
+                                          C.c_void_p(t["m"].data_ptr()), C.c_void_p(t["v"].data_ptr()), C.c_void_p(t["n"].data_ptr()),
+                                          C.c_void_p(t["hyper"].data_ptr()), st), "adam_step_hyper")
+            torch.autograd.graph.increment_version(ps)
+
+    def finish_capture(self):
+        """After the capture has ended: upload the gradient-pointer tables the captured Adam launches read."""
+        for t in self._tables.values():
+            if "gcap_host" in t:
+                t["gcap_dev"].copy_(t["gcap_host"])
+        torch.cuda.synchronize()
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
         loss = closure() if closure is not None else None
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if torch.cuda.is_current_stream_capturing():
+            self._captured_step(st)
+            return loss
         for gi, group in enumerate(self.param_groups):
             t = self._group_tables(gi, group)
             ps = t["ps"]

@@ -360,6 +360,13 @@ int biu_adam_step(int n, float* const* params, const float* const* grads, float*
                   float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2,
                   float eps, int step, float grad_scale, biu_stream stream);
 
+/* The same update with its scalars in device memory, for a step captured in a hipGraph (bio_image_unet_amd/graph.py): the graph holds
+ * biu_adam_step_hyper, and biu_adam_set_hyper -- launched in front of every replay, arguments by value -- writes
+ * hyper[6] = {lr, beta1, beta2, eps, grad_scale, step} for the step being replayed (ReduceLROnPlateau of unet/train.py:103 keeps working). */
+int biu_adam_set_hyper(float* hyper, float lr, float beta1, float beta2, float eps, int step, float grad_scale, biu_stream stream);
+int biu_adam_step_hyper(int n, float* const* params, const float* const* grads, float* const* exp_avg,
+                        float* const* exp_avg_sq, const int64_t* numel, const float* hyper, biu_stream stream);
+
 #ifdef __cplusplus
 }
 #endif
