@@ -4,6 +4,8 @@
 //   * per-channel two-term reductions (BatchNorm statistics, BatchNorm backward sums, channel sums) with 16-byte
 //     loads and deterministic per-block partials
 #include "biu_internal.h"
+#include <cstring>
+#include <cstdlib>
 #include <stdlib.h>
 
 #define TPB 256
@@ -951,6 +953,133 @@ __global__ __launch_bounds__(TPB, RED ? 3 : 4) void k_maxpool_bwd_rv(DAct x, DXf
     }
 }
 
+// The same pass with the window's two w-neighbours on two lanes: lane (c, g) owns fine voxels (.., 2w + c) and channels g*PE .. +PE-1, so the
+// 2*cg lanes of a pooled voxel read / write the two voxels' channel rows as ONE contiguous run (128 B at 32 bf16 channels with 16-byte lanes;
+// k_maxpool_bwd_rv's lanes touch 64-byte halves of two different lines per instruction) and hold 4 + 4 window pieces instead of 8 + 8.
+// The argmax of a channel is settled between the two lanes with one exchange (lane ^ cg): larger value wins, equal values go to the
+// smaller window index, a NaN wins over any number and the later NaN over the earlier -- exactly the scan order of the one-lane kernel.
+template <typename T, bool RED, int PE>
+__global__ __launch_bounds__(TPB, sizeof(T) * PE >= 16 ? 2 : 4) void k_maxpool_bwd_pair(DAct x, DXf xf, DAct dout, DAct dx, int pd, int accumulate, int cg, int rows,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             float* __restrict__ partial) {
+    extern __shared__ float sm[];                 // RED: [rows * 2][cg*PE][2]
+    const int q = threadIdx.x % (2 * cg), row = threadIdx.x / (2 * cg);
+    const int g = q % cg, c = q / cg;
+    const int c0 = g * PE;
+    const bool live = row < rows;
+    float sc[PE], sh[PE], sl[PE], s1[PE], s2[PE];
+#pragma unroll
+    for (int j = 0; j < PE; ++j) {
+        sc[j] = xf.scale ? xf.scale[c0 + j] : 1.f;
+        sh[j] = xf.shift ? xf.shift[c0 + j] : 0.f;
+        sl[j] = xf.slope ? xf.slope[c0 + j] : 1.f;
+        s1[j] = s2[j] = 0.f;
+    }
+    const i64 total = (i64)dout.n * dout.d * dout.h * dout.w;
+    const i64 step_b = x.w, step_a = (i64)x.h * x.w;
+    // software-pipelined: the 9 loads of the NEXT pooled voxel are in flight while this one is reduced and stored (a lane that issues,
+    // waits, computes and stores in turn leaves the memory system idle for half of its time; 18 more registers buy the overlap)
+    struct Win { Pack<T, PE> in[4], old[4], gq; const T* xp; T* dp; };
+    auto issue = [&](i64 ov, Win& w) {
+        const Vox4 p = unvox4(ov, dout.d, dout.h, dout.w);
+        const i64 base = (((i64)p.n * x.d + p.d * pd) * x.h + p.h * 2) * x.w + p.w * 2 + c;
+        w.xp = (const T*)x.p + base * x.pitch + c0;
+        w.dp = (T*)dx.p + base * dx.pitch + c0;
+        w.gq = *(const Pack<T, PE>*)((const T*)dout.p + ov * dout.pitch + c0);
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2)
+            if ((k2 >> 1) < pd) w.in[k2] = *(const Pack<T, PE>*)(w.xp + ((k2 >> 1) * step_a + (k2 & 1) * step_b) * x.pitch);
+        if (accumulate) {
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2)
+                if ((k2 >> 1) < pd) w.old[k2] = *(const Pack<T, PE>*)(w.dp + ((k2 >> 1) * step_a + (k2 & 1) * step_b) * dx.pitch);
+        }
+    };
+    auto finish = [&](const Win& w) {
+        unsigned argp = 0;                     // 3-bit window index of the maximum per channel
+#pragma unroll
+        for (int j = 0; j < PE; ++j) {
+            float best = -INFINITY;
+            int arg = c;                       // (all -inf: index 0 wins, as in the one-lane scan)
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+                if ((k2 >> 1) >= pd) continue;
+                float t = fmaf(sc[j], to_f(w.in[k2].v[j]), sh[j]);
+                t = t > 0.f ? t : sl[j] * t;
+                if (t > best || t != t) { best = t; arg = 2 * k2 + c; }
+            }
+            const float pb = __shfl_xor(best, cg);
+            const int pa = __shfl_xor(arg, cg);
+            const bool own_nan = best != best, p_nan = pb != pb;
+            const bool take_p = p_nan ? (!own_nan || pa > arg) : (!own_nan && (pb > best || (pb == best && pa < arg)));
+            argp |= (unsigned)(take_p ? pa : arg) << (3 * j);
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+            if ((k2 >> 1) >= pd) continue;
+            Pack<T, PE> o;
+#pragma unroll
+            for (int j = 0; j < PE; ++j) {
+                const float r = (((argp >> (3 * j)) & 7u) == (unsigned)(2 * k2 + c)) ? to_f(w.gq.v[j]) : 0.f;
+                o.v[j] = from_f<T>(accumulate ? to_f(w.old[k2].v[j]) + r : r);
+                if (RED) {
+                    const float yv = to_f(w.in[k2].v[j]);
+                    const float dz = to_f(o.v[j]) * (fmaf(sc[j], yv, sh[j]) > 0.f ? 1.f : sl[j]);
+                    s1[j] += dz;
+                    s2[j] = fmaf(dz, yv, s2[j]);
+                }
+            }
+            *(Pack<T, PE>*)(w.dp + ((k2 >> 1) * step_a + (k2 & 1) * step_b) * dx.pitch) = o;
+        }
+    };
+    const i64 stride = (i64)gridDim.x * rows;
+    i64 ov = (i64)blockIdx.x * rows + row;
+    if (live && ov < total) {
+        Win cur, nxt;
+        issue(ov, cur);
+        while (true) {
+            const i64 nov = ov + stride;
+            const bool more = nov < total;
+            if (more) issue(nov, nxt);
+            finish(cur);
+            if (!more) break;
+            cur = nxt;
+            ov = nov;
+        }
+    }
+    if (RED) {
+        const int C = cg * PE;
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < PE; ++j) {
+                sm[((row * 2 + c) * C + c0 + j) * 2 + 0] = s1[j];
+                sm[((row * 2 + c) * C + c0 + j) * 2 + 1] = s2[j];
+            }
+        }
+        __syncthreads();
+        for (int ch = threadIdx.x; ch < C; ch += TPB) {
+            float a0 = 0.f, a1 = 0.f;
+            for (int r = 0; r < rows * 2; ++r) { a0 += sm[(r * C + ch) * 2]; a1 += sm[(r * C + ch) * 2 + 1]; }
+            partial[((i64)blockIdx.x * C + ch) * 2 + 0] = a0;
+            partial[((i64)blockIdx.x * C + ch) * 2 + 1] = invstd[ch] * (a1 - mean[ch] * a0);        // sum dz * yhat
+        }
+    }
+}
+// lanes per pooled voxel = 2 * C / PE must fit a wave and divide the block: C / PE a power of two <= 32
+static bool pool_pair_ok(int C, int PE) {
+    static const bool off = [] { const char* e = getenv("BIU_DISABLE"); return e && strstr(e, "pool_pair") != nullptr; }();
+    const int cg = C / PE;
+    return !off && C % PE == 0 && cg >= 1 && cg <= 32 && (cg & (cg - 1)) == 0;      // (callers: bf16 only -- the fp32 one-lane kernel already runs at 5 TB/s)
+}
+static RowPlan pool_pair_plan(const biu_act* x, const biu_act* dout, int PE, i64 max_blocks) {
+    RowPlan p;
+    p.cg = x->c / PE;
+    p.rows = TPB / (2 * p.cg);
+    i64 want = (nvox(dout) + (i64)p.rows * 4 - 1) / ((i64)p.rows * 4);          // ~4 pooled voxels per lane pair
+    p.grid = (int)(want < 1 ? 1 : (want > max_blocks ? max_blocks : want));
+    return p;
+}
+
 template <int MODE>
 static int pool_rv_launch(const biu_act* x, const biu_xform* xf, const biu_act* small, const biu_act* dx, int pd, int accumulate, int dtype, hipStream_t st) {
     BIU_DISPATCH_DTYPE(dtype, {
@@ -971,10 +1100,17 @@ static RowPlan pool_bwd_plan(const biu_act* x, const biu_act* dout, int PE, i64 
 }
 int biu_maxpool_bwd_rv(const biu_act* x, const biu_xform* xf, const biu_act* dout, const biu_act* dx, int pd, int accumulate, int dtype, hipStream_t st) {
     BIU_DISPATCH_DTYPE(dtype, {
-        constexpr int PE = 4;
-        RowPlan p = pool_bwd_plan(x, dout, PE, 16384);
-        hipLaunchKernelGGL((k_maxpool_bwd_rv<T, false, PE>), dim3(p.grid), dim3(TPB), 0, st, dact(x), dxf(xf), dact(dout), dact(dx), pd, accumulate,
-                           p.cg, p.rows, nullptr, nullptr, nullptr);
+        constexpr int PW = 4;
+        if (sizeof(T) == 2 && pool_pair_ok(x->c, PW)) {
+            RowPlan p = pool_pair_plan(x, dout, PW, 16384);
+            hipLaunchKernelGGL((k_maxpool_bwd_pair<T, false, PW>), dim3(p.grid), dim3(TPB), 0, st, dact(x), dxf(xf), dact(dout), dact(dx), pd, accumulate,
+                               p.cg, p.rows, nullptr, nullptr, nullptr);
+        } else {
+            constexpr int PE = 4;
+            RowPlan p = pool_bwd_plan(x, dout, PE, 16384);
+            hipLaunchKernelGGL((k_maxpool_bwd_rv<T, false, PE>), dim3(p.grid), dim3(TPB), 0, st, dact(x), dxf(xf), dact(dout), dact(dx), pd, accumulate,
+                               p.cg, p.rows, nullptr, nullptr, nullptr);
+        }
     });
     BIU_CHECK_LAUNCH("maxpool_bwd_rv");
     return BIU_OK;
@@ -986,12 +1122,21 @@ int biu_maxpool_bwd_bnred_rv(const biu_act* x, const biu_xform* xf, const biu_ac
     i64 cap = (i64)(partial_floats / ((size_t)x->c * 2));
     if (cap > 8192) cap = 8192;
     BIU_DISPATCH_DTYPE(dtype, {
-        constexpr int PE = 4;
-        RowPlan p = pool_bwd_plan(x, dout, PE, cap);
-        const size_t shm = (size_t)p.rows * x->c * 2 * sizeof(float);
-        hipLaunchKernelGGL((k_maxpool_bwd_rv<T, true, PE>), dim3(p.grid), dim3(TPB), shm, st, dact(x), dxf(xf), dact(dout), dact(dx), pd, accumulate,
-                           p.cg, p.rows, mean, invstd, partial);
-        *nblk = p.grid;
+        constexpr int PW = 4;
+        if (sizeof(T) == 2 && pool_pair_ok(x->c, PW)) {
+            RowPlan p = pool_pair_plan(x, dout, PW, cap);
+            const size_t shm = (size_t)p.rows * 2 * x->c * 2 * sizeof(float);
+            hipLaunchKernelGGL((k_maxpool_bwd_pair<T, true, PW>), dim3(p.grid), dim3(TPB), shm, st, dact(x), dxf(xf), dact(dout), dact(dx), pd, accumulate,
+                               p.cg, p.rows, mean, invstd, partial);
+            *nblk = p.grid;
+        } else {
+            constexpr int PE = 4;
+            RowPlan p = pool_bwd_plan(x, dout, PE, cap);
+            const size_t shm = (size_t)p.rows * x->c * 2 * sizeof(float);
+            hipLaunchKernelGGL((k_maxpool_bwd_rv<T, true, PE>), dim3(p.grid), dim3(TPB), shm, st, dact(x), dxf(xf), dact(dout), dact(dx), pd, accumulate,
+                               p.cg, p.rows, mean, invstd, partial);
+            *nblk = p.grid;
+        }
     });
     BIU_CHECK_LAUNCH("maxpool_bwd_bnred_rv");
     return BIU_OK;

@@ -707,6 +707,30 @@ def test_maxpool_bwd_bnred(shape, dtype, accumulate):
     torch.testing.assert_close(sb, sa, rtol=1e-4, atol=1e-4 * float(sa.abs().max()) + 1e-9)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 32, 4, 8, 12), (1, 16, 1, 10, 6), (2, 64, 2, 4, 8), (1, 128, 2, 4, 4)])
+def test_maxpool_bwd_sends_ties_to_the_first_maximum(shape, dtype):
+    """Inputs on a coarse grid of values: most windows hold their maximum several times, in every (d, h, w) position.  The gradient goes
+    to the first one in window scan order (torch's rule) -- in the bf16 kernel the two w-neighbours of a window sit on two lanes and
+    settle the argmax with one exchange, which is where an ordering mistake would show."""
+    n, c, d, h, w = shape
+    nd = 2 if d == 1 else 3
+    x = (rnd(*shape, seed=21) * 1.5).round() / 2
+    xf = XF(c, seed=2)
+    xd = Dev(x, dtype=dtype)
+    xa = xf.apply(xd.ref()).requires_grad_(True)
+    xs = xa.squeeze(2) if nd == 2 else xa
+    ref = (F.max_pool2d if nd == 2 else F.max_pool3d)(xs, 2, 2)
+    g = rnd(*ref.shape, seed=3)
+    gd = Dev(g, dtype=dtype)
+    ref.backward(gd.ref().squeeze(2) if nd == 2 else gd.ref())
+    dxd = Dev(shape=shape, dtype=dtype, fill=0.0)
+    check(lib.biu_maxpool_bwd(xd.a(), xf.x(), gd.a(), dxd.a(), 0, DT[dtype][1], stream()), "maxpool_bwd")
+    got = dxd.get()
+    assert torch.equal(got != 0, xa.grad != 0), "gradient routed to a different window element"
+    assert_close(got, xa.grad, dtype, "maxpool_bwd with ties")
+
+
 def test_conv_mfma_sample_beyond_2gb():
     """Byte offsets inside a sample are 32-bit modular (buffer descriptors): a 2.6 GB sample must address correctly."""
     dtype, code = "bf16", DT["bf16"][1]
