@@ -865,6 +865,65 @@ __global__ __launch_bounds__(TPB) void k_pool_rv(DAct x, DXf xf, DAct small, DAc
         }
     }
 }
+// Max-pool forward, software-pipelined like k_maxpool_bwd_pair: the 8 (4) loads of the NEXT output voxel are in flight while this one is
+// reduced and stored.  Same arithmetic and NaN rule as k_pool_rv<T, 1>.
+template <typename T>
+__global__ __launch_bounds__(TPB, 2) void k_maxpool_fwd_pipe(DAct x, DXf xf, DAct out, int pd, int cg, int rows) {
+    constexpr int PE = 16 / sizeof(T);
+    const int g = threadIdx.x % cg, row = threadIdx.x / cg;
+    if (row >= rows) return;
+    const int c0 = g * PE;
+    float sc[PE], sh[PE], sl[PE];
+#pragma unroll
+    for (int j = 0; j < PE; ++j) {
+        sc[j] = xf.scale ? xf.scale[c0 + j] : 1.f;
+        sh[j] = xf.shift ? xf.shift[c0 + j] : 0.f;
+        sl[j] = xf.slope ? xf.slope[c0 + j] : 1.f;
+    }
+    const i64 total = (i64)out.n * out.d * out.h * out.w;
+    const i64 step_b = x.w, step_a = (i64)x.h * x.w;
+    struct Win { Pack<T, PE> in[8]; };
+    auto issue = [&](i64 ov, Win& w) {
+        const Vox4 p = unvox4(ov, out.d, out.h, out.w);
+        const i64 base = (((i64)p.n * x.d + p.d * pd) * x.h + p.h * 2) * x.w + p.w * 2;
+        const T* xp = (const T*)x.p + base * x.pitch + c0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if ((k >> 2) < pd) w.in[k] = *(const Pack<T, PE>*)(xp + ((k >> 2) * step_a + ((k >> 1) & 1) * step_b + (k & 1)) * x.pitch);
+    };
+    auto finish = [&](i64 ov, const Win& w) {
+        Pack<T, PE> o;
+#pragma unroll
+        for (int j = 0; j < PE; ++j) {
+            float best = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if ((k >> 2) >= pd) continue;
+                float t = fmaf(sc[j], to_f(w.in[k].v[j]), sh[j]);
+                t = t > 0.f ? t : sl[j] * t;
+                if (t > best || t != t) best = t;
+            }
+            o.v[j] = from_f<T>(best);
+        }
+        *(Pack<T, PE>*)((T*)out.p + ov * out.pitch + c0) = o;
+    };
+    const i64 stride = (i64)gridDim.x * rows;
+    i64 ov = (i64)blockIdx.x * rows + row;
+    if (ov < total) {
+        Win cur, nxt;
+        issue(ov, cur);
+        while (true) {
+            const i64 nov = ov + stride;
+            const bool more = nov < total;
+            if (more) issue(nov, nxt);
+            finish(ov, cur);
+            if (!more) break;
+            cur = nxt;
+            ov = nov;
+        }
+    }
+}
+
 // Max-pool backward with every load of a window in flight together (x, and dx when accumulating), and -- optionally -- the
 // BatchNorm-backward sums of the layer that produced x reduced from the finished gradient in the same pass:
 //   (sum dz, sum dz * yhat),  dz = dx_final * T'(scale*x + shift),  yhat = (x - mean) * invstd      -> partial[block][C][2]
@@ -1091,7 +1150,19 @@ static int pool_rv_launch(const biu_act* x, const biu_xform* xf, const biu_act* 
     return BIU_OK;
 }
 int biu_xform_apply_rv(const biu_act* x, const biu_xform* xf, const biu_act* out, int dtype, hipStream_t st) { return pool_rv_launch<0>(x, xf, out, nullptr, 1, 0, dtype, st); }
-int biu_maxpool_fwd_rv(const biu_act* x, const biu_xform* xf, const biu_act* out, int pd, int dtype, hipStream_t st) { return pool_rv_launch<1>(x, xf, out, nullptr, pd, 0, dtype, st); }
+int biu_maxpool_fwd_rv(const biu_act* x, const biu_xform* xf, const biu_act* out, int pd, int dtype, hipStream_t st) {
+    static const bool off = [] { const char* e = getenv("BIU_DISABLE"); return e && strstr(e, "pool_pipe") != nullptr; }();
+    if (off) return pool_rv_launch<1>(x, xf, out, nullptr, pd, 0, dtype, st);
+    BIU_DISPATCH_DTYPE(dtype, {
+        constexpr int PE = 16 / sizeof(T);
+        RowPlan p = row_plan(nvox(out), x->c, PE);
+        i64 want = (nvox(out) + (i64)p.rows * 4 - 1) / ((i64)p.rows * 4);          // ~4 output voxels per thread: the pipeline needs a loop
+        p.grid = (int)(want < 1 ? 1 : (want > 16384 ? 16384 : want));
+        hipLaunchKernelGGL(k_maxpool_fwd_pipe<T>, dim3(p.grid), dim3(TPB), 0, st, dact(x), dxf(xf), dact(out), pd, p.cg, p.rows);
+    });
+    BIU_CHECK_LAUNCH("maxpool_fwd_pipe");
+    return BIU_OK;
+}
 static RowPlan pool_bwd_plan(const biu_act* x, const biu_act* dout, int PE, i64 max_blocks) {
     RowPlan p = row_plan(nvox(dout), x->c, PE);
     i64 want = (nvox(dout) + (i64)p.rows * 4 - 1) / ((i64)p.rows * 4);          // ~4 pooled voxels (32 full-res) per thread
