@@ -52,7 +52,8 @@ def test_graphed_step_trains_like_the_eager_step(dtype):
     # fp32 pins the machinery (two runs differ by the weight gradient's atomics only).  bf16: two correct runs of this small network differ
     # by LeakyReLU / max-pool decision flips -- single tensors by up to ~10 %; a stale buffer or a lost ordering
     # in the graph gives O(1) or garbage (seen: 1e35 when a captured memset lost its order)
-    g_tol, b_tol = (1e-3, 1e-5) if dtype == "f32" else (0.2, 2e-2)
+    # (bf16: per tensor 0.5 -- a BatchNorm weight gradient is a small, cancelling sum -- and 0.1 over all gradients together)
+    g_tol, b_tol = (1e-3, 1e-5) if dtype == "f32" else (0.5, 2e-2)
     b1, b2, eps = 0.9, 0.999, 1e-8
     for i, (x, y) in enumerate(data):
         if i == 3:
@@ -68,10 +69,14 @@ def test_graphed_step_trains_like_the_eager_step(dtype):
         loss_e.backward()
         assert abs(loss_g - float(loss_e)) <= (1e-5 if dtype == "f32" else 2e-2) * max(1.0, abs(float(loss_e))), (i, loss_g, float(loss_e))
         pt = dict(twin.named_parameters())
+        num = den = 0.0
         for n, p in m.named_parameters():
             if ".0.bias" in n and "final" not in n:       # conv bias in front of a train-mode BatchNorm: true gradient 0, rounding noise
                 continue
             assert _rel(p.grad, pt[n].grad) <= g_tol, f"step {i} grad {n}: {_rel(p.grad, pt[n].grad)}"
+            num += float((p.grad - pt[n].grad).double().pow(2).sum())
+            den += float(pt[n].grad.double().pow(2).sum())
+        assert (num / den) ** 0.5 <= (1e-3 if dtype == "f32" else 0.1), f"step {i}: all gradients together differ by {(num / den) ** 0.5}"
         for (n, bg), (_, be) in zip(m.named_buffers(), twin.named_buffers()):
             if bg.dtype.is_floating_point:
                 assert _rel(bg, be) <= b_tol, f"step {i} buffer {n}"

@@ -22,4 +22,8 @@ for W in cfg1 cfg2 cfg3 cfg5; do
   python $R/bench.py --workload $W --no-cpu-baseline --breakdown $O/bench_breakdown_$W.txt > $O/bench_$W.json 2> $O/bench_$W.err
   echo "$W done" >> $O/progress.txt
 done
+for W in cfg1 cfg2; do        # opt-in bf16x3 products of the fp32 workloads
+  python $R/bench.py --workload $W --fp32-products bf16x3 --no-cpu-baseline --breakdown $O/bench_breakdown_${W}_bf16x3.txt > $O/bench_${W}_bf16x3.json 2> $O/bench_${W}_bf16x3.err
+  echo "$W bf16x3 done" >> $O/progress.txt
+done
 ls $O
