@@ -131,13 +131,13 @@ __device__ __forceinline__ void xp_commit(const C1Args& a, const XpRegs<KD, NTHR
 template <int KD, int NQ /* 16-channel pieces pairs: 1 -> cout 16, 2 -> cout 32 */>
 __global__ __launch_bounds__(256) void k_c1_fwd_mfma(C1Args a) {
     using G = Geo<KD>;
-    __shared__ __attribute__((aligned(16))) char smem[G::BV * ROWB + G::HV * 2 + 16 + 64 * 4 + 32 * 4];
+    __shared__ __attribute__((aligned(16))) char smem[G::BV * ROWB + G::HV * 2 + 16 + 4 * 64 * 4 + 32 * 4];
     char* lxp = smem;
     unsigned short* lx = (unsigned short*)(smem + G::BV * ROWB);
-    float* lred = (float*)(smem + G::BV * ROWB + ((G::HV * 2 + 15) & ~15));       // [32][2]
-    float* lbias = lred + 64;
+    float* lred = (float*)(smem + G::BV * ROWB + ((G::HV * 2 + 15) & ~15));       // [4 waves][32][2]: every wave its own row, summed in a fixed order
+    float* lbias = lred + 4 * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
-    if (tid < 64) lred[tid] = 0.f;
+    lred[tid] = 0.f;
     if (tid < 32) lbias[tid] = (a.bias && tid < a.cout) ? a.bias[a.co0 + tid] : 0.f;
     // A operand: W[co = r][tap = 16 ks + 8 hf + e], two k-steps, built once
     uint4 wf[2];
@@ -213,13 +213,13 @@ __global__ __launch_bounds__(256) void k_c1_fwd_mfma(C1Args a) {
                 float u = s1[q][e], w_ = s2[q][e];
 #pragma unroll
                 for (int o = 16; o > 0; o >>= 1) { u += __shfl_xor(u, o, 64); w_ += __shfl_xor(w_, o, 64); }
-                if (r == 0) { atomicAdd(&lred[2 * (16 * q + 8 * hf + e)], u); atomicAdd(&lred[2 * (16 * q + 8 * hf + e) + 1], w_); }
+                if (r == 0) { lred[wave * 64 + 2 * (16 * q + 8 * hf + e)] = u; lred[wave * 64 + 2 * (16 * q + 8 * hf + e) + 1] = w_; }   // (no atomics: the statistics are bit-reproducible)
             }
         __syncthreads();
         if (tid < a.cout) {
             float* dst = a.partial + ((size_t)blockIdx.x * a.ctot + a.co0 + tid) * 2;
-            dst[0] = lred[2 * tid];
-            dst[1] = lred[2 * tid + 1];
+            dst[0] = (lred[2 * tid] + lred[64 + 2 * tid]) + (lred[128 + 2 * tid] + lred[192 + 2 * tid]);
+            dst[1] = (lred[2 * tid + 1] + lred[64 + 2 * tid + 1]) + (lred[128 + 2 * tid + 1] + lred[192 + 2 * tid + 1]);
         }
     }
 }

@@ -106,16 +106,16 @@ def test_step_is_reproducible():
         loss, logits = step_loss(m, x, y)
         loss.backward()
         outs.append((float(loss), logits.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()}))
-    # forward: the BatchNorm statistics merge per-wave partial sums with LDS float atomics (order varies): 1e-7-level noise
-    # that a bf16 rounding boundary may amplify to one ulp of a few activations
-    assert abs(outs[0][0] - outs[1][0]) < 1e-5 * abs(outs[0][0])
-    assert float((outs[0][1] - outs[1][1]).abs().max()) < 2e-2 * float(outs[0][1].abs().max())
-    # backward: the gradient of this network is ill-conditioned (a train-mode BatchNorm after every conv amplifies a
-    # one-ulp bf16 change of an activation), so compare the whole gradient in norm, not element-wise
+    # forward: no atomics anywhere on it (per-wave partial rows, merged in a fixed order) -- the same bits every run
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1])
+    # backward: the weight gradient's fp32 atomics (and the LDS atomics of the ConvT data gradient's BatchNorm sums) vary in order:
+    # last-bit differences of fp32 sums, single bf16 roundings of dy downstream of them
     ga = torch.cat([outs[0][2][n].flatten().double() for n in outs[0][2]])
     gb = torch.cat([outs[1][2][n].flatten().double() for n in outs[0][2]])
-    assert float((ga - gb).norm() / ga.norm()) < 2e-2
-    assert float(torch.dot(ga, gb) / (ga.norm() * gb.norm())) > 0.9995
+    print(f"\n[reproducible] gradient run-to-run: rel {float((ga - gb).norm() / ga.norm()):.3e}")
+    assert float((ga - gb).norm() / ga.norm()) < 2e-3
+    assert float(torch.dot(ga, gb) / (ga.norm() * gb.norm())) > 0.99999
 
 
 def test_translation_equivariance_eval():

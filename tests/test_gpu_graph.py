@@ -52,9 +52,9 @@ def test_graphed_step_trains_like_the_eager_step(dtype):
     # fp32 pins the machinery (two runs differ by the weight gradient's atomics only).  bf16: two correct runs of this small network differ
     # by LeakyReLU / max-pool decision flips -- single tensors by up to ~10 %; a stale buffer or a lost ordering
     # in the graph gives O(1) or garbage (seen: 1e35 when a captured memset lost its order)
-    # (bf16: two EAGER runs of this 64 x 64, F = 16 network from the same weights differ by 5-8 % over all gradients together in about one
-    # step of eight, tools/diag_repro.py -- bounds of 0.6 per tensor and 0.3 overall still catch a stale buffer: O(1) or garbage)
-    g_tol, b_tol = (1e-3, 1e-5) if dtype == "f32" else (0.6, 2e-2)
+    # (bf16: the forward is bit-reproducible; backward sums vary in their last bits with the order of fp32 atomics, which single bf16
+    # roundings of dy pass on -- tools/diag_repro.py: two eager runs agree to ~1e-6 over all gradients together)
+    g_tol, b_tol = (1e-3, 1e-5) if dtype == "f32" else (5e-2, 1e-5)
     b1, b2, eps = 0.9, 0.999, 1e-8
     for i, (x, y) in enumerate(data):
         if i == 3:
@@ -68,7 +68,7 @@ def test_graphed_step_trains_like_the_eager_step(dtype):
         loss_e = crit(twin(x)[1], y)
         twin.zero_grad(set_to_none=True)
         loss_e.backward()
-        assert abs(loss_g - float(loss_e)) <= (1e-5 if dtype == "f32" else 2e-2) * max(1.0, abs(float(loss_e))), (i, loss_g, float(loss_e))
+        assert abs(loss_g - float(loss_e)) <= 1e-5 * max(1.0, abs(float(loss_e))), (i, loss_g, float(loss_e))
         pt = dict(twin.named_parameters())
         num = den = 0.0
         for n, p in m.named_parameters():
@@ -77,7 +77,7 @@ def test_graphed_step_trains_like_the_eager_step(dtype):
             assert _rel(p.grad, pt[n].grad) <= g_tol, f"step {i} grad {n}: {_rel(p.grad, pt[n].grad)}"
             num += float((p.grad - pt[n].grad).double().pow(2).sum())
             den += float(pt[n].grad.double().pow(2).sum())
-        assert (num / den) ** 0.5 <= (1e-3 if dtype == "f32" else 0.3), f"step {i}: all gradients together differ by {(num / den) ** 0.5}"
+        assert (num / den) ** 0.5 <= (1e-3 if dtype == "f32" else 1e-2), f"step {i}: all gradients together differ by {(num / den) ** 0.5}"
         for (n, bg), (_, be) in zip(m.named_buffers(), twin.named_buffers()):
             if bg.dtype.is_floating_point:
                 assert _rel(bg, be) <= b_tol, f"step {i} buffer {n}"
