@@ -1778,7 +1778,7 @@ __global__ void k_pack_batch(const biu_pack_job* __restrict__ jobs, int x3_on) {
 }
 int biu_mfma_pack_batch(const biu_pack_job* jobs_device, int n, int dtype, hipStream_t st) {
     if (n <= 0) return BIU_OK;
-    BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_batch<T>, dim3(64, n), dim3(256), 0, st, jobs_device, (dtype == BIU_F32 && !x3_disabled()) ? 1 : 0));
+    BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_batch<T>, dim3(256, n), dim3(256), 0, st, jobs_device, (dtype == BIU_F32 && !x3_disabled()) ? 1 : 0));
     BIU_CHECK_LAUNCH("pack_batch");
     return BIU_OK;
 }
