@@ -97,6 +97,9 @@ def make_step(wl, device, graph=False):
         opt.step()
         return loss
 
+    if graph and wl["model"] == "MultiOutputUnet3D":
+        print("bench: --graph ignored for the multi-head workload (GraphedTrainStep refuses steps with device-to-device copy nodes)", file=sys.stderr)
+        graph = False
     if graph:
         from bio_image_unet_amd.graph import GraphedTrainStep
         clip = (lambda: torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)) if wl["model"] == "MultiOutputUnet3D" else None

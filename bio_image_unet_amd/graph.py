@@ -12,6 +12,11 @@ What differs from the eager step, and how it is kept equal to it:
   * the warm-up steps that precede the capture run on copies: parameters, BatchNorm buffers and optimizer state are restored afterwards;
   * parameter version counters are bumped after every replay, so an eager forward in between (validation) re-packs the weights.
 Single process only: the gradient all-reduce of ``ddp.GradAverager`` is not captured.
+
+The graph must hold KERNEL nodes only.  A ``hipMemsetAsync`` captured in it was seen to lose its order against the kernels around it as soon
+as eager work ran between two replays (weight gradients accumulated onto stale workspace contents); the library therefore zero-fills with a
+kernel of its own, Adam's pointer table is uploaded after the capture, and networks whose step contains ``Tensor.copy_`` between device
+tensors (the stacked heads of ``MultiOutputUnet3D``) are refused.
 """
 from __future__ import annotations
 
@@ -35,6 +40,11 @@ class GraphedTrainStep:
             raise TypeError("GraphedTrainStep needs bio_image_unet_amd.optim.Adam (its step reads lr / bias correction from device memory)")
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             raise NotImplementedError("GraphedTrainStep is single-process: the gradient all-reduce is not captured")
+        if len(getattr(model, "output_heads", None) or {}) > 1:
+            # the stacked-head backward copies weights / d logits with Tensor.copy_: device-to-device copy NODES in the graph (12 per step
+            # of the bench's cfg5, rocprofv3 kernel trace) -- the kind of node that lost its order (module docstring); single-head steps
+            # are kernel nodes only (cfg4: 176 kernels, 0 copy / fill nodes per replay)
+            raise NotImplementedError("GraphedTrainStep: multi-head networks are not captured (their step holds device-to-device copy nodes)")
         self.model, self.loss_fn, self.opt, self.after_backward = model, loss_fn, optimizer, after_backward
         self.static_in = [t.detach().clone() for t in example_inputs]
         self.static_tgt = [t.detach().clone() for t in example_targets]

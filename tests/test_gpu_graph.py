@@ -114,3 +114,12 @@ def test_eager_forward_after_a_replay_sees_the_updated_weights():
         want = ref(x)[1]
     assert float((after - before).abs().max()) > 1e-4
     torch.testing.assert_close(after, want, rtol=1e-5, atol=1e-5)
+
+
+def test_multi_head_networks_are_refused():
+    heads = {"a": {"channels": 1, "activation": "sigmoid"}, "b": {"channels": 2, "activation": None}}
+    m = B.MultiOutputUnet3D(1, heads, n_filter=4).cuda()
+    opt = Adam(m.parameters(), lr=1e-3)
+    x = torch.rand(1, 1, 8, 16, 16).cuda()
+    with pytest.raises(NotImplementedError):
+        GraphedTrainStep(m, lambda outs: sum(o.mean() for o in outs.values()), opt, [x], [])
