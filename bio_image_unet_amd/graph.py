@@ -28,6 +28,34 @@ import torch
 from .optim import Adam
 
 
+_NODE_KINDS = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event", 7: "event_record"}
+
+
+def graph_node_kinds(graph: torch.cuda.CUDAGraph) -> dict:
+    """Node kinds of a captured graph (``hipGraphGetNodes`` / ``hipGraphNodeGetType`` on the runtime torch already loaded); the graph must
+    have been created with ``keep_graph=True``.  Empty dict when the runtime does not offer the calls."""
+    import ctypes as C
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        raw = C.c_void_p(graph.raw_cuda_graph())
+        n = C.c_size_t(0)
+        if hip.hipGraphGetNodes(raw, None, C.byref(n)) != 0:
+            return {}
+        nodes = (C.c_void_p * max(n.value, 1))()
+        if hip.hipGraphGetNodes(raw, nodes, C.byref(n)) != 0:
+            return {}
+        kinds: dict = {}
+        for i in range(n.value):
+            t = C.c_int(-1)
+            if hip.hipGraphNodeGetType(C.c_void_p(nodes[i]), C.byref(t)) != 0:
+                return {}
+            k = _NODE_KINDS.get(t.value, f"type{t.value}")
+            kinds[k] = kinds.get(k, 0) + 1
+        return kinds
+    except (OSError, AttributeError, RuntimeError):
+        return {}
+
+
 class GraphedTrainStep:
     """``step = GraphedTrainStep(model, loss_fn, optimizer, example_inputs, example_targets)``; then ``loss = step(inputs, targets)``.
 
@@ -63,11 +91,22 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         optimizer.prepare_for_capture()
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True)
         with torch.cuda.graph(self.graph, stream=side):
             self.loss = self._body()
             optimizer.step()                         # -> Adam._captured_step
         optimizer.finish_capture()
+        # what the capture holds: memset nodes are refused (see the module docstring), copy nodes -- e.g. the select-backward of a loss that
+        # indexes the logits, as unet/train.py:133-134 does -- are reported: they replayed in order in every test run so far
+        self.node_kinds = graph_node_kinds(self.graph)
+        if self.node_kinds.get("memset", 0):
+            raise RuntimeError(f"GraphedTrainStep: the captured step holds memset nodes {self.node_kinds}: they are not replayed in order "
+                               "on this runtime (zero tensors with a kernel: tensor.zero_() / torch.zeros, not hipMemsetAsync)")
+        if self.node_kinds.get("memcpy", 0):
+            import warnings
+            warnings.warn(f"GraphedTrainStep: the captured step holds device copy nodes {self.node_kinds}; a step of kernel nodes only is the "
+                          "verified configuration", stacklevel=2)
+        self.graph.instantiate()
         # nothing of the capture ran; undo the warm-up
         model.load_state_dict(model_state)
         with torch.no_grad():

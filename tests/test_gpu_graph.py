@@ -45,6 +45,7 @@ def test_graphed_step_trains_like_the_eager_step(dtype):
     data = _batches(K, shape)
     before = copy.deepcopy(m.state_dict())
     gstep = GraphedTrainStep(m, lambda outs, y: crit(outs[1], y), opt, [data[0][0]], [data[0][1]])
+    assert set(gstep.node_kinds) <= {"kernel"}, gstep.node_kinds      # this step is kernel nodes only
     for k, v in m.state_dict().items():                   # building it (warm-up steps + capture) left the model as it was
         assert torch.equal(v, before[k]), k
     assert not opt.state or all(int(st["step"]) == 0 for st in opt.state.values())
@@ -123,3 +124,33 @@ def test_multi_head_networks_are_refused():
     x = torch.rand(1, 1, 8, 16, 16).cuda()
     with pytest.raises(NotImplementedError):
         GraphedTrainStep(m, lambda outs: sum(o.mean() for o in outs.values()), opt, [x], [])
+
+
+def test_node_kinds_and_a_loss_with_copy_nodes():
+    """The reference's 2-D loss indexes the logits (unet/train.py:133-134): autograd's select-backward puts device copy NODES into the
+    captured step.  They must replay in order (a captured memset did not: GraphedTrainStep refuses those), and node_kinds reports them."""
+    import warnings
+    sd = O.init_unet2d(1, 1, 16, seed=4)
+    crit = BCEDiceLoss(0.5, 0.5)
+    lossf = lambda outs, y: crit(outs[1][0], y[0]) + crit(outs[1][1], y[1])      # noqa: E731
+    m, twin = B.Unet(1, 1, 16).cuda().train(), B.Unet(1, 1, 16).cuda().train()
+    m.load_state_dict(sd)
+    opt = Adam(m.parameters(), lr=1e-3)
+    data = _batches(4, (2, 1, 64, 64))
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        gstep = GraphedTrainStep(m, lossf, opt, [data[0][0]], [data[0][1]])
+    kinds = gstep.node_kinds
+    assert kinds.get("kernel", 0) > 100 and kinds.get("memset", 0) == 0, kinds
+    assert kinds.get("memcpy", 0) > 0 and any("copy nodes" in str(w.message) for w in rec), kinds
+    for x, y in data:
+        twin.load_state_dict(m.state_dict())
+        lg = float(gstep([x], [y]))
+        le = lossf(twin(x), y)
+        twin.zero_grad(set_to_none=True)
+        le.backward()
+        assert abs(lg - float(le)) <= 1e-5 * abs(float(le))
+        pt = dict(twin.named_parameters())
+        num = sum(float((p.grad - pt[n].grad).double().pow(2).sum()) for n, p in m.named_parameters())
+        den = sum(float(pt[n].grad.double().pow(2).sum()) for n, p in m.named_parameters())
+        assert (num / den) ** 0.5 <= 1e-3
