@@ -95,7 +95,7 @@ __global__ __launch_bounds__(NTHR) void k_convt_all(CtArgs a) {
     uint4* lw = lds;                                           // forward: [P][NTB][nKS][64] ; dgrad: [NTB][nKS][P][64]
     float* lxf = (float*)(lw + (size_t)P * NTB * nKS * 64);    // forward: [3][Clo] transform ; then [NTB*32] bias
     float* lbias = lxf + 3 * a.Clo;
-    float* lred = lbias + NTB * 32;                            // RED: [NTB*32][2]
+    float* lred = lbias + NTB * 32;                            // RED: [4 waves][NTB*32][2] -- every wave its own row, summed in a fixed order (no atomics)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hf = lane >> 5;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(NTHR) void k_convt_all(CtArgs a) {
             const int co = nt0 * 32 + tid;
             lbias[tid] = (!DGRAD && a.bias && co < a.Chi) ? a.bias[co] : 0.f;
             if (RED) {
-                lred[2 * tid] = 0.f; lred[2 * tid + 1] = 0.f;
+                for (int w_ = 0; w_ < NTHR / 64; ++w_) { lred[w_ * NTB * 64 + 2 * tid] = 0.f; lred[w_ * NTB * 64 + 2 * tid + 1] = 0.f; }
                 // the upstream block's transform vectors, read from LDS in the epilogue (lxf is free in the data-gradient kernels)
                 const bool okc = co < a.Clo;
                 lxf[tid] = okc ? a.red_scale[co] : 0.f;
@@ -300,8 +300,8 @@ __global__ __launch_bounds__(NTHR) void k_convt_all(CtArgs a) {
                     for (int o = 16; o > 0; o >>= 1) { u += __shfl_xor(u, o, 64); w += __shfl_xor(w, o, 64); }
                     if (r == 0) {
                         const int cc = nt * 32 + 16 * q + 8 * hf + e;
-                        atomicAdd(&lred[2 * cc], u);
-                        atomicAdd(&lred[2 * cc + 1], w);
+                        lred[wave * NTB * 64 + 2 * cc] = u;
+                        lred[wave * NTB * 64 + 2 * cc + 1] = w;
                     }
                 }
         __syncthreads();
@@ -309,7 +309,9 @@ __global__ __launch_bounds__(NTHR) void k_convt_all(CtArgs a) {
             const int ci = nt0 * 32 + tid;
             if (ci < a.Clo) {
                 float* dst = a.red_partial + ((size_t)blockIdx.x * a.Clo + ci) * 2;
-                const float l0 = lred[2 * tid], l1 = lred[2 * tid + 1];
+                float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+                for (int w_ = 0; w_ < NTHR / 64; ++w_) { l0 += lred[w_ * NTB * 64 + 2 * tid]; l1 += lred[w_ * NTB * 64 + 2 * tid + 1]; }
                 dst[0] = l0;
                 dst[1] = a.red_invstd[ci] * (l1 - a.red_mean[ci] * l0);       // sum dz * yhat
             }
@@ -386,7 +388,7 @@ int biu_convt_all_fwd(const biu_act* x, const biu_xform* xf, const void* packed,
     a.N = x->n; a.D = x->d; a.H = x->h; a.W = x->w; a.Clo = x->c; a.Chi = y->c;
     a.ntiles_total = y->c / 32; a.nKS = x->c / 16;
     const int P = kd * 4, ntb = pick_ntb(a.ntiles_total, a.nKS, P);
-    const size_t lds = (size_t)P * ntb * a.nKS * 1024 + (3 * (size_t)a.Clo + ntb * 32 * 3) * sizeof(float);
+    const size_t lds = (size_t)P * ntb * a.nKS * 1024 + (3 * (size_t)a.Clo + ntb * 32 * 9) * sizeof(float);
     const int per_cu = lds <= 72 * 1024 ? 2 : 1;
     const int gy = a.ntiles_total / ntb;
     int gx = per_cu * num_cus_() / gy;
@@ -399,7 +401,7 @@ int biu_convt_all_fwd(const biu_act* x, const biu_xform* xf, const void* packed,
 // rows of BatchNorm-backward partials the fused data gradient writes (= its grid.x)
 int biu_convt_all_dgrad_rows(const biu_act* dx, const biu_act* dy, int kd) {
     const int P = kd * 4, ntiles = dx->c / 32, nKS = dy->c / 16, ntb = pick_ntb(ntiles, nKS, P);
-    const size_t lds = (size_t)P * ntb * nKS * 1024 + (3 * (size_t)dx->c + ntb * 32 * 3) * sizeof(float);
+    const size_t lds = (size_t)P * ntb * nKS * 1024 + (3 * (size_t)dx->c + ntb * 32 * 9) * sizeof(float);
     const int per_cu = lds <= 72 * 1024 ? 2 : 1;
     int gx = per_cu * num_cus_() / (ntiles / ntb);
     if (gx < 1) gx = 1;
@@ -417,7 +419,7 @@ int biu_convt_all_dgrad(const biu_act* dy, const void* packed, int kd, const biu
     a.ntiles_total = dx->c / 32; a.nKS = dy->c / 16;
     a.accumulate = accumulate;
     const int P = kd * 4, ntb = pick_ntb(a.ntiles_total, a.nKS, P);
-    const size_t lds = (size_t)P * ntb * a.nKS * 1024 + (3 * (size_t)a.Clo + ntb * 32 * 3) * sizeof(float);
+    const size_t lds = (size_t)P * ntb * a.nKS * 1024 + (3 * (size_t)a.Clo + ntb * 32 * 9) * sizeof(float);
     const int gx = biu_convt_all_dgrad_rows(dx, dy, kd);
     if (red) {
         a.red_partial = bn_partial; a.red_y = (const char*)red->y->p; a.red_ypitch = red->y->pitch;

@@ -109,13 +109,11 @@ def test_step_is_reproducible():
     # forward: no atomics anywhere on it (per-wave partial rows, merged in a fixed order) -- the same bits every run
     assert outs[0][0] == outs[1][0]
     assert torch.equal(outs[0][1], outs[1][1])
-    # backward: the weight gradient's fp32 atomics (and the LDS atomics of the ConvT data gradient's BatchNorm sums) vary in order:
-    # last-bit differences of fp32 sums, single bf16 roundings of dy downstream of them
+    # backward: only the weight gradient's final fp32 atomics vary in order (nothing downstream of them): last-bit differences of dW
     ga = torch.cat([outs[0][2][n].flatten().double() for n in outs[0][2]])
     gb = torch.cat([outs[1][2][n].flatten().double() for n in outs[0][2]])
     print(f"\n[reproducible] gradient run-to-run: rel {float((ga - gb).norm() / ga.norm()):.3e}")
-    assert float((ga - gb).norm() / ga.norm()) < 2e-3
-    assert float(torch.dot(ga, gb) / (ga.norm() * gb.norm())) > 0.99999
+    assert float((ga - gb).norm() / ga.norm()) < 1e-5
 
 
 def test_translation_equivariance_eval():
