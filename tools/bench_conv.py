@@ -19,6 +19,8 @@ LAYERS = {
              ("decode6", 3, 4, 32, 16, (128, 128, 128)), ("middle2", 3, 4, 128, 256, (16, 16, 16))],
     "cfg1": [("encode6", 2, 2, 128, 128, (64, 64)), ("encode7", 2, 2, 128, 256, (32, 32)), ("encode8", 2, 2, 256, 256, (32, 32)), ("middle1", 2, 2, 256, 512, (16, 16)),
              ("middle2", 2, 2, 512, 512, (16, 16)), ("decode1", 2, 2, 512, 256, (32, 32))],
+    "cfg3": [("encode2", 2, 32, 32, 32, (512, 512)), ("encode4", 2, 32, 64, 64, (256, 256)), ("decode7", 2, 16, 64, 32, (512, 512)),
+             ("encode6", 2, 32, 128, 128, (128, 128)), ("encode8", 2, 32, 256, 256, (64, 64))],
     "cfg2": [("encode2", 2, 16, 64, 64, (512, 512)), ("decode7", 2, 16, 128, 64, (512, 512)), ("decode5", 2, 16, 256, 128, (256, 256)),
              ("middle2", 2, 16, 1024, 1024, (32, 32))],
 }
@@ -26,7 +28,7 @@ LAYERS = {
 
 def main():
     cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
-    dt = sys.argv[2] if len(sys.argv) > 2 else ("bf16" if cfg == "cfg4" else "f32")
+    dt = sys.argv[2] if len(sys.argv) > 2 else ("bf16" if cfg in ("cfg4", "cfg3") else "f32")
     only = sys.argv[3] if len(sys.argv) > 3 else None
     tdt, code = (torch.bfloat16, 1) if dt == "bf16" else (torch.float32, 0)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
