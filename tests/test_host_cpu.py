@@ -26,6 +26,18 @@ def test_library_exports_every_declared_symbol():
 
 
 @pytest.mark.parametrize("case", ["unet2d_f4", "unet2d_f4_o2_dil2", "unet3d_f4", "siam_f4_concat", "siam_f4_max", "mo3d_f4_interp", "mo3d_f4_convT"])
+
+def test_fp32_product_mode_switch_validates_its_argument():
+    """include/biu.h: biu_set_fp32_products(0 | 1); anything else is refused with a message (no GPU involved)."""
+    import bio_image_unet_amd as B
+    import bio_image_unet_amd._lib as L
+    assert L.lib.biu_set_fp32_products(0) == 0
+    assert L.lib.biu_set_fp32_products(7) != 0
+    assert b"mode" in L.lib.biu_last_error()
+    with pytest.raises(ValueError):
+        B.set_fp32_products("tf32")
+    B.set_fp32_products("exact")
+
 def test_state_dict_schema_and_checkpoint_loading(case):
     import bio_image_unet_amd as B
     from tests.golden_util import load_case
