@@ -25,8 +25,6 @@ def test_library_exports_every_declared_symbol():
     assert L.lib.biu_version() >= 100
 
 
-@pytest.mark.parametrize("case", ["unet2d_f4", "unet2d_f4_o2_dil2", "unet3d_f4", "siam_f4_concat", "siam_f4_max", "mo3d_f4_interp", "mo3d_f4_convT"])
-
 def test_fp32_product_mode_switch_validates_its_argument():
     """include/biu.h: biu_set_fp32_products(0 | 1); anything else is refused with a message (no GPU involved)."""
     import bio_image_unet_amd as B
@@ -38,6 +36,8 @@ def test_fp32_product_mode_switch_validates_its_argument():
         B.set_fp32_products("tf32")
     B.set_fp32_products("exact")
 
+
+@pytest.mark.parametrize("case", ["unet2d_f4", "unet2d_f4_o2_dil2", "unet3d_f4", "siam_f4_concat", "siam_f4_max", "mo3d_f4_interp", "mo3d_f4_convT"])
 def test_state_dict_schema_and_checkpoint_loading(case):
     import bio_image_unet_amd as B
     from tests.golden_util import load_case
