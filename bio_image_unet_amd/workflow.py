@@ -18,7 +18,7 @@ augmentation are out of scope).
 from __future__ import annotations
 
 import os
-from typing import Union
+from typing import Optional, Union
 
 import numpy as np
 import torch
@@ -116,7 +116,13 @@ class Trainer2D(_EpochLoop):
     def __init__(self, dataset, num_epochs, network=Unet, batch_size=4, lr=1e-3, in_channels=1, out_channels=1,
                  channel_weights=None, n_filter=64, dilation=1, val_split=0.2, save_dir="./", save_name="model.pt",
                  save_iter=False, load_weights=False, loss_function="BCEDice", loss_params=(0.5, 0.5),
-                 device: Union[torch.device, str] = "auto"):
+                 device: Union[torch.device, str] = "auto", fp32_products: Optional[str] = None):
+        """``fp32_products`` (not in the reference): ``"bf16x3"`` multiplies the fp32 tensors of this trainer as split bf16 products
+        (``bio_image_unet_amd.set_fp32_products``; process-wide, 2-3x faster steps) -- the role ``torch.backends.cudnn.allow_tf32``
+        plays for the reference; ``None`` leaves the process's mode alone (default: exact fp32)."""
+        if fp32_products is not None:
+            from . import set_fp32_products
+            set_fp32_products(fp32_products)
         self.device = _pick_device(device)
         self.network = network
         self.model = network(n_filter=n_filter, in_channels=in_channels, out_channels=out_channels, dilation=dilation).to(self.device)
@@ -234,7 +240,10 @@ class TrainerSiam(_EpochLoop):
 
     def __init__(self, dataset, num_epochs, batch_size=4, lr=1e-3, n_filter=32, mode="max", val_split=0.2,
                  save_dir="./", save_name="model.pt", save_iter=False, loss_function="BCEDice", loss_params=(1, 1),
-                 load_weights=None, device: Union[torch.device, str] = "auto"):
+                 load_weights=None, device: Union[torch.device, str] = "auto", fp32_products: Optional[str] = None):
+        if fp32_products is not None:                 # see Trainer2D
+            from . import set_fp32_products
+            set_fp32_products(fp32_products)
         self.device = _pick_device(device)
         self.model = Siam_UNet(n_filter=n_filter, mode=mode).to(self.device)      # no init_weights here (reference :61)
         self.n_filter, self.mode = n_filter, mode
