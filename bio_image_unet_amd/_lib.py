@@ -82,6 +82,8 @@ SIGNATURES = {
     "biu_pair_smooth_l1_blocks": (_I, [C.c_longlong]),
     "biu_pair_smooth_l1_fwd": (_I, [_P, _I, C.c_longlong, _P, _P]),
     "biu_pair_smooth_l1_bwd": (_I, [_P, _I, C.c_longlong, _P, _P, _I, _P]),
+    "biu_seg_loss_finish": (_I, [_P, _I, _I, C.c_longlong, _P, _I, _F, _F, _F, _I, _F, _F, _F, _I, _F, _P, _P]),
+    "biu_seg_loss_coef": (_I, [_P, _P, _I, C.c_longlong, _F, _F, _F, _I, _F, _F, _F, _I, _F, _P, _P, _P]),
     "biu_head_dlogits": (_I, [_P, _P, _P, _I, _I, _I, C.c_longlong, _P, _I, _I, _P]),
     "biu_trilinear_up_fwd": (_I, [_A, _X, _A, _I, _P]),
     "biu_trilinear_up_bwd": (_I, [_A, _A, _I, _I, _P]),

@@ -331,6 +331,104 @@ extern "C" int biu_head_dlogits(const float* g_logits, const float* g_act, const
     return BIU_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The scalar part of the fused segmentation losses (bio_image_unet_amd/losses.py: _FusedSegLoss) in two one-block kernels instead of
+// ~20 tiny torch launches per step: biu_seg_loss_finish merges the per-block partial sums and evaluates the loss, biu_seg_loss_coef
+// turns the incoming gradient into the per-sample coefficients biu_bce_dice_bwd / biu_pair_smooth_l1_bwd take.
+//   saved = { loss, sums[n][4] (BCE, P, T, P.T), den[n], tp, tden, tv }
+// ---------------------------------------------------------------------------------------------------------------------
+struct SegLossCfg { float a_bce, a_dice, smooth; int has_tv; float al, be, sm; int logcosh; float w_time; long long pairs; int nbt; };
+namespace {
+__global__ __launch_bounds__(256) void k_seg_loss_finish(const float* __restrict__ partial, int n, int nb, long long per,
+                                                        const float* __restrict__ pt, SegLossCfg c, float* __restrict__ saved) {
+    __shared__ double red[256];
+    float* sums = saved + 1;
+    for (int idx = threadIdx.x; idx < n * 4; idx += 256) {
+        const int i = idx >> 2, k = idx & 3;
+        double a = 0.0;
+        for (int b = 0; b < nb; ++b) a += (double)partial[((size_t)i * nb + b) * 4 + k];
+        sums[idx] = (float)a;
+    }
+    double tsum = 0.0;
+    if (pt)
+        for (int b = threadIdx.x; b < c.nbt; b += 256) tsum += (double)pt[b];
+    red[threadIdx.x] = tsum;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double loss = 0.0, bce = 0.0, dice = 0.0, tp = 0.0, ps = 0.0, ts = 0.0;
+        float* den = saved + 1 + 4 * n;
+        for (int i = 0; i < n; ++i) {
+            bce += (double)sums[4 * i];
+            ps += (double)sums[4 * i + 1]; ts += (double)sums[4 * i + 2]; tp += (double)sums[4 * i + 3];
+            const float d = sums[4 * i + 1] + sums[4 * i + 2] + c.smooth;
+            den[i] = d;
+            dice += 2.0 * ((double)sums[4 * i + 3] + c.smooth) / (double)d;
+        }
+        if (c.a_bce != 0.f) loss += (double)c.a_bce * bce / ((double)n * (double)per);
+        if (c.a_dice != 0.f) loss += (double)c.a_dice * (1.0 - dice / n);
+        float* tvs = den + n;
+        tvs[0] = tvs[1] = tvs[2] = 0.f;
+        if (c.has_tv) {
+            const double tden = tp + c.al * (ps - tp) + c.be * (ts - tp) + c.sm;
+            const double tv = (tp + c.sm) / tden;
+            tvs[0] = (float)tp; tvs[1] = (float)tden; tvs[2] = (float)tv;
+            loss += c.logcosh ? log(cosh(1.0 - tv)) : (1.0 - tv);
+        }
+        if (pt) loss += (double)c.w_time * red[0] / (double)c.pairs;
+        saved[0] = (float)loss;
+    }
+}
+// coef[n][3]: d loss / d logit_i = c0 (p_i - t_i) + (c1 + c2 t_i) p_i (1 - p_i) per sample; ctime[0]: the time term's factor
+__global__ void k_seg_loss_coef(const float* __restrict__ g, const float* __restrict__ saved, int n, long long per, SegLossCfg c,
+                                float* __restrict__ coef, float* __restrict__ ctime) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float gv = g[0];
+    if (i == 0 && ctime) ctime[0] = (n > 1) ? gv * (c.w_time / ((float)(n - 1) * (float)per)) : 0.f;
+    if (i >= n) return;
+    const float* sums = saved + 1 + 4 * i;
+    const float den = saved[1 + 4 * n + i];
+    const float* tvs = saved + 1 + 5 * n;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    if (c.a_bce != 0.f) c0 = gv * (c.a_bce / ((float)n * (float)per));
+    if (c.a_dice != 0.f) {
+        c1 += gv * (c.a_dice / n) * 2.0f * (sums[3] + c.smooth) / (den * den);
+        c2 += -gv * (c.a_dice / n) * 2.0f / den;
+    }
+    if (c.has_tv) {
+        const float tp = tvs[0], tden = tvs[1], tv = tvs[2];
+        const float outer = -gv * (c.logcosh ? tanhf(1.f - tv) : 1.f);                 // d loss / d Tversky
+        const float d_tp = (tden - (tp + c.sm) * (1.f - c.al - c.be)) / (tden * tden);
+        const float d_ps = -(tp + c.sm) * c.al / (tden * tden);
+        c1 += outer * d_ps;
+        c2 += outer * d_tp;
+    }
+    coef[3 * i] = c0; coef[3 * i + 1] = c1; coef[3 * i + 2] = c2;
+}
+}  // namespace
+
+extern "C" int biu_seg_loss_finish(const float* partial, int n, int nb, long long per_sample, const float* time_partial, int nbt,
+                                   float a_bce, float a_dice, float smooth, int has_tversky, float tv_alpha, float tv_beta, float tv_smooth,
+                                   int logcosh, float w_time, float* saved, biu_stream stream) {
+    BIU_REQUIRE(partial && saved && n > 0 && nb > 0 && per_sample > 0 && (!time_partial || (nbt > 0 && n > 1)), BIU_ERR_SHAPE, "seg_loss_finish: bad arguments");
+    const SegLossCfg c{a_bce, a_dice, smooth, has_tversky, tv_alpha, tv_beta, tv_smooth, logcosh, w_time, (long long)(n - 1) * per_sample, nbt};
+    hipLaunchKernelGGL(k_seg_loss_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n, nb, per_sample, time_partial, c, saved);
+    BIU_CHECK_LAUNCH("seg_loss_finish");
+    return BIU_OK;
+}
+extern "C" int biu_seg_loss_coef(const float* g, const float* saved, int n, long long per_sample, float a_bce, float a_dice, float smooth,
+                                 int has_tversky, float tv_alpha, float tv_beta, float tv_smooth, int logcosh, float w_time, float* coef,
+                                 float* time_coef, biu_stream stream) {
+    BIU_REQUIRE(g && saved && coef && n > 0 && per_sample > 0, BIU_ERR_SHAPE, "seg_loss_coef: bad arguments");
+    const SegLossCfg c{a_bce, a_dice, smooth, has_tversky, tv_alpha, tv_beta, tv_smooth, logcosh, w_time, (long long)(n - 1) * per_sample, 0};
+    hipLaunchKernelGGL(k_seg_loss_coef, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, g, saved, n, per_sample, c, coef, time_coef);
+    BIU_CHECK_LAUNCH("seg_loss_coef");
+    return BIU_OK;
+}
+
 extern "C" int biu_bce_dice_blocks(long long per_sample) {
     long long b = (per_sample + 256 * 8 - 1) / (256 * 8);
     return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));

@@ -46,6 +46,13 @@ class _FusedSegLoss(torch.autograd.Function):
     instead of the eager graph's ~15 full-tensor element-wise / reduction kernels.  ``cfg`` selects the terms."""
 
     @staticmethod
+    def _scalars(cfg):
+        tv = cfg.get("tversky")
+        return (float(cfg.get("bce", 0.0)), float(cfg.get("dice", 0.0)), float(cfg.get("smooth", 1.0)), 1 if tv else 0,
+                float(tv[0]) if tv else 0.0, float(tv[1]) if tv else 0.0, float(tv[2]) if tv else 0.0, 1 if (tv and tv[3]) else 0,
+                float(cfg.get("time", 0.0)))
+
+    @staticmethod
     def forward(ctx, logits, targets, cfg):
         import ctypes as C
         from ._lib import check, lib
@@ -56,30 +63,19 @@ class _FusedSegLoss(torch.autograd.Function):
         partial = torch.empty((n, nb, 4), dtype=torch.float32, device=logits.device)
         check(lib.biu_bce_dice_fwd(C.c_void_p(logits.data_ptr()), C.c_void_p(targets.data_ptr()), n, per,
                                    C.c_void_p(partial.data_ptr()), st), "bce_dice_fwd")
-        sums = partial.sum(1)                                    # [n, 4]: bce, p, t, p*t
-        loss = logits.new_zeros(())
-        saved = {"sums": sums}
-        a_bce, a_dice, smooth = cfg.get("bce", 0.0), cfg.get("dice", 0.0), cfg.get("smooth", 1.0)
-        if a_bce:
-            loss = loss + a_bce * sums[:, 0].sum() / (n * per)
-        if a_dice:
-            den = sums[:, 1] + sums[:, 2] + smooth
-            saved["den"] = den
-            loss = loss + a_dice * (1 - (2.0 * (sums[:, 3] + smooth) / den).mean())
-        if "tversky" in cfg:
-            al, be, sm, logcosh = cfg["tversky"]
-            tp, ps, ts = sums[:, 3].sum(), sums[:, 1].sum(), sums[:, 2].sum()
-            tden = tp + al * (ps - tp) + be * (ts - tp) + sm
-            tv = (tp + sm) / tden
-            saved.update(tp=tp, tden=tden, tv=tv)
-            loss = loss + (torch.log(torch.cosh(1 - tv)) if logcosh else (1 - tv))
-        w_time = cfg.get("time", 0.0)
+        sc = _FusedSegLoss._scalars(cfg)
+        w_time = sc[8]
+        pt, nbt = None, 0
         if w_time and n > 1:
-            pairs = (n - 1) * per
-            pt = torch.empty(lib.biu_pair_smooth_l1_blocks(pairs), dtype=torch.float32, device=logits.device)
+            nbt = lib.biu_pair_smooth_l1_blocks((n - 1) * per)
+            pt = torch.empty(nbt, dtype=torch.float32, device=logits.device)
             check(lib.biu_pair_smooth_l1_fwd(C.c_void_p(logits.data_ptr()), n, per, C.c_void_p(pt.data_ptr()), st), "pair_smooth_l1_fwd")
-            loss = loss + w_time * pt.sum() / pairs
-        elif w_time:                 # a batch of one: nn.SmoothL1Loss over empty slices is nan in the reference, and so here
+        # the per-block sums -> the loss value, in one launch (biu_seg_loss_finish); saved = {loss, sums, den, Tversky terms}
+        saved = torch.empty(1 + 5 * n + 3, dtype=torch.float32, device=logits.device)
+        check(lib.biu_seg_loss_finish(C.c_void_p(partial.data_ptr()), n, nb, per, C.c_void_p(pt.data_ptr()) if pt is not None else None, nbt,
+                                      *sc, C.c_void_p(saved.data_ptr()), st), "seg_loss_finish")
+        loss = saved[0]
+        if w_time and n <= 1:            # a batch of one: nn.SmoothL1Loss over empty slices is nan in the reference, and so here
             loss = loss + float("nan")
         ctx.save_for_backward(logits, targets)
         ctx.saved, ctx.cfg, ctx.np = saved, cfg, (n, per)
@@ -90,33 +86,21 @@ class _FusedSegLoss(torch.autograd.Function):
         import ctypes as C
         from ._lib import check, lib
         logits, targets = ctx.saved_tensors
-        cfg, sv, (n, per) = ctx.cfg, ctx.saved, ctx.np
-        sums = sv["sums"]
+        cfg, saved, (n, per) = ctx.cfg, ctx.saved, ctx.np
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        # d/dl_i = c0 * (p_i - t_i) + (c1 + c2 * t_i) * p_i (1 - p_i), per sample
-        coef = torch.zeros((n, 3), dtype=torch.float32, device=logits.device)
-        a_bce, a_dice, smooth = cfg.get("bce", 0.0), cfg.get("dice", 0.0), cfg.get("smooth", 1.0)
-        if a_bce:
-            coef[:, 0] = g * (a_bce / (n * per))
-        if a_dice:
-            den = sv["den"]
-            coef[:, 1] += g * (a_dice / n) * 2.0 * (sums[:, 3] + smooth) / (den * den)
-            coef[:, 2] += -g * (a_dice / n) * 2.0 / den
-        if "tversky" in cfg:
-            al, be, sm, logcosh = cfg["tversky"]
-            tp, tden, tv = sv["tp"], sv["tden"], sv["tv"]
-            outer = -g * (torch.tanh(1 - tv) if logcosh else 1.0)           # d loss / d Tversky
-            d_tp = (tden - (tp + sm) * (1 - al - be)) / (tden * tden)       # Tversky = (TP + s) / den, den = TP(1-al-be) + al P + be T + s
-            d_ps = -(tp + sm) * al / (tden * tden)
-            coef[:, 1] += outer * d_ps
-            coef[:, 2] += outer * d_tp
+        sc = _FusedSegLoss._scalars(cfg)
+        w_time = sc[8]
+        g = g.reshape(1).to(torch.float32).contiguous()
+        # d/dl_i = c0 * (p_i - t_i) + (c1 + c2 * t_i) * p_i (1 - p_i), per sample: coefficients in one launch (biu_seg_loss_coef)
+        coef = torch.empty((n, 3), dtype=torch.float32, device=logits.device)
+        ct = torch.empty(1, dtype=torch.float32, device=logits.device) if (w_time and n > 1) else None
+        check(lib.biu_seg_loss_coef(C.c_void_p(g.data_ptr()), C.c_void_p(saved.data_ptr()), n, per, *sc, C.c_void_p(coef.data_ptr()),
+                                    C.c_void_p(ct.data_ptr()) if ct is not None else None, st), "seg_loss_coef")
         dl = torch.empty_like(logits)
         check(lib.biu_bce_dice_bwd(C.c_void_p(logits.data_ptr()), C.c_void_p(targets.data_ptr()), n, per,
                                    C.c_void_p(coef.data_ptr()), C.c_void_p(dl.data_ptr()), 0, st), "bce_dice_bwd")
-        w_time = cfg.get("time", 0.0)
-        if w_time and n > 1:
-            c = (g * (w_time / ((n - 1) * per))).reshape(1).float().contiguous()
-            check(lib.biu_pair_smooth_l1_bwd(C.c_void_p(logits.data_ptr()), n, per, C.c_void_p(c.data_ptr()), C.c_void_p(dl.data_ptr()), 1, st),
+        if ct is not None:
+            check(lib.biu_pair_smooth_l1_bwd(C.c_void_p(logits.data_ptr()), n, per, C.c_void_p(ct.data_ptr()), C.c_void_p(dl.data_ptr()), 1, st),
                   "pair_smooth_l1_bwd")
         return dl, None, None
 

@@ -224,6 +224,19 @@ int biu_pair_smooth_l1_blocks(long long pairs);
 int biu_pair_smooth_l1_fwd(const float* logits, int n, long long per_sample, float* partial, biu_stream stream);
 int biu_pair_smooth_l1_bwd(const float* logits, int n, long long per_sample, const float* coef, float* dlogits, int accumulate,
                            biu_stream stream);
+/* The scalar arithmetic of the fused segmentation losses in two one-block launches (instead of ~20 element-wise torch kernels on [n, 4]
+ * tensors per step).  biu_seg_loss_finish: partial = biu_bce_dice_fwd's [n][nb][4] rows, time_partial = biu_pair_smooth_l1_fwd's nbt
+ * sums or NULL -> saved[1 + 4n + n + 3] = { loss, sums[n][4] (BCE, P, T, P.T), den[n] = P + T + smooth, tp, tden, Tversky } with
+ *   loss = a_bce * sum BCE / (n per) + a_dice * (1 - mean_n 2 (PT_n + smooth) / den_n)                    (unet/losses.py:78-112)
+ *        + [has_tversky] (1 - Tv) or log cosh(1 - Tv),  Tv = (TP + s) / (TP + alpha FP + beta FN + s)     (unet/losses.py:145-239)
+ *        + w_time * sum SmoothL1 / ((n - 1) per)                                                          (unet3d/train.py:140-145)
+ * biu_seg_loss_coef: g = d / d loss (device scalar) -> coef[n][3] for biu_bce_dice_bwd, time_coef[1] for biu_pair_smooth_l1_bwd.      */
+int biu_seg_loss_finish(const float* partial, int n, int nb, long long per_sample, const float* time_partial, int nbt,
+                        float a_bce, float a_dice, float smooth, int has_tversky, float tv_alpha, float tv_beta, float tv_smooth,
+                        int logcosh, float w_time, float* saved, biu_stream stream);
+int biu_seg_loss_coef(const float* g, const float* saved, int n, long long per_sample, float a_bce, float a_dice, float smooth,
+                      int has_tversky, float tv_alpha, float tv_beta, float tv_smooth, int logcosh, float w_time, float* coef,
+                      float* time_coef, biu_stream stream);
 /* d loss / d logits of one head from the caller's gradients w.r.t. its logits and / or its activated output (act as in
  * biu_head_fwd; multi_output_unet3d.py:97-104), written to channels [dst_c0, dst_c0 + ch) of a fp32 [n, dst_channels, spatial]
  * tensor -- the stacked operand of one biu_head_bwd over all heads that share a trunk.                                    */
