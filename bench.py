@@ -3,8 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload cfg4|cfg2|cfg3|cfg5|cfg1]
 
-N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
-(one rank per GPU, RCCL); per-GPU work is fixed (weak scaling), `value` is the whole-job aggregate.
+N > 1: one rank per GPU over RCCL, either launched by the driver as  python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N ...  (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or -- when WORLD_SIZE is NOT set -- by this
+script itself: `python bench.py --gpus N` starts N child ranks before anything touches a GPU (the parent never does), waits for
+them and exits non-zero if any of them failed; rank 0's JSON line is the only line on stdout.  Per-GPU work is fixed (weak
+scaling), `value` is the whole-job aggregate; `ddp.ranks_seen` (an all-reduce of 1 over the job) and the RCCL version are in the line.
 
 Workloads (BASELINE.json `configs`) -- synthetic data x ~ U[0,1), y = (U > 0.5), seed 1234:
   cfg4 (default, the north-star target): UNet3D(1,1,32), (4,1,128,128,128) per GPU, bf16 storage / fp32 accumulate
@@ -91,9 +94,9 @@ def make_step(wl, device, graph=False):
         loss = loss_of(outs)
         opt.zero_grad(set_to_none=True)
         loss.backward()
-        if wl["model"] == "MultiOutputUnet3D":     # multi_output_unet3d/train.py:201
+        avg.average()                              # (a no-op at N = 1) -- BEFORE the clip: buckets that left during backward are not re-read
+        if wl["model"] == "MultiOutputUnet3D":     # multi_output_unet3d/train.py:201, on the global-batch gradient
             torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
-        avg.average()
         opt.step()
         return loss
 
@@ -203,17 +206,53 @@ def cpu_baseline(wl_name, budget_s=22.0):
             "cfg1_verbatim": cfg1}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (the torchrun environment contract), one per
+    GPU.  Runs BEFORE this process has imported the HIP library or made any GPU call, and it never makes one: the children are
+    ordinary child processes (no exec of a GPU-initialised process), their stdout/stderr are inherited, so rank 0's JSON line is
+    the only JSON on stdout.  Exit code: 0 only if every rank exited 0; a failed rank takes the others down (exact PIDs)."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    env = dict(os.environ, MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port, WORLD_SIZE=str(n),
+               LOCAL_WORLD_SIZE=str(n), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(n)]
+    rc, alive = 0, list(procs)
+    while alive:
+        for p in list(alive):
+            try:
+                code = p.wait(timeout=0.2)
+            except subprocess.TimeoutExpired:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench: rank {procs.index(p)} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in alive:
+                    q.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N = 1 only)")
     ap.add_argument("--fp32-products", default="exact", choices=["exact", "bf16x3"], help="fp32 workloads: how the 3x3 kernels multiply (default: fp32 MFMA)")
     ap.add_argument("--breakdown", default=None, help="write the per-launch time table of one profiled step to this file")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     from bio_image_unet_amd import ddp
     from bio_image_unet_amd._lib import lib
@@ -221,7 +260,8 @@ def main():
     if os.environ.get("BIU_SINGLE_DEVICE") == "1":
         os.environ["LOCAL_RANK"] = "0"
     rank, local, world = ddp.init_from_env(os.environ.get("BIU_DDP_BACKEND", "nccl"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench: --gpus {args.gpus} but WORLD_SIZE={world} (launch one rank per GPU, or leave WORLD_SIZE unset)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     wl = WORKLOADS[args.workload]
@@ -258,21 +298,30 @@ def main():
 
     # ---- timed region --------------------------------------------------------------------------------------------------
     lib.watch, lib.watched = dom_key, []
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step stamps on the compute stream (median)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     if hasattr(step, "eager"):                  # graph mode: the dominant launch is timed in eager steps after the timed region
         for _ in range(3):
             step.eager()
         torch.cuda.synchronize()
     watched, lib.watch = lib.watched, None
+    ranks_seen = 1
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt, median_ms], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, median_ms = float(t[0].item()), float(t[1].item())
+        one = torch.ones(1, device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(one)                      # every rank adds 1: the driver can see that N ranks really ran
+        ranks_seen = int(one.item())
     ms_per_step = dt / args.steps * 1e3
 
     # forward-only (eval-style use, no_grad; BN in train mode exactly as the reference's validation loop)
@@ -320,7 +369,8 @@ def main():
     vps_gpu = nvox / (ms_per_step * 1e-3)
     out = {
         "metric": "voxels/sec fwd+bwd", "value": vps_gpu * world, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "median_ms_per_step": median_ms,
+        "value_at_median": nvox / (median_ms * 1e-3) * world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": dt_name, "data": "synthetic",
         "config": {"workload": f"{args.workload}: {wl['model']}({', '.join(f'{k}={v}' for k, v in wl['ctor'].items() if k != 'output_heads')}) input {wl['shape']} per GPU, "
                                "train step = forward + reference loss + backward + Adam", "parallelism": f"dp{world}"},
@@ -337,7 +387,12 @@ def main():
                              "operands split hi + lo in bf16, hi*hi + hi*lo + lo*hi on the bf16 MFMA, <= 2^-15 relative per product; "
                              "roofline peak = bf16 dense peak / 3")
     if world > 1:           # gradient all-reduce: decoder -> encoder buckets, issued from inside backward (bio_image_unet_amd/ddp.py)
-        out["ddp"] = {"buckets": len(avg.buckets), "launched_in_backward": avg.launched_in_backward,
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                               # gloo rehearsal on a box without the collective library loaded
+            rccl = None
+        out["ddp"] = {"ranks_seen": ranks_seen, "backend": torch.distributed.get_backend(), "rccl_version": rccl,
+                      "buckets": len(avg.buckets), "launched_in_backward": avg.launched_in_backward,
                       "bucket_mbytes": [round(b.flat.numel() * 4 / 2 ** 20, 2) for b in avg.buckets]}
     if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores, bounded sample)
         out["cpu_baseline"] = cpu_baseline(args.workload)

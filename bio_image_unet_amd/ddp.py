@@ -32,7 +32,7 @@ def init_from_env(backend: str | None = None):
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "views", "pending", "work")
+    __slots__ = ("flat", "params", "views", "pending", "work", "late")
 
     def __init__(self, params, device):
         n = sum(p.numel() for p in params)
@@ -41,7 +41,7 @@ class _Bucket:
         for p in params:
             self.views.append(self.flat[o:o + p.numel()].view_as(p))
             o += p.numel()
-        self.pending, self.work = set(), None
+        self.pending, self.work, self.late = set(), None, False
 
 
 class GradAverager:
@@ -54,7 +54,14 @@ class GradAverager:
     kernels (xGMI is point-to-point: a 19 MB UNet3D gradient is ~0.2 ms of ring time against a >= 10 ms step, so three or four
     buckets hide all of it behind the encoder's backward).  ``average()`` after backward launches whatever is still incomplete
     (parameters without a gradient count as zeros), waits, scales by 1/world and leaves ``p.grad`` = views of the flat buckets.
-    Any other ``nn.Module`` (no hook) is bucketed the same way, launched back to back from ``average()``."""
+    Any other ``nn.Module`` (no hook) is bucketed the same way, launched back to back from ``average()``.
+
+    Contract: between ``backward()`` and ``average()`` nobody may modify ``p.grad`` -- a bucket that went out during backward
+    is not re-read, so e.g. ``clip_grad_norm_`` belongs AFTER ``average()`` (it then clips the global-batch gradient, which is what
+    torch DDP users get too).  Gradient ACCUMULATION is supported: when a hook fires for a parameter whose ``p.grad`` already
+    holds something (second ``backward()`` before ``average()``, or ``zero_grad(set_to_none=False)`` / last step's bucket views
+    still installed), autograd is about to add into ``p.grad`` in place, so that bucket is not launched early (an in-flight
+    all-reduce of it is waited for and dropped) and ``average()`` takes the whole bucket from ``p.grad``."""
 
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 8.0):
         self.params: List[torch.nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
@@ -88,7 +95,7 @@ class GradAverager:
 
     def _reset(self):
         for b in self.buckets:
-            b.pending, b.work = set(range(len(b.params))), None
+            b.pending, b.work, b.late = set(range(len(b.params))), None, False
 
     def _launch(self, b: _Bucket):
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, async_op=True)
@@ -100,8 +107,15 @@ class GradAverager:
         if hit is None:
             return
         b, i = hit
-        if i not in b.pending:
-            return                                      # a second backward before average(): handled there
+        if b.late or i not in b.pending or p.grad is not None:
+            # the gradient is being accumulated: autograd adds ``g`` into the existing p.grad right after this hook, so the
+            # sum exists only there.  Nothing of this bucket may be on the wire while that happens (p.grad can BE a view of
+            # b.flat): wait out an early launch, and let average() read the whole bucket from p.grad.
+            b.late = True
+            if b.work is not None:
+                b.work.wait()
+                b.work = None
+            return
         b.views[i].copy_(g)
         b.pending.discard(i)
         if not b.pending and b.work is None:
@@ -116,11 +130,11 @@ class GradAverager:
         early = sum(1 for b in self.buckets if b.work is not None)
         for b in self.buckets:
             if b.work is None:
-                for i in b.pending:                     # not reported during backward: take p.grad (or zeros)
+                for i in (range(len(b.params)) if b.late else b.pending):    # not reported during backward (or accumulated): take p.grad (or zeros)
                     g = b.params[i].grad
                     if g is None:
                         b.views[i].zero_()
-                    else:
+                    elif g.data_ptr() != b.views[i].data_ptr():      # (p.grad may still be last step's view of this bucket)
                         b.views[i].copy_(g)
                 self._launch(b)
         for b in self.buckets:

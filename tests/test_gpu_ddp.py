@@ -48,6 +48,31 @@ for step in range(2):
         torch.testing.assert_close(p.grad, sum(parts) / world, rtol=1e-6, atol=1e-12)
         if k == "encode2.0.weight":
             assert not torch.equal(parts[0], parts[1]), "the two ranks must have seen different data"
+# gradient accumulation on the engine: two backwards before one average() (each forward/backward pair on its own turn of the engine)
+m.zero_grad(set_to_none=True)
+for xx in (x, x.flip(0)):
+    O.bce_dice_loss(m(xx)[1], y).backward()
+local_g = {k: p.grad.clone() for k, p in m.named_parameters()}
+avg.average()
+for k, p in m.named_parameters():
+    parts = [torch.zeros_like(local_g[k]) for _ in range(world)]
+    dist.all_gather(parts, local_g[k])
+    torch.testing.assert_close(p.grad, sum(parts) / world, rtol=1e-6, atol=1e-12)
+# the multi-head step of bench.py (cfg5): average, THEN clip (multi_output_unet3d/train.py:201 on the global-batch gradient)
+m.zero_grad(set_to_none=True)
+O.bce_dice_loss(m(x)[1], y).backward()
+local_g = {k: p.grad.clone() for k, p in m.named_parameters()}
+avg.average()
+torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=1e-3)
+mean_g = {}
+for k in local_g:
+    parts = [torch.zeros_like(local_g[k]) for _ in range(world)]
+    dist.all_gather(parts, local_g[k])
+    mean_g[k] = sum(parts) / world
+norm = torch.sqrt(sum((v.double() ** 2).sum() for v in mean_g.values()))
+assert float(norm) > 1e-3
+for k, p in m.named_parameters():
+    torch.testing.assert_close(p.grad, (mean_g[k] * (1e-3 / (norm + 1e-6))).float(), rtol=1e-5, atol=1e-12)
 # BatchNorm running statistics stay rank-local (plain nn.BatchNorm in the reference: no SyncBN)
 rm = m.encode1[1].running_mean.detach().clone()
 parts = [torch.zeros_like(rm) for _ in range(world)]
@@ -85,3 +110,24 @@ def test_bench_two_rank_path(tmp_path):
     assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["config"]["parallelism"] == "dp2" and "cpu_baseline" not in r
     assert r["value"] > 0 and abs(r["value"] - 2 * 2 * 256 * 256 / (r["ms_per_step"] * 1e-3)) < 1e-3 * r["value"]
     assert r["ddp"]["buckets"] >= 1 and r["ddp"]["launched_in_backward"] == r["ddp"]["buckets"]
+    assert r["ddp"]["ranks_seen"] == 2
+
+
+@pytest.mark.timeout(400)
+def test_bench_self_launches_its_ranks(tmp_path):
+    """Plain `python bench.py --gpus 2` with no launcher and no WORLD_SIZE: the script starts its own two ranks (before it
+    touches the GPU), one JSON line comes out, and the line shows that two ranks took part."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BIU_DDP_BACKEND="gloo", BIU_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--workload", "cfg1"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=360)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["parallelism"] == "dp2" and r["ddp"]["ranks_seen"] == 2
+    assert r["median_ms_per_step"] > 0 and r["steps"] == 3
+    # ranks that fail take the job down with a non-zero exit code and no JSON line (here: an unknown collective backend)
+    bad = subprocess.run(cmd, env=dict(env, BIU_DDP_BACKEND="no-such-backend"), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=240)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]

@@ -106,6 +106,38 @@ for p, lg in zip(m.parameters(), local_g):
     both = [torch.zeros_like(lg) for _ in range(world)]
     dist.all_gather(both, lg)
     torch.testing.assert_close(p.grad, sum(both) / world)
+# gradient accumulation: two backwards before one average() -- the hooked path must not ship the first micro-batch alone
+def mean_over_ranks(t):
+    both = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(both, t)
+    return sum(both) / world
+m.zero_grad(set_to_none=True)
+m(x).sum().backward()
+m(x * 3).sum().backward()
+local_g = [p.grad.clone() for p in m.parameters()]
+avg.average()
+for p, lg in zip(m.parameters(), local_g):
+    torch.testing.assert_close(p.grad, mean_over_ranks(lg))
+# p.grad kept across steps (zero_grad(set_to_none=False)): p.grad IS a view of the bucket now; autograd accumulates in place
+m.zero_grad(set_to_none=False)
+assert all(p.grad is not None and float(p.grad.abs().sum()) == 0.0 for p in m.parameters())
+m(x * 0.5).sum().backward()
+local_g = [p.grad.clone() for p in m.parameters()]
+avg.average()
+for p, lg in zip(m.parameters(), local_g):
+    torch.testing.assert_close(p.grad, mean_over_ranks(lg))
+# clipping: AFTER average() (GradAverager contract) == clip of the mean gradient, identical on every rank
+m.zero_grad(set_to_none=True)
+m(x * 2).sum().backward()
+local_g = [p.grad.clone() for p in m.parameters()]
+avg.average()
+torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=0.01)
+want = [mean_over_ranks(lg) for lg in local_g]
+norm = torch.sqrt(sum((w.double() ** 2).sum() for w in want))
+assert float(norm) > 0.01
+for p, w in zip(m.parameters(), want):
+    torch.testing.assert_close(p.grad, (w * (0.01 / (norm + 1e-6))).float())
+    torch.testing.assert_close(p.grad, mean_over_ranks(p.grad))
 dist.barrier()
 print("OK", rank)
 '''
