@@ -24,6 +24,10 @@ Reference citations (relative to /root/reference/bio_image_unet):
   * BCELoss2d / SoftDiceLoss / BCEDiceLoss / Tversky .. unet/losses.py:5-37, 40-75, 78-112, 145-191
   * 2D Trainer loss expression (batch-axis quirk) ..... unet/train.py:133-134
   * 3D Trainer loss (SmoothL1 "time" term) ............ unet3d/train.py:140-145
+  * mo3d Trainer: per-head loss menu, weighted sum,
+    clip_grad_norm_(1.0), Adam ........................ multi_output_unet3d/train.py:149-162, 183-201
+  * mo3d criteria (temporal L1 along Z) ............... multi_output_unet3d/losses.py:81-117, 250-298
+  * the optimisation step of every Trainer ............ unet/train.py:102,137-139 (torch.optim.Adam defaults)
   * init_weights ...................................... utils/utils.py:76-78
 """
 from __future__ import annotations
@@ -144,8 +148,28 @@ class forced_decisions:
         return False
 
 
+class _Rec:
+    q = None
+
+
+class record_decisions:
+    """Free-running counterpart of ``forced_decisions``: the forwards below append the decisions THEY take (same keys, same
+    order, same encoding) to the dict this context yields, so a test can count how many of an implementation's decisions
+    differ from the reference arithmetic's own (expected: the few elements within fp32 rounding of a boundary)."""
+
+    def __enter__(self):
+        self.prev, _Rec.q = _Rec.q, {"lrelu": [], "pool": [], "max": [], "relu": []}
+        return _Rec.q
+
+    def __exit__(self, *exc):
+        _Rec.q = self.prev
+        return False
+
+
 def _lrelu(t, slope=None):
     slope = LRELU_SLOPE if slope is None else slope
+    if _Rec.q is not None:
+        _Rec.q["lrelu"].append((t > 0).detach())
     if slope == 1.0:
         if _Forced.q is not None:
             _Forced.q["lrelu"].pop(0)            # the engine records a (meaningless) branch for every conv block
@@ -157,6 +181,8 @@ def _lrelu(t, slope=None):
 
 
 def _relu(t):
+    if _Rec.q is not None:
+        _Rec.q["relu"].append((t > 0).detach())
     if _Forced.q is not None:
         return torch.where(_Forced.q["relu"].pop(0), t, torch.zeros_like(t))
     return F.relu(t)
@@ -164,6 +190,8 @@ def _relu(t):
 
 def _maxpool(t):
     nd3 = t.dim() == 5
+    if _Rec.q is not None:
+        _Rec.q["pool"].append((F.max_pool3d if nd3 else F.max_pool2d)(t.detach(), 2, 2, return_indices=True)[1])
     if _Forced.q is not None:
         idx = _Forced.q["pool"].pop(0)                       # flat index into the (D*)H*W plane of each (n, c), as max_pool returns
         return t.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
@@ -171,6 +199,8 @@ def _maxpool(t):
 
 
 def _maximum(a, b):
+    if _Rec.q is not None:
+        _Rec.q["max"].append(torch.sign(a - b).detach())
     if _Forced.q is not None:               # sign(a - b) as the implementation under test saw it; a tie splits the gradient
         sgn = _Forced.q["max"].pop(0)
         return torch.where(sgn > 0, a, torch.where(sgn < 0, b, 0.5 * (a + b)))
@@ -479,6 +509,51 @@ def trainer3d_loss(logits, y, time_loss_weight: float = 0.1, criterion=bce_dice_
     """unet3d/train.py:140-145 -- SmoothL1 between neighbouring *batch* entries."""
     # batch == 1 gives empty slices -> nan, exactly as the reference does
     return criterion(logits, y) + F.smooth_l1_loss(logits[1:], logits[:-1]) * time_loss_weight
+
+
+def temporal_consistency_loss(pred):
+    """multi_output_unet3d/losses.py:250-263 -- L1 between consecutive slices of axis 2 (Z) of a (B, C, Z, X, Y) prediction."""
+    return F.l1_loss(pred[:, :, 1:], pred[:, :, :-1])
+
+
+def bce_dice_temporal_loss(pred, targets, loss_params=(1.0, 0.1)):
+    """multi_output_unet3d/losses.py:266-298 -- BCEDice(1, 1) + 0.1 * temporal consistency, both on ``pred`` as given."""
+    return loss_params[0] * bce_dice_loss(pred, targets, 1, 1) + loss_params[1] * temporal_consistency_loss(pred)
+
+
+MO3D_LOSS_MENU = {      # Trainer._get_loss_function, multi_output_unet3d/train.py:149-162
+    "BCEDiceLoss": lambda p, t: bce_dice_loss(p, t, 1, 1),
+    "DiceLoss": lambda p, t: bce_dice_loss(p, t, 0, 1),
+    "TverskyLoss": tversky_loss,
+    "logcoshTverskyLoss": logcosh_tversky_loss,
+    "BCEDiceTemporalLoss": bce_dice_temporal_loss,
+}
+
+
+def trainer_mo3d_loss(pred: Dict[str, torch.Tensor], targets: Dict[str, torch.Tensor], output_heads: Dict[str, dict]):
+    """multi_output_unet3d/train.py:183-196 -- sum over heads of weight * loss(pred, target); ``pred`` is the model's
+    ALREADY ACTIVATED output and the criteria apply their own sigmoid on top (quirk 4 of SURVEY 8a)."""
+    total = 0
+    for name, cfg in output_heads.items():
+        if cfg["loss"] not in MO3D_LOSS_MENU:
+            raise ValueError(f'Loss "{cfg["loss"]}" not defined!')
+        t = targets[name]
+        if t.dim() == 4:
+            t = t.unsqueeze(1)
+        total = total + cfg.get("weight", 1.0) * MO3D_LOSS_MENU[cfg["loss"]](pred[name], t)
+    return total
+
+
+def adam_step(sd: State, grads: Dict[str, torch.Tensor], lr: float = 1e-3, clip: Optional[float] = None):
+    """``optimizer.step()`` of a freshly built ``torch.optim.Adam(params, lr)`` (unet/train.py:102,139; betas (0.9, 0.999), eps 1e-8,
+    first step), after ``clip_grad_norm_(params, clip)`` when ``clip`` is given (multi_output_unet3d/train.py:201).  Returns
+    (updated parameters by key, total gradient norm before clipping or None)."""
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if is_param(k)}
+    for k, p in params.items():
+        p.grad = grads[k].detach().clone()
+    norm = torch.nn.utils.clip_grad_norm_(list(params.values()), max_norm=clip) if clip is not None else None
+    torch.optim.Adam(list(params.values()), lr=lr).step()
+    return {k: p.detach() for k, p in params.items()}, norm
 
 
 # --------------------------------------------------------------------------------------------------

@@ -18,6 +18,11 @@ Each fixture ``<case>.npz`` holds:
   grad.<key>                        d loss / d parameter for every parameter
   sd1.<key>                         BN buffers after that one train-mode forward
   eval.<out>                        outputs of an eval-mode forward from the *post-step-1* buffers
+  gradnorm                          (trainer cases with clipping) total L2 norm of the gradients before clip_grad_norm_(1.0)
+  adam1.<key>                       every parameter after ``optimizer.step()`` of torch.optim.Adam(lr=1e-3) on those gradients
+                                    (``zero_grad(); backward(); step()``, unet/train.py:137-139; mo3d: clipped first, :201)
+  loss2, sd2.<key>                  loss and BN buffers of the SECOND train-mode forward (from the Adam-updated parameters)
+  in.dropout_factor2                (Unet_v0 / BabyUnet) the Dropout2d draw of that second forward
 """
 import importlib.util
 import json
@@ -47,6 +52,7 @@ losses_mod = load("ref_losses", "unet/losses.py")
 att_mod = load("ref_attention_unet", "unet/attention_unet.py")
 v0_mod = load("ref_unet_v0", "unet/unet_v0.py")
 baby_mod = load("ref_baby_unet", "unet/baby_unet.py")
+mo3d_losses_mod = load("ref_mo3d_losses", "multi_output_unet3d/losses.py")   # the mo3d package's criteria (temporal term, Tversky defaults)
 siam_losses_mod = load("ref_siam_losses", "siam_unet/losses.py")     # the Siam package's own criteria (BCELoss on probabilities)
 
 
@@ -56,8 +62,9 @@ def ref_init_weights(m):
         torch.nn.init.kaiming_normal_(m.weight, nonlinearity="leaky_relu")
 
 
-def dump(case, meta, model, inputs, target, loss_fn, out_names, call):
-    """Drive one reference train-mode step (forward + loss + backward), then an eval forward."""
+def dump(case, meta, model, inputs, target, loss_fn, out_names, call, clip=None, after_step2=None):
+    """Drive one reference train-mode step (forward + loss + backward), an eval forward, the optimizer step of the reference
+    loop (Adam, lr 1e-3; ``clip``: clip_grad_norm_ to that norm first, as the mo3d trainer does) and a second train-mode forward."""
     arrays = {"meta_json": np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)}
     for k, v in inputs.items():
         arrays[f"in.{k}"] = v.numpy()
@@ -92,6 +99,22 @@ def dump(case, meta, model, inputs, target, loss_fn, out_names, call):
     outs_t = [outs[n] for n in out_names] if isinstance(outs, dict) else list(outs)
     for n, t in zip(out_names, outs_t):
         arrays[f"eval.{n}"] = t.detach().numpy()
+    # ---- the rest of the reference loop: (clip,) optimizer.step(), then the next iteration's forward -------------------
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    if clip is not None:
+        arrays["gradnorm"] = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=clip).detach().numpy()
+    opt.step()
+    for k, p in model.named_parameters():
+        arrays[f"adam1.{k}"] = p.detach().clone().numpy()
+    model.train()
+    outs = call(model)
+    arrays["loss2"] = loss_fn(outs).detach().numpy()
+    for k, v in model.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            arrays[f"sd2.{k}"] = v.detach().clone().numpy()
+    if after_step2 is not None:
+        for k, v in after_step2().items():
+            arrays[k] = v.numpy()
     path = os.path.join(HERE, f"{case}.npz")
     np.savez_compressed(path, **arrays)
     print(f"{case}: {os.path.getsize(path) / 1e6:.2f} MB, loss={float(loss):.6f}")
@@ -157,9 +180,15 @@ def main():
             m.load_state_dict(sd_keep)
         torch.set_rng_state(st)
         ins["dropout_factor"] = seen["f"].clone()
+        first = {}
+        def call(mod, x=x, first=first):                       # noqa: F811  (remembers the draw of the FIRST train-mode forward)
+            out = mod(x)
+            if mod.training and "f" not in first:
+                first["f"] = seen["f"].clone()
+            return out
         dump(case, dict(model=cls.__name__, ctor=kw, seed=5, loss="unet/train.py:133-134 with BCEDice(0.5,0.5), out_channels=1", init="init_weights"),
-             m, ins, y, loss_fn, ["prob", "logits"], call)
-        assert torch.equal(seen["f"], ins["dropout_factor"]), "the recorded Dropout2d draw must be the one of the dumped forward"
+             m, ins, y, loss_fn, ["prob", "logits"], call, after_step2=lambda: {"in.dropout_factor2": seen["f"].clone()})
+        assert torch.equal(first["f"], ins["dropout_factor"]), "the recorded Dropout2d draw must be the one of the dumped forward"
         h.remove()
 
     # ---- (ii) UNet3D ---------------------------------------------------------------------------
@@ -204,6 +233,35 @@ def main():
                                             for k, w in (("seg", 1.0), ("flow", 0.5), ("dist", 0.25)))
         dump(case, dict(model="MultiOutputUnet3D", ctor=kw, seed=3, loss="sum_k w_k*MSE(out_k, tgt_k), w=(1,.5,.25)", init="default"),
              m, {"x": x}, tgt, loss_fn, ["seg", "flow", "dist"], lambda mod, x=x: mod(x))
+
+    # ---- (v) the mo3d TRAINER's step: per-head criteria of multi_output_unet3d/losses.py on the activated outputs, weighted
+    #      sum, clip_grad_norm_(1.0), Adam  (multi_output_unet3d/train.py:149-162 loss menu, :183-201 loop) -------------------
+    menu = {"BCEDiceLoss": lambda: mo3d_losses_mod.BCEDiceLoss(1, 1), "DiceLoss": lambda: mo3d_losses_mod.BCEDiceLoss(0, 1),
+            "TverskyLoss": mo3d_losses_mod.TverskyLoss, "logcoshTverskyLoss": mo3d_losses_mod.logcoshTverskyLoss,
+            "BCEDiceTemporalLoss": mo3d_losses_mod.BCEDiceTemporalLoss}          # Trainer._get_loss_function, restated (:149-162)
+    for case, interp, heads_t in (
+        ("mo3d_f4_trainer_convT", False, {"mask": {"channels": 1, "activation": "sigmoid", "loss": "BCEDiceLoss", "weight": 1.0},
+                                          "flow": {"channels": 2, "activation": "tanh", "loss": "DiceLoss", "weight": 0.5},
+                                          "edge": {"channels": 1, "activation": None, "loss": "BCEDiceTemporalLoss", "weight": 0.25}}),
+        ("mo3d_f4_trainer_interp", True, {"mask": {"channels": 1, "activation": "sigmoid", "loss": "TverskyLoss", "weight": 1.0},
+                                          "dist": {"channels": 1, "activation": "relu", "loss": "logcoshTverskyLoss", "weight": 0.5},
+                                          "seg2": {"channels": 2, "activation": "sigmoid", "loss": "BCEDiceLoss"}}),
+    ):
+        torch.manual_seed(6)
+        kw = dict(in_channels=1, output_heads=heads_t, n_filter=4, use_interpolation=interp)
+        m = mo3d_mod.MultiOutputUnet3D(**kw)
+        x = torch.rand(2, 1, 8, 16, 16)
+        tgt = {k: (torch.rand(2, v["channels"], 8, 16, 16) > 0.5).float() for k, v in heads_t.items()}
+        crit = {k: menu[v["loss"]]() for k, v in heads_t.items()}
+        wts = {k: v.get("weight", 1.0) for k, v in heads_t.items()}
+        def loss_fn(outs, tgt=tgt, crit=crit, wts=wts, heads_t=heads_t):
+            total = 0
+            for name in heads_t:                                  # train.py:188-196
+                total += wts[name] * crit[name](outs[name], tgt[name])
+            return total
+        dump(case, dict(model="MultiOutputUnet3D", ctor=kw, seed=6, init="default",
+                        loss="multi_output_unet3d/train.py:183-201: sum_k weight_k * loss_k(activated out_k, tgt_k), clip_grad_norm_(1.0), Adam(1e-3)"),
+             m, {"x": x}, tgt, loss_fn, list(heads_t), lambda mod, x=x: mod(x), clip=1.0)
 
 
 if __name__ == "__main__":

@@ -74,9 +74,16 @@ def dact(raw, xf):
 class Report:
     def __init__(self):
         self.rows = []          # (label, what, worst normalised deviation, fraction within tolerance)
+        self.n_out = 0          # elements further than 1x their tolerance, over all element-wise checks
+        self.n_elem = 0         # elements compared
+        self.outliers = []      # (label, what, count beyond 1x, count, worst) of the checks that had any
 
-    def add(self, label, what, dev, frac):
+    def add(self, label, what, dev, frac, n_out=0, n=0):
         self.rows.append((label, what, dev, frac))
+        self.n_out += n_out
+        self.n_elem += n
+        if n_out:
+            self.outliers.append((label, what, n_out, n, dev))
 
     def worst(self):
         return max(self.rows, key=lambda r: r[2]) if self.rows else None
@@ -113,7 +120,7 @@ class InSitu:
             dev = torch.where(ignore, torch.zeros_like(dev), dev)
         frac_ok = float((dev <= 1.0).double().mean())
         worst = float(dev.max()) if dev.numel() else 0.0
-        self.rep.add(label, what, worst, frac_ok)
+        self.rep.add(label, what, worst, frac_ok, int((dev > 1.0).sum()), dev.numel())
         need = self.strict_frac if frac is None else frac
         if not (frac_ok >= need and worst <= 64.0) or not torch.isfinite(got).all():
             self.failures.append(f"{label}: {what}: only {frac_ok:.6f} of the elements within tolerance (need {need}), worst {worst:.1f}x")
@@ -512,3 +519,21 @@ def extract_decisions(eng):
         elif isinstance(nd, E.AddReluNode):
             q.setdefault("relu", []).append(sq(act_raw(nd.y) > 0))
     return q
+
+
+def decision_mismatch(q_engine, q_oracle):
+    """{kind: (decisions that differ, decisions taken)} between the engine's decisions (``extract_decisions``) and the ones a
+    free-running oracle forward recorded (``oracle.record_decisions``).  Blocks without an activation (slope 1: the branch is
+    meaningless) are counted too -- the sign of t is still a property of the stored tensor."""
+    out = {}
+    for k, mine in q_engine.items():
+        theirs = q_oracle.get(k, [])
+        assert len(mine) == len(theirs), f"{k}: engine took {len(mine)} decisions, oracle {len(theirs)}"
+        diff = tot = 0
+        for a, b in zip(mine, theirs):
+            assert a.shape == b.shape, (k, a.shape, b.shape)
+            diff += int((a != b).sum())
+            tot += a.numel()
+        if tot:
+            out[k] = (diff, tot)
+    return out

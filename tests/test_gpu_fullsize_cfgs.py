@@ -1,0 +1,181 @@
+"""Parity at BASELINE.json's FULL extents for cfg2 / cfg3 / cfg5 (cfg4: tests/test_gpu_fullsize.py), through properties that need no
+reference run of that size (the CPU oracle would take many minutes per step there):
+
+  cfg2  Unet(1, 2, 64)                      (16, 1, 512, 512)      fp32     reference unet/unet.py:69-104 at 16 x 512^2
+  cfg3  Siam_UNet(32, 'max')                2 x (16, 1, 512, 512)  bf16     siam_unet/siam_unet.py:85-148
+  cfg5  MultiOutputUnet3D(1, 3 heads, 64)   (1, 1, 128, 256, 256)  bf16     multi_output_unet3d/multi_output_unet3d.py:106-170 (interp)
+
+* a conv in front of a train-mode BatchNorm is invariant to a positive rescaling of its weights and to its bias -- every fused
+  statistics / transform path at full extent (2.1 GB activations in cfg2: 64-bit addressing of every kernel);
+* two runs of the same step agree: forward bit for bit, gradients to the order of the weight gradient's final fp32 atomics;
+* eval-mode translation equivariance: a crop with enough context reproduces the interior of the full result (pins brick / halo /
+  XCD-walk indexing at full extent);
+* bf16 and fp32 runs of the same weights agree on the predicted mask outside a narrow band around the threshold (cfg3, cfg5;
+  cfg2 IS the fp32 run: its check against bf16 runs the other way round);
+* fp32 (cfg2): the analytic gradient agrees with a central finite difference of the loss along a random direction.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import bio_image_unet_amd as B  # noqa: E402
+from bio_image_unet_amd.losses import BCEDiceLoss  # noqa: E402
+
+HEADS5 = {"seg": {"channels": 1, "activation": "sigmoid"}, "flow": {"channels": 2, "activation": None},
+          "dist": {"channels": 1, "activation": "sigmoid"}}          # bench.HEADS5
+
+CFG = {
+    "cfg2": dict(mk=lambda: B.Unet(1, 2, 64), shape=(16, 1, 512, 512), dtype="f32", nin=1, probe=("encode2", "decode7", "middle_conv1")),
+    "cfg3": dict(mk=lambda: B.Siam_UNet(32, "max"), shape=(16, 1, 512, 512), dtype="bf16", nin=2, probe=("encode2", "decode7", "middle_conv1")),
+    "cfg5": dict(mk=lambda: B.MultiOutputUnet3D(1, HEADS5, 64, True), shape=(1, 1, 128, 256, 256), dtype="bf16", nin=1,
+                 probe=("encode2", "decode5", "up3_conv")),
+}
+
+
+def make(cfg, dtype=None, seed=0):
+    torch.manual_seed(seed)
+    m = CFG[cfg]["mk"]().cuda()
+    if (dtype or CFG[cfg]["dtype"]) == "bf16":
+        m.set_compute_dtype(torch.bfloat16)
+    return m
+
+
+def data(cfg, seed=1, shape=None):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    shape = shape or CFG[cfg]["shape"]
+    xs = [torch.rand(shape, device="cuda", generator=g) for _ in range(CFG[cfg]["nin"])]
+    return xs, g
+
+
+def main_out(outs):
+    """The tensor the mask is taken from: logits (2-D / Siam) or the stacked head outputs (multi-head)."""
+    if isinstance(outs, dict):
+        return torch.cat([outs[k] for k in sorted(outs)], 1)
+    return outs[1]
+
+
+def loss_of(cfg, outs, gen):
+    """The reference trainers' loss expressions as bench.py uses them (targets drawn from ``gen``)."""
+    if cfg == "cfg5":         # multi_output_unet3d/train.py:183-195, BCEDiceLoss(1, 1) per head
+        crit = BCEDiceLoss(1, 1)
+        return sum(crit(outs[k], (torch.rand(outs[k].shape, device="cuda", generator=gen) > 0.5).float()) for k in sorted(outs))
+    crit = BCEDiceLoss(0.5, 0.5)
+    lg = outs[1]
+    y = (torch.rand(lg.shape, device="cuda", generator=gen) > 0.5).float()
+    if cfg == "cfg2":         # unet/train.py:133-134 (indexes the batch axis with the channel index)
+        return sum(crit(lg[ch], y[ch]) for ch in range(2)) / 2
+    return crit(lg, y)        # siam_unet/train.py:110
+
+
+@pytest.mark.parametrize("cfg", list(CFG))
+def test_conv_scale_and_bias_invariance_under_batchnorm(cfg):
+    m = make(cfg)
+    m.train()
+    xs, _ = data(cfg)
+    with torch.no_grad():
+        ref = main_out(m(*xs))
+        for name in CFG[cfg]["probe"]:
+            conv = getattr(m, name)[0]
+            conv.weight.mul_(3.0)
+            conv.bias.add_(0.7)
+        got = main_out(m(*xs))
+    tol = 2e-2 if CFG[cfg]["dtype"] == "bf16" else 2e-4
+    err = float((got - ref).abs().max()) / float(ref.abs().max())
+    assert err < tol, err
+
+
+@pytest.mark.parametrize("cfg", list(CFG))
+def test_step_is_reproducible(cfg):
+    m = make(cfg)
+    m.train()
+    xs, _ = data(cfg)
+    runs = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        outs = m(*xs)
+        loss = loss_of(cfg, outs, torch.Generator(device="cuda").manual_seed(9))
+        loss.backward()
+        runs.append((float(loss), main_out(outs).detach().clone(), torch.cat([p.grad.flatten().double() for p in m.parameters()])))
+        del outs, loss
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1]), "the forward pass must repeat bit for bit (no atomics on it)"
+    ga, gb = runs[0][2], runs[1][2]
+    rel = float((ga - gb).norm() / ga.norm())
+    print(f"\n[reproducible {cfg}] gradient run-to-run: rel {rel:.3e}")
+    assert torch.isfinite(ga).all() and rel < 1e-5
+
+
+@pytest.mark.parametrize("cfg", list(CFG))
+def test_translation_equivariance_eval(cfg):
+    """Eval mode: a fixed shift-equivariant map for shifts that are multiples of the total pooling stride (16 in 2-D, 8 in 3-D).
+    Context: the receptive-field radius is sum over 3x3 convs of 2^level = 2(1+2+4+8) + 2*16 + 2(8+4+2+1) = 92 for the 2-D nets;
+    44 + 7 (the three up*_conv blocks) = 51 for the interpolating 3-D net.  Crop offsets differ per axis."""
+    m = make(cfg)
+    with torch.no_grad():
+        m.train()                          # one training forward gives the running statistics non-trivial values
+        m(*data(cfg, seed=5)[0])
+        m.eval()
+        if cfg == "cfg5":
+            xs, _ = data(cfg, seed=6)
+            full = main_out(m(*xs))
+            crop = main_out(m(*[x[:, :, :, 16:240, 8:232].contiguous() for x in xs]))        # D kept whole: identical borders
+            a, b = full[:, :, :, 80:176, 72:168], crop[:, :, :, 64:160, 64:160]
+        else:
+            xs, _ = data(cfg, seed=6, shape=(4, 1, 512, 512))
+            full = main_out(m(*xs))
+            crop = main_out(m(*[x[:, :, 32:480, 16:464].contiguous() for x in xs]))
+            a, b = full[:, :, 144:368, 128:352], crop[:, :, 112:336, 112:336]
+    tol = 3e-2 if CFG[cfg]["dtype"] == "bf16" else 1e-4
+    assert float((a - b).abs().max()) < tol * float(full.abs().max()), float((a - b).abs().max()) / float(full.abs().max())
+
+
+@pytest.mark.parametrize("cfg", list(CFG))
+def test_bf16_mask_agrees_with_fp32(cfg):
+    xs, _ = data(cfg)
+    mb, mf = make(cfg, "bf16"), make(cfg, "f32")
+    mf.load_state_dict(mb.state_dict())
+    mb.train()
+    mf.train()
+    with torch.no_grad():
+        ob, of = m_out(mb, xs), m_out(mf, xs)
+    for lb, lf in zip(ob, of):
+        band = 0.05 * float(lf.abs().max())
+        safe = lf.abs() > band
+        assert float(safe.float().mean()) > 0.5
+        assert bool(((lb > 0) == (lf > 0))[safe].all())
+        assert float((lb - lf).abs().max()) < 0.1 * float(lf.abs().max())
+
+
+def m_out(m, xs):
+    """Tensors a mask is thresholded from, in logit space (mask = value > 0): the logits, or -- cfg5 returns activated outputs
+    only -- the two sigmoid heads mapped back through logit(p) (p > 0.5 <=> logit > 0)."""
+    outs = m(*xs)
+    if isinstance(outs, dict):
+        return [torch.logit(outs[k].clamp(1e-6, 1 - 1e-6)) for k in ("seg", "dist")]
+    return [outs[1]]
+
+
+def test_directional_derivative_fp32_cfg2():
+    m = make("cfg2")
+    m.train()
+    xs, _ = data("cfg2", shape=(4, 1, 512, 512))
+    params = [p for n, p in m.named_parameters() if n.endswith("weight") and p.dim() > 1]
+
+    def f():
+        return loss_of("cfg2", m(*xs), torch.Generator(device="cuda").manual_seed(9))
+
+    grads = torch.autograd.grad(f(), params)
+    torch.manual_seed(3)
+    dirs = [torch.randn_like(p) * p.detach().abs().mean() for p in params]
+    analytic = sum(float((g.double() * d.double()).sum()) for g, d in zip(grads, dirs))
+    eps, vals = 1e-2, []
+    with torch.no_grad():
+        for sgn in (+1.0, -1.0):
+            for p, d in zip(params, dirs):
+                p.add_(d, alpha=sgn * eps)
+            vals.append(float(f().double()))
+            for p, d in zip(params, dirs):
+                p.sub_(d, alpha=sgn * eps)
+    numeric = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(numeric - analytic) < 5e-2 * max(abs(analytic), 1e-3) + 1e-4, (numeric, analytic)

@@ -17,6 +17,10 @@ from tests import insitu  # noqa: E402
 HEADS = {"seg": {"channels": 1, "activation": "sigmoid"}, "flow": {"channels": 2, "activation": None},
          "dist": {"channels": 1, "activation": "tanh"}}
 
+HEADS5 = {"seg": {"channels": 1, "activation": "sigmoid"}, "flow": {"channels": 2, "activation": None},
+          "dist": {"channels": 1, "activation": "sigmoid"}}          # bench.HEADS5: cfg5 as benchmarked
+
+
 def _init_like(module, seed):
     """state_dict with the module's own (PyTorch default + Kaiming-normal Conv2d) initialisation under a fixed seed."""
     from bio_image_unet_amd.utils import init_weights
@@ -38,7 +42,13 @@ CASES = {
     "cfg4_unet3d_f32": (lambda: B.UNet3D(1, 1, 32), lambda: O.init_unet3d(1, 1, 32, seed=7), (2, 1, 16, 32, 32), 1),
     "cfg5_mo3d_f32_interp": (lambda: B.MultiOutputUnet3D(1, HEADS, 32, True), lambda: O.init_mo3d(1, HEADS, 32, True, seed=8), (1, 1, 16, 32, 32), 1),
     "cfg5_mo3d_f32_convT": (lambda: B.MultiOutputUnet3D(1, HEADS, 32, False), lambda: O.init_mo3d(1, HEADS, 32, False, seed=9), (1, 1, 16, 32, 32), 1),
+    # cfg5 at its stated width: base 64 (3-D layers of 512 / 768 input channels), heads and activations of bench.py
+    "cfg5_mo3d_f64_interp": (lambda: B.MultiOutputUnet3D(1, HEADS5, 64, True), lambda: O.init_mo3d(1, HEADS5, 64, True, seed=12), (1, 1, 16, 32, 32), 1),
+    "cfg5_mo3d_f64_convT": (lambda: B.MultiOutputUnet3D(1, HEADS5, 64, False), lambda: O.init_mo3d(1, HEADS5, 64, False, seed=13), (1, 1, 16, 32, 32), 1),
 }
+
+
+OUTLIER_FRAC = {"f32": 1e-3, "bf16": 1e-3}     # TIGHTEN after the first measured run (profiles/r03_insitu_outliers.txt)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -62,11 +72,23 @@ def test_every_kernel_call_of_a_train_step(case, dtype, capsys):
         loss = O.bce_dice_loss(outs[1], y) + 0.05 * outs[0].mean()          # both outputs carry gradient
     loss.backward()
     torch.cuda.synchronize()
-    w = chk.rep.worst()
+    w, rep = chk.rep.worst(), chk.rep
+    line = (f"[insitu {case} {dtype}] {len(rep.rows)} checks, {rep.n_elem} elements, {rep.n_out} beyond 1x tolerance "
+            f"({rep.n_out / max(rep.n_elem, 1):.2e}) in {len(rep.outliers)} checks; worst: {w[0]} / {w[1]} = {w[2]:.3f}x tolerance, {w[3]:.6f} within")
     with capsys.disabled():
-        print(f"\n[insitu {case} {dtype}] {len(chk.rep.rows)} checks, worst: {w[0]} / {w[1]} = {w[2]:.3f}x tolerance, {w[3]:.6f} within")
-    assert len(chk.rep.rows) > 100
-    assert not chk.failures, "\n".join(chk.failures[:20]) + "\n" + chk.rep.table()
+        print("\n" + line)
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "insitu_outliers.txt"), "a") as f:
+        f.write(line + "\n")
+        for lab, what, no, n, dev in sorted(rep.outliers, key=lambda r: -r[4])[:8]:
+            f.write(f"    {lab:28s} {what:22s} {no} of {n} beyond 1x, worst {dev:.2f}x\n")
+    assert len(rep.rows) > 100
+    assert not chk.failures, "\n".join(chk.failures[:20]) + "\n" + rep.table()
+    # over the whole step: elements beyond their tolerance are the rare ones whose decision / rounding boundary lies inside the
+    # kernel's own rounding (each check already needs 99.9 % within 1x and nothing beyond 64x); bounded here so that a drift shows
+    assert rep.n_out <= OUTLIER_FRAC[dtype] * rep.n_elem, line
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

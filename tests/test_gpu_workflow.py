@@ -301,6 +301,33 @@ def test_mo3d_trainer_and_predict(tmp_path):
     pred = O.mo3d_forward(osd, batch["volume"].unsqueeze(1), HEADS, use_interpolation=True, training=True)
     want = 1.0 * O.bce_dice_loss(pred["mask"], batch["mask"], 1, 1) + 0.5 * O.bce_dice_loss(pred["flow"], batch["flow"], 0, 1)
     assert abs(float(loss) - float(want)) < 1e-3 * max(1.0, abs(float(want)))
+    # ... and the rest of multi_output_unet3d/train.py:198-202: zero_grad, backward, clip_grad_norm_(1.0), Adam -- the clipped
+    # gradient's norm and the parameter update against the oracle stepped on the engine's branch of the discrete decisions
+    tr.optimizer.zero_grad()
+    loss.backward()
+    q = _engine_decisions(tr.model)
+    norm = torch.nn.utils.clip_grad_norm_(tr.model.parameters(), max_norm=1.0)
+    clipped = {k: p.grad.detach().cpu().clone() for k, p in tr.model.named_parameters()}
+    tr.optimizer.step()
+    torch.cuda.synchronize()
+    with O.forced_decisions(q):
+        pred = O.mo3d_forward(osd, batch["volume"].unsqueeze(1), HEADS, use_interpolation=True, training=True)
+    oloss = O.trainer_mo3d_loss(pred, {k: batch[k] for k in HEADS}, HEADS)
+    assert abs(float(oloss) - float(want)) < 1e-5 * max(1.0, abs(float(want)))          # decisions replayed: same value
+    og = O.grads_of(oloss, osd)
+    onorm = torch.sqrt(sum((v.double() ** 2).sum() for v in og.values()))
+    assert abs(float(norm) - float(onorm)) < 1e-3 * float(onorm), (float(norm), float(onorm))
+    scale = min(1.0, 1.0 / (float(onorm) + 1e-6))                                          # clip_grad_norm_'s coefficient
+    gmax = max(float(v.abs().max()) for v in og.values()) * scale
+    for k, v in og.items():
+        if not (k.endswith(".0.bias") and not k.startswith("output_layers")):              # (conv bias in front of BatchNorm: true gradient 0)
+            assert float((clipped[k] - v * scale).abs().max()) <= 1e-3 * float(v.abs().max()) * scale + 1e-5 * gmax, f"clipped grad {k}"
+    for k, v in osd.items():
+        if v.requires_grad:
+            v.grad = og[k].clone()
+    torch.nn.utils.clip_grad_norm_([v for v in osd.values() if v.requires_grad], max_norm=1.0)
+    torch.optim.Adam([v for v in osd.values() if v.requires_grad], lr=1e-3).step()
+    _adam_update_matches(tr.model.state_dict(), osd, sd0)
     tr.start()
     ck = torch.load(str(tmp_path / "m" / "model.pt"), weights_only=False)
     assert ck["output_heads"] == HEADS and ck["use_interpolation"] is True and len(ck["state_dict"]) > 100

@@ -12,7 +12,7 @@ from tests.golden_util import ALL_CASES, load_case
 RTOL, ATOL = 1e-5, 1e-6
 
 
-def run_oracle(g, sd, training):
+def run_oracle(g, sd, training, step2=False):
     meta = g["meta"]
     ctor = meta["ctor"]
     x = g["in"]["x"]
@@ -21,7 +21,7 @@ def run_oracle(g, sd, training):
     if meta["model"] == "AttentionUnet":
         return dict(zip(("prob", "logits"), O.attention_unet_forward(sd, x, dilation=ctor["dilation"], training=training)))
     if meta["model"] in ("Unet_v0", "BabyUnet"):
-        f = g["in"]["dropout_factor"] if training else None
+        f = g["in"]["dropout_factor2" if step2 else "dropout_factor"] if training else None
         return dict(zip(("prob", "logits"), O.legacy_unet_forward(sd, x, levels=4 if meta["model"] == "Unet_v0" else 3, training=training,
                                                                   dropout_factor=f)))
     if meta["model"] == "UNet3D":
@@ -48,6 +48,8 @@ def oracle_loss(g, outs):
     if meta["model"] == "Siam_UNet":       # the Siam package's own BCEDice (BCELoss on probabilities), loss_params (1, 1)
         return O.siam_bce_dice_loss(outs["logits"], g["in"]["target"], 1.0, 1.0)
     tg = {k.split(".", 1)[1]: v for k, v in g["in"].items() if k.startswith("target.")}
+    if "train.py:183-201" in meta["loss"]:          # the mo3d trainer's per-head loss menu on the activated outputs
+        return O.trainer_mo3d_loss(outs, tg, meta["ctor"]["output_heads"])
     return sum(((outs[k] - tg[k]) ** 2).mean() * w for k, w in (("seg", 1.0), ("flow", 0.5), ("dist", 0.25)))
 
 
@@ -78,6 +80,25 @@ def test_oracle_matches_reference_vectors(case):
         outs_e = run_oracle(g, sd, training=False)
     for k, v in g["eval"].items():
         torch.testing.assert_close(outs_e[k], v, rtol=RTOL, atol=ATOL, msg=lambda m: f"eval.{k}: {m}")
+    # the rest of the reference loop: (clip_grad_norm_,) Adam step, next iteration's forward (unet/train.py:137-139; mo3d :201)
+    clip = 1.0 if g["gradnorm"] is not None else None
+    new, norm = O.adam_step(sd, grads, lr=1e-3, clip=clip)
+    if clip is not None:
+        torch.testing.assert_close(norm, g["gradnorm"], rtol=1e-4, atol=0)
+    assert set(new) == set(g["adam1"])
+    for k, v in g["adam1"].items():
+        # one Adam step moves an entry by lr * g / (|g| + 1e-8): entries whose gradient is rounding noise (dead conv biases,
+        # |g| ~ 1e-8) move by an arbitrary fraction of lr in ANY implementation -- compare where the reference gradient is resolved
+        solid = g["grad"][k].abs() > 1e-4 * gscale
+        torch.testing.assert_close(new[k][solid], v[solid], rtol=1e-5, atol=2e-6, msg=lambda m: f"adam1.{k}: {m}")
+        assert float((new[k] - v).abs().max()) <= 2.0e-3 + 1e-6, f"adam1.{k}: an entry moved by more than 2 lr"
+    sd2 = O.clone_state({**{k: v for k, v in sd.items() if not O.is_param(k)}, **g["adam1"]}, requires_grad=False)
+    with torch.no_grad():
+        outs2 = run_oracle(g, sd2, training=True, step2=True)
+        loss2 = oracle_loss(g, outs2)
+    torch.testing.assert_close(loss2, g["loss2"], rtol=RTOL, atol=ATOL)
+    for k, v in g["sd2"].items():
+        torch.testing.assert_close(sd2[k], v, rtol=RTOL, atol=ATOL, msg=lambda m: f"sd2.{k}: {m}")
 
 
 @pytest.mark.parametrize("kind", ["unet2d", "siam_concat", "siam_max", "unet3d", "unet3d_interp", "mo3d", "mo3d_convT"])
