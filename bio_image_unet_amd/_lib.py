@@ -52,12 +52,13 @@ SIGNATURES = {
     "biu_conv_packed_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "biu_conv_pack": (_I, [_I, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "biu_pack_batch": (_I, [_P, _I, _I, _P]),
-    "biu_conv_fwd": (_I, [_A, _X, _P, _P, _P, _I, _I, _I, _I, _A, _I, _P]),
+    "biu_conv_split_workspace": (_Z, [_I, _A, _A, _I, _I, _I, _I, _I]),
+    "biu_conv_fwd": (_I, [_A, _X, _P, _P, _P, _I, _I, _I, _I, _A, _P, _Z, _I, _P]),
     "biu_conv_fwd_stats_floats": (_Z, [_A, _I]),
-    "biu_conv_fwd_stats": (_I, [_A, _X, _P, _P, _P, _I, _I, _I, _I, _A, _P, _Z, C.POINTER(C.c_int), _I, _P]),
-    "biu_conv_bwd_data": (_I, [_A, _P, _P, _I, _I, _I, _I, _A, _I, _I, _P]),
+    "biu_conv_fwd_stats": (_I, [_A, _X, _P, _P, _P, _I, _I, _I, _I, _A, _P, _Z, C.POINTER(C.c_int), _P, _Z, _I, _P]),
+    "biu_conv_bwd_data": (_I, [_A, _P, _P, _I, _I, _I, _I, _A, _I, _P, _Z, _I, _P]),
     "biu_bwd_data_bnred_floats": (_Z, [_A, _I, _I]),
-    "biu_conv_bwd_data_bnred": (_I, [_A, _P, _P, _I, _I, _I, _I, _A, _A, _P, _P, _P, _P, _P, _P, _Z, C.POINTER(C.c_int), _I, _P]),
+    "biu_conv_bwd_data_bnred": (_I, [_A, _P, _P, _I, _I, _I, _I, _A, _A, _P, _P, _P, _P, _P, _P, _Z, C.POINTER(C.c_int), _P, _Z, _I, _P]),
     "biu_convt_bwd_data_bnred": (_I, [_A, _P, _P, _I, _A, _A, _P, _P, _P, _P, _P, _P, _Z, C.POINTER(C.c_int), _I, _P]),
     "biu_conv_bwd_weight_workspace": (_Z, [_I, _I, _I, _I, _I, _I]),
     "biu_conv_bwd_weight": (_I, [_A, _X, _A, _I, _I, _I, _I, _P, _P, _P, _Z, _I, _P]),
@@ -90,8 +91,8 @@ SIGNATURES = {
     "biu_xcorr_fwd": (_I, [_A, _X, _A, _X, _A, _I, _P]),
     "biu_xcorr_bwd": (_I, [_A, _X, _A, _X, _A, _A, _A, _I, _I, _P]),
     "biu_conv_cat_ok": (_I, [_A, _A, _A, _I, _I, _I, _I, _I]),
-    "biu_conv_fwd_cat": (_I, [_A, _X, _A, _X, _P, _P, _P, _I, _I, _I, _I, _A, _P, _Z, C.POINTER(C.c_int), _I, _P]),
-    "biu_conv_bwd_data_cat": (_I, [_A, _P, _P, _I, _I, _I, _I, _A, _I, _A, _I, _I, _P]),
+    "biu_conv_fwd_cat": (_I, [_A, _X, _A, _X, _P, _P, _P, _I, _I, _I, _I, _A, _P, _Z, C.POINTER(C.c_int), _P, _Z, _I, _P]),
+    "biu_conv_bwd_data_cat": (_I, [_A, _P, _P, _I, _I, _I, _I, _A, _I, _A, _I, _P, _Z, _I, _P]),
     "biu_conv_bwd_weight_cat": (_I, [_A, _X, _A, _X, _A, _A, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _Z, _I, _P]),
     "biu_convt_packed_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "biu_convt_pack": (_I, [_I, _P, _I, _I, _I, _I, _P, _P]),

@@ -47,9 +47,26 @@ extern "C" int biu_pack_batch(const biu_pack_job* jobs, int n, int dtype, biu_st
     return biu_mfma_pack_batch(jobs, n, dtype, (hipStream_t)stream);
 }
 
+// does a launch writing y (| y1) from cin channels take the input-channel split with the scratch the caller handed in?
+static bool will_split(int cin, const biu_act* y, const biu_act* y1, int kd, int dtype, const void* ws, size_t ws_bytes) {
+    const size_t need = biu_mfma_conv_split_bytes(cin, y, y1, kd, dtype);
+    return need > 0 && ws && ws_bytes >= need;
+}
+
+extern "C" size_t biu_conv_split_workspace(int cin, const biu_act* y, const biu_act* y1, int kd, int kh, int kw, int dilation, int dtype) {
+    if (!y || !valid_act(y) || (y1 && !valid_act(y1)) || kh != 3 || kw != 3 || (kd != 1 && kd != 3) || dilation != 1) return 0;
+    biu_act xprobe = *y;                       // the input has y's extents; only its channel count and alignment matter here
+    xprobe.c = xprobe.pitch = cin;
+    biu_act yall = *y;
+    if (y1) yall.c = y->c + y1->c;
+    if (!biu_mfma_conv_ok(&xprobe, &yall, kd, kh, kw, dilation, dtype)) return 0;
+    return biu_mfma_conv_split_bytes(cin, y, y1, kd, dtype);
+}
+
 extern "C" int biu_conv_fwd_stats(const biu_act* x, const biu_xform* xf, const float* w, const void* packed,
                                   const float* bias, int kd, int kh, int kw, int dilation, const biu_act* y,
-                                  float* bn_partial, size_t bn_partial_floats, int* bn_nblk, int dtype, biu_stream stream) {
+                                  float* bn_partial, size_t bn_partial_floats, int* bn_nblk, void* ws, size_t ws_bytes, int dtype,
+                                  biu_stream stream) {
     BIU_REQUIRE(conv_args_ok(x, y, kd, kh, kw, dilation), BIU_ERR_SHAPE,
                 "conv_fwd: x/y extents differ or unsupported kernel %dx%dx%d dil %d", kd, kh, kw, dilation);
     BIU_REQUIRE(w && bn_partial && bn_nblk, BIU_ERR_SHAPE, "conv_fwd_stats: null pointer");
@@ -64,7 +81,7 @@ extern "C" int biu_conv_fwd_stats(const biu_act* x, const biu_xform* xf, const f
     }
     // (a launch split over the input channels cannot take its statistics from the epilogue: plain conv, then biu_bn_stats)
     if (packed && !disabled("conv_fwd") && !disabled("fused_stats") && biu_mfma_conv_ok(x, y, kd, kh, kw, dilation, dtype) &&
-        biu_mfma_conv_ksplit(x->c, y, kd, dtype) == 1) {
+        !will_split(x->c, y, nullptr, kd, dtype, ws, ws_bytes)) {
         const int nb = biu_mfma_conv_stat_rows(y, kd, x, dtype);           // one partial row per workgroup column
         if ((size_t)nb * y->c * 2 <= bn_partial_floats) {
             int rc = biu_mfma_conv(x, xf, packed, bias, kd, kh, kw, y, 0, bn_partial, dtype, (hipStream_t)stream);
@@ -72,7 +89,7 @@ extern "C" int biu_conv_fwd_stats(const biu_act* x, const biu_xform* xf, const f
             return rc;
         }
     }
-    int rc = biu_conv_fwd(x, xf, w, packed, bias, kd, kh, kw, dilation, y, dtype, stream);
+    int rc = biu_conv_fwd(x, xf, w, packed, bias, kd, kh, kw, dilation, y, ws, ws_bytes, dtype, stream);
     if (rc != BIU_OK) return rc;
     BIU_REQUIRE(bn_partial_floats >= (size_t)BIU_BN_MAX_PARTIALS * y->c * 2, BIU_ERR_WORKSPACE, "conv_fwd_stats: partial buffer too small");
     return biu_bn_stats(y, bn_partial, bn_nblk, dtype, stream);
@@ -84,8 +101,8 @@ extern "C" size_t biu_conv_fwd_stats_floats(const biu_act* y, int kd) {
 }
 
 extern "C" int biu_conv_fwd(const biu_act* x, const biu_xform* xf, const float* w, const void* packed,
-                            const float* bias, int kd, int kh, int kw, int dilation, const biu_act* y, int dtype,
-                            biu_stream stream) {
+                            const float* bias, int kd, int kh, int kw, int dilation, const biu_act* y, void* ws, size_t ws_bytes,
+                            int dtype, biu_stream stream) {
     BIU_REQUIRE(conv_args_ok(x, y, kd, kh, kw, dilation), BIU_ERR_SHAPE,
                 "conv_fwd: x/y extents differ or unsupported kernel %dx%dx%d dil %d", kd, kh, kw, dilation);
     BIU_REQUIRE(w, BIU_ERR_SHAPE, "conv_fwd: null weight");
@@ -94,17 +111,17 @@ extern "C" int biu_conv_fwd(const biu_act* x, const biu_xform* xf, const float* 
     if (!disabled("c1") && biu_c1_conv_ok(x, y, kd, kh, kw, dilation, dtype))
         return biu_c1_conv_fwd(x, xf, w, bias, kd, y, dtype, (hipStream_t)stream);
     if (packed && !disabled("conv_fwd") && biu_mfma_conv_ok(x, y, kd, kh, kw, dilation, dtype))
-        return biu_mfma_conv(x, xf, packed, bias, kd, kh, kw, y, 0, nullptr, dtype, (hipStream_t)stream);
+        return biu_mfma_conv(x, xf, packed, bias, kd, kh, kw, y, 0, nullptr, dtype, (hipStream_t)stream, nullptr, nullptr, ws, ws_bytes);
     warn_slow_path("conv_fwd", x, y, kd * kh * kw);
     return biu_conv_fwd_direct(x, xf, w, bias, kd, kh, kw, dilation, y, dtype, (hipStream_t)stream);
 }
 
 extern "C" int biu_conv_bwd_data(const biu_act* dy, const float* w, const void* packed, int kd, int kh, int kw,
-                                 int dilation, const biu_act* dx, int accumulate, int dtype, biu_stream stream) {
+                                 int dilation, const biu_act* dx, int accumulate, void* ws, size_t ws_bytes, int dtype, biu_stream stream) {
     BIU_REQUIRE(conv_args_ok(dy, dx, kd, kh, kw, dilation), BIU_ERR_SHAPE, "conv_bwd_data: dy/dx extents differ");
     BIU_REQUIRE(w, BIU_ERR_SHAPE, "conv_bwd_data: null weight");
     if (packed && !disabled("conv_dgrad") && biu_mfma_conv_ok(dy, dx, kd, kh, kw, dilation, dtype))
-        return biu_mfma_conv(dy, nullptr, packed, nullptr, kd, kh, kw, dx, accumulate, nullptr, dtype, (hipStream_t)stream);
+        return biu_mfma_conv(dy, nullptr, packed, nullptr, kd, kh, kw, dx, accumulate, nullptr, dtype, (hipStream_t)stream, nullptr, nullptr, ws, ws_bytes);
     warn_slow_path("conv_bwd_data", dx, dy, kd * kh * kw);
     return biu_conv_bwd_data_direct(dy, w, kd, kh, kw, dilation, dx, accumulate, dtype, (hipStream_t)stream);
 }
@@ -120,14 +137,14 @@ extern "C" size_t biu_bwd_data_bnred_floats(const biu_act* dx, int kd, int trans
 extern "C" int biu_conv_bwd_data_bnred(const biu_act* dy, const float* w, const void* packed, int kd, int kh, int kw, int dilation,
                                        const biu_act* dx, const biu_act* y_up, const float* scale, const float* shift,
                                        const float* slope, const float* mean, const float* invstd, float* partial,
-                                       size_t partial_floats, int* nblk, int dtype, biu_stream stream) {
+                                       size_t partial_floats, int* nblk, void* ws, size_t ws_bytes, int dtype, biu_stream stream) {
     BIU_REQUIRE(conv_args_ok(dy, dx, kd, kh, kw, dilation) && valid_act(y_up) && same_space(y_up, dx) && y_up->c == dx->c, BIU_ERR_SHAPE,
                 "conv_bwd_data_bnred: extents differ");
     BIU_REQUIRE(w && scale && shift && mean && invstd && partial && nblk, BIU_ERR_SHAPE, "conv_bwd_data_bnred: null pointer");
     const size_t es = dsize(dtype);
     const bool yok = ((uintptr_t)y_up->p % 16) == 0 && ((size_t)y_up->pitch * es) % 16 == 0;
     if (packed && yok && !disabled("conv_dgrad") && !disabled("dgrad_bnred") && biu_mfma_conv_ok(dy, dx, kd, kh, kw, dilation, dtype) &&
-        biu_mfma_conv_ksplit(dy->c, dx, kd, dtype) == 1) {
+        !will_split(dy->c, dx, nullptr, kd, dtype, ws, ws_bytes)) {
         const int nb = biu_mfma_conv_stat_rows(dx, kd, dy, dtype);           // one partial row per workgroup column (as the forward)
         if ((size_t)nb * dx->c * 2 <= partial_floats) {
             BnRedFuse red{y_up, scale, shift, slope, mean, invstd};
@@ -136,7 +153,7 @@ extern "C" int biu_conv_bwd_data_bnred(const biu_act* dy, const float* w, const 
             return rc;
         }
     }
-    int rc = biu_conv_bwd_data(dy, w, packed, kd, kh, kw, dilation, dx, 0, dtype, stream);
+    int rc = biu_conv_bwd_data(dy, w, packed, kd, kh, kw, dilation, dx, 0, ws, ws_bytes, dtype, stream);
     if (rc != BIU_OK) return rc;
     BIU_REQUIRE(partial_floats >= (size_t)BIU_BN_MAX_PARTIALS * dx->c * 2, BIU_ERR_WORKSPACE, "conv_bwd_data_bnred: partial buffer too small");
     return biu_bn_bwd_reduce(dx, y_up, scale, shift, slope, mean, invstd, partial, nblk, dtype, stream);
@@ -247,13 +264,14 @@ extern "C" int biu_conv_cat_ok(const biu_act* x0, const biu_act* x1, const biu_a
 }
 extern "C" int biu_conv_fwd_cat(const biu_act* x0, const biu_xform* xf0, const biu_act* x1, const biu_xform* xf1, const float* w,
                                 const void* packed, const float* bias, int kd, int kh, int kw, int dilation, const biu_act* y,
-                                float* bn_partial, size_t bn_partial_floats, int* bn_nblk, int dtype, biu_stream stream) {
+                                float* bn_partial, size_t bn_partial_floats, int* bn_nblk, void* ws, size_t ws_bytes, int dtype,
+                                biu_stream stream) {
     BIU_REQUIRE(biu_conv_cat_ok(x0, x1, y, kd, kh, kw, dilation, dtype) && w && packed, BIU_ERR_UNSUPPORTED,
                 "conv_fwd_cat: shapes not served by the two-source kernels (ask biu_conv_cat_ok)");
     ConvCat cat{x1, xf1, nullptr, 0};
-    if (bn_partial && biu_mfma_conv_ksplit(x0->c + x1->c, y, kd, dtype) > 1) {       // split launch: statistics in a pass of their own
+    if (bn_partial && will_split(x0->c + x1->c, y, nullptr, kd, dtype, ws, ws_bytes)) {       // split launch: statistics in a pass of their own
         BIU_REQUIRE(bn_nblk, BIU_ERR_SHAPE, "conv_fwd_cat: null bn_nblk");
-        int rc = biu_mfma_conv(x0, xf0, packed, bias, kd, kh, kw, y, 0, nullptr, dtype, (hipStream_t)stream, nullptr, &cat);
+        int rc = biu_mfma_conv(x0, xf0, packed, bias, kd, kh, kw, y, 0, nullptr, dtype, (hipStream_t)stream, nullptr, &cat, ws, ws_bytes);
         if (rc != BIU_OK) return rc;
         BIU_REQUIRE(bn_partial_floats >= (size_t)BIU_BN_MAX_PARTIALS * y->c * 2, BIU_ERR_WORKSPACE, "conv_fwd_cat: partial buffer too small");
         return biu_bn_stats(y, bn_partial, bn_nblk, dtype, stream);
@@ -266,15 +284,15 @@ extern "C" int biu_conv_fwd_cat(const biu_act* x0, const biu_xform* xf0, const b
         if (rc == BIU_OK) *bn_nblk = nb;
         return rc;
     }
-    return biu_mfma_conv(x0, xf0, packed, bias, kd, kh, kw, y, 0, nullptr, dtype, (hipStream_t)stream, nullptr, &cat);
+    return biu_mfma_conv(x0, xf0, packed, bias, kd, kh, kw, y, 0, nullptr, dtype, (hipStream_t)stream, nullptr, &cat, ws, ws_bytes);
 }
 extern "C" int biu_conv_bwd_data_cat(const biu_act* dy, const float* w, const void* packed, int kd, int kh, int kw, int dilation,
-                                     const biu_act* dx0, int accumulate0, const biu_act* dx1, int accumulate1, int dtype,
-                                     biu_stream stream) {
+                                     const biu_act* dx0, int accumulate0, const biu_act* dx1, int accumulate1, void* ws, size_t ws_bytes,
+                                     int dtype, biu_stream stream) {
     BIU_REQUIRE(biu_conv_cat_ok(dx0, dx1, dy, kd, kh, kw, dilation, dtype) && w && packed, BIU_ERR_UNSUPPORTED,
                 "conv_bwd_data_cat: shapes not served by the two-source kernels (ask biu_conv_cat_ok)");
     ConvCat cat{nullptr, nullptr, dx1, accumulate1};
-    return biu_mfma_conv(dy, nullptr, packed, nullptr, kd, kh, kw, dx0, accumulate0, nullptr, dtype, (hipStream_t)stream, nullptr, &cat);
+    return biu_mfma_conv(dy, nullptr, packed, nullptr, kd, kh, kw, dx0, accumulate0, nullptr, dtype, (hipStream_t)stream, nullptr, &cat, ws, ws_bytes);
 }
 // y == NULL: plain weight gradient (da is dy); y != NULL: BatchNorm backward fused as in biu_conv_bwd_weight_bn
 extern "C" int biu_conv_bwd_weight_cat(const biu_act* x0, const biu_xform* xf0, const biu_act* x1, const biu_xform* xf1,

@@ -1392,32 +1392,14 @@ int biu_mfma_conv_ksplit(int cin, const biu_act* y, int kd, int dtype) {
     while (blocks * ks * 2 <= num_cus() && nchunks / (ks * 2) >= 4 && ks < 32) ks *= 2;
     return ks;
 }
-// Scratch for the input-channel split: one buffer per (device, stream), grown on demand and kept (a hipMallocAsync / hipFreeAsync pair
-// per call cost the host ~30 us, and the small layers that split are host-bound).  Calls on one stream are ordered, so a buffer is never
-// in use by two launches at once; growing synchronises that stream before the old buffer is released.
-static char* split_scratch(size_t bytes, hipStream_t st) {
-    struct Slot { int dev; hipStream_t st; char* p; size_t cap; };
-    static Slot slots[16];
-    static int nslots = 0;
-    static std::mutex mu;                                   // the table, not the buffers: a buffer belongs to one stream
-    std::lock_guard<std::mutex> lock(mu);
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    Slot* s = nullptr;
-    for (int i = 0; i < nslots; ++i)
-        if (slots[i].dev == dev && slots[i].st == st) { s = &slots[i]; break; }
-    if (!s) {
-        if (nslots == 16) return nullptr;                   // more streams than slots: the caller falls back to the unsplit launch
-        s = &slots[nslots++];
-        *s = Slot{dev, st, nullptr, 0};
-    }
-    if (s->cap < bytes) {
-        if (s->p) { (void)hipStreamSynchronize(st); (void)hipFree(s->p); s->p = nullptr; s->cap = 0; }
-        size_t cap = bytes < ((size_t)32 << 20) ? ((size_t)32 << 20) : bytes + bytes / 4;
-        if (hipMalloc((void**)&s->p, cap) != hipSuccess) { (void)hipGetLastError(); s->p = nullptr; return nullptr; }
-        s->cap = cap;
-    }
-    return s->p;
+// Scratch of a split launch: ks slices laid out like y (then ks like y1), owned by the CALLER (include/biu.h, biu_conv_split_workspace).
+size_t biu_mfma_conv_split_bytes(int cin, const biu_act* y, const biu_act* y1, int kd, int dtype) {
+    biu_act yall = *y;
+    if (y1) yall.c = y->c + y1->c;
+    const int ks = biu_mfma_conv_ksplit(cin, &yall, kd, dtype);
+    if (ks <= 1) return 0;
+    const size_t sl0 = (size_t)nvox(y) * y->pitch * sizeof(float), sl1 = y1 ? (size_t)nvox(y1) * y1->pitch * sizeof(float) : 0;
+    return (size_t)ks * (sl0 + sl1);
 }
 
 // y[v][c] = (accumulate ? y[v][c] : 0) + sum_z ws[z][v][c]   (ws slices share y's pitch)
@@ -1562,7 +1544,8 @@ bool biu_mfma_conv_cat_ok(const biu_act* x0, const biu_act* x1, const biu_act* y
 }
 
 int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, int kh, int kw,
-                  const biu_act* y, int accumulate, float* bn_partial, int dtype, hipStream_t st, const BnRedFuse* red, const ConvCat* cat) {
+                  const biu_act* y, int accumulate, float* bn_partial, int dtype, hipStream_t st, const BnRedFuse* red, const ConvCat* cat,
+                  void* split_ws, size_t split_ws_bytes) {
     ConvArgs a;
     clear_cat(a);
     a.bn_partial = bn_partial;
@@ -1615,7 +1598,7 @@ int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, con
             // scratch for the partial results: slices laid out like y (and y1), summed into the outputs afterwards
             const biu_act* y1t = (cat && cat->y1) ? cat->y1 : nullptr;
             const size_t sl0 = (size_t)nvox(y) * y->pitch * sizeof(float), sl1 = y1t ? (size_t)nvox(y1t) * y1t->pitch * sizeof(float) : 0;
-            char* ws = split_scratch((size_t)ks * (sl0 + sl1), st);
+            char* ws = (split_ws && split_ws_bytes >= (size_t)ks * (sl0 + sl1)) ? (char*)split_ws : nullptr;     // no scratch given: unsplit launch
             if (ws) {
                 ConvArgs b = a;
                 b.ksplit = ks;

@@ -34,7 +34,8 @@ struct ConvCat {              // channel concatenation without a concat buffer: 
 };
 int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, int kh, int kw,
                   const biu_act* y, int accumulate, float* bn_partial, int dtype, hipStream_t st, const BnRedFuse* red = nullptr,
-                  const ConvCat* cat = nullptr);
+                  const ConvCat* cat = nullptr, void* split_ws = nullptr, size_t split_ws_bytes = 0);
+size_t biu_mfma_conv_split_bytes(int cin, const biu_act* y, const biu_act* y1, int kd, int dtype);   // 0: the launch is not split
 int biu_mfma_convt_dgrad_bricks(const biu_act* dx, int kd);
 int biu_mfma_convt_dgrad_rows(const biu_act* dx, int kd);
 int biu_mfma_pack_batch(const biu_pack_job* jobs_device, int n, int dtype, hipStream_t st);

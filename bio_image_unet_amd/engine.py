@@ -254,6 +254,13 @@ class ConvBlockNode(Node):
         self.pk_b = eng.packed_slot(1, xin.c, cout, self.kd, self.kh, self.kw, self.dil)
         self.ws_bytes = lib.biu_conv_bwd_weight_workspace(xin.c, cout, self.kd, self.kh, self.kw, eng.dtype)
         eng.need_ws(self.ws_bytes)
+        # scratch of the input-channel split (small fp32 grids): the forward writes y, the data gradient the input's gradient(s).
+        # Sized here into the engine's one workspace -- the library owns no memory (include/biu.h, biu_conv_split_workspace)
+        eng.need_ws(lib.biu_conv_split_workspace(xin.c, yout.a(), None, self.kd, self.kh, self.kw, self.dil, eng.dtype))
+        if isinstance(xin, CatAct):
+            eng.need_ws(lib.biu_conv_split_workspace(cout, xin.parts[0].a(), xin.parts[1].a(), self.kd, self.kh, self.kw, self.dil, eng.dtype))
+        else:
+            eng.need_ws(lib.biu_conv_split_workspace(cout, xin.a(), None, self.kd, self.kh, self.kw, self.dil, eng.dtype))
 
     def fwd(self, eng):
         st = _stream()
@@ -268,10 +275,10 @@ class ConvBlockNode(Node):
             if cat:
                 check(lib.biu_conv_fwd_cat(cat[0].a(), cat[0].xf(), cat[1].a(), cat[1].xf(), _ptr(w), packed, _ptr(b), self.kd,
                                            self.kh, self.kw, self.dil, self.y.a(), _ptr(eng.partial), eng.partial.numel(),
-                                           C.byref(nblk), eng.dtype, st), "conv_fwd_cat")
+                                           C.byref(nblk), _ptr(eng.ws), eng.ws_bytes, eng.dtype, st), "conv_fwd_cat")
             else:
                 check(lib.biu_conv_fwd_stats(self.xin.a(), self.xin.xf(), _ptr(w), packed, _ptr(b), self.kd, self.kh, self.kw,
-                                             self.dil, self.y.a(), _ptr(eng.partial), eng.partial.numel(), C.byref(nblk),
+                                             self.dil, self.y.a(), _ptr(eng.partial), eng.partial.numel(), C.byref(nblk), _ptr(eng.ws), eng.ws_bytes,
                                              eng.dtype, st), "conv_fwd_stats")
             mom = bn.momentum if bn.momentum is not None else 0.1
             track = bn.track_running_stats and bn.running_mean is not None
@@ -285,10 +292,10 @@ class ConvBlockNode(Node):
         else:
             if cat:
                 check(lib.biu_conv_fwd_cat(cat[0].a(), cat[0].xf(), cat[1].a(), cat[1].xf(), _ptr(w), packed, _ptr(b), self.kd,
-                                           self.kh, self.kw, self.dil, self.y.a(), None, 0, None, eng.dtype, st), "conv_fwd_cat")
+                                           self.kh, self.kw, self.dil, self.y.a(), None, 0, None, _ptr(eng.ws), eng.ws_bytes, eng.dtype, st), "conv_fwd_cat")
             else:
                 check(lib.biu_conv_fwd(self.xin.a(), self.xin.xf(), _ptr(w), packed, _ptr(b), self.kd, self.kh, self.kw,
-                                       self.dil, self.y.a(), eng.dtype, st), "conv_fwd")
+                                       self.dil, self.y.a(), _ptr(eng.ws), eng.ws_bytes, eng.dtype, st), "conv_fwd")
             check(lib.biu_bn_eval_affine(self.y.c, _ptr(bn.weight.data), _ptr(bn.bias.data), _ptr(bn.running_mean),
                                          _ptr(bn.running_var), bn.eps, _ptr(scale), _ptr(shift), st), "bn_eval_affine")
             self.batch_stats = False
@@ -337,7 +344,7 @@ class ConvBlockNode(Node):
         if cat:
             packed = eng.pack(self.pk_b, 1, self.conv.weight, self.xin.c, cout, self.kd, self.kh, self.kw)
             check(lib.biu_conv_bwd_data_cat(y.g(), _ptr(self.conv.weight.data), packed, self.kd, self.kh, self.kw, self.dil,
-                                            cat[0].g(), int(cat[0].g_written()), cat[1].g(), int(cat[1].g_written()), eng.dtype, st),
+                                            cat[0].g(), int(cat[0].g_written()), cat[1].g(), int(cat[1].g_written()), _ptr(eng.ws), eng.ws_bytes, eng.dtype, st),
                   "conv_bwd_data_cat")
             cat[0].mark_g()
             cat[1].mark_g()
@@ -349,11 +356,11 @@ class ConvBlockNode(Node):
                 n_up = C.c_int(0)
                 check(lib.biu_conv_bwd_data_bnred(y.g(), _ptr(self.conv.weight.data), packed, self.kd, self.kh, self.kw,
                                                   self.dil, self.xin.g(), self.xin.a(), *up.red_coeffs(), _ptr(part),
-                                                  part.numel(), C.byref(n_up), eng.dtype, st), "conv_bwd_data_bnred")
+                                                  part.numel(), C.byref(n_up), _ptr(eng.ws), eng.ws_bytes, eng.dtype, st), "conv_bwd_data_bnred")
                 up.red_nblk = n_up.value
             else:
                 check(lib.biu_conv_bwd_data(y.g(), _ptr(self.conv.weight.data), packed, self.kd, self.kh, self.kw, self.dil,
-                                            self.xin.g(), int(self.xin.g_written()), eng.dtype, st), "conv_bwd_data")
+                                            self.xin.g(), int(self.xin.g_written()), _ptr(eng.ws), eng.ws_bytes, eng.dtype, st), "conv_bwd_data")
             self.xin.mark_g()
 
     # ---- receiving side of the fused BatchNorm-backward reduction -----------------------------------

@@ -31,12 +31,30 @@ from .optim import Adam
 _NODE_KINDS = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event", 7: "event_record"}
 
 
+def _loaded_hip_runtime():
+    """The HIP runtime THIS process already runs on (the copy torch loaded), never a second one: a box can hold another
+    ``libamdhip64.so`` (/opt/rocm next to torch's own), and a ``hipGraph_t`` handed to a different runtime is undefined behaviour.
+    The path comes from /proc/self/maps and is opened with RTLD_NOLOAD, which fails instead of loading anything new."""
+    import ctypes as C
+    import os
+    path = None
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64.so" in line:
+                path = line.split()[-1]
+                break
+    if path is None:
+        raise OSError("no libamdhip64.so is mapped into this process")
+    return C.CDLL(path, mode=getattr(os, "RTLD_NOLOAD", 4) | getattr(os, "RTLD_NOW", 2))
+
+
 def graph_node_kinds(graph: torch.cuda.CUDAGraph) -> dict:
     """Node kinds of a captured graph (``hipGraphGetNodes`` / ``hipGraphNodeGetType`` on the runtime torch already loaded); the graph must
-    have been created with ``keep_graph=True``.  Empty dict when the runtime does not offer the calls."""
+    have been created with ``keep_graph=True``.  Empty dict when the node kinds cannot be determined (the caller decides what that means:
+    ``GraphedTrainStep`` warns, because its no-memset-node check is then skipped)."""
     import ctypes as C
     try:
-        hip = C.CDLL("libamdhip64.so")
+        hip = _loaded_hip_runtime()
         raw = C.c_void_p(graph.raw_cuda_graph())
         n = C.c_size_t(0)
         if hip.hipGraphGetNodes(raw, None, C.byref(n)) != 0:
@@ -99,6 +117,10 @@ class GraphedTrainStep:
         # what the capture holds: memset nodes are refused (see the module docstring), copy nodes -- e.g. the select-backward of a loss that
         # indexes the logits, as unet/train.py:133-134 does -- are reported: they replayed in order in every test run so far
         self.node_kinds = graph_node_kinds(self.graph)
+        if not self.node_kinds:
+            import warnings
+            warnings.warn("GraphedTrainStep: the node kinds of the captured step could not be read (hipGraphGetNodes on the loaded runtime): "
+                          "the check that it holds no memset nodes was SKIPPED", stacklevel=2)
         if self.node_kinds.get("memset", 0):
             raise RuntimeError(f"GraphedTrainStep: the captured step holds memset nodes {self.node_kinds}: they are not replayed in order "
                                "on this runtime (zero tensors with a kernel: tensor.zero_() / torch.zeros, not hipMemsetAsync)")
@@ -107,6 +129,9 @@ class GraphedTrainStep:
             warnings.warn(f"GraphedTrainStep: the captured step holds device copy nodes {self.node_kinds}; a step of kernel nodes only is the "
                           "verified configuration", stacklevel=2)
         self.graph.instantiate()
+        # the captured launches write the buffers of exactly these engines (activations, statistics, workspace): hold them here --
+        # not only through self.loss.grad_fn -- so that an engine-cache eviction or set_compute_dtype cannot free what a replay writes
+        self.engines = [e for lst in getattr(model, "_engines", {}).values() for e in lst]
         # nothing of the capture ran; undo the warm-up
         model.load_state_dict(model_state)
         with torch.no_grad():
@@ -129,6 +154,14 @@ class GraphedTrainStep:
         return loss
 
     def __call__(self, inputs: Sequence[torch.Tensor], targets: Sequence[torch.Tensor]) -> torch.Tensor:
+        for e in self.engines:
+            # a replay overwrites the engine's saved activations exactly like a forward does: an eager forward still waiting for its
+            # backward on the same engine must fail loudly there (generation check of _NetFn.backward), not be corrupted silently.
+            # (The capture's own autograd node -- alive through self.loss -- does not count: its backward is part of the replay.)
+            if e.busy():
+                raise RuntimeError("GraphedTrainStep: an eager forward on this model still awaits its backward; a replay would overwrite "
+                                   "its saved activations (run that backward, or drop its outputs, first)")
+            e.generation += 1
         for dst, src in zip(self.static_in, inputs):
             dst.copy_(src, non_blocking=True)
         for dst, src in zip(self.static_tgt, targets):

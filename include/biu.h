@@ -96,11 +96,20 @@ typedef struct biu_pack_job {
 } biu_pack_job;
 int biu_pack_batch(const biu_pack_job* jobs, int n, int dtype, biu_stream stream);
 
+/* Split workspace (caller-owned, like every other byte the library touches).  An fp32 3x3(x3) launch whose bricks x channel
+ * tiles would fill under half of the CUs (U-Net bottlenecks) splits its INPUT channels over workgroups: every split writes a
+ * partial result into its slice of `ws`, a second kernel sums the slices into the output.  biu_conv_split_workspace returns the
+ * bytes such a launch writing y (and y1: the second output of a two-tensor data gradient, else NULL) from `cin` input channels
+ * needs; 0 = that launch is never split.  The calls below that take (ws, ws_bytes) split only when ws_bytes covers the query;
+ * with ws == NULL (or too small) they run the same arithmetic unsplit.  The library keeps no scratch of its own: nothing is
+ * allocated, cached or freed behind the caller's back, so a launch captured in a hipGraph refers to caller memory only.       */
+size_t biu_conv_split_workspace(int cin, const biu_act* y, const biu_act* y1, int kd, int kh, int kw, int dilation, int dtype);
+
 /* y = conv(T(x), w) + bias.  w: PyTorch layout fp32; packed: result of biu_conv_pack(kind 0), or NULL
- * when biu_conv_packed_bytes() returned 0 for this shape.                                                */
+ * when biu_conv_packed_bytes() returned 0 for this shape.  ws: biu_conv_split_workspace(x->c, y, NULL, ...) bytes or NULL.  */
 int biu_conv_fwd(const biu_act* x, const biu_xform* xf, const float* w, const void* packed,
                  const float* bias, int kd, int kh, int kw, int dilation,
-                 const biu_act* y, int dtype, biu_stream stream);
+                 const biu_act* y, void* ws, size_t ws_bytes, int dtype, biu_stream stream);
 
 /* Same, and additionally emits the BatchNorm statistics partials of y: float[nblk][cout][2] = (sum, sum of squares)
  * per block.  On the MFMA path they come out of the convolution's own epilogue (no extra pass over y); otherwise a
@@ -108,13 +117,15 @@ int biu_conv_fwd(const biu_act* x, const biu_xform* xf, const float* w, const vo
 size_t biu_conv_fwd_stats_floats(const biu_act* y, int kd);
 int biu_conv_fwd_stats(const biu_act* x, const biu_xform* xf, const float* w, const void* packed,
                        const float* bias, int kd, int kh, int kw, int dilation, const biu_act* y,
-                       float* bn_partial, size_t bn_partial_floats, int* bn_nblk, int dtype, biu_stream stream);
+                       float* bn_partial, size_t bn_partial_floats, int* bn_nblk, void* ws, size_t ws_bytes, int dtype,
+                       biu_stream stream);
 
 /* dx = conv_transpose_of_the_above(dy): dx[v,ci] = sum_{tap,co} dy[v - off(tap), co] * w[co,ci,tap].
- * packed: result of biu_conv_pack(kind 1) or NULL.  accumulate != 0 adds into dx.                       */
+ * packed: result of biu_conv_pack(kind 1) or NULL.  accumulate != 0 adds into dx.
+ * ws: biu_conv_split_workspace(dy->c, dx, NULL, ...) bytes or NULL.                                      */
 int biu_conv_bwd_data(const biu_act* dy, const float* w, const void* packed,
                       int kd, int kh, int kw, int dilation,
-                      const biu_act* dx, int accumulate, int dtype, biu_stream stream);
+                      const biu_act* dx, int accumulate, void* ws, size_t ws_bytes, int dtype, biu_stream stream);
 
 /* Data gradient that also emits the BatchNorm-backward partial sums (biu_bn_bwd_reduce's output) of the conv block that
  * PRODUCED the tensor whose gradient dx is: y_up is that block's raw conv output, (scale, shift, slope, mean, invstd) its
@@ -124,7 +135,7 @@ size_t biu_bwd_data_bnred_floats(const biu_act* dx, int kd, int transposed);
 int biu_conv_bwd_data_bnred(const biu_act* dy, const float* w, const void* packed, int kd, int kh, int kw, int dilation,
                             const biu_act* dx, const biu_act* y_up, const float* scale, const float* shift,
                             const float* slope, const float* mean, const float* invstd, float* partial,
-                            size_t partial_floats, int* nblk, int dtype, biu_stream stream);
+                            size_t partial_floats, int* nblk, void* ws, size_t ws_bytes, int dtype, biu_stream stream);
 int biu_convt_bwd_data_bnred(const biu_act* dy, const float* w, const void* packed, int kd, const biu_act* dx,
                              const biu_act* y_up, const float* scale, const float* shift, const float* slope,
                              const float* mean, const float* invstd, float* partial, size_t partial_floats, int* nblk,
@@ -263,14 +274,16 @@ int biu_xcorr_bwd(const biu_act* cur, const biu_xform* xc, const biu_act* prev, 
  * that are multiples of 32 -- x0's of 64 when the total is an even number of 32-tiles --, dilation 1, aligned dense rows).
  * fwd: bn_partial may be NULL (no statistics).  bwd_weight: y == NULL gives the plain weight gradient (da is dy), otherwise the
  * BatchNorm backward is fused exactly as in biu_conv_bwd_weight_bn.  bwd_data writes dx0 and dx1 (each with its own
- * accumulate flag).                                                                                                     */
+ * accumulate flag).  (ws, ws_bytes) of fwd / bwd_data: biu_conv_split_workspace(x0->c + x1->c, y, NULL, ...) resp.
+ * (dy->c, dx0, dx1, ...) bytes, or NULL.                                                                                  */
 int biu_conv_cat_ok(const biu_act* x0, const biu_act* x1, const biu_act* y, int kd, int kh, int kw, int dilation, int dtype);
 int biu_conv_fwd_cat(const biu_act* x0, const biu_xform* xf0, const biu_act* x1, const biu_xform* xf1, const float* w,
                      const void* packed, const float* bias, int kd, int kh, int kw, int dilation, const biu_act* y,
-                     float* bn_partial, size_t bn_partial_floats, int* bn_nblk, int dtype, biu_stream stream);
+                     float* bn_partial, size_t bn_partial_floats, int* bn_nblk, void* ws, size_t ws_bytes, int dtype,
+                     biu_stream stream);
 int biu_conv_bwd_data_cat(const biu_act* dy, const float* w, const void* packed, int kd, int kh, int kw, int dilation,
-                          const biu_act* dx0, int accumulate0, const biu_act* dx1, int accumulate1, int dtype,
-                          biu_stream stream);
+                          const biu_act* dx0, int accumulate0, const biu_act* dx1, int accumulate1, void* ws, size_t ws_bytes,
+                          int dtype, biu_stream stream);
 int biu_conv_bwd_weight_cat(const biu_act* x0, const biu_xform* xf0, const biu_act* x1, const biu_xform* xf1,
                             const biu_act* da, const biu_act* y, const float* scale, const float* shift, const float* slope,
                             const float* coefA, const float* coefB, const float* coefC, int kd, int kh, int kw, int dilation,

@@ -58,7 +58,7 @@ def test_conv_fwd_bwd(case, dtype):
     kd = 3 if nd == 3 else 1
     wd, bd = w.cuda(), b.cuda()
     yd = Dev(shape=(n, cout, 1 if nd == 2 else sp[0], sp[-2], sp[-1]), dtype=dtype, pitch=cout + 1, c0=1)
-    check(lib.biu_conv_fwd(dx_.a(), xf.x(), ptr(wd), None, ptr(bd), kd, 3, 3, dil, yd.a(), DT[dtype][1], stream()), "conv_fwd")
+    check(lib.biu_conv_fwd(dx_.a(), xf.x(), ptr(wd), None, ptr(bd), kd, 3, 3, dil, yd.a(), None, 0, DT[dtype][1], stream()), "conv_fwd")
     got = yd.get(squeeze2d=(nd == 2))
     assert_close(got, yref.detach(), dtype, "conv_fwd")
     # backward: data gradient is wrt T(x) (the activated input), weight gradient sees T(x)
@@ -66,7 +66,7 @@ def test_conv_fwd_bwd(case, dtype):
     dyr = dyd.ref().squeeze(2) if nd == 2 else dyd.ref()
     yref.backward(dyr)
     dxd = Dev(shape=(n, cin, 1 if nd == 2 else sp[0], sp[-2], sp[-1]), dtype=dtype)
-    check(lib.biu_conv_bwd_data(dyd.a(), ptr(wd), None, kd, 3, 3, dil, dxd.a(), 0, DT[dtype][1], stream()), "conv_bwd_data")
+    check(lib.biu_conv_bwd_data(dyd.a(), ptr(wd), None, kd, 3, 3, dil, dxd.a(), 0, None, 0, DT[dtype][1], stream()), "conv_bwd_data")
     assert_close(dxd.get(squeeze2d=(nd == 2)), xa.grad, dtype, "conv_bwd_data")
     dw = torch.empty_like(wd)
     db = torch.empty_like(bd)
@@ -76,7 +76,7 @@ def test_conv_fwd_bwd(case, dtype):
     assert_close(dw.cpu(), wr.grad, dtype, "conv_bwd_weight")
     assert_close(db.cpu(), br.grad, dtype, "conv dbias")
     # accumulate flag
-    check(lib.biu_conv_bwd_data(dyd.a(), ptr(wd), None, kd, 3, 3, dil, dxd.a(), 1, DT[dtype][1], stream()), "conv_bwd_data acc")
+    check(lib.biu_conv_bwd_data(dyd.a(), ptr(wd), None, kd, 3, 3, dil, dxd.a(), 1, None, 0, DT[dtype][1], stream()), "conv_bwd_data acc")
     assert_close(dxd.get(squeeze2d=(nd == 2)), 2 * xa.grad, dtype, "conv_bwd_data(accumulate)")
 
 
@@ -299,7 +299,7 @@ def test_shape_errors_are_reported_not_thrown():
     x = Dev(rnd(1, 4, 1, 8, 8), dtype="f32")
     y = Dev(shape=(1, 4, 1, 4, 8), dtype="f32")
     w = torch.zeros(4, 4, 3, 3, device="cuda")
-    rc = lib.biu_conv_fwd(x.a(), None, ptr(w), None, None, 1, 3, 3, 1, y.a(), 0, stream())
+    rc = lib.biu_conv_fwd(x.a(), None, ptr(w), None, None, 1, 3, 3, 1, y.a(), None, 0, 0, stream())
     assert rc == -1 and b"conv_fwd" in lib.biu_last_error()
     rc = lib.biu_maxpool_fwd(x.a(), None, x.a(), 0, stream())
     assert rc == -1
@@ -352,7 +352,7 @@ def test_conv_mfma_fwd_dgrad(case, dtype):
     check(lib.biu_conv_pack(0, ptr(wd), cin, cout, kd, 3, 3, code, ptr(pk), stream()), "conv_pack")
     oshape = (n, cout, 1 if nd == 2 else sp[0], sp[-2], sp[-1])
     yd = Dev(shape=oshape, dtype=dtype, pitch=cout + 8, c0=8)
-    check(lib.biu_conv_fwd(xd.a(), xf.x(), ptr(wd), ptr(pk), ptr(bd), kd, 3, 3, 1, yd.a(), code, stream()), "conv_fwd(mfma)")
+    check(lib.biu_conv_fwd(xd.a(), xf.x(), ptr(wd), ptr(pk), ptr(bd), kd, 3, 3, 1, yd.a(), None, 0, code, stream()), "conv_fwd(mfma)")
     got = yd.get(squeeze2d=(nd == 2))
     t = dict(rtol=1e-4, atol=1e-4 * float(yref.abs().max())) if dtype == "f32" else dict(rtol=1e-2, atol=1e-2 * float(yref.abs().max()))
     torch.testing.assert_close(got, yref.detach(), **t)
@@ -365,10 +365,10 @@ def test_conv_mfma_fwd_dgrad(case, dtype):
     pk2 = torch.empty(nb2, dtype=torch.uint8, device="cuda")
     check(lib.biu_conv_pack(1, ptr(wd), cin, cout, kd, 3, 3, code, ptr(pk2), stream()), "conv_pack(dgrad)")
     dxd = Dev(shape=(n, cin, 1 if nd == 2 else sp[0], sp[-2], sp[-1]), dtype=dtype, pitch=cin + 8, c0=0)
-    check(lib.biu_conv_bwd_data(dyd.a(), ptr(wd), ptr(pk2), kd, 3, 3, 1, dxd.a(), 0, code, stream()), "conv_bwd_data(mfma)")
+    check(lib.biu_conv_bwd_data(dyd.a(), ptr(wd), ptr(pk2), kd, 3, 3, 1, dxd.a(), 0, None, 0, code, stream()), "conv_bwd_data(mfma)")
     t2 = dict(rtol=1e-4, atol=1e-4 * float(xa.grad.abs().max())) if dtype == "f32" else dict(rtol=1e-2, atol=1e-2 * float(xa.grad.abs().max()))
     torch.testing.assert_close(dxd.get(squeeze2d=(nd == 2)), xa.grad, **t2)
-    check(lib.biu_conv_bwd_data(dyd.a(), ptr(wd), ptr(pk2), kd, 3, 3, 1, dxd.a(), 1, code, stream()), "conv_bwd_data(mfma, acc)")
+    check(lib.biu_conv_bwd_data(dyd.a(), ptr(wd), ptr(pk2), kd, 3, 3, 1, dxd.a(), 1, None, 0, code, stream()), "conv_bwd_data(mfma, acc)")
     torch.testing.assert_close(dxd.get(squeeze2d=(nd == 2)), 2 * xa.grad, rtol=t2["rtol"] * 2, atol=t2["atol"] * 2)
     # the pad region of the output buffer (channels outside the slice) must be untouched
     assert torch.isnan(yd.buf[..., :8].float()).all()
@@ -490,12 +490,12 @@ def test_conv_bwd_data_bnred(case, dtype):
     md, isd = mean.cuda(), invstd.cuda()
     dshape = (n, cin, 1 if nd == 2 else sp[0], sp[-2], sp[-1])
     dx_ref, dx = Dev(shape=dshape, dtype=dtype), Dev(shape=dshape, dtype=dtype)
-    check(lib.biu_conv_bwd_data(dyd.a(), ptr(wd), ptr(pk2) if nb2 else None, kd, 3, 3, 1, dx_ref.a(), 0, code, stream()), "dgrad")
+    check(lib.biu_conv_bwd_data(dyd.a(), ptr(wd), ptr(pk2) if nb2 else None, kd, 3, 3, 1, dx_ref.a(), 0, None, 0, code, stream()), "dgrad")
     nfl = lib.biu_bwd_data_bnred_floats(dx.a(), kd, 0)
     part = torch.full((nfl,), float("nan"), device="cuda")
     nblk = C.c_int(0)
     check(lib.biu_conv_bwd_data_bnred(dyd.a(), ptr(wd), ptr(pk2) if nb2 else None, kd, 3, 3, 1, dx.a(), yup.a(), ptr(xf.d[0]),
-                                      ptr(xf.d[1]), ptr(xf.d[2]), ptr(md), ptr(isd), ptr(part), nfl, C.byref(nblk), code,
+                                      ptr(xf.d[1]), ptr(xf.d[2]), ptr(md), ptr(isd), ptr(part), nfl, C.byref(nblk), None, 0, code,
                                       stream()), "conv_bwd_data_bnred")
     assert torch.equal(dx.buf, dx_ref.buf), "the fused epilogue must not change the data gradient"
     sums = part[:nblk.value * cin * 2].view(nblk.value, cin, 2).double().sum(0).cpu()
@@ -747,14 +747,14 @@ def test_conv_mfma_sample_beyond_2gb():
     pk = torch.empty(lib.biu_conv_packed_bytes(0, cin, cout, 3, 3, 3, 1, code), dtype=torch.uint8, device="cuda")
     check(lib.biu_conv_pack(0, ptr(wd), cin, cout, 3, 3, 3, code, ptr(pk), stream()), "pack")
     yd = Dev(shape=(n, cout) + sp, dtype=dtype)
-    check(lib.biu_conv_fwd(xd.a(), None, ptr(wd), ptr(pk), None, 3, 3, 3, 1, yd.a(), code, stream()), "conv_fwd")
+    check(lib.biu_conv_fwd(xd.a(), None, ptr(wd), ptr(pk), None, 3, 3, 3, 1, yd.a(), None, 0, code, stream()), "conv_fwd")
     torch.testing.assert_close(yd.get(), ref.detach(), rtol=1e-2, atol=1e-2 * float(ref.abs().max()))
     gd = Dev(rnd(n, cout, *sp, seed=3), dtype=dtype, pitch=1024, c0=8)
     ref.backward(gd.ref())
     pk1 = torch.empty(lib.biu_conv_packed_bytes(1, cin, cout, 3, 3, 3, 1, code), dtype=torch.uint8, device="cuda")
     check(lib.biu_conv_pack(1, ptr(wd), cin, cout, 3, 3, 3, code, ptr(pk1), stream()), "pack1")
     dxd = Dev(shape=(n, cin) + sp, dtype=dtype)
-    check(lib.biu_conv_bwd_data(gd.a(), ptr(wd), ptr(pk1), 3, 3, 3, 1, dxd.a(), 0, code, stream()), "conv_bwd_data")
+    check(lib.biu_conv_bwd_data(gd.a(), ptr(wd), ptr(pk1), 3, 3, 3, 1, dxd.a(), 0, None, 0, code, stream()), "conv_bwd_data")
     torch.testing.assert_close(dxd.get(), xq.grad, rtol=1e-2, atol=1e-2 * float(xq.grad.abs().max()))
     ws = torch.empty(lib.biu_conv_bwd_weight_workspace(cin, cout, 3, 3, 3, code), dtype=torch.uint8, device="cuda")
     dw = torch.full_like(wd, float("nan"))
@@ -835,8 +835,8 @@ def test_conv_cat_forms_match_concat_buffer(case, dtype):
     nfl = lib.biu_conv_fwd_stats_floats(ya.a(), kd)
     pa, pb = torch.zeros(nfl, device="cuda"), torch.zeros(nfl, device="cuda")
     na, nb = C.c_int(0), C.c_int(0)
-    check(lib.biu_conv_fwd_stats(dc.a(), C.byref(xfc), ptr(wd), ptr(pk0), ptr(bd), kd, 3, 3, 1, ya.a(), ptr(pa), nfl, C.byref(na), code, stream()), "fwd")
-    check(lib.biu_conv_fwd_cat(d0.a(), xf0.x(), d1.a(), None, ptr(wd), ptr(pk0), ptr(bd), kd, 3, 3, 1, yb.a(), ptr(pb), nfl, C.byref(nb), code,
+    check(lib.biu_conv_fwd_stats(dc.a(), C.byref(xfc), ptr(wd), ptr(pk0), ptr(bd), kd, 3, 3, 1, ya.a(), ptr(pa), nfl, C.byref(na), None, 0, code, stream()), "fwd")
+    check(lib.biu_conv_fwd_cat(d0.a(), xf0.x(), d1.a(), None, ptr(wd), ptr(pk0), ptr(bd), kd, 3, 3, 1, yb.a(), ptr(pb), nfl, C.byref(nb), None, 0, code,
                                stream()), "fwd_cat")
     assert torch.equal(ya.buf, yb.buf)
     # ... and against torch: conv of the concatenation of the two transformed sources (operands as the MFMA kernel packs them)
@@ -854,10 +854,10 @@ def test_conv_cat_forms_match_concat_buffer(case, dtype):
     # data gradient into two tensors (second one accumulating)
     gd = Dev(rnd(*yshape, seed=7).squeeze(2) if nd == 2 else rnd(*yshape, seed=7), dtype=dtype)
     dxc = Dev(shape=dc.buf.permute(0, 4, 1, 2, 3).shape, dtype=dtype)
-    check(lib.biu_conv_bwd_data(gd.a(), ptr(wd), ptr(pk1), kd, 3, 3, 1, dxc.a(), 0, code, stream()), "dgrad")
+    check(lib.biu_conv_bwd_data(gd.a(), ptr(wd), ptr(pk1), kd, 3, 3, 1, dxc.a(), 0, None, 0, code, stream()), "dgrad")
     base1 = rnd(n, c1, *sp, seed=8)
     g0, g1 = Dev(shape=d0.buf.permute(0, 4, 1, 2, 3).shape, dtype=dtype), Dev(base1, dtype=dtype)
-    check(lib.biu_conv_bwd_data_cat(gd.a(), ptr(wd), ptr(pk1), kd, 3, 3, 1, g0.a(), 0, g1.a(), 1, code, stream()), "dgrad_cat")
+    check(lib.biu_conv_bwd_data_cat(gd.a(), ptr(wd), ptr(pk1), kd, 3, 3, 1, g0.a(), 0, g1.a(), 1, None, 0, code, stream()), "dgrad_cat")
     assert torch.equal(g0.buf, dxc.buf[..., :c0])
     gr = gd.ref().squeeze(2) if nd == 2 else gd.ref()
     (gx_ref,) = torch.autograd.grad(yref, xa, gr, retain_graph=True)                 # torch: data gradient of the concatenation
@@ -962,7 +962,7 @@ def test_batchnorm_statistics_with_a_large_offset(path):
         check(lib.biu_conv_pack(0, ptr(wd), cin, c, 3, 3, 3, 0, ptr(pk), stream()), "conv_pack")
         nfl = lib.biu_conv_fwd_stats_floats(yd.a(), 3)
         partial = torch.empty(nfl, device="cuda")
-        check(lib.biu_conv_fwd_stats(xd.a(), None, ptr(wd), ptr(pk), ptr(bd), 3, 3, 3, 1, yd.a(), ptr(partial), nfl, C.byref(nblk), 0, stream()),
+        check(lib.biu_conv_fwd_stats(xd.a(), None, ptr(wd), ptr(pk), ptr(bd), 3, 3, 3, 1, yd.a(), ptr(partial), nfl, C.byref(nblk), None, 0, 0, stream()),
               "conv_fwd_stats")
         yref = yd.get()
     check(lib.biu_bn_finalize(ptr(partial), nblk.value, c, float(nvox), ptr(g_d), ptr(b_d), ptr(rm_d), ptr(rv_d), 0.1, 1e-5,
@@ -973,3 +973,58 @@ def test_batchnorm_statistics_with_a_large_offset(path):
     torch.testing.assert_close(mean.cpu().double(), m_ref, rtol=1e-5, atol=0)
     var = 1.0 / invstd.cpu().double() ** 2 - 1e-5
     torch.testing.assert_close(var, v_ref, rtol=1e-2, atol=0)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# input-channel split of small fp32 launches with CALLER-OWNED scratch (include/biu.h: biu_conv_split_workspace)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nd,n,cin,cout,sp", [(2, 1, 256, 256, (16, 16)), (2, 2, 512, 256, (16, 32)), (3, 1, 128, 128, (8, 8, 16))])
+def test_conv_split_workspace_is_the_callers(nd, n, cin, cout, sp):
+    """The library keeps no scratch: the split runs only inside the workspace the caller hands in, gives the unsplit launch's result
+    (and torch's), never writes past the queried size, and without a workspace the same call runs unsplit."""
+    kd = 3 if nd == 3 else 1
+    x = rnd(n, cin, *sp, seed=1)
+    w = rnd(cout, cin, *([3] * nd), seed=2) * 0.05
+    b = rnd(cout, seed=3)
+    xd = Dev(x, dtype="f32")
+    xa = xd.ref().squeeze(2) if nd == 2 else xd.ref()
+    yref = conv_ref(xa, w, b, 1)
+    wd, bd = w.cuda(), b.cuda()
+    pk = [torch.empty(max(lib.biu_conv_packed_bytes(k, cin, cout, kd, 3, 3, 1, DT["f32"][1]), 16), dtype=torch.uint8, device="cuda") for k in (0, 1)]
+    for k in (0, 1):
+        check(lib.biu_conv_pack(k, ptr(wd), cin, cout, kd, 3, 3, DT["f32"][1], ptr(pk[k]), stream()), "conv_pack")
+    shape_y = (n, cout, 1 if nd == 2 else sp[0], sp[-2], sp[-1])
+    y0, y1 = Dev(shape=shape_y, dtype="f32"), Dev(shape=shape_y, dtype="f32")
+    need = lib.biu_conv_split_workspace(cin, y0.a(), None, kd, 3, 3, 1, DT["f32"][1])
+    assert need > 0, "this shape is meant to split (grid under half of the CUs)"
+    assert lib.biu_conv_split_workspace(cin, y0.a(), None, kd, 3, 3, 1, DT["bf16"][1]) == 0          # fp32 launches only
+    guard = 4096
+    ws = torch.full((need + guard,), 0x5A, dtype=torch.uint8, device="cuda")
+    check(lib.biu_conv_fwd(xd.a(), None, ptr(wd), ptr(pk[0]), ptr(bd), kd, 3, 3, 1, y0.a(), ptr(ws), need, DT["f32"][1], stream()), "conv_fwd split")
+    check(lib.biu_conv_fwd(xd.a(), None, ptr(wd), ptr(pk[0]), ptr(bd), kd, 3, 3, 1, y1.a(), None, 0, DT["f32"][1], stream()), "conv_fwd unsplit")
+    assert bool((ws[need:] == 0x5A).all()), "the split wrote past the size its own query asked for"
+    assert not bool((ws[:need] == 0x5A).all()), "the scratch was not used: the launch did not split"
+    assert_close(y0.get(squeeze2d=(nd == 2)), yref, "f32", "conv_fwd (split)")
+    torch.testing.assert_close(y0.get(), y1.get(), rtol=1e-5, atol=1e-5 * float(yref.abs().max()))
+    # a workspace that is too small is not an error: the launch runs unsplit
+    check(lib.biu_conv_fwd(xd.a(), None, ptr(wd), ptr(pk[0]), ptr(bd), kd, 3, 3, 1, y1.a(), ptr(ws), need - 1, DT["f32"][1], stream()), "conv_fwd small ws")
+    torch.testing.assert_close(y0.get(), y1.get(), rtol=1e-5, atol=1e-5 * float(yref.abs().max()))
+    # data gradient (accumulate = 1 on a pre-filled dx) and statistics through the split
+    dy = rnd(*yref.shape, seed=5)
+    dyd = Dev(dy, dtype="f32")
+    xg = xa.clone().requires_grad_(True)
+    conv_ref(xg, w, b, 1).backward(dy)
+    dxd = Dev(torch.ones_like(x), dtype="f32")
+    needb = lib.biu_conv_split_workspace(cout, dxd.a(), None, kd, 3, 3, 1, DT["f32"][1])
+    assert needb > 0
+    wsb = torch.empty(needb, dtype=torch.uint8, device="cuda")
+    check(lib.biu_conv_bwd_data(dyd.a(), ptr(wd), ptr(pk[1]), kd, 3, 3, 1, dxd.a(), 1, ptr(wsb), needb, DT["f32"][1], stream()), "conv_bwd_data split")
+    assert_close(dxd.get(squeeze2d=(nd == 2)), xg.grad + 1, "f32", "conv_bwd_data (split, accumulate)")
+    part = torch.empty(lib.biu_conv_fwd_stats_floats(y0.a(), kd), device="cuda")
+    nblk = C.c_int(0)
+    check(lib.biu_conv_fwd_stats(xd.a(), None, ptr(wd), ptr(pk[0]), ptr(bd), kd, 3, 3, 1, y1.a(), ptr(part), part.numel(), C.byref(nblk),
+                                 ptr(ws), need, DT["f32"][1], stream()), "conv_fwd_stats split")
+    st_ = part[:nblk.value * cout * 2].view(nblk.value, cout, 2).double().sum(0).cpu()
+    yy = yref.transpose(0, 1).flatten(1).double()
+    torch.testing.assert_close(st_[:, 0], yy.sum(1), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(st_[:, 1], (yy * yy).sum(1), rtol=1e-4, atol=1e-3)

@@ -20,7 +20,7 @@ def timeit(f, reps=20):
     for _ in range(reps): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-fw = lambda: check(lib.biu_conv_fwd(C.byref(ax), None, p(wt), None, p(b), 3, 3, 3, 1, C.byref(ay), BIU_BF16, st), "fwd")
+fw = lambda: check(lib.biu_conv_fwd(C.byref(ax), None, p(wt), None, p(b), 3, 3, 3, 1, C.byref(ay), None, 0, BIU_BF16, st), "fwd")
 wg = lambda: check(lib.biu_conv_bwd_weight(C.byref(ax), None, C.byref(ady), 3, 3, 3, 1, p(dw), None, p(ws), wsz, BIU_BF16, st), "wgrad")
 bytes_f = n * d * h * w * (1 + co) * 2
 print(f"c1 fwd   {timeit(fw):.3f} ms  ({bytes_f / timeit(fw) / 1e6:.0f} GB/s)   wgrad {timeit(wg):.3f} ms ({bytes_f / timeit(wg) / 1e6:.0f} GB/s)  BIU_C1_TPW={os.environ.get('BIU_C1_TPW')}")

@@ -68,13 +68,13 @@ def main():
         stat = torch.empty(lib.biu_conv_fwd_stats_floats(C.byref(ay), kd), device="cuda")
         nblk = C.c_int(0)
         calls = {
-            "fwd": lambda: lib.biu_conv_fwd(C.byref(ax), None if noxf else C.byref(xf), P(wt), P(pk0), P(bias), kd, 3, 3, 1, C.byref(ay), code, st),
-            "dgrad": lambda: lib.biu_conv_bwd_data(C.byref(ady), P(wt), P(pk1), kd, 3, 3, 1, C.byref(adx), 0, code, st),
+            "fwd": lambda: lib.biu_conv_fwd(C.byref(ax), None if noxf else C.byref(xf), P(wt), P(pk0), P(bias), kd, 3, 3, 1, C.byref(ay), None, 0, code, st),
+            "dgrad": lambda: lib.biu_conv_bwd_data(C.byref(ady), P(wt), P(pk1), kd, 3, 3, 1, C.byref(adx), 0, None, 0, code, st),
             "wgrad": lambda: lib.biu_conv_bwd_weight(C.byref(ax), C.byref(xf), C.byref(ady), kd, 3, 3, 1, P(dw), None, P(ws), ws.numel(), code, st),
             # the training step's forms: forward + BatchNorm statistics; weight gradient with BatchNorm backward in its loader
             # (cA = 1, cB = cC = 0 keeps dy bounded over the repeats)
             "fwd_st": lambda: lib.biu_conv_fwd_stats(C.byref(ax), None if noxf else C.byref(xf), P(wt), P(pk0), P(bias), kd, 3, 3, 1, C.byref(ay),
-                                                     P(stat), stat.numel(), C.byref(nblk), code, st),
+                                                     P(stat), stat.numel(), C.byref(nblk), None, 0, code, st),
             "wg_bn": lambda: lib.biu_conv_bwd_weight_bn(C.byref(ax), C.byref(xf), C.byref(ady), C.byref(ay), P(kvec[0]), P(kvec[1]), P(kvec[2]),
                                                         P(kvec[3]), P(kvec[4]), P(kvec[5]), kd, 3, 3, 1, P(dw), P(ws), ws.numel(), code, st),
         }
@@ -90,7 +90,7 @@ def main():
             if lib.biu_conv_cat_ok(C.byref(ax0), C.byref(ax1), C.byref(ay), kd, 3, 3, 1, code):
                 keep.extend([x0, x1])
                 calls["fwd_cat"] = lambda: lib.biu_conv_fwd_cat(C.byref(ax0), C.byref(xs0), C.byref(ax1), C.byref(xs1), P(wt), P(pk0), P(bias), kd, 3, 3, 1,
-                                                                 C.byref(ay), P(stat), stat.numel(), C.byref(nblk), code, st)
+                                                                 C.byref(ay), P(stat), stat.numel(), C.byref(nblk), None, 0, code, st)
                 calls["wg_cat"] = lambda: lib.biu_conv_bwd_weight_cat(C.byref(ax0), C.byref(xs0), C.byref(ax1), C.byref(xs1), C.byref(ady), C.byref(ay),
                                                                       P(kvec[0]), P(kvec[1]), P(kvec[2]), P(kvec[3]), P(kvec[4]), P(kvec[5]), kd, 3, 3, 1,
                                                                       P(dw), P(ws), ws.numel(), code, st)

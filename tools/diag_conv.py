@@ -23,7 +23,7 @@ for name, cin, cout, (d,h,w) in shapes:
     lib.biu_conv_pack(0,P(wt),cin,cout,3,3,3,1,P(pk),st)
     ax = biu_act(x.data_ptr(),n,d,h,w,cin,cin); ay = biu_act(y.data_ptr(),n,d,h,w,cout,cout)
     stat = torch.empty(lib.biu_conv_fwd_stats_floats(C.byref(ay), 3), device="cuda"); nblk = C.c_int(0)
-    fwd = (lambda: lib.biu_conv_fwd_stats(C.byref(ax),XF,P(wt),P(pk),None,3,3,3,1,C.byref(ay),P(stat),stat.numel(),C.byref(nblk),1,st)) if os.environ.get("DIAG_STATS") == "1" else (lambda: lib.biu_conv_fwd(C.byref(ax),XF,P(wt),P(pk),None,3,3,3,1,C.byref(ay),1,st))
+    fwd = (lambda: lib.biu_conv_fwd_stats(C.byref(ax),XF,P(wt),P(pk),None,3,3,3,1,C.byref(ay),P(stat),stat.numel(),C.byref(nblk), None,0,1,st)) if os.environ.get("DIAG_STATS") == "1" else (lambda: lib.biu_conv_fwd(C.byref(ax),XF,P(wt),P(pk),None,3,3,3,1,C.byref(ay), None,0,1,st))
     fwd(); torch.cuda.synchronize()
     diag.zero_()
     e0,e1 = torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
