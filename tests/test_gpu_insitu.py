@@ -48,7 +48,10 @@ CASES = {
 }
 
 
-OUTLIER_FRAC = {"f32": 1e-3, "bf16": 1e-3}     # TIGHTEN after the first measured run (profiles/r03_insitu_outliers.txt)
+# measured (profiles/r03_insitu_outliers.txt): fp32 0 of 2.4e8 elements over all networks; bf16 0 everywhere except Unet_v0 (70 of 3.9e6 =
+# 1.8e-5 at 1.2-1.5x: tensors whose gradient has two writers / the 1-channel block, where an intermediate bf16 rounding of the engine
+# and of the checker's float64 model fall on different sides of a rounding boundary)
+OUTLIER_FRAC = {"f32": 2e-6, "bf16": 1e-4}
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
