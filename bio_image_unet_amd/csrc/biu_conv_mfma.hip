@@ -2528,6 +2528,492 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     }
 }
 
+// ===============================================================================================================
+// Rolling-window weight gradient (3x3x3, stride 1, bf16): the kernel the 3-D conv blocks of a train step use.
+//
+// k_wgrad_pipe above spends 45 % of a brick outside its MFMA phase: every brick's tiles come through registers (global load ->
+// VALU -> ds_write_b128 at ~79 B/clk/CU) between two barriers while the matrix cores wait, and 2 of the 6 halo planes of the
+// tapped operand are re-read by the next brick along D (in-kernel stamps: MFMA phase 54 %, commit 20 %, barriers 25 %;
+// profiles/r03_wgrad_roll.md).  Here a block walks a COLUMN of the volume -- an 8 x 16 window in (H, W), all of D in steps of
+// 2 planes -- and keeps the tapped operand in a RING of 6 halo planes in LDS:
+//   * a step needs planes d0-1 .. d0+2; the 2 planes of the NEXT step and its 2 x 8 x 16 plain-operand tile are fetched by
+//     LDS-DMA (`buffer_load_dwordx4 ... lds`: no VGPRs, no ds_write, out-of-volume pieces arrive as zeros from the descriptor's
+//     range check) into the ring slots / the second A buffer nobody reads during the step, issued in front of the step's MFMAs;
+//   * halo traffic falls from 2.1x to 1.4x of the tensor (4 of 6 planes are re-used from LDS);
+//   * a producer transform (BatchNorm-affine + LeakyReLU of a lazy source) is applied IN PLACE in LDS by the lane that fetched the
+//     piece, after its own vmcnt(0) -- no barrier in between; the fused BatchNorm backward of the plain operand (da, y -> dy, written
+//     back over da) keeps the register path (2 pieces per thread);
+//   * the fetch runs TWO steps ahead (ring of 4 plane pairs, 3 plain-operand buffers): one step (~2.5 us) is shorter than the memory
+//     latency of a loaded chip -- with one step of lookahead every step stalled ~1 us on its fetch (ablation: profiles/r03_wgrad_roll.md);
+//     the wave waits with a counted vmcnt that leaves the younger fetch in flight;
+//   * ONE barrier per step.  MFMA work per step and SIMD: 112 MFMAs = 3584 cycles; everything else ~600.
+// Work split inside the step is k_wgrad_pipe's row-reuse scheme: wave w owns the three kh taps of the (kd, kw) pair (w / 3, w % 3),
+// the ninth pair's taps are the fourth slot of waves 0-2; a 4-slot fragment ring takes one new transposed B read per 16-voxel row.
+// LDS: 4 x 24 KiB ring + 3 x 16 KiB plain-operand tiles + vectors = 145 KiB.
+// ===============================================================================================================
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void bload_lds16(unsigned voff, v4u_t rsrc, unsigned lds_base_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_base_uniform)
+                 : "memory");
+}
+__device__ __forceinline__ v4u_t raw_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long pa = (unsigned long long)base;
+    v4u_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)pa);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32) & 0xffffu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
+
+// Energy ablation builds (tools/build_variant.sh x -DBIU_WROLL_ABL=n; results are WRONG, timing only): bit 0 = no fetches after the first
+// step of a column (MFMAs + LDS fragment reads only), bit 1 = fragments read once per step and re-used for every row (no LDS reads).
+#ifndef BIU_WROLL_ABL
+#define BIU_WROLL_ABL 0
+#endif
+#ifndef BIU_DIAG_WAVE
+#define BIU_DIAG_WAVE 0        // which wave of a block stamps (BIU_DIAG builds)
+#endif
+constexpr int WR_TD = 2, WR_TH = 8, WR_TW = 16;
+constexpr int WR_HH = WR_TH + 2, WR_HW = WR_TW + 2, WR_PL = WR_HH * WR_HW;      // 180 voxels per halo plane
+constexpr int WR_RS = 64;                                                       // bytes per voxel row of a 32-channel bf16 tile
+constexpr int WR_PLB = WR_PL * WR_RS;                                           // 11520
+constexpr int WR_NBI = 24;                                                      // DMA instructions (1 KiB) per pair of planes: 23040 B, rounded up to 3 per wave
+constexpr int WR_PAIRB = WR_NBI * 1024;
+constexpr int WR_NPAIR = 4;                                                     // ring: 2 pairs read by the step, 2 being fetched (steps s + 1, s + 2)
+constexpr int WR_BV = WR_TD * WR_TH * WR_TW;                                    // 256 voxels per step
+constexpr int WR_AB = WR_BV * WR_RS;                                            // 16 KiB
+constexpr int WR_NAI = WR_AB / 1024;                                            // 16
+constexpr int WR_NABUF = 3;
+constexpr size_t WR_LDS = (size_t)WR_NPAIR * WR_PAIRB + WR_NABUF * WR_AB + 9 * 32 * sizeof(float);
+
+// A wave-uniform value the optimiser must not see through: keeps per-step offsets (plane * bytes, ring pair * bytes) out of strength
+// reduction / loop-invariant hoisting, which turned every (piece, step parity, ring slot) combination into a live VGPR and spilled.
+__device__ __forceinline__ unsigned opaque_s(unsigned x) { asm volatile("" : "+s"(x)); return x; }
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <bool BNF>
+__global__ __launch_bounds__(512, 2) void k_wgrad_roll(WgradArgs a) {
+    using T = bf16_t;
+    using F = Frag<T>;
+    constexpr int TD = WR_TD, TH = WR_TH, TW = WR_TW, HW = WR_HW, PL = WR_PL, RS = WR_RS, PLB = WR_PLB, PAIRB = WR_PAIRB;
+    constexpr int CT = 32, PE = 8, TAPS = 27, IPW = 4, NROW = TD * TH;
+    constexpr int NBK = WR_NBI / 8, NAK = WR_NAI / 8;                         // DMA instructions per wave and fetch: tapped pair 3, plain tile 2
+
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+    char* bring = (char*)lds;                          // [4][PAIRB]: pair p holds the halo planes gp with ((gp + 1) / 2) % 4 == p
+    char* abuf = bring + WR_NPAIR * PAIRB;             // [3][WR_AB]: plain-operand tile of step s in buffer s % 3, rows [voxel][32 ch]
+    float* lxf = (float*)(abuf + WR_NABUF * WR_AB);    // [3][CT] transform of B, [6][CT] BatchNorm backward of A
+    constexpr int LB = 0, LBN = 3 * CT;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int it = blockIdx.y / a.jt_count, jt = a.jt_begin + blockIdx.y % a.jt_count;
+    const int piece = lane & 3;
+    const int ac0 = it * CT + piece * PE, bc0 = jt * CT + piece * PE;
+    const bool apiece_ok = ac0 < a.CA, bpiece_ok = bc0 < a.CB;
+    const bool b_src1 = a.pb1 && jt * CT >= a.bsplit;
+    const char* pb_ = b_src1 ? a.pb1 : a.pb;
+    const int bpitch_ = b_src1 ? a.bpitch1 : a.bpitch;
+    const int bc_local = bc0 - (b_src1 ? a.bsplit : 0);
+    const float* bs_ = b_src1 ? a.bs1_ : a.bs_;
+    const float* bb_ = b_src1 ? a.bb1_ : a.bb_;
+    const float* bl_ = b_src1 ? a.bl1_ : a.bl_;
+    const bool b_xf = bs_ != nullptr;
+    constexpr bool bn_fused = BNF;                       // (a.py != nullptr: the launcher picks the instantiation)
+    const bool wb = bn_fused && a.write_back;
+    if (tid < CT && bn_fused) {
+        const int ca = it * CT + tid;
+        const bool ok = ca < a.CA;
+        lxf[LBN + 0 * CT + tid] = ok ? a.bn_scale[ca] : 1.f;
+        lxf[LBN + 1 * CT + tid] = ok ? a.bn_shift[ca] : 0.f;
+        lxf[LBN + 2 * CT + tid] = (ok && a.bn_slope) ? a.bn_slope[ca] : 1.f;
+        lxf[LBN + 3 * CT + tid] = ok ? a.bn_cA[ca] : 0.f;
+        lxf[LBN + 4 * CT + tid] = ok ? a.bn_cB[ca] : 0.f;
+        lxf[LBN + 5 * CT + tid] = ok ? a.bn_cC[ca] : 0.f;
+    }
+    if (tid < CT) {
+        const int cb = jt * CT + tid;
+        const int cbl = cb - (b_src1 ? a.bsplit : 0);
+        lxf[LB + 0 * CT + tid] = (b_xf && cb < a.CB) ? bs_[cbl] : 1.f;
+        lxf[LB + 1 * CT + tid] = (b_xf && cb < a.CB) ? bb_[cbl] : 0.f;
+        lxf[LB + 2 * CT + tid] = (b_xf && cb < a.CB) ? bl_[cbl] : 1.f;
+    }
+
+    floatx16 acc[IPW];
+#pragma unroll
+    for (int t = 0; t < IPW; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    // wave w: (kd, kw) pair (w / 3, w % 3); waves 0-2 also take tap (2, kh = w, 2) of the ninth pair
+    const int wkd = wave / 3, wkw = wave % 3;
+    const bool has_x = wave < 3;
+    int tapid[IPW];
+#pragma unroll
+    for (int t = 0; t < IPW; ++t) tapid[t] = (t < 3) ? (wkd * 3 + t) * 3 + wkw : (has_x ? (2 * 3 + wave) * 3 + 2 : TAPS);
+    int ab_lane;
+    {
+        const int g = lane >> 4, li = lane & 15, qrow = li >> 2, p = li & 3, cg = g & 1, h = g >> 1;
+        ab_lane = (8 * h + qrow) * RS + (16 * cg + 4 * p) * 2;                  // same lane map for both operands (row stride 64 B, stride 1)
+    }
+
+    // ---- this thread's DMA pieces (column-invariant): tapped pair instruction wave + 8k (k < 3), plain tile instruction wave + 8k (k < 2)
+    unsigned bco[NBK], aco[NAK];                         // packed (plane | hh << 10 | hw << 20) / (ld | lh << 10 | lw << 20); 0xffffffff = no piece
+#pragma unroll
+    for (int k = 0; k < NBK; ++k) {
+        const int v = ((wave + 8 * k) * 64 + lane) >> 2;
+        const int pl = v / PL, r = v % PL;
+        bco[k] = (v < 2 * PL && bpiece_ok) ? (unsigned)(pl | ((r / HW) << 10) | ((r % HW) << 20)) : 0xffffffffu;
+    }
+#pragma unroll
+    for (int k = 0; k < NAK; ++k) {
+        const int v = ((wave + 8 * k) * 64 + lane) >> 2;
+        aco[k] = apiece_ok ? (unsigned)((v >> 7) | (((v >> 4) & 7) << 10) | ((v & 15) << 20)) : 0xffffffffu;
+    }
+    const unsigned rowA = (unsigned)a.apitch * 2u, rowY = (unsigned)a.ypitch * 2u, rowB = (unsigned)bpitch_ * 2u;
+    const size_t sampA = (size_t)a.GD * a.GH * a.GW * rowA, sampY = (size_t)a.GD * a.GH * a.GW * rowY, sampB = (size_t)a.BD * a.BH * a.BW * rowB;
+    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)bring);
+
+    // column state
+    int cn = 0, ch0 = 0, cw0 = 0;
+    v4u_t rsB, rsA;
+    __amdgpu_buffer_rsrc_t rsAr, rsYr;
+    // two fetches are in flight at any time (steps s + 1 and s + 2): the fetch of step k keeps its masks / staging registers in slot k & 1
+    struct Slot { unsigned bmask, amask; uint4 pa[BNF ? NAK : 1], pyv[BNF ? NAK : 1]; };
+    Slot sl0, sl1;
+    sl0.bmask = sl0.amask = sl1.bmask = sl1.amask = 0;
+    // per column and piece: byte offset of the piece at plane 0 of its kind (tapped: halo plane gp = 0; plain: d = 0) inside the sample, or
+    // 0xffffffff when the piece lies outside the volume in (H, W) / has no channels -- a fetch then only adds plane * (bytes per plane)
+    unsigned bbase[NBK], abase_[NAK], ybase_[BNF ? NAK : 1];
+    unsigned planeB = 0, planeA = 0, planeY = 0;
+    auto set_column = [&](int col) __attribute__((always_inline)) {
+        int c = col;
+        const int wb_ = c % a.nbw; c /= a.nbw;
+        const int hb = c % a.nbh;
+        cn = c / a.nbh;
+        ch0 = hb * TH; cw0 = wb_ * TW;
+        rsB = raw_rsrc(pb_ + (size_t)cn * sampB, (unsigned)sampB);
+        rsA = raw_rsrc(a.pa + (size_t)cn * sampA, (unsigned)sampA);
+        rsAr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pa + (size_t)cn * sampA), 0, (int)(unsigned)sampA, 0x00020000);
+        rsYr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.py + (size_t)cn * sampY), 0, bn_fused ? (int)(unsigned)sampY : 0, 0x00020000);
+        planeB = (unsigned)(a.BH * a.BW) * rowB; planeA = (unsigned)(a.GH * a.GW) * rowA; planeY = (unsigned)(a.GH * a.GW) * rowY;
+#pragma unroll
+        for (int k = 0; k < NBK; ++k) {
+            const unsigned x = bco[k];
+            const int gh = ch0 - 1 + (int)((x >> 10) & 1023u), gw = cw0 - 1 + (int)(x >> 20);
+            const bool ok = x != 0xffffffffu && (unsigned)gh < (unsigned)a.BH && (unsigned)gw < (unsigned)a.BW;
+            bbase[k] = ok ? (unsigned)(gh * a.BW + gw) * rowB + (unsigned)bc_local * 2u + (x & 1023u) * planeB : 0xffffffffu;
+        }
+#pragma unroll
+        for (int k = 0; k < NAK; ++k) {
+            const unsigned x = aco[k];
+            const int gh = ch0 + (int)((x >> 10) & 1023u), gw = cw0 + (int)(x >> 20);
+            const bool ok = x != 0xffffffffu && gh < a.GH && gw < a.GW;
+            const unsigned vox = (unsigned)(gh * a.GW + gw);
+            abase_[k] = ok ? vox * rowA + (unsigned)ac0 * 2u + (x & 1023u) * planeA : 0xffffffffu;
+            if constexpr (BNF) ybase_[k] = ok ? vox * rowY + (unsigned)ac0 * 2u + (x & 1023u) * planeY : 0xffffffffu;
+        }
+    };
+    // A fetch = NBK pieces of the tapped operand (halo planes gp0, gp0 + 1 -> ring pair `pair`) + NAK pieces of the plain operand (planes
+    // d0, d0 + 1 -> A buffer `buf` by LDS-DMA, or -- fused BatchNorm backward -- (da, y) into the slot's registers).  Piece by piece, so that
+    // a step can spread them over its MFMA rows: issued back to back at the head of the step the 5 DMA instructions of each of the 8 waves
+    // took ~1000 cycles during which no wave multiplied (in-kernel stamps, profiles/r03_wgrad_roll.md).
+    struct FetchCtx { int pair, buf; bool bd0, bd1, ad0, ad1; unsigned dofB, dofA, dofY; };
+    auto fetch_ctx = [&](int pair, int gp0, int buf, int d0) __attribute__((always_inline)) -> FetchCtx {
+        FetchCtx f;
+        f.pair = pair; f.buf = buf;
+        f.bd0 = (unsigned)gp0 < (unsigned)a.BD; f.bd1 = (unsigned)(gp0 + 1) < (unsigned)a.BD;
+        f.ad0 = d0 < a.GD; f.ad1 = d0 + 1 < a.GD;
+        f.dofB = opaque_s((unsigned)gp0 * planeB);            // (mod 2^32: gp0 = -1 pairs with plane index 1 or an invalid plane)
+        f.dofA = opaque_s((unsigned)d0 * planeA); f.dofY = opaque_s((unsigned)d0 * planeY);
+        f.pair = (int)opaque_s((unsigned)pair); f.buf = (int)opaque_s((unsigned)buf);
+        return f;
+    };
+    auto fetch_piece = [&](Slot& sl, const FetchCtx& f, int i) __attribute__((always_inline)) {      // i < NBK: tapped piece i; else plain piece i - NBK
+        if (i < NBK) {
+            const int k = i;
+            const bool ok = bbase[k] != 0xffffffffu && ((bco[k] & 1u) ? f.bd1 : f.bd0);
+            bload_lds16(ok ? bbase[k] + f.dofB : 0xffffffffu, rsB, lds0 + (unsigned)(f.pair * PAIRB + (wave + 8 * k) * 1024));
+            sl.bmask = (k == 0 ? 0u : sl.bmask) | (ok ? (1u << k) : 0u);
+        } else {
+            const int k = i - NBK;
+            const bool ok = abase_[k] != 0xffffffffu && ((aco[k] & 1u) ? f.ad1 : f.ad0);
+            if constexpr (BNF) {
+                const auto v0 = __builtin_amdgcn_raw_buffer_load_b128(rsAr, ok ? (int)(abase_[k] + f.dofA) : -1, 0, 0);
+                const auto v1 = __builtin_amdgcn_raw_buffer_load_b128(rsYr, ok ? (int)(ybase_[k] + f.dofY) : -1, 0, 0);
+                sl.pa[k] = make_uint4(v0[0], v0[1], v0[2], v0[3]);
+                sl.pyv[k] = make_uint4(v1[0], v1[1], v1[2], v1[3]);
+            } else {
+                bload_lds16(ok ? abase_[k] + f.dofA : 0xffffffffu, rsA, lds0 + (unsigned)(WR_NPAIR * PAIRB + f.buf * WR_AB + (wave + 8 * k) * 1024));
+            }
+            sl.amask = (k == 0 ? 0u : sl.amask) | (ok ? (1u << k) : 0u);
+        }
+    };
+    auto fetch_all = [&](Slot& sl, const FetchCtx& f, bool with_a) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NBK + NAK; ++i)
+            if (i < NBK || with_a) fetch_piece(sl, f, i);
+    };
+    // once this thread's own fetch of a slot has landed: producer transform of its tapped pieces in place; BatchNorm backward of its
+    // plain pieces into the A buffer (+ dy written back over da: always NAK store instructions per wave, masked lanes out of range)
+    auto finish = [&](Slot& sl, int pair_, int buf_, int d0, bool with_a) __attribute__((always_inline)) {
+        const int pair = (int)opaque_s((unsigned)pair_), buf = (int)opaque_s((unsigned)buf_);
+        const unsigned dofA = opaque_s((unsigned)d0 * planeA);
+        if (b_xf) {
+            float sc[PE], sh[PE], sl_[PE];
+#pragma unroll
+            for (int e = 0; e < PE; ++e) { sc[e] = lxf[LB + piece * PE + e]; sh[e] = lxf[LB + CT + piece * PE + e]; sl_[e] = lxf[LB + 2 * CT + piece * PE + e]; }
+#pragma unroll
+            for (int k = 0; k < NBK; ++k) {
+                if ((sl.bmask >> k) & 1u) {
+                    uint4* p_ = (uint4*)(bring + pair * PAIRB + (wave + 8 * k) * 1024 + lane * 16);
+                    *p_ = apply_xf16<T, PE>(*p_, sc, sh, sl_);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (BNF) if (with_a) {
+            // two sweeps, three coefficient vectors live at a time (dz parked in the storage type in between, as k_wgrad_pipe does:
+            // same rounding sequence, so both kernels write the same dy)
+            {
+                float ks[PE], kh[PE], kl[PE];
+#pragma unroll
+                for (int e = 0; e < PE; ++e) { ks[e] = lxf[LBN + piece * PE + e]; kh[e] = lxf[LBN + CT + piece * PE + e]; kl[e] = lxf[LBN + 2 * CT + piece * PE + e]; }
+#pragma unroll
+                for (int k = 0; k < NAK; ++k) {
+                    if ((sl.amask >> k) & 1u) {
+                        float g[PE], yy[PE];
+                        F::unpack(sl.pa[k], g);
+                        F::unpack(sl.pyv[k], yy);
+#pragma unroll
+                        for (int e = 0; e < PE; ++e) g[e] *= (fmaf(ks[e], yy[e], kh[e]) > 0.f ? 1.f : kl[e]);
+                        sl.pa[k] = F::pack(g);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                float ka[PE], kb[PE], kc[PE];
+#pragma unroll
+                for (int e = 0; e < PE; ++e) { ka[e] = lxf[LBN + 3 * CT + piece * PE + e]; kb[e] = lxf[LBN + 4 * CT + piece * PE + e]; kc[e] = lxf[LBN + 5 * CT + piece * PE + e]; }
+#pragma unroll
+                for (int k = 0; k < NAK; ++k) {
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    const bool ok = (sl.amask >> k) & 1u;
+                    if (ok) {
+                        float g[PE], yy[PE];
+                        F::unpack(sl.pa[k], g);
+                        F::unpack(sl.pyv[k], yy);
+#pragma unroll
+                        for (int e = 0; e < PE; ++e) g[e] = fmaf(ka[e], g[e], fmaf(kb[e], yy[e], kc[e]));
+                        v = F::pack(g);
+                    }
+                    if (wb) __builtin_amdgcn_raw_buffer_store_b128(v4u_t{v.x, v.y, v.z, v.w}, rsAr, ok ? (int)(abase_[k] + dofA) : -1, 0, 0);
+                    *(uint4*)(abuf + buf * WR_AB + (wave + 8 * k) * 1024 + lane * 16) = v;
+                }
+            }
+        }
+    };
+    // wait until this wave's fetch of the OLDER slot has landed while the younger one (issued this step) stays in flight.  Vector-memory
+    // operations retire in order; younger than the fetch waited for are: the write-back stores of the previous finish (NAK, when dy is
+    // written back) and this step's fetch (NBK DMA + NAK DMA, or NBK DMA + 2 NAK register loads with the fused BatchNorm backward).
+    auto wait_older = [&](bool younger_in_flight) __attribute__((always_inline)) {
+        if (!younger_in_flight) { wait_vmcnt<0>(); return; }
+        if (wb) wait_vmcnt<NAK + NBK + 2 * NAK>();
+        else if (bn_fused) wait_vmcnt<NBK + 2 * NAK>();
+        else wait_vmcnt<NBK + NAK>();
+    };
+
+    typedef bf16x4 __attribute__((address_space(3))) * lp;
+    auto rd = [&](const char* p_) -> bf16x8 {
+        const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p_));
+        const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p_ + 4 * RS));
+        return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    // one step: rows r = 0 .. 15 (plane ld = r / 8, row lh = r % 8) of the tile in A buffer `buf`; halo plane j (0..3) of the step at pj(j)
+    auto mfma_step = [&](auto has_x_c, int s4, int buf, auto&& issue) __attribute__((always_inline)) {
+        constexpr bool HAS_X = decltype(has_x_c)::value;
+        auto pj = [&](int j) -> const char* { return bring + opaque_s((unsigned)(((s4 + (j >> 1)) & 3) * PAIRB + (j & 1) * PLB)); };
+        const char* b0 = pj(wkd) + wkw * RS + ab_lane;           // plane of row-plane 0 for this wave's kd
+        const char* b1 = pj(wkd + 1) + wkw * RS + ab_lane;       // ... of row-plane 1
+        const char* x0 = pj(2) + (wave * HW + 2) * RS + ab_lane; // extra tap (2, kh = wave, 2)
+        const char* x1 = pj(3) + (wave * HW + 2) * RS + ab_lane;
+        const char* ab = abuf + opaque_s((unsigned)(buf * WR_AB)) + ab_lane;
+        bf16x8 ring[4], fxx[2], faa[2];
+        faa[0] = rd(ab);
+        if constexpr (HAS_X) fxx[0] = rd(x0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ring[j] = rd(b0 + j * HW * RS);
+        if (BIU_WROLL_ABL & 2) {                         // ablation: every fragment register holds real data, none is read again
+            faa[1] = rd(ab + 16 * RS);
+            ring[3] = rd(b0 + 3 * HW * RS);
+            if constexpr (HAS_X) fxx[1] = rd(x0 + HW * RS);
+        }
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) {
+            const int lh = r % TH;
+            const int r1 = r + 1, ld1 = r1 / TH, lh1 = r1 % TH;
+            if (r1 < NROW && !(BIU_WROLL_ABL & 2)) {
+                faa[r1 & 1] = rd(ab + r1 * 16 * RS);
+                if constexpr (HAS_X) fxx[r1 & 1] = rd((ld1 ? x1 : x0) + lh1 * HW * RS);
+                if (lh1 != 0) ring[(lh1 + 2) & 3] = rd((ld1 ? b1 : b0) + (lh1 + 2) * HW * RS);
+            }
+#pragma unroll
+            for (int tb = 0; tb < 3; ++tb) acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faa[r & 1], ring[(lh + tb) & 3], acc[tb], 0, 0, 0);
+            if constexpr (HAS_X) acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faa[r & 1], fxx[r & 1], acc[3], 0, 0, 0);
+            if (r1 < NROW && lh1 == 0 && !(BIU_WROLL_ABL & 2)) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) ring[j] = rd((ld1 ? b1 : b0) + j * HW * RS);
+            }
+            if (r % 3 == 1 && r / 3 < NBK + NAK) issue(r / 3);          // one piece of the fetch behind rows 1, 4, 7, 10, 13
+            if ((r & 1) == 1 || r % 3 == 1) __builtin_amdgcn_sched_barrier(0);   // keeps the scheduler from hoisting a whole step's fragment reads (spills)
+        }
+    };
+
+    const int G = gridDim.x;
+    const int ncols = a.N * a.nbh * a.nbw, nsteps = (a.GD + TD - 1) / TD;
+    auto column_of = [&](int k) -> int {
+        if ((G & 7) == 0) return k * G + (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);
+        return k * G + (int)blockIdx.x;
+    };
+    // step s: the fetch of step s + 2 goes out (slot s & 1), the MFMAs of step s run, the fetch of step s + 1 (slot (s + 1) & 1) is finished
+#ifdef BIU_DIAG
+    unsigned long long* wdiag = a.diag;
+    unsigned long long tprev_ = __builtin_readcyclecounter();
+    unsigned long long dsum_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t0c_ = tprev_, t0r_ = __builtin_amdgcn_s_memrealtime();
+#define RSTAMP(k_) do { if (wdiag && (tid & 63) == 0 && (tid >> 6) == (BIU_DIAG_WAVE)) { unsigned long long now_ = __builtin_readcyclecounter(); dsum_[k_] += now_ - tprev_; tprev_ = now_; } } while (0)
+#else
+#define RSTAMP(k_) do { } while (0)
+#endif
+    auto step = [&](Slot& mine, Slot& other, int s) __attribute__((always_inline)) {
+        const bool f2 = (s + 2 < nsteps) && !((BIU_WROLL_ABL & 1) && s >= 1);
+        const bool f1 = (s + 1 < nsteps) && !((BIU_WROLL_ABL & 1) && s >= 2);
+        RSTAMP(0);
+        const FetchCtx fc = fetch_ctx((s + 3) & 3, 2 * s + 5, (s + 2) % 3, 2 * s + 4);
+        RSTAMP(1);
+        auto issue = [&](int i) __attribute__((always_inline)) { if (f2) fetch_piece(mine, fc, i); };           // block-uniform f2
+        if (has_x) mfma_step(std::true_type{}, s & 3, s % 3, issue); else mfma_step(std::false_type{}, s & 3, s % 3, issue);
+        __builtin_amdgcn_sched_barrier(0);
+        RSTAMP(2);
+        if (f1) {
+            wait_older(f2);
+            RSTAMP(3);
+            finish(other, (s + 2) & 3, (s + 1) % 3, 2 * s + 2, true);
+        }
+        RSTAMP(4);
+        __syncthreads();
+        RSTAMP(5);
+#ifdef BIU_DIAG
+        dsum_[7] += 1;
+#endif
+    };
+    __syncthreads();                                     // lxf visible
+    for (int kc = 0;; ++kc) {
+        const int col = column_of(kc);
+        if (col >= ncols) break;                         // block-uniform
+        set_column(col);
+        // prologue: planes -1, 0 -> pair 0 (finished at once); step 0: planes 1, 2 -> pair 1 + A buffer 0 (slot 0); step 1: planes 3, 4 ->
+        // pair 2 + A buffer 1 (slot 1)
+        fetch_all(sl0, fetch_ctx(0, -1, 0, 0), false);
+        wait_vmcnt<0>();
+        finish(sl0, 0, 0, 0, false);
+        fetch_all(sl0, fetch_ctx(1, 1, 0, 0), true);
+        if (nsteps > 1) fetch_all(sl1, fetch_ctx(2, 3, 1, 2), true);
+        wait_vmcnt<0>();
+        finish(sl0, 1, 0, 0, true);                      // (step 1's fetch, slot 1, is finished by step 0 like every later one)
+        __syncthreads();
+        for (int s = 0; s < nsteps; s += 2) {
+            step(sl0, sl1, s);
+            if (s + 1 < nsteps) step(sl1, sl0, s + 1);
+        }
+    }
+
+#ifdef BIU_DIAG
+    if (wdiag && (tid & 63) == 0 && (tid >> 6) == (BIU_DIAG_WAVE)) {
+        for (int q_ = 0; q_ < 8; ++q_) atomicAdd(wdiag + q_, dsum_[q_]);
+        atomicAdd(wdiag + 8, __builtin_readcyclecounter() - t0c_);
+        atomicAdd(wdiag + 9, __builtin_amdgcn_s_memrealtime() - t0r_);
+    }
+#endif
+    // ---- flush once per block (k_wgrad_pipe's layout: ws[tap][i][j], two 128-B segments per wave-instruction) ----------------------
+    const int hf = lane >> 5;
+    const int jj = jt * CT + (lane & 31);
+    if (jj < a.CB) {
+#pragma unroll
+        for (int t2 = 0; t2 < IPW; ++t2) {
+            const int tap = tapid[t2];
+            if (tap < TAPS) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ii = it * CT + (e & 3) + 8 * (e >> 2) + 4 * hf;
+                    if (ii < a.CA) atomicAdd(a.ws + ((size_t)tap * a.CA + ii) * a.CB + jj, acc[t2][e]);
+                }
+            }
+        }
+    }
+}
+
+static bool wroll_disabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("BIU_DISABLE"); v = (e && strstr(e, "wroll")) ? 1 : 0; }
+    return v == 1;
+}
+
+// Worth it when a column is long enough to amortise its prologue (two exposed fetch latencies per column) and there are enough columns
+// to give every block of a (plain tile, tapped tile) pair at least one.
+static bool wroll_fits(const WgradArgs& a) {
+    const int ncols = a.N * ((a.GH + WR_TH - 1) / WR_TH) * ((a.GW + WR_TW - 1) / WR_TW);
+    return a.GD >= 8 && ncols >= 8;
+}
+
+static int launch_wgrad_roll(WgradArgs a, hipStream_t st) {
+    a.nbd = 1;
+    a.nbh = (a.GH + WR_TH - 1) / WR_TH;
+    a.nbw = (a.GW + WR_TW - 1) / WR_TW;
+    const int ncols = a.N * a.nbh * a.nbw;
+    a.nbricks = ncols;
+    const int nit = (a.CA + 31) / 32;
+    a.njt = (a.CB + 31) / 32;
+    a.bricks_per_block = 0;
+#ifdef BIU_DIAG
+    a.diag = biu_diag_buffer;
+#else
+    a.diag = nullptr;
+#endif
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_wgrad_roll<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_wgrad_roll<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess)
+            return biu_fail(BIU_ERR_LAUNCH, "wgrad_roll: cannot reserve %zu bytes of LDS", WR_LDS);
+        attr_set = true;
+    }
+    auto launch = [&](int jt_begin, int jt_count, int write_back, bool with_bn) {
+        WgradArgs b = a;
+        if (!with_bn) b.py = nullptr;
+        b.jt_begin = jt_begin; b.jt_count = jt_count; b.write_back = write_back;
+        const int pairs = nit * jt_count;
+        int g = num_cus() / pairs;
+        if (g >= 16) g = grid_per_column(num_cus(), pairs);
+        if (g < 1) g = 1;
+        if (g > ncols) g = ncols;
+        if (with_bn) hipLaunchKernelGGL(k_wgrad_roll<true>, dim3(g, pairs), dim3(512), WR_LDS, st, b);
+        else hipLaunchKernelGGL(k_wgrad_roll<false>, dim3(g, pairs), dim3(512), WR_LDS, st, b);
+    };
+    if (a.py && a.njt > 1) {             // as launch_wgrad: the first input-channel tile turns da into dy in place, the others read the finished dy
+        launch(0, 1, 1, true);
+        BIU_CHECK_LAUNCH("wgrad_roll");
+        launch(1, a.njt - 1, 0, false);
+    } else {
+        launch(0, a.njt, a.py ? 1 : 0, a.py != nullptr);
+    }
+    BIU_CHECK_LAUNCH("wgrad_roll");
+    return BIU_OK;
+}
+
 // ws[tap][i][j] -> dw[i][j][tap]
 __global__ void k_wgrad_finalize(const float* __restrict__ ws, int rows, int cols, int taps, float* __restrict__ dw) {
     const size_t total = (size_t)rows * cols * taps;
@@ -2682,6 +3168,7 @@ int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int
     static int rr16_off = -1;
     if (rr16_off < 0) { const char* e = getenv("BIU_DISABLE"); rr16_off = (e && strstr(e, "rr16")) ? 1 : 0; }
     if (dtype == BIU_BF16 && kd == 3 && a.CB == 16 && !x1 && !rr16_off) rc = launch_wgrad<bf16_t, 3, 3, 1, 4, 8, 16, 1, 1, true>(a, st);   // paired taps
+    else if (dtype == BIU_BF16 && kd == 3 && !wroll_disabled() && wroll_fits(a)) rc = launch_wgrad_roll(a, st);      // rolling window + LDS-DMA
     else if (dtype == BIU_BF16) rc = (kd == 3) ? launch_wgrad<bf16_t, 3, 3, 1, 4, 8, 16, 1>(a, st) : launch_wgrad<bf16_t, 1, 3, 1, 1, 16, 32, 4>(a, st);
     else if (kd == 1 && !x3_disabled()) rc = launch_wgrad<f32x3_t, 1, 3, 1, 1, 16, 16, 4>(a, st);        // fp32 tensors, bf16x3 products
     else rc = (kd == 3) ? launch_wgrad<float, 3, 3, 1, 4, 4, 16, 1>(a, st) : launch_wgrad<float, 1, 3, 1, 1, 16, 16, 4>(a, st);

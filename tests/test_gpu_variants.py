@@ -1,5 +1,5 @@
 """The kernel variants a launch can take must agree with the kernels they replace: the 16-row MFMA kernel (BIU_DISABLE=m16 falls back to
-the 32-row one), the paired-tap weight gradient of a 16-channel input (BIU_DISABLE=rr16), the input-channel split of small fp32 launches (BIU_DISABLE=ksplit) and the opt-in bf16x3 products of the fp32 2-D kernels
+the 32-row one), the paired-tap weight gradient of a 16-channel input (BIU_DISABLE=rr16), the rolling-window weight gradient (BIU_DISABLE=wroll), the input-channel split of small fp32 launches (BIU_DISABLE=ksplit) and the opt-in bf16x3 products of the fp32 2-D kernels
 (BIU_FP32_PRODUCTS=bf16x3) against the exact fp32 MFMA.  The switches are read once per process, so
 each side runs in its own subprocess (tests/variant_probe.py)."""
 import os
@@ -37,6 +37,9 @@ def _run(which, disable, tmp_path):
     # bf16: two correct bf16 kernels differ by output rounding; discrete LeakyReLU / max-pool decisions then move gradients by ~1 %
     #  -- a wrong tap or tile would move them by tens of percent
     ("unet3d_bf16", "m16,rr16", 2e-2, 6e-2),
+    # the rolling-window weight gradient (k_wgrad_roll) against the brick kernel it replaces (BIU_DISABLE=wroll): the forward is untouched
+    # and the dy both write back over da is the same rounding sequence, so only the order of the fp32 sums inside dW differs
+    ("unet3d_bf16", "wroll", 1e-6, 1e-3),
 ])
 def test_variant_matches_the_kernel_it_replaces(which, disable, tol_out, tol_grad, tmp_path):
     on, off = _run(which, None, tmp_path), _run(which, disable, tmp_path)
