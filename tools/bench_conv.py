@@ -94,6 +94,11 @@ def main():
                 calls["wg_cat"] = lambda: lib.biu_conv_bwd_weight_cat(C.byref(ax0), C.byref(xs0), C.byref(ax1), C.byref(xs1), C.byref(ady), C.byref(ay),
                                                                       P(kvec[0]), P(kvec[1]), P(kvec[2]), P(kvec[3]), P(kvec[4]), P(kvec[5]), kd, 3, 3, 1,
                                                                       P(dw), P(ws), ws.numel(), code, st)
+                dx0, dx1 = torch.empty_like(x0), torch.empty_like(x1)
+                adx0 = biu_act(dx0.data_ptr(), n, d, h, w, c0, c0)
+                adx1 = biu_act(dx1.data_ptr(), n, d, h, w, cin - c0, cin - c0)
+                keep.extend([dx0, dx1])
+                calls["dg_cat"] = lambda: lib.biu_conv_bwd_data_cat(C.byref(ady), P(wt), P(pk1), kd, 3, 3, 1, C.byref(adx0), 0, C.byref(adx1), 0, None, 0, code, st)
         legs = os.environ.get("BENCH_LEGS")
         if legs:
             calls = {k: v for k, v in calls.items() if k in legs.split(",")}
