@@ -2595,12 +2595,17 @@ constexpr size_t WR_LDS = (size_t)WR_NPAIR * WR_PAIRB + WR_NABUF * WR_AB + 9 * 3
 __device__ __forceinline__ unsigned opaque_s(unsigned x) { asm volatile("" : "+s"(x)); return x; }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <bool BNF>
+// K2D: a BATCH of 2-D images through the same kernel -- the images are the planes of the "volume" (the tensors' memory layout [N][H][W][C] is
+// that of a volume of depth N), only the centre depth tap exists (kd = 1: the 9 taps of a 3 x 3 kernel), so nothing couples two
+// images: a step takes 2 images x 8 rows x 16 voxels, wave w < 6 owns the three kh taps of kw = w % 3 on image w / 3 of the step.  The
+// 2-D weight gradients of a U-Net are memory-bound (32-64 channels: 68-140 FLOP/B); what they need from this kernel is its fetch pipeline
+// (LDS-DMA two steps ahead, no VGPR staging, no commit phase), not its MFMA schedule.
+template <bool BNF, bool K2D>
 __global__ __launch_bounds__(512, 2) void k_wgrad_roll(WgradArgs a) {
     using T = bf16_t;
     using F = Frag<T>;
     constexpr int TD = WR_TD, TH = WR_TH, TW = WR_TW, HW = WR_HW, PL = WR_PL, RS = WR_RS, PLB = WR_PLB, PAIRB = WR_PAIRB;
-    constexpr int CT = 32, PE = 8, TAPS = 27, IPW = 4, NROW = TD * TH;
+    constexpr int CT = 32, PE = 8, TAPS = K2D ? 9 : 27, IPW = K2D ? 3 : 4, NROW = TD * TH;
     constexpr int NBK = WR_NBI / 8, NAK = WR_NAI / 8;                         // DMA instructions per wave and fetch: tapped pair 3, plain tile 2
 
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
@@ -2648,12 +2653,16 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_roll(WgradArgs a) {
     for (int t = 0; t < IPW; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    // wave w: (kd, kw) pair (w / 3, w % 3); waves 0-2 also take tap (2, kh = w, 2) of the ninth pair
+    // wave w: (kd, kw) pair (w / 3, w % 3); waves 0-2 also take tap (2, kh = w, 2) of the ninth pair.  K2D: wave w < 6 = (image w / 3 of
+    // the step, kw = w % 3), taps kh = 0..2 -> 2-D tap kh * 3 + kw; waves 6, 7 only fetch.
     const int wkd = wave / 3, wkw = wave % 3;
-    const bool has_x = wave < 3;
+    const bool has_x = !K2D && wave < 3;
     int tapid[IPW];
 #pragma unroll
-    for (int t = 0; t < IPW; ++t) tapid[t] = (t < 3) ? (wkd * 3 + t) * 3 + wkw : (has_x ? (2 * 3 + wave) * 3 + 2 : TAPS);
+    for (int t = 0; t < IPW; ++t) {
+        if constexpr (K2D) tapid[t] = (wave < 6) ? t * 3 + wkw : TAPS;
+        else tapid[t] = (t < 3) ? (wkd * 3 + t) * 3 + wkw : (has_x ? (2 * 3 + wave) * 3 + 2 : TAPS);
+    }
     int ab_lane;
     {
         const int g = lane >> 4, li = lane & 15, qrow = li >> 2, p = li & 3, cg = g & 1, h = g >> 1;
@@ -2837,6 +2846,32 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_roll(WgradArgs a) {
     auto mfma_step = [&](auto has_x_c, int s4, int buf, auto&& issue) __attribute__((always_inline)) {
         constexpr bool HAS_X = decltype(has_x_c)::value;
         auto pj = [&](int j) -> const char* { return bring + opaque_s((unsigned)(((s4 + (j >> 1)) & 3) * PAIRB + (j & 1) * PLB)); };
+        if constexpr (K2D) {
+            // image ld = wave / 3 of the step (halo plane j = ld + 1: the centre depth tap), its 8 rows in order, ring over the kh taps
+            if (wave < 6) {                                              // wave-uniform; waves 6, 7 issue their share of the fetch below
+                const char* b0 = pj(wkd + 1) + wkw * RS + ab_lane;
+                const char* ab = abuf + opaque_s((unsigned)(buf * WR_AB + wkd * TH * 16 * RS)) + ab_lane;
+                bf16x8 ring[4], faa[2];
+                faa[0] = rd(ab);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) ring[j] = rd(b0 + j * HW * RS);
+#pragma unroll
+                for (int r = 0; r < TH; ++r) {
+                    if (r + 1 < TH) {
+                        faa[(r + 1) & 1] = rd(ab + (r + 1) * 16 * RS);
+                        ring[(r + 3) & 3] = rd(b0 + (r + 3) * HW * RS);
+                    }
+#pragma unroll
+                    for (int tb = 0; tb < 3; ++tb) acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faa[r & 1], ring[(r + tb) & 3], acc[tb], 0, 0, 0);
+                    if (r < NBK + NAK) issue(r);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NBK + NAK; ++i) issue(i);
+            }
+            return;
+        }
         const char* b0 = pj(wkd) + wkw * RS + ab_lane;           // plane of row-plane 0 for this wave's kd
         const char* b1 = pj(wkd + 1) + wkw * RS + ab_lane;       // ... of row-plane 1
         const char* x0 = pj(2) + (wave * HW + 2) * RS + ab_lane; // extra tap (2, kh = wave, 2)
@@ -2965,12 +3000,24 @@ static bool wroll_disabled() {
 
 // Worth it when a column is long enough to amortise its prologue (two exposed fetch latencies per column) and there are enough columns
 // to give every block of a (plain tile, tapped tile) pair at least one.
+static bool wroll2d_disabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("BIU_DISABLE"); v = (e && strstr(e, "wroll2d")) ? 1 : 0; }
+    return v == 1;
+}
 static bool wroll_fits(const WgradArgs& a) {
     const int ncols = a.N * ((a.GH + WR_TH - 1) / WR_TH) * ((a.GW + WR_TW - 1) / WR_TW);
     return a.GD >= 8 && ncols >= 8;
 }
+// 2-D (kd = 1): the batch is the depth axis (images are contiguous, [N][1][H][W][C] == [D = N][H][W][C]); worth it from 8 images on, when
+// the whole batch stays inside one buffer descriptor (32-bit offsets)
+static bool wroll2d_fits(const WgradArgs& a, i64 bytesA, i64 bytesB, i64 bytesY) {
+    const int ncols = ((a.GH + WR_TH - 1) / WR_TH) * ((a.GW + WR_TW - 1) / WR_TW);
+    return a.N >= 8 && ncols >= 8 && bytesA < BIU_MAX_SAMPLE_BYTES && bytesB < BIU_MAX_SAMPLE_BYTES && bytesY < BIU_MAX_SAMPLE_BYTES;
+}
 
-static int launch_wgrad_roll(WgradArgs a, hipStream_t st) {
+static int launch_wgrad_roll(WgradArgs a, hipStream_t st, bool k2d = false) {
+    if (k2d) { a.GD = a.BD = a.N; a.N = 1; }
     a.nbd = 1;
     a.nbh = (a.GH + WR_TH - 1) / WR_TH;
     a.nbw = (a.GW + WR_TW - 1) / WR_TW;
@@ -2986,8 +3033,10 @@ static int launch_wgrad_roll(WgradArgs a, hipStream_t st) {
 #endif
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_wgrad_roll<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_wgrad_roll<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)k_wgrad_roll<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_wgrad_roll<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_wgrad_roll<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_wgrad_roll<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess)
             return biu_fail(BIU_ERR_LAUNCH, "wgrad_roll: cannot reserve %zu bytes of LDS", WR_LDS);
         attr_set = true;
     }
@@ -3000,8 +3049,13 @@ static int launch_wgrad_roll(WgradArgs a, hipStream_t st) {
         if (g >= 16) g = grid_per_column(num_cus(), pairs);
         if (g < 1) g = 1;
         if (g > ncols) g = ncols;
-        if (with_bn) hipLaunchKernelGGL(k_wgrad_roll<true>, dim3(g, pairs), dim3(512), WR_LDS, st, b);
-        else hipLaunchKernelGGL(k_wgrad_roll<false>, dim3(g, pairs), dim3(512), WR_LDS, st, b);
+        if (k2d) {
+            if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, true>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
+            else hipLaunchKernelGGL((k_wgrad_roll<false, true>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
+        } else {
+            if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, false>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
+            else hipLaunchKernelGGL((k_wgrad_roll<false, false>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
+        }
     };
     if (a.py && a.njt > 1) {             // as launch_wgrad: the first input-channel tile turns da into dy in place, the others read the finished dy
         launch(0, 1, 1, true);
@@ -3169,6 +3223,10 @@ int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int
     if (rr16_off < 0) { const char* e = getenv("BIU_DISABLE"); rr16_off = (e && strstr(e, "rr16")) ? 1 : 0; }
     if (dtype == BIU_BF16 && kd == 3 && a.CB == 16 && !x1 && !rr16_off) rc = launch_wgrad<bf16_t, 3, 3, 1, 4, 8, 16, 1, 1, true>(a, st);   // paired taps
     else if (dtype == BIU_BF16 && kd == 3 && !wroll_disabled() && wroll_fits(a)) rc = launch_wgrad_roll(a, st);      // rolling window + LDS-DMA
+    else if (dtype == BIU_BF16 && kd == 1 && !wroll_disabled() && !wroll2d_disabled() &&
+             wroll2d_fits(a, (i64)nvox(dy) * dy->pitch * 2, (i64)nvox(x) * x->pitch * 2 > (x1 ? (i64)nvox(x1) * x1->pitch * 2 : 0) ? (i64)nvox(x) * x->pitch * 2 : (i64)nvox(x1) * x1->pitch * 2,
+                          bn ? (i64)nvox(bn->y) * bn->y->pitch * 2 : 0))
+        rc = launch_wgrad_roll(a, st, true);                                                                                 // batch of images as the depth axis
     else if (dtype == BIU_BF16) rc = (kd == 3) ? launch_wgrad<bf16_t, 3, 3, 1, 4, 8, 16, 1>(a, st) : launch_wgrad<bf16_t, 1, 3, 1, 1, 16, 32, 4>(a, st);
     else if (kd == 1 && !x3_disabled()) rc = launch_wgrad<f32x3_t, 1, 3, 1, 1, 16, 16, 4>(a, st);        // fp32 tensors, bf16x3 products
     else rc = (kd == 3) ? launch_wgrad<float, 3, 3, 1, 4, 4, 16, 1>(a, st) : launch_wgrad<float, 1, 3, 1, 1, 16, 16, 4>(a, st);

@@ -321,6 +321,10 @@ MFMA_CASES = [
     (3, 2, 32, 48, (9, 20, 24)),
     (3, 1, 64, 16, (8, 24, 40)),
     (3, 1, 96, 32, (10, 24, 32)),
+    # a batch of >= 8 images: the 2-D weight gradient takes the rolling-window kernel with the batch as its depth axis (odd batch, H / W off
+    # the 8 x 16 window, 48 = one and a half channel tiles)
+    (2, 8, 32, 32, (24, 40)),
+    (2, 9, 64, 48, (20, 50)),
     (2, 2, 16, 32, (32, 32)),
     (2, 1, 64, 64, (24, 40)),
     (2, 1, 128, 128, (16, 16)),
@@ -551,7 +555,8 @@ def test_convt_bwd_data_bnred(case, dtype):
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(3, 2, 96, 32, (8, 16, 32)), (3, 1, 32, 64, (6, 10, 20)), (2, 2, 128, 64, (24, 40)), (3, 2, 16, 32, (9, 10, 20)),
-                                  (3, 1, 6, 8, (4, 6, 10)), (3, 2, 64, 48, (9, 20, 24)), (3, 1, 32, 16, (11, 16, 40))])
+                                  (3, 1, 6, 8, (4, 6, 10)), (3, 2, 64, 48, (9, 20, 24)), (3, 1, 32, 16, (11, 16, 40)),
+                                  (2, 8, 64, 32, (24, 40)), (2, 11, 32, 64, (16, 48))])
 def test_conv_bwd_weight_bn(case, dtype):
     """Several 32-wide input-channel tiles (Cin = 96, 128) read the same da that one of them overwrites with dy."""
     nd, n, cin, cout, sp = case
@@ -809,6 +814,7 @@ CAT_CASES = [
     (2, 2, 128, 64, 64, (24, 40)),
     (3, 1, 64, 32, 48, (5, 7, 9)),
     (3, 2, 64, 32, 32, (10, 16, 40)),     # columns long enough for the rolling-window weight gradient
+    (2, 8, 64, 32, 32, (24, 48)),         # ... and a batch of 8 images through its 2-D form
 ]
 
 

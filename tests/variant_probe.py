@@ -18,6 +18,11 @@ if which == "unet3d_bf16":            # UNet3D(n_filter=32): decode6 forward and
     m.load_state_dict(O.init_unet3d(1, 1, 32, seed=7))
     m.set_compute_dtype(torch.bfloat16)
     shape = (2, 1, 16, 32, 32)
+elif which == "unet2d_bf16_n8":       # Unet(n_filter=32) bf16 on 8 images: the 64^2 and 32^2 levels take the 2-D form of the rolling-window weight gradient
+    m = B.Unet(1, 1, 32).cuda()
+    m.load_state_dict(O.init_unet2d(1, 1, 32, seed=3))
+    m.set_compute_dtype(torch.bfloat16)
+    shape = (8, 1, 64, 64)
 else:                                 # Unet(n_filter=32) fp32, 2 x 64 x 64: the 8x8 / 4x4 layers split over their input channels
     m = B.Unet(1, 1, 32).cuda()
     m.load_state_dict(O.init_unet2d(1, 1, 32, seed=3))
