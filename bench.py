@@ -301,13 +301,36 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step stamps on the compute stream (median)
     barrier()
     t0 = time.perf_counter()
-    marks[0].record()
+    # The interpreter's cyclic garbage collector is paused inside the timed region, exactly as the package's Trainers pause it inside an
+    # epoch's batch loop (workflow._EpochLoop._train_epoch): a generation-2 collection walks every object torch has imported and stalls
+    # the host for 60-140 ms -- with steps of 5 ms (cfg1) the GPU queue runs dry and ONE such step took 60-115 ms (BENCH_GC=on shows it).
+    # A step creates no reference cycles; reference counting frees everything it allocates.
+    import gc
+    gc_paused = os.environ.get("BENCH_GC") != "on"
+    if gc_paused:
+        gc.collect()
+        gc.disable()
+    use_marks = os.environ.get("BENCH_NO_MARKS") != "1"
+    t_host = []
+    if use_marks:
+        marks[0].record()
     for i in range(args.steps):
         step()
-        marks[i + 1].record()
+        if use_marks:
+            marks[i + 1].record()
+        t_host.append(time.perf_counter())
+    t_loop = time.perf_counter()
     barrier()
     dt = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    if gc_paused:
+        gc.enable()
+    if os.environ.get("BENCH_DEBUG_STEPS") == "1":
+        print(f"bench: host enqueue ms/step {(t_loop - t0) / args.steps * 1e3:.2f}, barrier wait {(t0 + dt - t_loop) * 1e3:.1f} ms; host per-step " +
+              " ".join(f"{(b - a) * 1e3:.1f}" for a, b in zip([t0] + t_host[:-1], t_host)), file=sys.stderr)
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)] if use_marks else [dt / args.steps * 1e3] * args.steps
+    if os.environ.get("BENCH_DEBUG_STEPS") == "1":
+        print("bench: per-step ms " + " ".join(f"{v:.2f}" for v in per_step), file=sys.stderr)
+    per_step.sort()
     median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     if hasattr(step, "eager"):                  # graph mode: the dominant launch is timed in eager steps after the timed region
         for _ in range(3):
@@ -370,8 +393,9 @@ def main():
     out = {
         "metric": "voxels/sec fwd+bwd", "value": vps_gpu * world, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "median_ms_per_step": median_ms,
-        "value_at_median": nvox / (median_ms * 1e-3) * world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": dt_name, "data": "synthetic",
+        "value_at_median": nvox / (median_ms * 1e-3) * world, "step_ms_min_max": [per_step[0], per_step[-1]],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": dt_name, "data": "synthetic", "host": "cyclic GC paused inside the timed region (as in the package's Trainers)" if gc_paused else "cyclic GC on",
         "config": {"workload": f"{args.workload}: {wl['model']}({', '.join(f'{k}={v}' for k, v in wl['ctor'].items() if k != 'output_heads')}) input {wl['shape']} per GPU, "
                                "train step = forward + reference loss + backward + Adam", "parallelism": f"dp{world}"},
         "fwd_only": {"value": nvox / (fwd_ms * 1e-3) * world, "unit": "voxels/s", "ms": fwd_ms},

@@ -3013,7 +3013,8 @@ static bool wroll_fits(const WgradArgs& a) {
 // the whole batch stays inside one buffer descriptor (32-bit offsets)
 static bool wroll2d_fits(const WgradArgs& a, i64 bytesA, i64 bytesB, i64 bytesY) {
     const int ncols = ((a.GH + WR_TH - 1) / WR_TH) * ((a.GW + WR_TW - 1) / WR_TW);
-    return a.N >= 8 && ncols >= 8 && bytesA < BIU_MAX_SAMPLE_BYTES && bytesB < BIU_MAX_SAMPLE_BYTES && bytesY < BIU_MAX_SAMPLE_BYTES;
+    // (measured, cfg3 shapes: 64->64 @256^2 -7 %, 256->256 @64^2 -11 %, 32->32 @512^2 +2 % -- a single-tile layer already sits on the HBM roofline)
+    return a.N >= 8 && ncols >= 8 && a.CA * a.CB > 1024 && bytesA < BIU_MAX_SAMPLE_BYTES && bytesB < BIU_MAX_SAMPLE_BYTES && bytesY < BIU_MAX_SAMPLE_BYTES;
 }
 
 static int launch_wgrad_roll(WgradArgs a, hipStream_t st, bool k2d = false) {
