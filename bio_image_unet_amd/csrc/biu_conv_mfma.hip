@@ -812,7 +812,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
 // ===============================================================================================================
 typedef float floatx4m __attribute__((ext_vector_type(4)));
 
-template <int KD, int TD, int TH, bool RED>
+// MTL = 16-row output tiles per block column (16 * MTL output channels: 1 for a 16-channel layer; 2 -- round 3 -- for 32-channel tiles
+// of a layer whose reduction is ONE 32-channel chunk, so that its 27 x MTL KiB weight slab stays in LDS for the life of the block).
+template <int KD, int TD, int TH, int MTL, bool RED>
 __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
     using T = bf16_t;
     using F = Frag<T>;
@@ -824,17 +826,19 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
     static_assert(TH % R == 0 && R >= 2 && (TD * TH) % NWAVE == 0, "rows of a wave must stay inside one plane");
     constexpr int TAPS = KD * 9;
     constexpr int NPA = (HV * CKP + NTHR - 1) / NTHR;
-    constexpr int WN = TAPS * 64;                     // weight fragments (16 B) per chunk
+    constexpr int WN = TAPS * MTL * 64;               // weight fragments (16 B) per chunk: [tap][m][lane]
+    constexpr int NWB = MTL == 1 ? 2 : 1;             // MTL > 1: single-chunk layers only, one resident slab
+    constexpr int CB = 16 * MTL;                      // output channels of a block column
     constexpr int NPW = (WN + NTHR - 1) / NTHR;
     constexpr int NG = KD * 3;                        // MFMA groups per item: (kd tap, kw tap)
 
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     uint4* lact = lds;                       // [CKP][PSV]
-    uint4* lw = lds + CKP * PSV;             // [2][TAPS][64]
-    float* lxf = (float*)(lw + 2 * WN);      // [3][Cin]
-    float* lred = lxf + 3 * a.Cin;           // [NWAVE][16][2]
-    float* lbias = lred + NWAVE * 16 * 2;    // [16]
-    float* lrs = lbias + 16;                 // [3][16]
+    uint4* lw = lds + CKP * PSV;             // [NWB][TAPS][MTL][64]
+    float* lxf = (float*)(lw + NWB * WN);    // [3][Cin]
+    float* lred = lxf + 3 * a.Cin;           // [NWAVE][CB][2]
+    float* lbias = lred + NWAVE * CB * 2;    // [CB]
+    float* lrs = lbias + CB;                 // [3][CB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n16 = lane & 15, q4 = lane >> 4;
@@ -843,14 +847,16 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
     const int nbricks = a.N * a.nbd * a.nbh * a.nbw;
     const int p_mine = tid % CKP;
 
-    if (tid < NWAVE * 16 * 2) lred[tid] = 0.f;
-    if (tid < 16) {
-        lbias[tid] = (a.bias && tid < a.Cout) ? a.bias[tid] : 0.f;
+    const int co0 = (int)blockIdx.y * CB;                 // first output channel of this block column
+    for (int i = tid; i < NWAVE * CB * 2; i += NTHR) lred[i] = 0.f;
+    if (tid < CB) {
+        const int co = co0 + tid;
+        lbias[tid] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
         if constexpr (RED) {
-            const bool okc = tid < a.Cout && a.red_scale != nullptr;
-            lrs[tid] = okc ? a.red_scale[tid] : 0.f;
-            lrs[16 + tid] = okc ? a.red_shift[tid] : 0.f;
-            lrs[32 + tid] = (okc && a.red_slope) ? a.red_slope[tid] : 1.f;
+            const bool okc = co < a.Cout && a.red_scale != nullptr;
+            lrs[tid] = okc ? a.red_scale[co] : 0.f;
+            lrs[CB + tid] = okc ? a.red_shift[co] : 0.f;
+            lrs[2 * CB + tid] = (okc && a.red_slope) ? a.red_slope[co] : 1.f;
         }
     }
     if (has_xf) {
@@ -879,8 +885,8 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
     const int ld_w = (wave * R) / TH, lh_w = (wave * R) % TH;
     const int hvb = q4 * PSV + (ld_w * HH + lh_w) * HW + n16;      // fragment address of row 0, tap (0, 0, 0)
 
-    floatx4m acc[R];
-    uint2 yrp[RED ? R : 1];
+    floatx4m acc[MTL][R];
+    uint2 yrp[RED ? MTL : 1][RED ? R : 1];
     uint4 pa[NPA];
     int wcur = 0;
     constexpr unsigned GBITS = (1u << 9) | (1u << 19) | (1u << 29);
@@ -900,8 +906,8 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
     auto issue_wpiece = [&](int ch, bool live, int j) {
         const int q = tid + NTHR * j;
         if (q < WN && live) {                          // wave-uniform: WN is a multiple of 64
-            const uint4* src = a.wpk + (size_t)ch * WN + q;
-            uint4* dstw = lw + (wcur ^ 1) * WN + (q - lane);
+            const uint4* src = a.wpk + ((size_t)blockIdx.y * nchunks + ch) * WN + q;
+            uint4* dstw = lw + (NWB == 2 ? (wcur ^ 1) * WN : 0) + (q - lane);
             const unsigned lbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)dstw));
             glds16(src, lbase);
         }
@@ -954,8 +960,12 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
     };
     // per-channel sums: a lane holds channels 4 q4 .. + 3 of its voxel; the 16 lanes of a DPP row share them
     const bool want_stats = a.bn_partial != nullptr;
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    auto reduce4 = [&](float (&u_)[4], float (&v_)[4]) {
+    float s1[MTL][4], s2[MTL][4];
+#pragma unroll
+    for (int m = 0; m < MTL; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s1[m][e] = s2[m][e] = 0.f;
+    auto reduce4 = [&](float (&u_)[4], float (&v_)[4], int m) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float u = u_[e], v = v_[e];
@@ -967,23 +977,24 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
             v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));
             u += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x121, 0xf, 0xf, false));
             v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));
-            if (n16 == 0) { float2* sl_ = (float2*)(lred + ((wave * 16) + 4 * q4 + e) * 2); float2 o = *sl_; o.x += u; o.y += v; *sl_ = o; }
+            if (n16 == 0) { float2* sl_ = (float2*)(lred + ((wave * CB) + 16 * m + 4 * q4 + e) * 2); float2 o = *sl_; o.x += u; o.y += v; *sl_ = o; }
             u_[e] = v_[e] = 0.f;
         }
     };
     auto flush_stats = [&](int row) {
         __syncthreads();
-        if (tid < 16) {
+        if (tid < CB) {
             float l0 = 0.f, l1 = 0.f;
 #pragma unroll
             for (int w2 = 0; w2 < NWAVE; ++w2) {
-                const float2 t = *(const float2*)(lred + (w2 * 16 + tid) * 2);
+                const float2 t = *(const float2*)(lred + (w2 * CB + tid) * 2);
                 l0 += t.x; l1 += t.y;
             }
-            if (tid < a.Cout) {
-                float* dstp = a.bn_partial + ((size_t)row * a.Cout + tid) * 2;
+            const int co = co0 + tid;
+            if (co < a.Cout) {
+                float* dstp = a.bn_partial + ((size_t)row * a.Cout + co) * 2;
                 dstp[0] = l0;
-                if constexpr (RED) dstp[1] = a.red_invstd[tid] * (l1 - a.red_mean[tid] * l0);
+                if constexpr (RED) dstp[1] = a.red_invstd[co] * (l1 - a.red_mean[co] * l0);
                 else dstp[1] = l1;
             }
         }
@@ -1005,22 +1016,24 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
     for (int j = 0; j < NPW; ++j) issue_wpiece(0, true, j);
     __syncthreads();                         // lxf visible
     commit(0);
-    wcur ^= 1;
+    if (NWB == 2) wcur ^= 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     while (true) {
         if (ch == 0) {
 #pragma unroll
-            for (int mt = 0; mt < R; ++mt)
+            for (int m = 0; m < MTL; ++m)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[mt][e] = lbias[4 * q4 + e];
+                for (int mt = 0; mt < R; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[m][mt][e] = lbias[16 * m + 4 * q4 + e];
         }
         int nbrick = brick, nch = ch + 1, nk = k;
         if (nch == nchunks) { nch = 0; nk = k + 1; nbrick = brick_of(nk); }
         const bool have_next = nbrick < nbricks;
         DIAG_STAMP(0);
-        const uint4* lwc = lw + wcur * WN + lane;
+        const uint4* lwc = lw + (NWB == 2 ? wcur * WN : 0) + lane;
         issue_prep(have_next ? nbrick : brick, nch, have_next);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -1033,84 +1046,102 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
 #pragma unroll
                     for (int mt = 0; mt < R; ++mt) {
                         const int gd = o.d0 + ld_w, gh = o.h0 + lh_w + mt, gw = o.w0 + n16;
-                        const bool ok = 4 * q4 < a.Cout && gd < a.GD && gh < a.GH && gw < a.GW;
                         const size_t vox = ((size_t)(o.n * a.OD + gd) * a.OH + gh) * a.OW + gw;
-                        yrp[mt] = ok ? *(const uint2*)((const T*)a.red_y + vox * a.red_ypitch + 4 * q4) : make_uint2(0, 0);
+#pragma unroll
+                        for (int m = 0; m < MTL; ++m) {
+                            const int cl = co0 + 16 * m + 4 * q4;
+                            const bool ok = cl < a.Cout && gd < a.GD && gh < a.GH && gw < a.GW;
+                            yrp[m][mt] = ok ? *(const uint2*)((const T*)a.red_y + vox * a.red_ypitch + cl) : make_uint2(0, 0);
+                        }
                     }
                 }
             }
 #pragma unroll
             for (int j = pf_lo(g, NPA, NG); j < pf_lo(g + 1, NPA, NG); ++j) issue_piece(j);
 #pragma unroll
-            for (int j = pf_lo(g, NPW, NG); j < pf_lo(g + 1, NPW, NG); ++j) issue_wpiece(nch, have_next && nchunks > 1, j);
+            for (int j = pf_lo(g, NPW, NG); j < pf_lo(g + 1, NPW, NG); ++j) issue_wpiece(nch, have_next && nchunks > 1 && NWB == 2, j);
             uint4 rows[R + 2];
             const uint4* lap = lact + hvb + ta * HH * HW + tc;
 #pragma unroll
             for (int j = 0; j < R + 2; ++j) rows[j] = lap[j * HW];
 #pragma unroll
             for (int tb = 0; tb < 3; ++tb) {
-                const uint4 wf = lwc[((ta * 3 + tb) * 3 + tc) * 64];
+                uint4 wf[MTL];
+#pragma unroll
+                for (int m = 0; m < MTL; ++m) wf[m] = lwc[(((ta * 3 + tb) * 3 + tc) * MTL + m) * 64];
 #pragma unroll
                 for (int mt = 0; mt < R; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, rows[mt + tb]), acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < MTL; ++m)
+                        acc[m][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[m]), __builtin_bit_cast(bf16x8, rows[mt + tb]), acc[m][mt], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         DIAG_STAMP(1);
         DIAG_STAMP(2);
         if (ch == nchunks - 1) {
-            // epilogue: lane = (voxel n16 of row mt, channels 4 q4 .. + 3): 8-byte stores, 16 voxels x 32 B contiguous per wave-store
+            // epilogue: lane = (voxel n16 of row mt, channels 16 m + 4 q4 .. + 3 of the block column): 8-byte stores.  The column's
+            // destination follows k_conv_pipe: the second tensor of a split output when the column lies beyond osplit.
             const Org o = origin(brick);
-            const bool c_ok = 4 * q4 < a.Cout;
-            float rsc[4], rsh[4], rsl[4], t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (RED) {
+            const bool o1 = a.y1 && co0 >= a.osplit;
+            char* ybase = o1 ? a.y1 : a.y;
+            const int ypitch_o = o1 ? a.ypitch1 : a.ypitch;
+            const int coff = o1 ? a.osplit : 0;
+            const int accum_o = o1 ? a.accumulate1 : a.accumulate;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { rsc[e] = lrs[4 * q4 + e]; rsh[e] = lrs[16 + 4 * q4 + e]; rsl[e] = lrs[32 + 4 * q4 + e]; }
-            }
+            for (int m = 0; m < MTL; ++m) {
+                const int cl = co0 + 16 * m + 4 * q4;
+                const bool c_ok = cl < a.Cout;
+                float rsc[4], rsh[4], rsl[4], t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (RED) {
 #pragma unroll
-            for (int mt = 0; mt < R; ++mt) {
-                const int gd = o.d0 + ld_w, gh = o.h0 + lh_w + mt, gw = o.w0 + n16;
-                if (!(c_ok && gd < a.GD && gh < a.GH && gw < a.GW)) continue;
-                const size_t vox = ((size_t)(o.n * a.OD + gd) * a.OH + gh) * a.OW + gw;
-                Pack<T, 4> pk;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pk.v[e] = (T)acc[mt][e];
-                uint2 piece = __builtin_bit_cast(uint2, pk);
-                uint2* dst = (uint2*)((T*)a.y + vox * a.ypitch + 4 * q4);
-                float f[4];
-                if (a.accumulate) {
-                    const uint2 old = *dst;
-                    f[0] = __uint_as_float(piece.x << 16) + __uint_as_float(old.x << 16);
-                    f[1] = __uint_as_float(piece.x & 0xffff0000u) + __uint_as_float(old.x & 0xffff0000u);
-                    f[2] = __uint_as_float(piece.y << 16) + __uint_as_float(old.y << 16);
-                    f[3] = __uint_as_float(piece.y & 0xffff0000u) + __uint_as_float(old.y & 0xffff0000u);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pk.v[e] = (T)f[e];
-                    piece = __builtin_bit_cast(uint2, pk);
+                    for (int e = 0; e < 4; ++e) { rsc[e] = lrs[16 * m + 4 * q4 + e]; rsh[e] = lrs[CB + 16 * m + 4 * q4 + e]; rsl[e] = lrs[2 * CB + 16 * m + 4 * q4 + e]; }
                 }
-                *dst = piece;
-                if (want_stats) {
-                    f[0] = __uint_as_float(piece.x << 16); f[1] = __uint_as_float(piece.x & 0xffff0000u);      // values as stored
-                    f[2] = __uint_as_float(piece.y << 16); f[3] = __uint_as_float(piece.y & 0xffff0000u);
-                    if constexpr (!RED) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { s1[e] += f[e]; s2[e] = fmaf(f[e], f[e], s2[e]); }
-                    } else {
-                        const uint2 yr = yrp[mt];
-                        const float yv[4] = {__uint_as_float(yr.x << 16), __uint_as_float(yr.x & 0xffff0000u), __uint_as_float(yr.y << 16),
-                                             __uint_as_float(yr.y & 0xffff0000u)};
+                for (int mt = 0; mt < R; ++mt) {
+                    const int gd = o.d0 + ld_w, gh = o.h0 + lh_w + mt, gw = o.w0 + n16;
+                    if (!(c_ok && gd < a.GD && gh < a.GH && gw < a.GW)) continue;
+                    const size_t vox = ((size_t)(o.n * a.OD + gd) * a.OH + gh) * a.OW + gw;
+                    Pack<T, 4> pk;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float tt = fmaf(rsc[e], yv[e], rsh[e]);
-                            const float dz = f[e] * (tt > 0.f ? 1.f : rsl[e]);
-                            t1[e] += dz;
-                            t2[e] = fmaf(dz, yv[e], t2[e]);
+                    for (int e = 0; e < 4; ++e) pk.v[e] = (T)acc[m][mt][e];
+                    uint2 piece = __builtin_bit_cast(uint2, pk);
+                    uint2* dst = (uint2*)((T*)ybase + vox * ypitch_o + (cl - coff));
+                    float f[4];
+                    if (accum_o) {
+                        const uint2 old = *dst;
+                        f[0] = __uint_as_float(piece.x << 16) + __uint_as_float(old.x << 16);
+                        f[1] = __uint_as_float(piece.x & 0xffff0000u) + __uint_as_float(old.x & 0xffff0000u);
+                        f[2] = __uint_as_float(piece.y << 16) + __uint_as_float(old.y << 16);
+                        f[3] = __uint_as_float(piece.y & 0xffff0000u) + __uint_as_float(old.y & 0xffff0000u);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk.v[e] = (T)f[e];
+                        piece = __builtin_bit_cast(uint2, pk);
+                    }
+                    *dst = piece;
+                    if (want_stats) {
+                        f[0] = __uint_as_float(piece.x << 16); f[1] = __uint_as_float(piece.x & 0xffff0000u);      // values as stored
+                        f[2] = __uint_as_float(piece.y << 16); f[3] = __uint_as_float(piece.y & 0xffff0000u);
+                        if constexpr (!RED) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { s1[m][e] += f[e]; s2[m][e] = fmaf(f[e], f[e], s2[m][e]); }
+                        } else {
+                            const uint2 yr = yrp[m][mt];
+                            const float yv[4] = {__uint_as_float(yr.x << 16), __uint_as_float(yr.x & 0xffff0000u), __uint_as_float(yr.y << 16),
+                                                 __uint_as_float(yr.y & 0xffff0000u)};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float tt = fmaf(rsc[e], yv[e], rsh[e]);
+                                const float dz = f[e] * (tt > 0.f ? 1.f : rsl[e]);
+                                t1[e] += dz;
+                                t2[e] = fmaf(dz, yv[e], t2[e]);
+                            }
                         }
                     }
                 }
-            }
-            if constexpr (RED) {
-                if (want_stats) reduce4(t1, t2);
+                if constexpr (RED) {
+                    if (want_stats) reduce4(t1, t2, m);
+                }
             }
         }
         DIAG_STAMP(3);
@@ -1126,7 +1157,7 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
         __syncthreads();                     // everyone is done reading the tile
         DIAG_STAMP(4);
         commit(nch);
-        if (nchunks > 1) wcur ^= 1;                           // (one chunk per brick: the slab loaded for the first item stays)
+        if (nchunks > 1 && NWB == 2) wcur ^= 1;               // (one chunk per brick: the slab loaded for the first item stays)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // weight DMA landed
         DIAG_STAMP(5);
         __syncthreads();
@@ -1134,22 +1165,28 @@ __global__ __launch_bounds__(512, 2) void k_conv16_pipe(ConvArgs a) {
         brick = nbrick; ch = nch; k = nk;
     }
     if constexpr (!RED) {
-        if (want_stats) reduce4(s1, s2);
+        if (want_stats) {
+#pragma unroll
+            for (int m = 0; m < MTL; ++m) reduce4(s1[m], s2[m], m);
+        }
     }
     if (want_stats) flush_stats((int)blockIdx.x);
 }
 
-// packed weights of the 16-channel variant: out[kstep32][tap][lane]; lane (n = l & 15, q = l >> 4) holds W[row n][k = 32 ks + 8 q + e]
-__global__ void k_pack_weights16(const float* __restrict__ w, int cin, int cout, int taps, int kind, int Kc, int Nc, uint4* __restrict__ out) {
+// packed weights of the 16-row variant: out[col][kstep32][tap][m][lane]; lane (n = l & 15, q = l >> 4) of tile (col, m) holds
+// W[row 16 (col * mtl + m) + n][k = 32 ks + 8 q + e]   (mtl = row tiles per block column: k_conv16_pipe's MTL)
+__global__ void k_pack_weights16(const float* __restrict__ w, int cin, int cout, int taps, int kind, int Kc, int Nc, int mtl, uint4* __restrict__ out) {
     using F = Frag<bf16_t>;
-    const int nKS = Kc / 32;
-    const size_t total = (size_t)nKS * taps * 64;
+    const int nKS = Kc / 32, ncol = (Nc + 16 * mtl - 1) / (16 * mtl);
+    const size_t total = (size_t)ncol * nKS * taps * mtl * 64;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int lane = (int)(idx % 64);
         size_t t = idx / 64;
-        const int tap = (int)(t % taps);
-        const int ks = (int)(t / taps);
-        const int i = lane & 15;
+        const int m = (int)(t % mtl); t /= mtl;
+        const int tap = (int)(t % taps); t /= taps;
+        const int ks = (int)(t % nKS);
+        const int col = (int)(t / nKS);
+        const int i = (col * mtl + m) * 16 + (lane & 15);
         float f[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -1253,7 +1290,23 @@ int biu_mfma_set_fp32_products(int mode) {
     return BIU_OK;
 }
 static bool x3_ok(int K, int kd, int dtype) { return dtype == BIU_F32 && kd == 1 && K >= 16 && K % 16 == 0 && !x3_disabled(); }
-static bool m16_chan_ok(int K, int Nn, int dtype) { return dtype == BIU_BF16 && Nn == 16 && K >= 32 && K % 32 == 0; }
+// 16-row tiles per block column of the 16x16x32 kernel for a layer with K reduction and Nn output channels (0: the layer does not take it):
+// 1 for a 16-channel output; 2 for 32-channel tiles when the reduction is ONE 32-channel chunk (its weight slab stays resident in LDS) --
+// the data gradient of a layer with 32 output channels (decode5 of cfg4: dy 32 ch -> dx 64 | 32), 32 -> 32 layers both ways.
+// BIU_DISABLE=m16 switches all of it off, =m16x2 only the two-tile form.
+static int m16_mtl(int K, int Nn, int dtype) {
+    if (dtype != BIU_BF16 || K < 32 || K % 32 != 0) return 0;
+    if (Nn == 16) return 1;
+    static int x2off = -1;
+    if (x2off < 0) { const char* e = getenv("BIU_DISABLE"); x2off = (e && strstr(e, "m16x2")) ? 1 : 0; }
+    if (!x2off && K == 32 && Nn >= 32 && Nn % 32 == 0) return 2;
+    return 0;
+}
+static bool m16_chan_ok(int K, int Nn, int dtype) { return m16_mtl(K, Nn, dtype) > 0; }
+static size_t m16_packed_bytes(int K, int Nn, int taps, int dtype) {
+    const int mtl = m16_mtl(K, Nn, dtype);
+    return mtl ? (size_t)((Nn + 16 * mtl - 1) / (16 * mtl)) * (K / 32) * taps * mtl * 1024 : 0;
+}
 static size_t regular_packed_bytes(int K, int Nn, int taps, int dtype) {
     const size_t ntiles = (Nn + 31) / 32, nKS = K / ks_of(dtype);
     return ntiles * nKS * (size_t)taps * 1024;
@@ -1265,7 +1318,7 @@ size_t biu_mfma_packed_bytes(int kind, int cin, int cout, int kd, int kh, int kw
     const int K = kind == 0 ? cin : cout, Nn = kind == 0 ? cout : cin;
     if (!chan_ok(K, Nn, dtype)) return 0;
     size_t b = regular_packed_bytes(K, Nn, kd * 9, dtype);
-    if (m16_chan_ok(K, Nn, dtype)) b += (size_t)(K / 32) * (kd * 9) * 1024;
+    b += m16_packed_bytes(K, Nn, kd * 9, dtype);
     return b;
 }
 
@@ -1277,9 +1330,9 @@ int biu_mfma_pack(int kind, const float* w, int cin, int cout, int kd, int kh, i
                                                  cout, taps, kind, K, Nn, nKS, ntiles, (uint4*)packed, x3_ok(K, kd, dtype) ? 1 : 0));
     BIU_CHECK_LAUNCH("pack_weights");
     if (m16_chan_ok(K, Nn, dtype)) {
-        const size_t total16 = (size_t)(K / 32) * taps * 64;
+        const size_t total16 = m16_packed_bytes(K, Nn, taps, dtype) / 16;
         hipLaunchKernelGGL(k_pack_weights16, dim3(grid_for((i64)total16, 256, 4096)), dim3(256), 0, st, w, cin, cout, taps, kind, K, Nn,
-                           (uint4*)((char*)packed + regular_packed_bytes(K, Nn, taps, dtype)));
+                           m16_mtl(K, Nn, dtype), (uint4*)((char*)packed + regular_packed_bytes(K, Nn, taps, dtype)));
         BIU_CHECK_LAUNCH("pack_weights16");
     }
     return BIU_OK;
@@ -1451,13 +1504,18 @@ int biu_mfma_convt_dgrad_rows(const biu_act* dx, int kd) {
     return g > nbricks ? nbricks : g;
 }
 
-// the 16-channel kernel takes a launch when the channels fit, the tensors are plain (no concatenation) and it is not switched off
+// the 16-row kernel takes a launch when the channels fit (m16_mtl), the input is one tensor and it is not switched off
 static bool m16_ok(const biu_act* x, const biu_act* y, int dtype) {
     return x && !m16_disabled() && m16_chan_ok(x->c, y->c, dtype);
 }
 static BrickDim m16_brick(int kd) { return kd == 3 ? BrickDim{4, 8, 16} : BrickDim{1, 32, 16}; }
 static int bricks_of(const biu_act* y, BrickDim b) {
     return y->n * ((y->d + b.td - 1) / b.td) * ((y->h + b.th - 1) / b.th) * ((y->w + b.tw - 1) / b.tw);
+}
+// blocks per column of a 16-row launch with `cols` block columns (multiple of 8: XCD-grouped brick walk)
+static int m16_grid_x(int cols) {
+    int g = (num_cus() / cols) & ~7;
+    return g < 8 ? 8 : g;
 }
 
 // number of bricks of a 3x3(x3) launch writing y (= BatchNorm-backward partial rows of the data-gradient kernels).  x (the tensor the
@@ -1466,15 +1524,14 @@ int biu_mfma_conv_bricks(const biu_act* y, int kd, const biu_act* x, int dtype) 
     const int ntiles = (y->c + 31) / 32;
     const int reg = bricks_of(y, conv3_brick(kd, pick_nt(ntiles), y->w % 32 == 0));
     if (x) return m16_ok(x, y, dtype) ? bricks_of(y, m16_brick(kd)) : reg;
-    const int m16 = (y->c == 16) ? bricks_of(y, m16_brick(kd)) : 0;
+    const int m16 = (y->c == 16 || y->c % 32 == 0) ? bricks_of(y, m16_brick(kd)) : 0;
     return reg > m16 ? reg : m16;
 }
 // number of workgroup columns of that launch (= BatchNorm statistics partial rows of the forward kernels: one per block);
 // must mirror launch_cfg_r's / launch_conv16's grid computation
 int biu_mfma_conv_stat_rows(const biu_act* y, int kd, const biu_act* x, int dtype) {
     if (m16_ok(x, y, dtype)) {
-        int g = num_cus() & ~7;
-        if (g < 8) g = 8;
+        const int g = m16_grid_x(y->c / (16 * m16_mtl(x->c, y->c, dtype)));
         const int nbricks = bricks_of(y, m16_brick(kd));
         return g > nbricks ? nbricks : g;
     }
@@ -1485,19 +1542,21 @@ int biu_mfma_conv_stat_rows(const biu_act* y, int kd, const biu_act* x, int dtyp
     return g > nbricks ? nbricks : g;
 }
 
-template <int KD, int TD, int TH>
+template <int KD, int TD, int TH, int MTL>
 static int launch_conv16(ConvArgs a, hipStream_t st) {
     constexpr int HV = (TD + KD - 1) * (TH + 2) * 18;
     constexpr int PSV = (HV + 15) & ~15;
-    constexpr int WN = KD * 9 * 64;
-    const size_t lds_bytes = (size_t)(4 * PSV + 2 * WN) * 16 + (size_t)3 * a.Cin * sizeof(float) + (size_t)(8 * 16 * 2 + 16 + 48) * sizeof(float);
+    constexpr int WN = KD * 9 * MTL * 64;
+    constexpr int NWB = MTL == 1 ? 2 : 1;
+    const size_t lds_bytes = (size_t)(4 * PSV + NWB * WN) * 16 + (size_t)3 * a.Cin * sizeof(float) + (size_t)(8 * 16 * MTL * 2 + 16 * MTL + 48 * MTL) * sizeof(float);
     if (lds_bytes > (size_t)160 * 1024) return biu_fail(BIU_ERR_UNSUPPORTED, "conv16_pipe: %zu bytes of LDS (Cin=%d)", lds_bytes, a.Cin);
+    if (MTL > 1 && a.Cin != 32) return biu_fail(BIU_ERR_UNSUPPORTED, "conv16_pipe: the two-tile form takes single-chunk layers (Cin=%d)", a.Cin);
     a.nbd = (a.GD + TD - 1) / TD;
     a.nbh = (a.GH + TH - 1) / TH;
     a.nbw = (a.GW + 15) / 16;
     const int nbricks = a.N * a.nbd * a.nbh * a.nbw;
-    int g = num_cus() & ~7;
-    if (g < 8) g = 8;
+    const int cols = a.Cout / (16 * MTL);
+    int g = m16_grid_x(cols);
     if (g > nbricks) g = nbricks;
     auto launch = [&](auto kern) -> int {
         static size_t attr_set = 0;
@@ -1506,12 +1565,12 @@ static int launch_conv16(ConvArgs a, hipStream_t st) {
                 return biu_fail(BIU_ERR_LAUNCH, "conv16_pipe: cannot reserve %zu bytes of LDS", lds_bytes);
             attr_set = lds_bytes;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(512), lds_bytes, st, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)g, (unsigned)cols), dim3(512), lds_bytes, st, a);
         BIU_CHECK_LAUNCH("conv16_pipe");
         return BIU_OK;
     };
-    if (a.red_mode) return launch(k_conv16_pipe<KD, TD, TH, true>);
-    return launch(k_conv16_pipe<KD, TD, TH, false>);
+    if (a.red_mode) return launch(k_conv16_pipe<KD, TD, TH, MTL, true>);
+    return launch(k_conv16_pipe<KD, TD, TH, MTL, false>);
 }
 
 static void clear_cat(ConvArgs& a) {
@@ -1619,9 +1678,15 @@ int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, con
             }
         }
     }
-    if (!(cat && (cat->x1 || cat->y1)) && m16_ok(x, y, dtype)) {
-        a.wpk = (const uint4*)((const char*)packed + regular_packed_bytes(x->c, y->c, kd * 9, dtype));
-        return kd == 3 ? launch_conv16<3, 4, 8>(a, st) : launch_conv16<1, 1, 32>(a, st);
+    {   // the 16-row kernel: one input tensor; one output, or the two outputs of a split data gradient when every 32-channel column lies in one of them
+        biu_act yall = *y;
+        yall.c = a.Cout;
+        const int mtl = (!(cat && cat->x1) && m16_ok(x, &yall, dtype)) ? m16_mtl(x->c, a.Cout, dtype) : 0;
+        if (mtl && (!(cat && cat->y1) || (mtl == 2 && a.osplit % 32 == 0))) {
+            a.wpk = (const uint4*)((const char*)packed + regular_packed_bytes(x->c, a.Cout, kd * 9, dtype));
+            if (mtl == 2) return kd == 3 ? launch_conv16<3, 4, 8, 2>(a, st) : launch_conv16<1, 1, 32, 2>(a, st);
+            return kd == 3 ? launch_conv16<3, 4, 8, 1>(a, st) : launch_conv16<1, 1, 32, 1>(a, st);
+        }
     }
     if (dtype == BIU_BF16) return launch_conv<bf16_t>(a, kd, st);
     if (x3_ok(a.Cin, kd, dtype)) return launch_conv_x3(a, st);
@@ -1716,7 +1781,7 @@ __global__ void k_pack_batch(const biu_pack_job* __restrict__ jobs, int x3_on) {
         else { tap = (int)(t % taps); t /= taps; ks = (int)(t % nKS); nt = (int)(t / nKS); }
         const int i = nt * 32 + (lane & 31);
         if constexpr (sizeof(T) == 4) {
-            if (x3_on && j.kd == 1 && Kc % 16 == 0) {        // == x3_ok(): the bf16x3 image of a 2-D layer (3x3 conv or ConvTranspose k2)
+            if ((x3_on & 1) && j.kd == 1 && Kc % 16 == 0) {        // == x3_ok(): the bf16x3 image of a 2-D layer (3x3 conv or ConvTranspose k2)
                 out[idx] = x3_weight_piece(ks, lane >> 5, [&](int k) -> float {
                     if (i >= Nc || k >= Kc) return 0.f;
                     if (j.transposed) return kind == 0 ? w[((size_t)k * cout + i) * taps + tap] : w[((size_t)i * cout + k) * taps + tap];
@@ -1738,21 +1803,26 @@ __global__ void k_pack_batch(const biu_pack_job* __restrict__ jobs, int x3_on) {
         }
         out[idx] = F::pack(f);
     }
-    // the 16-channel kernel's fragment image follows the regular one (biu_mfma_packed_bytes / k_pack_weights16)
+    // the 16-row kernel's fragment image follows the regular one (biu_mfma_packed_bytes / k_pack_weights16: [col][ks][tap][m][lane])
     if constexpr (sizeof(T) == 2) {
-        if (!j.transposed && Nc == 16 && Kc >= 32 && Kc % 32 == 0) {
+        const int mtl = (j.transposed || Kc < 32 || Kc % 32 != 0) ? 0 : (Nc == 16 ? 1 : ((x3_on & 2) && Kc == 32 && Nc >= 32 && Nc % 32 == 0 ? 2 : 0));   // == m16_mtl()
+        if (mtl) {
             uint4* __restrict__ out16 = out + total;
-            const size_t total16 = (size_t)(Kc / 32) * taps * 64;
+            const int nKS32 = Kc / 32, ncol = (Nc + 16 * mtl - 1) / (16 * mtl);
+            const size_t total16 = (size_t)ncol * nKS32 * taps * mtl * 64;
             for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total16; idx += (size_t)gridDim.x * blockDim.x) {
                 const int lane = (int)(idx % 64);
-                const size_t t = idx / 64;
-                const int tap = (int)(t % taps), ks = (int)(t / taps);
-                const int i = lane & 15;
+                size_t t = idx / 64;
+                const int m = (int)(t % mtl); t /= mtl;
+                const int tap = (int)(t % taps); t /= taps;
+                const int ks = (int)(t % nKS32);
+                const int col = (int)(t / nKS32);
+                const int i = (col * mtl + m) * 16 + (lane & 15);
                 float f[PE];
 #pragma unroll
                 for (int e = 0; e < PE; ++e) {
                     const int k = ks * 32 + (lane >> 4) * 8 + e;
-                    f[e] = kind == 0 ? w[((size_t)i * cin + k) * taps + tap] : w[((size_t)k * cin + i) * taps + (taps - 1 - tap)];
+                    f[e] = (i < Nc && k < Kc) ? (kind == 0 ? w[((size_t)i * cin + k) * taps + tap] : w[((size_t)k * cin + i) * taps + (taps - 1 - tap)]) : 0.f;
                 }
                 out16[idx] = F::pack(f);
             }
@@ -1761,7 +1831,9 @@ __global__ void k_pack_batch(const biu_pack_job* __restrict__ jobs, int x3_on) {
 }
 int biu_mfma_pack_batch(const biu_pack_job* jobs_device, int n, int dtype, hipStream_t st) {
     if (n <= 0) return BIU_OK;
-    BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_batch<T>, dim3(256, n), dim3(256), 0, st, jobs_device, (dtype == BIU_F32 && !x3_disabled()) ? 1 : 0));
+    // flags: bit 0 = bf16x3 images (fp32), bit 1 = two-tile images of the 16-row kernel (bf16; m16_mtl's switch)
+    const int flags = ((dtype == BIU_F32 && !x3_disabled()) ? 1 : 0) | ((dtype == BIU_BF16 && m16_mtl(32, 32, BIU_BF16) == 2) ? 2 : 0);
+    BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_batch<T>, dim3(256, n), dim3(256), 0, st, jobs_device, flags));
     BIU_CHECK_LAUNCH("pack_batch");
     return BIU_OK;
 }

@@ -37,24 +37,31 @@ def _run(which, disable, tmp_path):
     # bf16: two correct bf16 kernels differ by output rounding; discrete LeakyReLU / max-pool decisions then move gradients by ~1 %
     #  -- a wrong tap or tile would move them by tens of percent
     ("unet3d_bf16", "m16,rr16", 2e-2, 6e-2),
+    ("unet3d_bf16", "m16x2", 2e-2, 6e-2),                 # only the two-tile form of the 16-row kernel (32-channel tiles of single-chunk layers)
     # the rolling-window weight gradient (k_wgrad_roll) against the brick kernel it replaces (BIU_DISABLE=wroll): the forward is untouched
     # and the dy both write back over da is the same rounding sequence, so only the order of the fp32 sums inside dW differs
-    ("unet3d_bf16", "wroll", 1e-6, 1e-3),
-    ("unet2d_bf16_n8", "wroll2d", 1e-6, 1e-3),            # its 2-D form (a batch of images as the depth axis)
+    ("unet3d_bf16", "wroll", 1e-6, 2.5e-4),
+    ("unet2d_bf16_n8", "wroll2d", 1e-6, 2.5e-4),            # its 2-D form (a batch of images as the depth axis)
 ])
 def test_variant_matches_the_kernel_it_replaces(which, disable, tol_out, tol_grad, tmp_path):
     on, off = _run(which, None, tmp_path), _run(which, disable, tmp_path)
     assert abs(on["loss"] - off["loss"]) <= tol_out * max(1.0, abs(off["loss"]))
     d = float((on["logits"] - off["logits"]).norm() / off["logits"].norm())
     assert d <= tol_out, f"logits differ by {d:.3e}"
+    # all gradients together (the large weight tensors dominate) within tol_grad; a single tensor within 4 x that: the small BatchNorm
+    # vectors at the bottleneck (a few dozen voxels per channel) move by ~10 % when ONE LeakyReLU / max-pool decision upstream falls the
+    # other way, which any two kernels that round a bf16 output differently produce (the sharp per-kernel statement is
+    # tests/test_gpu_insitu.py)
+    keys = [k for k in on if k not in ("loss", "logits")]
+    num = sum(float((on[k] - off[k]).double().pow(2).sum()) for k in keys)
+    den = sum(float(off[k].double().pow(2).sum()) for k in keys)
+    assert (num / den) ** 0.5 <= tol_grad, f"all gradients together differ by {(num / den) ** 0.5:.3e}"
     worst = ("", 0.0)
-    for k in on:
-        if k in ("loss", "logits"):
-            continue
+    for k in keys:
         r = float((on[k] - off[k]).norm() / (off[k].norm() + 1e-30))
         if r > worst[1]:
             worst = (k, r)
-    assert worst[1] <= tol_grad, f"gradient of {worst[0]} differs by {worst[1]:.3e} between the variants"
+    assert worst[1] <= 4 * tol_grad, f"gradient of {worst[0]} differs by {worst[1]:.3e} between the variants"
 
 
 @pytest.mark.timeout(600)
