@@ -299,8 +299,6 @@ def main():
     # ---- timed region --------------------------------------------------------------------------------------------------
     lib.watch, lib.watched = dom_key, []
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step stamps on the compute stream (median)
-    barrier()
-    t0 = time.perf_counter()
     # The interpreter's cyclic garbage collector is paused inside the timed region, exactly as the package's Trainers pause it inside an
     # epoch's batch loop (workflow._EpochLoop._train_epoch): a generation-2 collection walks every object torch has imported and stalls
     # the host for 60-140 ms -- with steps of 5 ms (cfg1) the GPU queue runs dry and ONE such step took 60-115 ms (BENCH_GC=on shows it).
@@ -310,6 +308,8 @@ def main():
     if gc_paused:
         gc.collect()
         gc.disable()
+    barrier()
+    t0 = time.perf_counter()
     use_marks = os.environ.get("BENCH_NO_MARKS") != "1"
     t_host = []
     if use_marks:
