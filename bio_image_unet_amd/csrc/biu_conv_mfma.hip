@@ -1513,10 +1513,7 @@ static int bricks_of(const biu_act* y, BrickDim b) {
     return y->n * ((y->d + b.td - 1) / b.td) * ((y->h + b.th - 1) / b.th) * ((y->w + b.tw - 1) / b.tw);
 }
 // blocks per column of a 16-row launch with `cols` block columns (multiple of 8: XCD-grouped brick walk)
-static int m16_grid_x(int cols) {
-    int g = (num_cus() / cols) & ~7;
-    return g < 8 ? 8 : g;
-}
+static int m16_grid_x(int cols) { return grid_per_column(num_cus(), cols); }      // (3 columns: 85 blocks each, not 80 -- 16 CUs would idle)
 
 // number of bricks of a 3x3(x3) launch writing y (= BatchNorm-backward partial rows of the data-gradient kernels).  x (the tensor the
 // launch reads) and dtype select the kernel; without them the count is an upper bound over the kernels that could run (buffer sizing).
