@@ -2669,13 +2669,20 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // images: a step takes 2 images x 8 rows x 16 voxels, wave w < 6 owns the three kh taps of kw = w % 3 on image w / 3 of the step.  The
 // 2-D weight gradients of a U-Net are memory-bound (32-64 channels: 68-140 FLOP/B); what they need from this kernel is its fetch pipeline
 // (LDS-DMA two steps ahead, no VGPR staging, no commit phase), not its MFMA schedule.
-template <bool BNF, bool K2D>
+// A16: the plain operand has 16 channels (dy of a 16-filter layer: decode6 of UNet3D(n_filter = 32)) -- a 32-row tile would multiply 16 rows
+// of zeros.  Instead a row of the A tile holds the 16 channels of BOTH planes of the step ([plane 0 | plane 1], 64 bytes), i.e. rows 0-15 of an
+// MFMA's result belong to plane 0 and rows 16-31 to plane 1: against halo plane j of the tapped operand that is depth tap kd = j for the upper
+// half and kd = j - 1 for the lower one.  Four halo planes x 9 (kh, kw) = 36 accumulators cover all 27 taps of both planes with 288 MFMAs per
+// step instead of 432; unit (j, kw): waves 0-3 own (w, 0) and (w, 2), waves 4-7 own (w - 4, 1) -- 72 MFMAs per SIMD and step.
+template <bool BNF, bool K2D, bool A16 = false>
 __global__ __launch_bounds__(512, 2) void k_wgrad_roll(WgradArgs a) {
+    static_assert(!(K2D && A16), "the 16-channel plain operand form exists for volumes only");
     using T = bf16_t;
     using F = Frag<T>;
     constexpr int TD = WR_TD, TH = WR_TH, TW = WR_TW, HW = WR_HW, PL = WR_PL, RS = WR_RS, PLB = WR_PLB, PAIRB = WR_PAIRB;
     constexpr int CT = 32, PE = 8, TAPS = K2D ? 9 : 27, IPW = K2D ? 3 : 4, NROW = TD * TH;
-    constexpr int NBK = WR_NBI / 8, NAK = WR_NAI / 8;                         // DMA instructions per wave and fetch: tapped pair 3, plain tile 2
+    constexpr int NBK = WR_NBI / 8, NAK = A16 ? 1 : WR_NAI / 8;               // DMA instructions per wave and fetch: tapped pair 3, plain tile 2 (A16: 1)
+    constexpr int NACC = A16 ? 6 : IPW;
 
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     char* bring = (char*)lds;                          // [4][PAIRB]: pair p holds the halo planes gp with ((gp + 1) / 2) % 4 == p
@@ -2687,7 +2694,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_roll(WgradArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int it = blockIdx.y / a.jt_count, jt = a.jt_begin + blockIdx.y % a.jt_count;
     const int piece = lane & 3;
-    const int ac0 = it * CT + piece * PE, bc0 = jt * CT + piece * PE;
+    const int apc = A16 ? (piece & 1) : piece;           // channel piece of the plain operand this lane stages (A16: pieces 2, 3 are plane 1)
+    const int ac0 = it * CT + apc * PE, bc0 = jt * CT + piece * PE;
     const bool apiece_ok = ac0 < a.CA, bpiece_ok = bc0 < a.CB;
     const bool b_src1 = a.pb1 && jt * CT >= a.bsplit;
     const char* pb_ = b_src1 ? a.pb1 : a.pb;
@@ -2717,15 +2725,15 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_roll(WgradArgs a) {
         lxf[LB + 2 * CT + tid] = (b_xf && cb < a.CB) ? bl_[cbl] : 1.f;
     }
 
-    floatx16 acc[IPW];
+    floatx16 acc[NACC];
 #pragma unroll
-    for (int t = 0; t < IPW; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
     // wave w: (kd, kw) pair (w / 3, w % 3); waves 0-2 also take tap (2, kh = w, 2) of the ninth pair.  K2D: wave w < 6 = (image w / 3 of
     // the step, kw = w % 3), taps kh = 0..2 -> 2-D tap kh * 3 + kw; waves 6, 7 only fetch.
     const int wkd = wave / 3, wkw = wave % 3;
-    const bool has_x = !K2D && wave < 3;
+    const bool has_x = A16 ? (wave < 4) : (!K2D && wave < 3);        // A16: waves 0-3 own a second unit
     int tapid[IPW];
 #pragma unroll
     for (int t = 0; t < IPW; ++t) {
@@ -2749,7 +2757,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_roll(WgradArgs a) {
 #pragma unroll
     for (int k = 0; k < NAK; ++k) {
         const int v = ((wave + 8 * k) * 64 + lane) >> 2;
-        aco[k] = apiece_ok ? (unsigned)((v >> 7) | (((v >> 4) & 7) << 10) | ((v & 15) << 20)) : 0xffffffffu;
+        if constexpr (A16) aco[k] = apiece_ok ? (unsigned)((piece >> 1) | ((v >> 4) << 10) | ((v & 15) << 20)) : 0xffffffffu;     // row v = (lh, lw), plane = piece >> 1
+        else aco[k] = apiece_ok ? (unsigned)((v >> 7) | (((v >> 4) & 7) << 10) | ((v & 15) << 20)) : 0xffffffffu;
     }
     const unsigned rowA = (unsigned)a.apitch * 2u, rowY = (unsigned)a.ypitch * 2u, rowB = (unsigned)bpitch_ * 2u;
     const size_t sampA = (size_t)a.GD * a.GH * a.GW * rowA, sampY = (size_t)a.GD * a.GH * a.GW * rowY, sampB = (size_t)a.BD * a.BH * a.BW * rowB;
@@ -2859,7 +2868,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_roll(WgradArgs a) {
             {
                 float ks[PE], kh[PE], kl[PE];
 #pragma unroll
-                for (int e = 0; e < PE; ++e) { ks[e] = lxf[LBN + piece * PE + e]; kh[e] = lxf[LBN + CT + piece * PE + e]; kl[e] = lxf[LBN + 2 * CT + piece * PE + e]; }
+                for (int e = 0; e < PE; ++e) { ks[e] = lxf[LBN + apc * PE + e]; kh[e] = lxf[LBN + CT + apc * PE + e]; kl[e] = lxf[LBN + 2 * CT + apc * PE + e]; }
 #pragma unroll
                 for (int k = 0; k < NAK; ++k) {
                     if ((sl.amask >> k) & 1u) {
@@ -2876,7 +2885,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_roll(WgradArgs a) {
             {
                 float ka[PE], kb[PE], kc[PE];
 #pragma unroll
-                for (int e = 0; e < PE; ++e) { ka[e] = lxf[LBN + 3 * CT + piece * PE + e]; kb[e] = lxf[LBN + 4 * CT + piece * PE + e]; kc[e] = lxf[LBN + 5 * CT + piece * PE + e]; }
+                for (int e = 0; e < PE; ++e) { ka[e] = lxf[LBN + 3 * CT + apc * PE + e]; kb[e] = lxf[LBN + 4 * CT + apc * PE + e]; kc[e] = lxf[LBN + 5 * CT + apc * PE + e]; }
 #pragma unroll
                 for (int k = 0; k < NAK; ++k) {
                     uint4 v = make_uint4(0, 0, 0, 0);
@@ -2915,6 +2924,36 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_roll(WgradArgs a) {
     auto mfma_step = [&](auto has_x_c, int s4, int buf, auto&& issue) __attribute__((always_inline)) {
         constexpr bool HAS_X = decltype(has_x_c)::value;
         auto pj = [&](int j) -> const char* { return bring + opaque_s((unsigned)(((s4 + (j >> 1)) & 3) * PAIRB + (j & 1) * PLB)); };
+        if constexpr (A16) {
+            const int uj = wave & 3, ukw = wave >> 2;
+            const char* b0 = pj(uj) + ukw * RS + ab_lane;            // primary unit (halo plane uj, kw = 0 | 1)
+            const char* c0 = pj(uj) + 2 * RS + ab_lane;              // second unit of waves 0-3 (halo plane uj, kw = 2)
+            const char* ab = abuf + opaque_s((unsigned)(buf * WR_AB)) + ab_lane;
+            bf16x8 ring[4], ring2[HAS_X ? 4 : 1], faa[2];
+            faa[0] = rd(ab);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                ring[j] = rd(b0 + j * HW * RS);
+                if constexpr (HAS_X) ring2[j] = rd(c0 + j * HW * RS);
+            }
+#pragma unroll
+            for (int r = 0; r < TH; ++r) {
+                if (r + 1 < TH) {
+                    faa[(r + 1) & 1] = rd(ab + (r + 1) * 16 * RS);
+                    ring[(r + 3) & 3] = rd(b0 + (r + 3) * HW * RS);
+                    if constexpr (HAS_X) ring2[(r + 3) & 3] = rd(c0 + (r + 3) * HW * RS);
+                }
+#pragma unroll
+                for (int tb = 0; tb < 3; ++tb) acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faa[r & 1], ring[(r + tb) & 3], acc[tb], 0, 0, 0);
+                if constexpr (HAS_X) {
+#pragma unroll
+                    for (int tb = 0; tb < 3; ++tb) acc[3 + tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faa[r & 1], ring2[(r + tb) & 3], acc[3 + tb], 0, 0, 0);
+                }
+                if ((r & 1) == 0 && r / 2 < NBK + NAK) issue(r / 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
         if constexpr (K2D) {
             // image ld = wave / 3 of the step (halo plane j = ld + 1: the centre depth tap), its 8 rows in order, ring over the kh taps
             if (wave < 6) {                                              // wave-uniform; waves 6, 7 issue their share of the fetch below
@@ -3046,6 +3085,25 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_roll(WgradArgs a) {
     // ---- flush once per block (k_wgrad_pipe's layout: ws[tap][i][j], two 128-B segments per wave-instruction) ----------------------
     const int hf = lane >> 5;
     const int jj = jt * CT + (lane & 31);
+    if constexpr (A16) {
+        // accumulator (unit u, kh = tb): rows 0-15 = tap (kd = j, kh, kw) of plane 0, rows 16-31 = tap (kd = j - 1, kh, kw) of plane 1
+        const int uj = wave & 3;
+        if (jj < a.CB) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !has_x) break;
+                const int kw = u ? 2 : (wave >> 2);
+#pragma unroll
+                for (int tb = 0; tb < 3; ++tb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int kd = uj - (e >> 3), ii = (e & 3) + 8 * ((e >> 2) & 1) + 4 * hf;
+                        if (kd >= 0 && kd <= 2 && ii < a.CA) atomicAdd(a.ws + ((size_t)((kd * 3 + tb) * 3 + kw) * a.CA + ii) * a.CB + jj, acc[u * 3 + tb][e]);
+                    }
+            }
+        }
+        return;
+    }
     if (jj < a.CB) {
 #pragma unroll
         for (int t2 = 0; t2 < IPW; ++t2) {
@@ -3088,6 +3146,9 @@ static bool wroll2d_fits(const WgradArgs& a, i64 bytesA, i64 bytesB, i64 bytesY)
 
 static int launch_wgrad_roll(WgradArgs a, hipStream_t st, bool k2d = false) {
     if (k2d) { a.GD = a.BD = a.N; a.N = 1; }
+    static int a16off = -1;
+    if (a16off < 0) { const char* e = getenv("BIU_DISABLE"); a16off = (e && strstr(e, "wroll16")) ? 1 : 0; }
+    const bool a16 = !k2d && a.CA == 16 && !a16off;      // 16-channel plain operand: both planes of a step share the tile's 32 rows
     a.nbd = 1;
     a.nbh = (a.GH + WR_TH - 1) / WR_TH;
     a.nbw = (a.GW + WR_TW - 1) / WR_TW;
@@ -3106,7 +3167,9 @@ static int launch_wgrad_roll(WgradArgs a, hipStream_t st, bool k2d = false) {
         if (hipFuncSetAttribute((const void*)k_wgrad_roll<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
             hipFuncSetAttribute((const void*)k_wgrad_roll<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
             hipFuncSetAttribute((const void*)k_wgrad_roll<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_wgrad_roll<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess)
+            hipFuncSetAttribute((const void*)k_wgrad_roll<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_wgrad_roll<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_wgrad_roll<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess)
             return biu_fail(BIU_ERR_LAUNCH, "wgrad_roll: cannot reserve %zu bytes of LDS", WR_LDS);
         attr_set = true;
     }
@@ -3122,6 +3185,9 @@ static int launch_wgrad_roll(WgradArgs a, hipStream_t st, bool k2d = false) {
         if (k2d) {
             if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, true>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
             else hipLaunchKernelGGL((k_wgrad_roll<false, true>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
+        } else if (a16) {
+            if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, false, true>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
+            else hipLaunchKernelGGL((k_wgrad_roll<false, false, true>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
         } else {
             if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, false>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
             else hipLaunchKernelGGL((k_wgrad_roll<false, false>), dim3(g, pairs), dim3(512), WR_LDS, st, b);

@@ -555,7 +555,7 @@ def test_convt_bwd_data_bnred(case, dtype):
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(3, 2, 96, 32, (8, 16, 32)), (3, 1, 32, 64, (6, 10, 20)), (2, 2, 128, 64, (24, 40)), (3, 2, 16, 32, (9, 10, 20)),
-                                  (3, 1, 6, 8, (4, 6, 10)), (3, 2, 64, 48, (9, 20, 24)), (3, 1, 32, 16, (11, 16, 40)),
+                                  (3, 1, 6, 8, (4, 6, 10)), (3, 2, 64, 48, (9, 20, 24)), (3, 1, 32, 16, (11, 16, 40)), (3, 2, 96, 16, (9, 12, 24)),
                                   (2, 8, 64, 32, (24, 40)), (2, 11, 32, 64, (16, 48))])
 def test_conv_bwd_weight_bn(case, dtype):
     """Several 32-wide input-channel tiles (Cin = 96, 128) read the same da that one of them overwrites with dy."""

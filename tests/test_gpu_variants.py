@@ -41,6 +41,7 @@ def _run(which, disable, tmp_path):
     # the rolling-window weight gradient (k_wgrad_roll) against the brick kernel it replaces (BIU_DISABLE=wroll): the forward is untouched
     # and the dy both write back over da is the same rounding sequence, so only the order of the fp32 sums inside dW differs
     ("unet3d_bf16", "wroll", 1e-6, 2.5e-4),
+    ("unet3d_bf16", "wroll16", 1e-6, 2.5e-4),             # its form for a 16-channel plain operand (decode6) against the half-empty 32-row tile
     ("unet2d_bf16_n8", "wroll2d", 1e-6, 2.5e-4),            # its 2-D form (a batch of images as the depth axis)
 ])
 def test_variant_matches_the_kernel_it_replaces(which, disable, tol_out, tol_grad, tmp_path):
