@@ -30,8 +30,9 @@ import torch  # noqa: E402
 
 HBM_PEAK = 8.0e12            # B/s   (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
 MFMA_PEAK = {"bf16": 2.5e15, "f32": 157.3e12}
-# --fp32-products bf16x3 (opt-in, fp32 workloads only): the 2-D 3x3 kernels multiply fp32 tensors as three bf16 MFMAs per product with
-# fp32 accumulation; the ceiling of those launches is a third of the bf16 peak.
+# --fp32-products (fp32 workloads only): how the 2-D 3x3 kernels multiply fp32 tensors.  bf16x6 (the library's default): six
+# bf16 MFMA terms per product, fp32-grade; exact: the fp32 MFMA; bf16x3 (opt-in): three terms, <= 2^-15 per product.  The ceiling of
+# the split launches is the bf16 dense peak over their number of terms.
 
 HEADS5 = {"seg": {"channels": 1, "activation": "sigmoid"}, "flow": {"channels": 2, "activation": None},
           "dist": {"channels": 1, "activation": "sigmoid"}}
@@ -248,7 +249,8 @@ def main():
     ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N = 1 only)")
-    ap.add_argument("--fp32-products", default="exact", choices=["exact", "bf16x3"], help="fp32 workloads: how the 3x3 kernels multiply (default: fp32 MFMA)")
+    ap.add_argument("--fp32-products", default="bf16x6", choices=["exact", "bf16x3", "bf16x6"],
+                    help="fp32 workloads: how the 2-D 3x3 kernels multiply (default: bf16x6, the library's default -- fp32-grade split products)")
     ap.add_argument("--breakdown", default=None, help="write the per-launch time table of one profiled step to this file")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -265,7 +267,7 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     wl = WORKLOADS[args.workload]
-    if args.fp32_products != "exact":
+    if wl["dtype"] == "f32":
         import bio_image_unet_amd
         bio_image_unet_amd.set_fp32_products(args.fp32_products)
     model, step, fwd, nvox, avg = make_step(wl, device, graph=args.graph and world == 1)
@@ -365,8 +367,9 @@ def main():
     dom_launch_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in watched) / max(len(watched), 1)
     fl, by = call_cost(eng, *dom_key)
     dt_name = wl["dtype"]
-    x3 = dt_name == "f32" and wl["model"] in ("Unet", "Siam_UNet") and args.fp32_products == "bf16x3"
-    mfma_peak = MFMA_PEAK["bf16"] / 3 if x3 else MFMA_PEAK[dt_name]
+    x3 = dt_name == "f32" and wl["model"] in ("Unet", "Siam_UNet") and args.fp32_products != "exact"
+    nterms = {"bf16x3": 3, "bf16x6": 6}.get(args.fp32_products, 1)
+    mfma_peak = MFMA_PEAK["bf16"] / nterms if x3 else MFMA_PEAK[dt_name]
     ai = fl / by if by else 0.0
     ridge = mfma_peak / HBM_PEAK
     if fl > 0 and ai >= ridge * 0.5:
@@ -406,10 +409,16 @@ def main():
     }
     if hasattr(step, "eager"):
         out["graph"] = "step replayed from one captured hipGraph; roofline.launch_ms from eager steps after the timed region"
-    if x3:
+    if x3 and nterms == 3:
         out["arithmetic"] = ("fp32 tensors and accumulators; the products of the 3x3 convolutions (forward, data and weight gradient) are bf16x3: "
                              "operands split hi + lo in bf16, hi*hi + hi*lo + lo*hi on the bf16 MFMA, <= 2^-15 relative per product; "
                              "roofline peak = bf16 dense peak / 3")
+    elif x3:
+        out["arithmetic"] = ("fp32 tensors and accumulators; the products of the 3x3 convolutions (forward, data and weight gradient) are bf16x6: "
+                             "operands split hi + mid + lo in bf16 (24 significant bits), the six terms of order >= 2^-16 on the bf16 MFMA, "
+                             "<= 2^-23 relative per product (fp32-grade; every fp32 parity test runs in this mode); roofline peak = bf16 dense peak / 6")
+    elif dt_name == "f32":
+        out["arithmetic"] = "fp32 tensors, fp32 MFMA (v_mfma_f32_32x32x2_f32)"
     if world > 1:           # gradient all-reduce: decoder -> encoder buckets, issued from inside backward (bio_image_unet_amd/ddp.py)
         try:
             rccl = ".".join(str(v) for v in torch.cuda.nccl.version())

@@ -65,18 +65,41 @@ template <> struct Frag<float> {
 // (round to nearest even; v - hi is exact in fp32), and a product is taken as hi*hi' + hi*lo' + lo*hi' with fp32 accumulation -- the
 // dropped lo*lo' term and the rounding of lo are each <= 2^-16 of |v v'|.  Three 32x32x16 bf16 MFMAs (96 cycles) cover the 16 reduction
 // channels that take eight 32x32x2 fp32 MFMAs (512 cycles).  Global memory stays fp32 on both sides; the split happens while staging.
+//
+// "bf16x6" (round 3, the DEFAULT of the fp32 2-D kernels): three parts v = hi + mid + lo (lo = bf16(v - hi - mid): 24 significant bits, the split
+// is exact up to 2^-24 |v|) and the six products of order >= 2^-16: lo*hi', hi*lo', mid*mid', mid*hi', hi*mid', hi*hi' (small terms first).
+// What is dropped (mid*lo', lo*mid', lo*lo') is <= 2^-23 |v v'|: the products are as good as fp32's own rounding, so every test written
+// for the exact fp32 MFMA holds unchanged, at 192 matrix-pipe cycles per 16 channels instead of 512.
 struct f32x3_t { float v; };
+struct f32x6_t { float v; };
 template <> struct Frag<f32x3_t> : Frag<float> {};
+template <> struct Frag<f32x6_t> : Frag<float> {};
+// parts per value (0: not a split type), number of product terms, and the (a part, b part) of term t, small terms first
+template <typename T> struct SplitOf { static constexpr int parts = 0, terms = 0; };
+template <> struct SplitOf<f32x3_t> { static constexpr int parts = 2, terms = 3; };
+template <> struct SplitOf<f32x6_t> { static constexpr int parts = 3, terms = 6; };
+template <int XP> __device__ __forceinline__ constexpr int term_a(int t) { return XP == 2 ? (t == 0 ? 1 : 0) : (t == 0 ? 2 : t == 1 ? 0 : t == 2 ? 1 : t == 3 ? 1 : 0); }
+template <int XP> __device__ __forceinline__ constexpr int term_b(int t) { return XP == 2 ? (t == 1 ? 1 : 0) : (t == 0 ? 0 : t == 1 ? 2 : t == 2 ? 1 : t == 4 ? 1 : 0); }
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split_bf16x3(const float (&f)[4], uint2& hi, uint2& lo) {
-    bf16x4 h, l;
+template <int XP>
+__device__ __forceinline__ void split_bf16(const float (&f)[4], uint2 (&out)[XP]) {
+    bf16x4 p[XP];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        h[e] = (__bf16)f[e];
-        l[e] = (__bf16)(f[e] - (float)h[e]);
+        float r = f[e];
+#pragma unroll
+        for (int k = 0; k < XP; ++k) {
+            p[k][e] = (__bf16)r;
+            r -= (float)p[k][e];          // exact in fp32
+        }
     }
-    hi = __builtin_bit_cast(uint2, h);
-    lo = __builtin_bit_cast(uint2, l);
+#pragma unroll
+    for (int k = 0; k < XP; ++k) out[k] = __builtin_bit_cast(uint2, p[k]);
+}
+__device__ __forceinline__ void split_bf16x3(const float (&f)[4], uint2& hi, uint2& lo) {
+    uint2 o[2];
+    split_bf16<2>(f, o);
+    hi = o[0]; lo = o[1];
 }
 __device__ __forceinline__ void mma_bf16(const uint4& a, const uint4& b, floatx16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -205,8 +228,9 @@ template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, in
 __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     using F = Frag<T>;
     constexpr int NTHR = NW * 64, NWAVE = NW;         // NW = 8: one block per CU; NW = 4: two (half the LDS each)
-    constexpr bool X3 = std::is_same<T, f32x3_t>::value;     // fp32 tensors, bf16x3 products: a chunk is 16 channels = planes [hi|lo][hf] of 8 bf16
-    static_assert(!X3 || CKP == 4, "bf16x3 chunks are 16 channels (4 fp32 pieces)");
+    constexpr int XP = SplitOf<T>::parts, XT = SplitOf<T>::terms;
+    constexpr bool X3 = XP > 0;                               // fp32 tensors, split bf16 products: a chunk is 16 channels = planes [part][hf] of 8 bf16
+    static_assert(!X3 || CKP == 4, "split-product chunks are 16 channels (4 fp32 pieces)");
     constexpr int PE = F::PE;
     constexpr int PD = (KD == 3) ? 1 : 0;
     constexpr int PHW = (KHW == 3) ? 1 : 0;
@@ -222,7 +246,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
 #endif
     constexpr bool RH = BIU_CONV_RH && TW == 32 && S == 1 && KHW == 3 && MT >= 2 && TH % MT == 0;   // row-stacked fragment reuse
     constexpr int TAPS = KD * KHW * KHW;
-    constexpr int SPC = CKP / 2;
+    constexpr int SPC = X3 ? XP : CKP / 2;                       // k-steps (weight fragments) per tap and chunk
+    constexpr int ACT16 = X3 ? 2 * XP * PSV : CKP * PSV;         // activation tile, 16-byte units
     constexpr int NSTEP = TAPS * SPC;
     constexpr int CK = CKP * PE;
     constexpr int NPA = (HV * CKP + NTHR - 1) / NTHR;            // activation pieces per thread
@@ -231,14 +256,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     // weight slab path: async global->LDS copies into a double buffer (no VGPRs) when two slabs fit; otherwise
     // register-staged like the activations
     constexpr size_t BUD = conv_lds_budget(NW);
-    constexpr bool W2 = (size_t)(CKP * PSV + 2 * WN) * 16 <= BUD;            // double-buffered slab, DMA issued an item ahead
-    constexpr bool W1 = !W2 && (size_t)(CKP * PSV + WN) * 16 <= BUD;         // one slab, DMA issued between the two barriers
+    constexpr bool W2 = (size_t)(ACT16 + 2 * WN) * 16 <= BUD;                // double-buffered slab, DMA issued an item ahead
+    constexpr bool W1 = !W2 && (size_t)(ACT16 + WN) * 16 <= BUD;             // one slab, DMA issued between the two barriers
     constexpr bool WGLDS = W2 || W1;
     constexpr int NWB = W2 ? 2 : 1;
 
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-    uint4* lact = lds;                       // [CKP][PSV]
-    uint4* lw = lds + CKP * PSV;             // [NWB][NSTEP][NT][64]
+    uint4* lact = lds;                       // [CKP][PSV]   (split products: [part][2][PSV])
+    uint4* lw = lds + ACT16;                 // [NWB][NSTEP][NT][64]
     float* lxf = (float*)(lw + NWB * WN);    // [3][Cin] transform vectors (if any)
     float* lred = lxf + 3 * a.Cin;           // [NWAVE][NT*32][2] per-wave partial sums of the epilogue reduction
     float* lbias = lred + NWAVE * NT * 32 * 2;   // [NT*32] bias of this block's output channels (zero when there is none)
@@ -420,11 +445,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
                     float f[4];
                     F::unpack(pa[j], f);
                     if (xf_here && ((inb_mask >> j) & 1u)) lrelu_affine<4>(f, sc, sh, sl);
-                    uint2 hi, lo;
-                    split_bf16x3(f, hi, lo);
+                    uint2 parts[XP];
+                    split_bf16<XP>(f, parts);
                     const int slot = ((p_mine & 1) * PSV + i / CKP) * 2 + (p_mine >> 1);
-                    l2[slot] = hi;
-                    l2[slot + 4 * PSV] = lo;
+#pragma unroll
+                    for (int k2 = 0; k2 < XP; ++k2) l2[slot + k2 * 4 * PSV] = parts[k2];
                 }
             }
         } else {
@@ -549,17 +574,26 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
             if constexpr (X3) {
 #pragma unroll
                 for (int tc = 0; tc < KHW; ++tc) {
-                    uint4 wh[NT], wl[NT], bh[MT], bl[MT];
+                    // one activation part at a time (lo first), against the weight parts it pairs with (part a of the weights with part b of
+                    // the activations when a + b < XP): only MT + XP * NT fragments are live; MT * NT independent accumulators lie between
+                    // dependent MFMAs
+                    uint4 wv[XP][NT];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) { wh[nt] = lwp[(tc * 2 * NT + nt) * 64]; wl[nt] = lwp[((tc * 2 + 1) * NT + nt) * 64]; }
+                    for (int k2 = 0; k2 < XP; ++k2)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) { bh[mt] = lap[hvb[mt] + tc]; bl[mt] = lap[hvb[mt] + 2 * PSV + tc]; }
+                        for (int nt = 0; nt < NT; ++nt) wv[k2][nt] = lwp[((tc * XP + k2) * NT + nt) * 64];
 #pragma unroll
-                    for (int term = 0; term < 3; ++term)        // small terms first; MT * NT independent accumulators between dependent MFMAs
+                    for (int kb = XP - 1; kb >= 0; --kb) {
+                        uint4 bv[MT];
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
+                        for (int mt = 0; mt < MT; ++mt) bv[mt] = lap[hvb[mt] + 2 * kb * PSV + tc];
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) mma_bf16(term == 0 ? wl[nt] : wh[nt], term == 1 ? bl[mt] : bh[mt], acc[nt][mt]);
+                        for (int ka = XP - 1 - kb; ka >= 0; --ka)
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) mma_bf16(wv[ka][nt], bv[mt], acc[nt][mt]);
+                    }
                 }
                 return;
             }
@@ -583,24 +617,28 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
         // 4 SIMDs * 1.25 KiB per 32-cycle MFMA).
         auto window_h = [&](int ta, int tc) {
             if constexpr (X3) {
-                uint4 rh[MT + 2], rl[MT + 2];
+                // one activation part at a time (lo first): its MT + 2 row fragments stay live across the three kh taps, whose weight parts
+                // (part a pairs with activation part b when a + b < XP) are read per tap
                 const uint4* lap = lact + hvb[0] + ta * HH * HW + tc;
 #pragma unroll
-                for (int j = 0; j < MT + 2; ++j) { rh[j] = lap[j * HW]; rl[j] = lap[2 * PSV + j * HW]; }
+                for (int kb = XP - 1; kb >= 0; --kb) {
+                    uint4 rv[MT + 2];
 #pragma unroll
-                for (int tb = 0; tb < KHW; ++tb) {
-                    uint4 wh[NT], wl[NT];
+                    for (int j = 0; j < MT + 2; ++j) rv[j] = lap[2 * kb * PSV + j * HW];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        wh[nt] = lwc[((((ta * KHW + tb) * KHW + tc) * 2) * NT + nt) * 64];
-                        wl[nt] = lwc[((((ta * KHW + tb) * KHW + tc) * 2 + 1) * NT + nt) * 64];
+                    for (int tb = 0; tb < KHW; ++tb) {
+                        uint4 wv[XP][NT];
+#pragma unroll
+                        for (int ka = 0; ka < XP - kb; ++ka)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) wv[ka][nt] = lwc[((((ta * KHW + tb) * KHW + tc) * XP + ka) * NT + nt) * 64];
+#pragma unroll
+                        for (int ka = XP - 1 - kb; ka >= 0; --ka)
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) mma_bf16(wv[ka][nt], rv[mt + tb], acc[nt][mt]);
                     }
-#pragma unroll
-                    for (int term = 0; term < 3; ++term)
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) mma_bf16(term == 0 ? wl[nt] : wh[nt], term == 1 ? rl[mt + tb] : rh[mt + tb], acc[nt][mt]);
                 }
                 return;
             }
@@ -1207,15 +1245,24 @@ __global__ void k_pack_weights16(const float* __restrict__ w, int cin, int cout,
 // ---------------------------------------------------------------------------------------------------------------
 // bf16x3 image of an fp32 weight fragment (k_conv_pipe<f32x3_t>): the k-steps 2s and 2s+1 of a lane hold the hi halves and the lo halves
 // of its 8 weights k = 8 (2s + (u >> 2)) + 4 hf + (u & 3), u = 0..7 -- the order the kernel stages the activations in
-template <typename Load>
-__device__ __forceinline__ uint4 x3_weight_piece(int ks, int hf, Load&& wload) {
+// (bf16x6: three k-steps 3s, 3s+1, 3s+2 = hi, mid, lo of the same 16 channels)
+template <int XP, typename Load>
+__device__ __forceinline__ uint4 xs_weight_piece(int ks, int hf, Load&& wload) {
+    const int s16 = ks / XP, part = ks % XP;
     float f0[4], f1[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { f0[e] = wload((ks & ~1) * 8 + hf * 4 + e); f1[e] = wload((ks | 1) * 8 + hf * 4 + e); }
-    uint2 h0, l0, h1, l1;
-    split_bf16x3(f0, h0, l0);
-    split_bf16x3(f1, h1, l1);
-    return (ks & 1) ? make_uint4(l0.x, l0.y, l1.x, l1.y) : make_uint4(h0.x, h0.y, h1.x, h1.y);
+    for (int e = 0; e < 4; ++e) { f0[e] = wload(s16 * 16 + hf * 4 + e); f1[e] = wload(s16 * 16 + 8 + hf * 4 + e); }
+    uint2 p0[XP], p1[XP];
+    split_bf16<XP>(f0, p0);
+    split_bf16<XP>(f1, p1);
+    uint4 r = make_uint4(p0[0].x, p0[0].y, p1[0].x, p1[0].y);
+#pragma unroll
+    for (int k = 1; k < XP; ++k) if (part == k) r = make_uint4(p0[k].x, p0[k].y, p1[k].x, p1[k].y);
+    return r;
+}
+template <typename Load>
+__device__ __forceinline__ uint4 x3_weight_piece(int mode, int ks, int hf, Load&& wload) {       // mode 1 = bf16x3, 2 = bf16x6
+    return mode == 2 ? xs_weight_piece<3>(ks, hf, wload) : xs_weight_piece<2>(ks, hf, wload);
 }
 
 template <typename T>
@@ -1233,7 +1280,7 @@ __global__ void k_pack_weights(const float* __restrict__ w, int cin, int cout, i
         const int i = nt * 32 + (lane & 31);
         if constexpr (sizeof(T) == 4) {
             if (x3) {
-                out[idx] = x3_weight_piece(ks, lane >> 5, [&](int k) -> float {
+                out[idx] = x3_weight_piece(x3, ks, lane >> 5, [&](int k) -> float {
                     if (i >= Nc || k >= Kc) return 0.f;
                     return kind == 0 ? w[((size_t)i * cin + k) * taps + tap] : w[((size_t)k * cin + i) * taps + (taps - 1 - tap)];
                 });
@@ -1269,27 +1316,35 @@ static bool m16_disabled() {
     if (v < 0) { const char* e = getenv("BIU_DISABLE"); v = (e && strstr(e, "m16")) ? 1 : 0; }
     return v == 1;
 }
-// Opt-in (biu_set_fp32_products(1), or BIU_FP32_PRODUCTS=bf16x3 in the environment): the fp32 2-D 3x3 convolutions -- forward, data gradient
-// (reduction channels in chunks of 16) and weight gradient -- run as bf16x3 products; the packed weights of such a layer carry the (hi, lo)
-// image (x3_weight_piece).  The mode is fixed by its first use in the process: packed images of one mode must never meet launches of the other.
+// How the fp32 2-D 3x3 convolutions and ConvTranspose k2 -- forward, data gradient (reduction channels in chunks of 16) and weight gradient --
+// multiply (biu_set_fp32_products(mode), or BIU_FP32_PRODUCTS=exact|bf16x3|bf16x6 in the environment):
+//   2 = bf16x6 (DEFAULT): fp32-grade split products on the bf16 matrix pipe;  0 = exact: v_mfma_f32_32x32x2_f32;  1 = bf16x3 (opt-in, <= 2^-15 per product).
+// The packed weights of such a layer carry the image of the mode (x3_weight_piece).  The mode is fixed by its first use in the process: packed
+// images of one mode must never meet launches of another.
 static int g_x3_mode = -1;           // -1: not decided yet
 static bool g_x3_used = false;
 static std::mutex g_x3_mu;
-static bool x3_disabled() {
+static int fp32_split_mode() {
     std::lock_guard<std::mutex> lock(g_x3_mu);
-    if (g_x3_mode < 0) { const char* e = getenv("BIU_FP32_PRODUCTS"); g_x3_mode = (e && strstr(e, "bf16x3")) ? 1 : 0; }
+    if (g_x3_mode < 0) {
+        const char* e = getenv("BIU_FP32_PRODUCTS");
+        g_x3_mode = (e && strstr(e, "bf16x3")) ? 1 : (e && strstr(e, "exact")) ? 0 : 2;
+    }
     g_x3_used = true;
-    return g_x3_mode != 1;
+    return g_x3_mode;
 }
 int biu_mfma_set_fp32_products(int mode) {
     std::lock_guard<std::mutex> lock(g_x3_mu);
-    if (mode != 0 && mode != 1) return biu_fail(BIU_ERR_UNSUPPORTED, "set_fp32_products: mode %d (0 = exact fp32 MFMA, 1 = bf16x3)", mode);
+    if (mode < 0 || mode > 2) return biu_fail(BIU_ERR_UNSUPPORTED, "set_fp32_products: mode %d (0 = exact fp32 MFMA, 1 = bf16x3, 2 = bf16x6)", mode);
     if (g_x3_used && g_x3_mode != mode)
-        return biu_fail(BIU_ERR_UNSUPPORTED, "set_fp32_products: fp32 kernels already ran in the other mode (set it before the first forward)");
+        return biu_fail(BIU_ERR_UNSUPPORTED, "set_fp32_products: fp32 kernels already ran in another mode (set it before the first forward)");
     g_x3_mode = mode;
     return BIU_OK;
 }
-static bool x3_ok(int K, int kd, int dtype) { return dtype == BIU_F32 && kd == 1 && K >= 16 && K % 16 == 0 && !x3_disabled(); }
+// split mode of a launch with K reduction channels (0: the exact fp32 kernels take it)
+static int x3_ok(int K, int kd, int dtype) { return (dtype == BIU_F32 && kd == 1 && K >= 16 && K % 16 == 0) ? fp32_split_mode() : 0; }
+// k-steps (packed weight fragments per tap and row tile) of a layer with K reduction channels
+static int nks_of(int K, int kd, int dtype) { return x3_ok(K, kd, dtype) == 2 ? K / 16 * 3 : K / (dtype == BIU_BF16 ? 16 : 8); }
 // 16-row tiles per block column of the 16x16x32 kernel for a layer with K reduction and Nn output channels (0: the layer does not take it):
 // 1 for a 16-channel output; 2 for 32-channel tiles when the reduction is ONE 32-channel chunk (its weight slab stays resident in LDS) --
 // the data gradient of a layer with 32 output channels (decode5 of cfg4: dy 32 ch -> dx 64 | 32), 32 -> 32 layers both ways.
@@ -1308,7 +1363,7 @@ static size_t m16_packed_bytes(int K, int Nn, int taps, int dtype) {
     return mtl ? (size_t)((Nn + 16 * mtl - 1) / (16 * mtl)) * (K / 32) * taps * mtl * 1024 : 0;
 }
 static size_t regular_packed_bytes(int K, int Nn, int taps, int dtype) {
-    const size_t ntiles = (Nn + 31) / 32, nKS = K / ks_of(dtype);
+    const size_t ntiles = (Nn + 31) / 32, nKS = nks_of(K, taps / 9, dtype);
     return ntiles * nKS * (size_t)taps * 1024;
 }
 
@@ -1324,10 +1379,10 @@ size_t biu_mfma_packed_bytes(int kind, int cin, int cout, int kd, int kh, int kw
 
 int biu_mfma_pack(int kind, const float* w, int cin, int cout, int kd, int kh, int kw, int dtype, void* packed, hipStream_t st) {
     const int K = kind == 0 ? cin : cout, Nn = kind == 0 ? cout : cin;
-    const int taps = kd * kh * kw, ntiles = (Nn + 31) / 32, nKS = K / ks_of(dtype);
+    const int taps = kd * kh * kw, ntiles = (Nn + 31) / 32, nKS = nks_of(K, kd, dtype);
     const size_t total = (size_t)ntiles * nKS * taps * 64;
     BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_weights<T>, dim3(grid_for((i64)total, 256, 4096)), dim3(256), 0, st, w, cin,
-                                                 cout, taps, kind, K, Nn, nKS, ntiles, (uint4*)packed, x3_ok(K, kd, dtype) ? 1 : 0));
+                                                 cout, taps, kind, K, Nn, nKS, ntiles, (uint4*)packed, x3_ok(K, kd, dtype)));
     BIU_CHECK_LAUNCH("pack_weights");
     if (m16_chan_ok(K, Nn, dtype)) {
         const size_t total16 = m16_packed_bytes(K, Nn, taps, dtype) / 16;
@@ -1381,9 +1436,11 @@ static int launch_cfg_r(const ConvArgs& a0, int ntiles, int nz, hipStream_t st) 
     ConvArgs a = a0;
     constexpr int HV = BrickGeo<KD, KHW, S, TD, TH, TW>::HV;
     constexpr int PSV = cpad_planes(HV, CKP);
-    constexpr int WN = KD * KHW * KHW * (CKP / 2) * NT * 64;
-    constexpr int NWB = ((size_t)(CKP * PSV + 2 * WN) * 16 <= conv_lds_budget(NW)) ? 2 : 1;        // must mirror k_conv_pipe::W2
-    const size_t lds_bytes = (size_t)(CKP * PSV + NWB * WN) * 16 + (size_t)3 * a.Cin * sizeof(float) + (size_t)NT * 32 * (2 * NW + 4) * sizeof(float);
+    constexpr int XP = SplitOf<T>::parts;
+    constexpr int SPC = XP ? XP : CKP / 2, ACT16 = XP ? 2 * XP * PSV : CKP * PSV;                    // must mirror k_conv_pipe
+    constexpr int WN = KD * KHW * KHW * SPC * NT * 64;
+    constexpr int NWB = ((size_t)(ACT16 + 2 * WN) * 16 <= conv_lds_budget(NW)) ? 2 : 1;             // must mirror k_conv_pipe::W2
+    const size_t lds_bytes = (size_t)(ACT16 + NWB * WN) * 16 + (size_t)3 * a.Cin * sizeof(float) + (size_t)NT * 32 * (2 * NW + 4) * sizeof(float);
     if (lds_bytes > (size_t)(NW == 8 ? 160 : 80) * 1024) return biu_fail(BIU_ERR_UNSUPPORTED, "conv_pipe: %zu bytes of LDS (Cin=%d)", lds_bytes, a.Cin);
     a.nbd = (a.GD + TD - 1) / TD;
     a.nbh = (a.GH + TH - 1) / TH;
@@ -1480,15 +1537,17 @@ static int launch_conv(const ConvArgs& a, int kd, hipStream_t st) {
     return wide ? launch_cfg<T, 1, 3, 1, 1, 16, 32, 2, 2>(a, ntiles, nz, st) : launch_cfg<T, 1, 3, 1, 1, 32, 16, 2, 2>(a, ntiles, nz, st);
 }
 
-// fp32 2-D 3x3 as bf16x3 products (x3_ok): the bricks of launch_conv<float>, 16-channel chunks
-static int launch_conv_x3(const ConvArgs& a, hipStream_t st) {
+// fp32 2-D 3x3 as split bf16 products (x3_ok): the bricks of launch_conv<float>, 16-channel chunks
+template <typename TS>
+static int launch_conv_xs(const ConvArgs& a, hipStream_t st) {
     const int ntiles = (a.Cout + 31) / 32;
     const int nt = pick_nt(ntiles);
     const bool wide = (a.GW % 32 == 0);
     const int nz = a.ksplit > 1 ? a.ksplit : 1;
-    if (nt == 1) return wide ? launch_cfg<f32x3_t, 1, 3, 1, 1, 32, 32, 1, 4>(a, ntiles, nz, st) : launch_cfg<f32x3_t, 1, 3, 1, 1, 64, 16, 1, 4>(a, ntiles, nz, st);
-    return wide ? launch_cfg<f32x3_t, 1, 3, 1, 1, 16, 32, 2, 4>(a, ntiles, nz, st) : launch_cfg<f32x3_t, 1, 3, 1, 1, 32, 16, 2, 4>(a, ntiles, nz, st);
+    if (nt == 1) return wide ? launch_cfg<TS, 1, 3, 1, 1, 32, 32, 1, 4>(a, ntiles, nz, st) : launch_cfg<TS, 1, 3, 1, 1, 64, 16, 1, 4>(a, ntiles, nz, st);
+    return wide ? launch_cfg<TS, 1, 3, 1, 1, 16, 32, 2, 4>(a, ntiles, nz, st) : launch_cfg<TS, 1, 3, 1, 1, 32, 16, 2, 4>(a, ntiles, nz, st);
 }
+static int launch_conv_x3(const ConvArgs& a, int mode, hipStream_t st) { return mode == 2 ? launch_conv_xs<f32x6_t>(a, st) : launch_conv_xs<f32x3_t>(a, st); }
 
 // number of bricks of a ConvTranspose data-gradient launch on the coarse tensor dx
 int biu_mfma_convt_dgrad_bricks(const biu_act* dx, int kd) {
@@ -1635,7 +1694,7 @@ int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, con
         a.y1 = (char*)cat->y1->p; a.ypitch1 = cat->y1->pitch; a.osplit = y->c; a.accumulate1 = cat->accumulate1;
         a.Cout = y->c + cat->y1->c;
     }
-    a.nKS = a.Cin / ks_of(dtype);
+    a.nKS = nks_of(a.Cin, kd, dtype);
     a.wz_stride = 0;
     a.accumulate = accumulate;
     a.nbd = a.nbh = a.nbw = 0;
@@ -1660,7 +1719,7 @@ int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, con
                 b.ksplit = ks;
                 b.y = ws; b.y_zstride = sl0; b.accumulate = 0;
                 if (y1t) { b.y1 = ws + (size_t)ks * sl0; b.y1_zstride = sl1; b.accumulate1 = 0; }
-                rc = x3_ok(b.Cin, kd, dtype) ? launch_conv_x3(b, st) : launch_conv<float>(b, kd, st);
+                rc = x3_ok(b.Cin, kd, dtype) ? launch_conv_x3(b, x3_ok(b.Cin, kd, dtype), st) : launch_conv<float>(b, kd, st);
                 if (rc == BIU_OK) {
                     hipLaunchKernelGGL(k_split_reduce, dim3(grid_for((i64)nvox(y) * y->c, 256, 2048)), dim3(256), 0, st, (const float*)ws, sl0 / sizeof(float),
                                        ks, (float*)y->p, (long)nvox(y), y->c, y->pitch, accumulate);
@@ -1686,7 +1745,7 @@ int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, con
         }
     }
     if (dtype == BIU_BF16) return launch_conv<bf16_t>(a, kd, st);
-    if (x3_ok(a.Cin, kd, dtype)) return launch_conv_x3(a, st);
+    if (x3_ok(a.Cin, kd, dtype)) return launch_conv_x3(a, x3_ok(a.Cin, kd, dtype), st);
     return launch_conv<float>(a, kd, st);
 }
 
@@ -1701,7 +1760,7 @@ __global__ void k_pack_convt(const float* __restrict__ w, int cin, int cout, int
     using F = Frag<T>;
     constexpr int PE = F::PE;
     const int Kc = kind == 0 ? cin : cout, Nc = kind == 0 ? cout : cin;
-    const int nKS = Kc / (2 * PE), ntiles = (Nc + 31) / 32;
+    const int nKS = (sizeof(T) == 4 && x3 == 2) ? Kc / 16 * 3 : Kc / (2 * PE), ntiles = (Nc + 31) / 32;
     const size_t total = (size_t)taps * ntiles * nKS * 64;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int lane = (int)(idx % 64);
@@ -1712,7 +1771,7 @@ __global__ void k_pack_convt(const float* __restrict__ w, int cin, int cout, int
         const int i = nt * 32 + (lane & 31);
         if constexpr (sizeof(T) == 4) {
             if (x3) {
-                out[idx] = x3_weight_piece(ks, lane >> 5, [&](int k) -> float {
+                out[idx] = x3_weight_piece(x3, ks, lane >> 5, [&](int k) -> float {
                     if (i >= Nc || k >= Kc) return 0.f;
                     return kind == 0 ? w[((size_t)k * cout + i) * taps + tap] : w[((size_t)i * cout + k) * taps + tap];
                 });
@@ -1740,7 +1799,7 @@ size_t biu_mfma_convt_packed_bytes(int kind, int cin, int cout, int kd, int dtyp
     if (kd != 1 && kd != 2) return 0;
     const int K = kind == 0 ? cin : cout, Nn = kind == 0 ? cout : cin;
     if (!chan_ok(K, Nn, dtype)) return 0;
-    const size_t ntiles = (Nn + 31) / 32, nKS = K / ks_of(dtype);
+    const size_t ntiles = (Nn + 31) / 32, nKS = nks_of(K, kd, dtype);
     return ntiles * nKS * (size_t)(kd * 4) * 1024;
 }
 
@@ -1748,7 +1807,7 @@ int biu_mfma_convt_pack(int kind, const float* w, int cin, int cout, int kd, int
     const size_t total = biu_mfma_convt_packed_bytes(kind, cin, cout, kd, dtype) / 16;
     BIU_REQUIRE(total > 0, BIU_ERR_UNSUPPORTED, "convt_pack: shape is served by the direct kernels");
     BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_convt<T>, dim3(grid_for((i64)total, 256, 4096)), dim3(256), 0, st, w, cin, cout,
-                                                 kd * 4, kind, (uint4*)packed, x3_ok(kind == 0 ? cin : cout, kd, dtype) ? 1 : 0));
+                                                 kd * 4, kind, (uint4*)packed, x3_ok(kind == 0 ? cin : cout, kd, dtype)));
     BIU_CHECK_LAUNCH("pack_convt");
     return BIU_OK;
 }
@@ -1767,7 +1826,9 @@ __global__ void k_pack_batch(const biu_pack_job* __restrict__ jobs, int x3_on) {
     uint4* __restrict__ out = (uint4*)j.packed;
     const int cin = j.cin, cout = j.cout, kind = j.kind;
     const int Kc = kind == 0 ? cin : cout, Nc = kind == 0 ? cout : cin;
-    const int nKS = Kc / (2 * PE), ntiles = (Nc + 31) / 32;
+    const bool split_img = sizeof(T) == 4 && (x3_on & 1) && j.kd == 1 && Kc % 16 == 0;      // == x3_ok(): the split-product image of a 2-D layer (3x3 conv or ConvTranspose k2)
+    const int xmode = (x3_on & 4) ? 2 : 1;
+    const int nKS = (split_img && xmode == 2) ? Kc / 16 * 3 : Kc / (2 * PE), ntiles = (Nc + 31) / 32;
     const int taps = j.transposed ? j.kd * 4 : j.kd * j.kh * j.kw;
     const size_t total = (size_t)ntiles * nKS * taps * 64;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -1778,8 +1839,8 @@ __global__ void k_pack_batch(const biu_pack_job* __restrict__ jobs, int x3_on) {
         else { tap = (int)(t % taps); t /= taps; ks = (int)(t % nKS); nt = (int)(t / nKS); }
         const int i = nt * 32 + (lane & 31);
         if constexpr (sizeof(T) == 4) {
-            if ((x3_on & 1) && j.kd == 1 && Kc % 16 == 0) {        // == x3_ok(): the bf16x3 image of a 2-D layer (3x3 conv or ConvTranspose k2)
-                out[idx] = x3_weight_piece(ks, lane >> 5, [&](int k) -> float {
+            if (split_img) {
+                out[idx] = x3_weight_piece(xmode, ks, lane >> 5, [&](int k) -> float {
                     if (i >= Nc || k >= Kc) return 0.f;
                     if (j.transposed) return kind == 0 ? w[((size_t)k * cout + i) * taps + tap] : w[((size_t)i * cout + k) * taps + tap];
                     return kind == 0 ? w[((size_t)i * cin + k) * taps + tap] : w[((size_t)k * cin + i) * taps + (taps - 1 - tap)];
@@ -1828,8 +1889,9 @@ __global__ void k_pack_batch(const biu_pack_job* __restrict__ jobs, int x3_on) {
 }
 int biu_mfma_pack_batch(const biu_pack_job* jobs_device, int n, int dtype, hipStream_t st) {
     if (n <= 0) return BIU_OK;
-    // flags: bit 0 = bf16x3 images (fp32), bit 1 = two-tile images of the 16-row kernel (bf16; m16_mtl's switch)
-    const int flags = ((dtype == BIU_F32 && !x3_disabled()) ? 1 : 0) | ((dtype == BIU_BF16 && m16_mtl(32, 32, BIU_BF16) == 2) ? 2 : 0);
+    // flags: bit 0 = split-product images (fp32), bit 2 = ... of the six-term form; bit 1 = two-tile images of the 16-row kernel (bf16; m16_mtl's switch)
+    const int xm = dtype == BIU_F32 ? fp32_split_mode() : 0;
+    const int flags = (xm ? 1 : 0) | (xm == 2 ? 4 : 0) | ((dtype == BIU_BF16 && m16_mtl(32, 32, BIU_BF16) == 2) ? 2 : 0);
     BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_batch<T>, dim3(256, n), dim3(256), 0, st, jobs_device, flags));
     BIU_CHECK_LAUNCH("pack_batch");
     return BIU_OK;
@@ -1901,14 +1963,15 @@ int biu_mfma_convt_fwd(const biu_act* x, const biu_xform* xf, const void* packed
     a.OD = y->d; a.OH = y->h; a.OW = y->w;
     a.osd = kd; a.osh = 2; a.osw = 2;
     a.Cin = x->c; a.Cout = y->c;
-    a.nKS = x->c / ks_of(dtype);
+    a.nKS = nks_of(x->c, kd, dtype);
     a.wz_stride = ((a.Cout + 31) / 32) * a.nKS * 64;
     a.accumulate = 0;
     a.diag = nullptr;
     a.nbd = a.nbh = a.nbw = 0;
     if (dtype == BIU_BF16) return launch_convt_fwd<bf16_t>(a, kd, st);
-    if (x3_ok(a.Cin, kd, dtype)) {       // 2-D, fp32 tensors, bf16x3 products: 16-channel chunks
+    if (const int xm = x3_ok(a.Cin, kd, dtype)) {       // 2-D, fp32 tensors, split bf16 products: 16-channel chunks
         const int ntiles = (a.Cout + 31) / 32;
+        if (xm == 2) return pick_nt(ntiles) == 1 ? launch_cfg<f32x6_t, 1, 1, 1, 1, 32, 16, 1, 4>(a, ntiles, 4, st) : launch_cfg<f32x6_t, 1, 1, 1, 1, 32, 16, 2, 4>(a, ntiles, 4, st);
         return pick_nt(ntiles) == 1 ? launch_cfg<f32x3_t, 1, 1, 1, 1, 32, 16, 1, 4>(a, ntiles, 4, st) : launch_cfg<f32x3_t, 1, 1, 1, 1, 32, 16, 2, 4>(a, ntiles, 4, st);
     }
     return launch_convt_fwd<float>(a, kd, st);
@@ -1936,14 +1999,15 @@ int biu_mfma_convt_dgrad(const biu_act* dy, const void* packed, int kd, const bi
     a.ID = dy->d; a.IH = dy->h; a.IW = dy->w;
     a.osd = a.osh = a.osw = 1;
     a.Cin = dy->c; a.Cout = dx->c;
-    a.nKS = dy->c / ks_of(dtype);
+    a.nKS = nks_of(dy->c, kd, dtype);
     a.wz_stride = 0;
     a.accumulate = accumulate;
     a.diag = nullptr;
     a.nbd = a.nbh = a.nbw = 0;
     if (dtype == BIU_BF16) return launch_convt_dgrad<bf16_t>(a, kd, st);
-    if (x3_ok(a.Cin, kd, dtype)) {
+    if (const int xm = x3_ok(a.Cin, kd, dtype)) {
         const int ntiles = (a.Cout + 31) / 32;
+        if (xm == 2) return pick_nt(ntiles) == 1 ? launch_cfg<f32x6_t, 1, 2, 2, 1, 16, 16, 1, 4>(a, ntiles, 1, st) : launch_cfg<f32x6_t, 1, 2, 2, 1, 16, 16, 2, 4>(a, ntiles, 1, st);
         return pick_nt(ntiles) == 1 ? launch_cfg<f32x3_t, 1, 2, 2, 1, 16, 16, 1, 4>(a, ntiles, 1, st) : launch_cfg<f32x3_t, 1, 2, 2, 1, 16, 16, 2, 4>(a, ntiles, 1, st);
     }
     return launch_convt_dgrad<float>(a, kd, st);
@@ -2029,10 +2093,11 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     constexpr int PPV = CT / PE;
     // X3 (T = f32x3_t): fp32 tensors, bf16x3 products -- the LDS tiles are TWO bf16 tiles each (hi plane, lo plane: split_bf16x3 while
     // committing), read through the bf16 kernels' transposing fragment reads; three MFMAs per (A, B) fragment pair
-    constexpr bool X3 = std::is_same<T, f32x3_t>::value;
+    constexpr int XP = SplitOf<T>::parts, XT = SplitOf<T>::terms;      // (bf16x6: three planes, six MFMAs per fragment pair)
+    constexpr bool X3 = XP > 0;
     constexpr bool BFM = sizeof(T) == 2 || X3;            // bf16 fragments (32x32x16) out of LDS
     constexpr int LES = BFM ? 2 : 4;                       // bytes per element of an LDS tile
-    constexpr int NPL = X3 ? 2 : 1;                        // planes per tile
+    constexpr int NPL = X3 ? XP : 1;                       // planes per tile
     constexpr int CTA = CT * NI, PPVA = CTA / PE, RSA = CTA * LES;
     constexpr int PD = (KD == 3) ? 1 : 0;
     constexpr int PHW = (KHW == 3) ? 1 : 0;
@@ -2297,10 +2362,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                 if constexpr (X3) {
                     float f[4];
                     F::unpack(v, f);
-                    uint2 hi, lo;
-                    split_bf16x3(f, hi, lo);
-                    ((uint2*)at)[i] = hi;
-                    ((uint2*)(at + BV * RSA))[i] = lo;
+                    uint2 parts[NPL];
+                    split_bf16<NPL>(f, parts);
+#pragma unroll
+                    for (int k2 = 0; k2 < NPL; ++k2) ((uint2*)(at + k2 * (BV * RSA)))[i] = parts[k2];
                 } else {
                     ((uint4*)at)[i] = v;
                 }
@@ -2327,10 +2392,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                 if constexpr (X3) {
                     float f[4];
                     F::unpack(v, f);
-                    uint2 hi, lo;
-                    split_bf16x3(f, hi, lo);
-                    ((uint2*)bt)[i] = hi;
-                    ((uint2*)(bt + HV * RS))[i] = lo;
+                    uint2 parts[NPL];
+                    split_bf16<NPL>(f, parts);
+#pragma unroll
+                    for (int k2 = 0; k2 < NPL; ++k2) ((uint2*)(bt + k2 * (HV * RS)))[i] = parts[k2];
                 } else {
                     ((uint4*)bt)[i] = v;
                 }
@@ -2435,13 +2500,13 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                     if constexpr (X3) {
                         // lo * hi, hi * lo, hi * hi: term-major, so IPW * NI independent accumulators separate the dependent MFMAs
 #pragma unroll
-                        for (int term = 0; term < 3; ++term)
+                        for (int term = 0; term < XT; ++term)
 #pragma unroll
                             for (int t2 = 0; t2 < NTAP; ++t2)
 #pragma unroll
                                 for (int ni = 0; ni < NI; ++ni) {
                                     if (TAIL_BRANCH && t2 == IPW - 1 && !last_tap_live) continue;
-                                    acc[t2][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[idx & 1][ni * 2 + (term == 0 ? 1 : 0)], fb[idx & 1][t2 * 2 + (term == 1 ? 1 : 0)],
+                                    acc[t2][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[idx & 1][ni * NPL + term_a<X3 ? XP : 2>(term)], fb[idx & 1][t2 * NPL + term_b<X3 ? XP : 2>(term)],
                                                                                          acc[t2][ni], 0, 0, 0);
                                 }
                     } else {
@@ -3269,7 +3334,7 @@ static int launch_wgrad(WgradArgs a, hipStream_t st) {
     constexpr int BV = TD * TH * TW;
     constexpr int PPV_ = 32 / (16 / (int)sizeof(T));
     constexpr int NA_ = (BV * PPV_ * NI + 511) / 512, NB_ = (HV * PPV_ + 511) / 512;
-    const size_t tile_bytes = (size_t)(HV + BV * NI) * 32 * sizeof(T);
+    const size_t tile_bytes = (size_t)(HV + BV * NI) * 32 * (SplitOf<T>::parts ? 2 * SplitOf<T>::parts : sizeof(T));    // split products: one bf16 plane per part
     const size_t lds_bytes = tile_bytes + (9 + 3 * NI) * 32 * sizeof(float) + (wgrad_tab_in_lds(tile_bytes, NA_ + NB_) ? (size_t)(NA_ + NB_) * 512 * sizeof(unsigned) : 0);
     a.nbd = (a.GD + TD - 1) / TD;
     a.nbh = (a.GH + TH - 1) / TH;
@@ -3364,7 +3429,8 @@ int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int
                           bn ? (i64)nvox(bn->y) * bn->y->pitch * 2 : 0))
         rc = launch_wgrad_roll(a, st, true);                                                                                 // batch of images as the depth axis
     else if (dtype == BIU_BF16) rc = (kd == 3) ? launch_wgrad<bf16_t, 3, 3, 1, 4, 8, 16, 1>(a, st) : launch_wgrad<bf16_t, 1, 3, 1, 1, 16, 32, 4>(a, st);
-    else if (kd == 1 && !x3_disabled()) rc = launch_wgrad<f32x3_t, 1, 3, 1, 1, 16, 16, 4>(a, st);        // fp32 tensors, bf16x3 products
+    else if (kd == 1 && fp32_split_mode() == 2) rc = launch_wgrad<f32x6_t, 1, 3, 1, 1, 16, 16, 2>(a, st);  // fp32 tensors, bf16x6 products (3 tap slots per wave: 9 fragments of B in flight)
+    else if (kd == 1 && fp32_split_mode() == 1) rc = launch_wgrad<f32x3_t, 1, 3, 1, 1, 16, 16, 4>(a, st);  // fp32 tensors, bf16x3 products
     else rc = (kd == 3) ? launch_wgrad<float, 3, 3, 1, 4, 4, 16, 1>(a, st) : launch_wgrad<float, 1, 3, 1, 1, 16, 16, 4>(a, st);
     if (rc != BIU_OK) return rc;
     hipLaunchKernelGGL(k_wgrad_finalize, dim3(grid_for((i64)a.CA * a.CB * taps, 256, 2048)), dim3(256), 0, st, (const float*)ws,
@@ -3400,7 +3466,8 @@ int biu_mfma_convt_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* d
         if (wide) rc = (kd == 2) ? launch_wgrad<bf16_t, 2, 2, 2, 2, 4, 16, 2, 2>(a, st) : launch_wgrad<bf16_t, 1, 2, 2, 1, 8, 16, 4, 2>(a, st);
         else rc = (kd == 2) ? launch_wgrad<bf16_t, 2, 2, 2, 2, 4, 16, 2>(a, st) : launch_wgrad<bf16_t, 1, 2, 2, 1, 8, 16, 4>(a, st);
     } else {
-        if (kd == 1 && !x3_disabled()) rc = wide ? launch_wgrad<f32x3_t, 1, 2, 2, 1, 8, 16, 4, 2>(a, st) : launch_wgrad<f32x3_t, 1, 2, 2, 1, 8, 16, 4>(a, st);
+        if (kd == 1 && fp32_split_mode() == 2) rc = wide ? launch_wgrad<f32x6_t, 1, 2, 2, 1, 8, 16, 4, 2>(a, st) : launch_wgrad<f32x6_t, 1, 2, 2, 1, 8, 16, 4>(a, st);
+        else if (kd == 1 && fp32_split_mode() == 1) rc = wide ? launch_wgrad<f32x3_t, 1, 2, 2, 1, 8, 16, 4, 2>(a, st) : launch_wgrad<f32x3_t, 1, 2, 2, 1, 8, 16, 4>(a, st);
         else if (wide && kd == 1) rc = launch_wgrad<float, 1, 2, 2, 1, 8, 16, 4, 2>(a, st);      // (the fp32 3-D tiles leave no LDS for a second A tile)
         else rc = (kd == 2) ? launch_wgrad<float, 2, 2, 2, 2, 4, 16, 2>(a, st) : launch_wgrad<float, 1, 2, 2, 1, 8, 16, 4>(a, st);
     }

@@ -61,14 +61,16 @@ typedef struct {
 const char* biu_last_error(void);
 int  biu_version(void);
 
-/* How fp32 tensors are multiplied by the 2-D 3x3 convolution kernels (forward, data gradient, weight gradient).
- *   0 (default): v_mfma_f32_32x32x2_f32 -- IEEE fp32 products, fp32 accumulation.
- *   1 "bf16x3" : every operand is split hi + lo in bf16 while it is staged, a product is hi*hi' + hi*lo' + lo*hi' on the bf16 matrix
- *                pipe with fp32 accumulation: <= 2^-15 relative per product (32 x tighter than the TF32 products torch.backends.cudnn
- *                .allow_tf32 = True -- the reference's default on Ampere and later -- uses), 2.5-3 x the throughput.  Tensors, accumulators
- *                and every other kernel stay fp32.
+/* How fp32 tensors are multiplied by the 2-D 3x3 convolution and ConvTranspose kernels (forward, data gradient, weight gradient).
+ *   2 "bf16x6" (default): every operand is split hi + mid + lo in bf16 while it is staged (24 significant bits: the split is exact up to
+ *                2^-24), a product is the six terms of order >= 2^-16 -- hi*hi' + hi*mid' + mid*hi' + mid*mid' + hi*lo' + lo*hi' -- on the
+ *                bf16 matrix pipe with fp32 accumulation: <= 2^-23 relative per product, i.e. as good as an fp32 product's own rounding, at
+ *                2.7 x the matrix-pipe rate of the fp32 MFMA.  Tensors, accumulators and every other kernel stay fp32.
+ *   0 "exact"  : v_mfma_f32_32x32x2_f32 -- IEEE fp32 products, fp32 accumulation.
+ *   1 "bf16x3" : hi + lo, three terms: <= 2^-15 relative per product (32 x tighter than the TF32 products torch.backends.cudnn
+ *                .allow_tf32 = True -- the reference's default on Ampere and later -- uses), twice the rate of mode 2.
  * Process-wide; must be chosen before the first fp32 convolution or weight packing call (the packed weights differ), else BIU_ERR_UNSUPPORTED.
- * BIU_FP32_PRODUCTS=bf16x3 in the environment selects mode 1 when this function was never called.
+ * BIU_FP32_PRODUCTS=exact|bf16x3|bf16x6 in the environment selects the mode when this function was never called.
  * Replaces: torch.backends.cudnn.allow_tf32 / torch.set_float32_matmul_precision as used around unet/train.py:70-139. */
 int  biu_set_fp32_products(int mode);
 

@@ -34,6 +34,9 @@ def _run(which, disable, tmp_path):
     # opt-in: fp32 tensors multiplied as bf16x3 products (three bf16 MFMAs, <= 2^-15 per product) against the exact fp32 MFMA: 18 conv layers
     # deep the logits stay within 3e-4 (north-star tolerance for fp32: 1e-3); gradients as above
     ("unet2d_f32", "+bf16x3", 3e-4, 2e-2),
+    # the default fp32 products (bf16x6: hi + mid + lo, six bf16 MFMA terms, <= 2^-23 per product) against the exact fp32 MFMA
+    # (BIU_FP32_PRODUCTS=exact): 18 layers deep the logits agree like two fp32 summation orders do
+    ("unet2d_f32", "+exact", 1e-5, 2e-2),
     # bf16: two correct bf16 kernels differ by output rounding; discrete LeakyReLU / max-pool decisions then move gradients by ~1 %
     #  -- a wrong tap or tile would move them by tens of percent
     ("unet3d_bf16", "m16,rr16", 2e-2, 6e-2),
@@ -66,12 +69,14 @@ def test_variant_matches_the_kernel_it_replaces(which, disable, tol_out, tol_gra
 
 
 @pytest.mark.timeout(600)
-def test_fp32_op_tests_hold_with_bf16x3_products():
+@pytest.mark.parametrize("mode", ["bf16x3", "exact"])
+def test_fp32_op_tests_hold_in_the_other_product_modes(mode):
     """Every fp32 op test of tests/test_gpu_ops.py (MFMA convolutions, data / weight gradients, two-source and BatchNorm-fused forms,
-    compared with torch fp32 at rtol 1e-4) once more with the opt-in bf16x3 products -- one child process, the mode is process-wide."""
+    compared with torch fp32 at rtol 1e-4) runs with the default bf16x6 products in the main test process; here once more with the opt-in
+    bf16x3 products and with the exact fp32 MFMA -- one child process each, the mode is process-wide."""
     env = dict(os.environ)
     env.pop("BIU_DISABLE", None)
-    env["BIU_FP32_PRODUCTS"] = "bf16x3"
+    env["BIU_FP32_PRODUCTS"] = mode
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_ops.py"), "-q", "-x", "-k", "f32", "-p", "no:cacheprovider"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=550)
     assert r.returncode == 0, r.stdout[-3000:]

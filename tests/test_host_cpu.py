@@ -26,9 +26,10 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_fp32_product_mode_switch_validates_its_argument():
-    """include/biu.h: biu_set_fp32_products(0 | 1); anything else is refused with a message (no GPU involved)."""
+    """include/biu.h: biu_set_fp32_products(0 | 1 | 2); anything else is refused with a message (no GPU involved)."""
     import bio_image_unet_amd as B
     import bio_image_unet_amd._lib as L
+    assert L.lib.biu_set_fp32_products(2) == 0
     assert L.lib.biu_set_fp32_products(0) == 0
     assert L.lib.biu_set_fp32_products(7) != 0
     assert b"mode" in L.lib.biu_last_error()
