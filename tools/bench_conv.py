@@ -16,7 +16,8 @@ from bio_image_unet_amd._lib import biu_act, biu_xform, check, lib  # noqa: E402
 LAYERS = {
     "cfg4": [("encode2", 3, 4, 16, 32, (128, 128, 128)), ("encode4", 3, 4, 32, 64, (64, 64, 64)), ("decode1", 3, 4, 384, 128, (32, 32, 32)),
              ("decode3", 3, 4, 192, 64, (64, 64, 64)), ("decode4", 3, 4, 64, 64, (64, 64, 64)), ("decode5", 3, 4, 96, 32, (128, 128, 128)),
-             ("decode6", 3, 4, 32, 16, (128, 128, 128)), ("middle2", 3, 4, 128, 256, (16, 16, 16))],
+             ("decode6", 3, 4, 32, 16, (128, 128, 128)), ("middle2", 3, 4, 128, 256, (16, 16, 16)),
+             ("decode5b", 3, 4, 32, 32, (128, 128, 128)), ("encode3", 3, 4, 32, 64, (64, 64, 64))],
     "cfg1": [("encode6", 2, 2, 128, 128, (64, 64)), ("encode7", 2, 2, 128, 256, (32, 32)), ("encode8", 2, 2, 256, 256, (32, 32)), ("middle1", 2, 2, 256, 512, (16, 16)),
              ("middle2", 2, 2, 512, 512, (16, 16)), ("decode1", 2, 2, 512, 256, (32, 32))],
     "cfg3": [("encode2", 2, 32, 32, 32, (512, 512)), ("encode4", 2, 32, 64, 64, (256, 256)), ("decode7", 2, 16, 64, 32, (512, 512)),

@@ -29,7 +29,12 @@ def main():
                  "dispatches_per_call": nf / calls, "kernel": sub,
                  "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of tools/bench_conv.py; "
                            "FETCH_SIZE x2 (gfx950 wide-read correction), x1024 B; summed over the call's dispatches"}}
-    json.dump(res, open(out, "w"), indent=1)
+    try:                                   # one file per workload, one key per call: keep the other calls' entries
+        old = json.load(open(out))
+    except (OSError, ValueError):
+        old = {}
+    old.update(res)
+    json.dump(old, open(out, "w"), indent=1)
     print(json.dumps(res))
 
 
