@@ -138,9 +138,9 @@ class Trainer2D(_EpochLoop):
                  channel_weights=None, n_filter=64, dilation=1, val_split=0.2, save_dir="./", save_name="model.pt",
                  save_iter=False, load_weights=False, loss_function="BCEDice", loss_params=(0.5, 0.5),
                  device: Union[torch.device, str] = "auto", fp32_products: Optional[str] = None):
-        """``fp32_products`` (not in the reference): ``"bf16x3"`` multiplies the fp32 tensors of this trainer as split bf16 products
-        (``bio_image_unet_amd.set_fp32_products``; process-wide, 2-3x faster steps) -- the role ``torch.backends.cudnn.allow_tf32``
-        plays for the reference; ``None`` leaves the process's mode alone (default: exact fp32)."""
+        """``fp32_products`` (not in the reference): ``"exact"`` | ``"bf16x3"`` | ``"bf16x6"`` -- how the fp32 tensors of this trainer are
+        multiplied (``bio_image_unet_amd.set_fp32_products``; process-wide).  ``"bf16x3"`` plays the role ``torch.backends.cudnn.allow_tf32``
+        plays for the reference; ``None`` leaves the process's mode alone (default: bf16x6, fp32-grade split products)."""
         if fp32_products is not None:
             from . import set_fp32_products
             set_fp32_products(fp32_products)
