@@ -102,7 +102,8 @@ def make_step(wl, device, graph=False):
         return loss
 
     if graph and wl["model"] == "MultiOutputUnet3D":
-        print("bench: --graph ignored for the multi-head workload (GraphedTrainStep refuses steps with device-to-device copy nodes)", file=sys.stderr)
+        print("bench: --graph ignored for the multi-head workload (its step clips the gradient norm between backward and Adam; that "
+              "capture is not among the verified ones -- tests/test_gpu_graph.py covers multi-head steps without the clip)", file=sys.stderr)
         graph = False
     if graph:
         from bio_image_unet_amd.graph import GraphedTrainStep

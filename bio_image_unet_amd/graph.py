@@ -13,10 +13,15 @@ What differs from the eager step, and how it is kept equal to it:
   * parameter version counters are bumped after every replay, so an eager forward in between (validation) re-packs the weights.
 Single process only: the gradient all-reduce of ``ddp.GradAverager`` is not captured.
 
-The graph must hold KERNEL nodes only.  A ``hipMemsetAsync`` captured in it was seen to lose its order against the kernels around it as soon
-as eager work ran between two replays (weight gradients accumulated onto stale workspace contents); the library therefore zero-fills with a
-kernel of its own, Adam's pointer table is uploaded after the capture, and networks whose step contains ``Tensor.copy_`` between device
-tensors (the stacked heads of ``MultiOutputUnet3D``) are refused.
+The graph must hold no MEMSET nodes.  Round 2 saw weight gradients of 1e35 at the third replay of a step whose workspace was zeroed with
+``hipMemsetAsync`` and took it for lost ordering.  Round 3 found the cause (``tools/probes/graph_memset.py``, ``graph_memset2.py``;
+``tests/test_gpu_graph.py``): on this stack (ROCm 7.0 runtime under torch 2.10) a memset NODE writes the right pattern at the first launch
+of the instantiated graph and a corrupted 16-byte pattern (zeros except for a few bytes that look like launch parameters, the byte count
+among them) at every later launch -- a graph of ONE memset node shows it, all three widths (``hipMemsetAsync`` / ``D16`` / ``D32``), any
+size from 4 KiB to 4 MiB, with or without eager work in between; the node's dependencies (``hipGraphNodeGetDependencies``) are captured
+correctly, so it never was an ordering problem.  Device-to-device copy nodes replay correctly (4 KiB - 16 MiB, source changed between
+replays), so steps that contain them -- the select-backward of an indexed loss, the stacked heads of ``MultiOutputUnet3D`` -- are captured;
+the library zero-fills with a kernel of its own (``k_zero_f32``) and Adam's pointer table is uploaded after the capture.
 """
 from __future__ import annotations
 
@@ -86,11 +91,6 @@ class GraphedTrainStep:
             raise TypeError("GraphedTrainStep needs bio_image_unet_amd.optim.Adam (its step reads lr / bias correction from device memory)")
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             raise NotImplementedError("GraphedTrainStep is single-process: the gradient all-reduce is not captured")
-        if len(getattr(model, "output_heads", None) or {}) > 1:
-            # the stacked-head backward copies weights / d logits with Tensor.copy_: device-to-device copy NODES in the graph (12 per step
-            # of the bench's cfg5, rocprofv3 kernel trace) -- the kind of node that lost its order (module docstring); single-head steps
-            # are kernel nodes only (cfg4: 176 kernels, 0 copy / fill nodes per replay)
-            raise NotImplementedError("GraphedTrainStep: multi-head networks are not captured (their step holds device-to-device copy nodes)")
         self.model, self.loss_fn, self.opt, self.after_backward = model, loss_fn, optimizer, after_backward
         self.static_in = [t.detach().clone() for t in example_inputs]
         self.static_tgt = [t.detach().clone() for t in example_targets]
@@ -114,20 +114,18 @@ class GraphedTrainStep:
             self.loss = self._body()
             optimizer.step()                         # -> Adam._captured_step
         optimizer.finish_capture()
-        # what the capture holds: memset nodes are refused (see the module docstring), copy nodes -- e.g. the select-backward of a loss that
-        # indexes the logits, as unet/train.py:133-134 does -- are reported: they replayed in order in every test run so far
+        # what the capture holds: memset nodes are refused (this runtime replays them with a corrupted fill pattern: module docstring); copy
+        # nodes -- the select-backward of a loss that indexes the logits as unet/train.py:133-134 does, the stacked heads of
+        # MultiOutputUnet3D -- replay correctly and are only reported in node_kinds
         self.node_kinds = graph_node_kinds(self.graph)
         if not self.node_kinds:
             import warnings
             warnings.warn("GraphedTrainStep: the node kinds of the captured step could not be read (hipGraphGetNodes on the loaded runtime): "
                           "the check that it holds no memset nodes was SKIPPED", stacklevel=2)
         if self.node_kinds.get("memset", 0):
-            raise RuntimeError(f"GraphedTrainStep: the captured step holds memset nodes {self.node_kinds}: they are not replayed in order "
-                               "on this runtime (zero tensors with a kernel: tensor.zero_() / torch.zeros, not hipMemsetAsync)")
-        if self.node_kinds.get("memcpy", 0):
-            import warnings
-            warnings.warn(f"GraphedTrainStep: the captured step holds device copy nodes {self.node_kinds}; a step of kernel nodes only is the "
-                          "verified configuration", stacklevel=2)
+            raise RuntimeError(f"GraphedTrainStep: the captured step holds memset nodes {self.node_kinds}: from its second launch on this "
+                               "runtime replays a memset node with a corrupted fill pattern (zero tensors with a kernel: tensor.zero_() / "
+                               "torch.zeros, not hipMemsetAsync)")
         self.graph.instantiate()
         # the captured launches write the buffers of exactly these engines (activations, statistics, workspace): hold them here --
         # not only through self.loss.grad_fn -- so that an engine-cache eviction or set_compute_dtype cannot free what a replay writes

@@ -117,18 +117,101 @@ def test_eager_forward_after_a_replay_sees_the_updated_weights():
     torch.testing.assert_close(after, want, rtol=1e-5, atol=1e-5)
 
 
-def test_multi_head_networks_are_refused():
+def test_multi_head_step_replays_like_the_eager_step():
+    """The stacked heads of MultiOutputUnet3D put device-to-device copy nodes into the captured step; copy nodes replay correctly on this
+    runtime (test_memset_nodes_are_the_ones_that_break), so the step is captured and must train like its eager twin."""
     heads = {"a": {"channels": 1, "activation": "sigmoid"}, "b": {"channels": 2, "activation": None}}
-    m = B.MultiOutputUnet3D(1, heads, n_filter=4).cuda()
+    m, twin = B.MultiOutputUnet3D(1, heads, n_filter=4).cuda().train(), B.MultiOutputUnet3D(1, heads, n_filter=4).cuda().train()
+    m.load_state_dict(O.init_mo3d(1, heads, 4, True, seed=6))
+    twin.load_state_dict(m.state_dict())
+    lossf = lambda outs, ya, yb: ((outs["a"] - ya) ** 2).mean() + ((outs["b"] - yb) ** 2).mean()      # noqa: E731
+    opt, topt = Adam(m.parameters(), lr=1e-3), Adam(twin.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(3)
+    data = [(torch.rand(1, 1, 8, 16, 16, generator=g).cuda(), torch.rand(1, 1, 8, 16, 16, generator=g).cuda(), torch.rand(1, 2, 8, 16, 16, generator=g).cuda())
+            for _ in range(4)]
+    gstep = GraphedTrainStep(m, lossf, opt, [data[0][0]], [data[0][1], data[0][2]])
+    assert gstep.node_kinds.get("memcpy", 0) > 0 and gstep.node_kinds.get("memset", 0) == 0, gstep.node_kinds
+    for x, ya, yb in data:
+        lg = float(gstep([x], [ya, yb]))
+        le = lossf(twin(x), ya, yb)
+        topt.zero_grad(set_to_none=True)
+        le.backward()
+        topt.step()
+        assert abs(lg - float(le)) <= 1e-5 * max(1.0, abs(float(le)))
+    for (n, p), (_, q) in zip(m.named_parameters(), twin.named_parameters()):
+        assert _rel(p.detach(), q.detach()) < 2e-4, n
+
+
+def _raw_graph(record):
+    """A graph holding what `record(stream_handle)` enqueues, instantiated: (graph, node kinds)."""
+    from bio_image_unet_amd.graph import graph_node_kinds
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.stream(side):
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            record(torch.cuda.current_stream().cuda_stream)
+    kinds = graph_node_kinds(g)
+    g.instantiate()
+    return g, kinds
+
+
+def test_memset_nodes_are_the_ones_that_break():
+    """Root cause of the round-2 'captured memset lost its order' report (tools/probes/graph_memset2.py): a graph of ONE memset node fills
+    correctly at its first launch and with a corrupted pattern at every later one on this runtime; a device-to-device copy node replays
+    correctly.  If the first half stops failing the runtime was fixed and GraphedTrainStep's refusal of memset nodes can go."""
+    import ctypes as C
+    from bio_image_unet_amd.graph import _loaded_hip_runtime
+    hip = _loaded_hip_runtime()
+    nbytes = 27 * 32 * 32 * 4                                                   # a 32 x 32 x 27-tap weight-gradient workspace
+    src, dst = torch.zeros(nbytes // 4, device="cuda"), torch.zeros(nbytes // 4, device="cuda")
+    gc, kc = _raw_graph(lambda st: hip.hipMemcpyAsync(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), C.c_size_t(nbytes), 3, C.c_void_p(st)))
+    assert kc == {"memcpy": 1}, kc
+    for r in range(4):
+        src.fill_(float(r + 1)); dst.fill_(-1.0)
+        torch.cuda.synchronize()
+        gc.replay()
+        torch.cuda.synchronize()
+        assert bool((dst == float(r + 1)).all()), f"copy node wrong at replay {r}"
+    ws = torch.empty(nbytes // 4, device="cuda")
+    gm, km = _raw_graph(lambda st: hip.hipMemsetAsync(C.c_void_p(ws.data_ptr()), 0, C.c_size_t(nbytes), C.c_void_p(st)))
+    assert km == {"memset": 1}, km
+    wrong = []
+    for r in range(3):
+        ws.fill_(5.0)
+        torch.cuda.synchronize()
+        gm.replay()
+        torch.cuda.synchronize()
+        wrong.append(int((ws.view(torch.uint8) != 0).sum()))
+    assert wrong[0] == 0, "the first launch of a memset node was always right"
+    if wrong[1] == 0 and wrong[2] == 0:
+        pytest.skip("memset nodes replay correctly on this runtime: the refusal in GraphedTrainStep is no longer needed")
+    # the same 16-byte pattern over the whole range at every later launch: 13 zero bytes + the non-zero bytes of what look like launch
+    # parameters (the byte count among them: 0x0001b000 here -> 2 + 2 wrong bytes of every 16)
+    assert wrong[1] == wrong[2] and wrong[1] > 0 and wrong[1] % (nbytes // 16) == 0, wrong
+
+
+def test_a_step_with_a_memset_node_is_refused():
+    import ctypes as C
+    from bio_image_unet_amd.graph import _loaded_hip_runtime
+    hip = _loaded_hip_runtime()
+    m = B.Unet(1, 1, 16).cuda().train()
     opt = Adam(m.parameters(), lr=1e-3)
-    x = torch.rand(1, 1, 8, 16, 16).cuda()
-    with pytest.raises(NotImplementedError):
-        GraphedTrainStep(m, lambda outs: sum(o.mean() for o in outs.values()), opt, [x], [])
+    crit = BCEDiceLoss(0.5, 0.5)
+    scratch = torch.empty(1024, device="cuda")
+    (x, y), = _batches(1, (2, 1, 64, 64))
+
+    def lossf(outs, t):
+        assert hip.hipMemsetAsync(C.c_void_p(scratch.data_ptr()), 0, C.c_size_t(4096), C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+        return crit(outs[1], t)
+    with pytest.raises(RuntimeError, match="memset"):
+        GraphedTrainStep(m, lossf, opt, [x], [y])
 
 
 def test_node_kinds_and_a_loss_with_copy_nodes():
     """The reference's 2-D loss indexes the logits (unet/train.py:133-134): autograd's select-backward puts device copy NODES into the
-    captured step.  They must replay in order (a captured memset did not: GraphedTrainStep refuses those), and node_kinds reports them."""
+    captured step.  They replay correctly (memset nodes do not: test_memset_nodes_are_the_ones_that_break), and node_kinds reports them."""
     import warnings
     sd = O.init_unet2d(1, 1, 16, seed=4)
     crit = BCEDiceLoss(0.5, 0.5)
@@ -142,7 +225,7 @@ def test_node_kinds_and_a_loss_with_copy_nodes():
         gstep = GraphedTrainStep(m, lossf, opt, [data[0][0]], [data[0][1]])
     kinds = gstep.node_kinds
     assert kinds.get("kernel", 0) > 100 and kinds.get("memset", 0) == 0, kinds
-    assert kinds.get("memcpy", 0) > 0 and any("copy nodes" in str(w.message) for w in rec), kinds
+    assert kinds.get("memcpy", 0) > 0, kinds
     for x, y in data:
         twin.load_state_dict(m.state_dict())
         lg = float(gstep([x], [y]))
