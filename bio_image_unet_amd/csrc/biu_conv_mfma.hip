@@ -2436,7 +2436,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
             constexpr int KPG = KPW / NG;
             WSTAMP(0);
             using FragR = typename std::conditional<BFM, bf16x8, float>::type;
-            FragR fa[2][NI * NPL], fb[2][IPW * NPL];                  // X3: [.. * 2 + plane], plane 0 = hi
+            FragR fa[2][NI * NPL], fb[2][IPW * NPL];                  // split products: fa[.. * parts + part], part 0 = hi; their B fragments live in mfma_phase_split (fb unused)
             // 2-D fp32 kernels: 9 taps on 2 x 5 slots leave one empty; a second copy of the phase spills there, a wave-uniform branch around
             // the last slot's reads and 64-cycle MFMA does not (cfg2 weight gradients 96 -> 104-112 TFLOP/s)
             constexpr bool TWO_PHASES_ = IPW > 1 && (IPW * WPQ - TAPS) * BIU_TWO_PHASE_DIV >= IPW * WPQ;
@@ -2479,8 +2479,86 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                 }
             };
             issue_prep(have_next ? nbrick : brick, have_next);
+            // Split products (X3): ONE part of the tapped operand at a time (lo first) against the parts of the plain operand it pairs with
+            // (a + b < parts).  A step = (k-group, part of B): IPW fragments of B in flight instead of IPW * parts, so bf16x6 keeps the
+            // balanced 2 x 5 tap slots of the exact kernel (K split 4: every SIMD holds a 5-tap and a 4-tap wave) where the all-parts-at-once
+            // form needed 15 fragments per k-group and fell back to 4 x 3 slots (5 : 4 taps per SIMD).
+            auto load_a_parts = [&](int kg, FragR (&af)[NI * NPL]) {
+                if constexpr (BFM) {
+                    typedef bf16x4 __attribute__((address_space(3))) * lp;
+                    const int q0 = kg * KUNIT;
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int pl = 0; pl < NPL; ++pl) {
+                            const char* ap = at + pl * (BV * RSA) + q0 * RSA + a_lane + ni * CT * 2;
+                            bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap));
+                            bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap + 4 * RSA));
+                            af[ni * NPL + pl] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+                }
+            };
+            auto load_b_part = [&](auto ntap_c, int kg, int pl, FragR (&bfr)[IPW]) {
+                constexpr int NTAP = decltype(ntap_c)::value;
+                if constexpr (BFM) {
+                    typedef bf16x4 __attribute__((address_space(3))) * lp;
+                    const int q0 = kg * KUNIT;
+                    const int lw0 = q0 % TW;
+                    const int t = q0 / TW;
+                    const int hbase = (((t / TH) * SD * HH + (t % TH) * S) * HW + lw0 * S) * RS;
+#pragma unroll
+                    for (int t2 = 0; t2 < NTAP; ++t2) {
+                        if (TAIL_BRANCH && t2 == IPW - 1 && !last_tap_live) continue;
+                        const char* bp = bt + pl * (HV * RS) + hbase + tapoff[t2] + b_lane;
+                        bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp));
+                        bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp + 4 * S * RS));
+                        bfr[t2] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                }
+            };
+            auto mfma_phase_split = [&](auto ntap_c) {
+                constexpr int NTAP = decltype(ntap_c)::value;
+                FragR fbs[2][IPW];
+                load_a_parts(wq * KPW, fa[0]);
+                load_b_part(ntap_c, wq * KPW, NPL - 1, fbs[0]);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                    for (int j = pf_lo(g, NA, NG); j < pf_lo(g + 1, NA, NG); ++j) issue_a(j);
+#pragma unroll
+                    for (int j = pf_lo(g, NB, NG); j < pf_lo(g + 1, NB, NG); ++j) issue_b(j);
+#pragma unroll
+                    for (int kk = 0; kk < KPG; ++kk) {
+                        const int idx = g * KPG + kk;
+#pragma unroll
+                        for (int kbi = 0; kbi < NPL; ++kbi) {
+                            const int kb = NPL - 1 - kbi, step = idx * NPL + kbi;
+                            // the next step's fragments, one step ahead, in the other register set
+                            if (kbi + 1 < NPL) load_b_part(ntap_c, wq * KPW + idx, kb - 1, fbs[(step + 1) & 1]);
+                            else if (idx + 1 < KPW) {
+                                load_a_parts(wq * KPW + idx + 1, fa[(idx + 1) & 1]);
+                                load_b_part(ntap_c, wq * KPW + idx + 1, NPL - 1, fbs[(step + 1) & 1]);
+                            }
+#pragma unroll
+                            for (int ka = NPL - 1 - kb; ka >= 0; --ka)
+#pragma unroll
+                                for (int t2 = 0; t2 < NTAP; ++t2)
+#pragma unroll
+                                    for (int ni = 0; ni < NI; ++ni) {
+                                        if (TAIL_BRANCH && t2 == IPW - 1 && !last_tap_live) continue;
+                                        if constexpr (BFM) acc[t2][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[idx & 1][ni * NPL + ka], fbs[step & 1][t2], acc[t2][ni], 0, 0, 0);
+                                    }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
             auto mfma_phase = [&](auto ntap_c) {
             constexpr int NTAP = decltype(ntap_c)::value;
+#ifndef BIU_WGRAD_SPLIT_STEPPED
+#define BIU_WGRAD_SPLIT_STEPPED 1
+#endif
+            if constexpr (X3 && BIU_WGRAD_SPLIT_STEPPED) { mfma_phase_split(ntap_c); return; }
             load_frags(ntap_c, wq * KPW, fa[0], fb[0]);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -3429,7 +3507,7 @@ int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int
                           bn ? (i64)nvox(bn->y) * bn->y->pitch * 2 : 0))
         rc = launch_wgrad_roll(a, st, true);                                                                                 // batch of images as the depth axis
     else if (dtype == BIU_BF16) rc = (kd == 3) ? launch_wgrad<bf16_t, 3, 3, 1, 4, 8, 16, 1>(a, st) : launch_wgrad<bf16_t, 1, 3, 1, 1, 16, 32, 4>(a, st);
-    else if (kd == 1 && fp32_split_mode() == 2) rc = launch_wgrad<f32x6_t, 1, 3, 1, 1, 16, 16, 2>(a, st);  // fp32 tensors, bf16x6 products (3 tap slots per wave: 9 fragments of B in flight)
+    else if (kd == 1 && fp32_split_mode() == 2) rc = launch_wgrad<f32x6_t, 1, 3, 1, 1, 16, 16, BIU_WGRAD_SPLIT_STEPPED ? 4 : 2>(a, st);  // fp32 tensors, bf16x6 products
     else if (kd == 1 && fp32_split_mode() == 1) rc = launch_wgrad<f32x3_t, 1, 3, 1, 1, 16, 16, 4>(a, st);  // fp32 tensors, bf16x3 products
     else rc = (kd == 3) ? launch_wgrad<float, 3, 3, 1, 4, 4, 16, 1>(a, st) : launch_wgrad<float, 1, 3, 1, 1, 16, 16, 4>(a, st);
     if (rc != BIU_OK) return rc;
