@@ -1,5 +1,5 @@
-"""Stability run: hundreds of steps of the bench workloads (eager, graph replay, opt-in bf16x3 in a child process); memory must not grow and
-the parameters must stay finite.    python tools/soak.py"""
+"""Stability run: hundreds of steps of the bench workloads (eager, graph replay; fp32 in the default bf16x6 products, the opt-in bf16x3 in a
+child process); memory must not grow and the parameters must stay finite.    python tools/soak.py"""
 import os
 import subprocess
 import sys
@@ -16,7 +16,7 @@ if MODE == "x3":
     bio_image_unet_amd.set_fp32_products("bf16x3")
     runs = [("cfg1", False, 600), ("cfg2", False, 30)]
 else:
-    runs = [("cfg4", False, 300), ("cfg1", False, 600), ("cfg1", True, 600), ("cfg3", True, 100)]
+    runs = [("cfg4", False, 300), ("cfg1", False, 600), ("cfg1", True, 600), ("cfg3", True, 100), ("cfg2", False, 30), ("cfg5", False, 20)]
 for W, graph, n in runs:
     wl = bench.WORKLOADS[W]
     model, step, fwd, nvox, _ = bench.make_step(wl, torch.device("cuda", 0), graph=graph)
