@@ -324,6 +324,36 @@ extern "C" int biu_convt_pack(int kind, const float* w, int cin, int cout, int k
     BIU_REQUIRE(w && packed, BIU_ERR_SHAPE, "convt_pack: null pointer");
     return biu_mfma_convt_pack(kind, w, cin, cout, kd, dtype, packed, (hipStream_t)stream);
 }
+// ---- nearest-neighbour up-sampling folded into the 3x3x3 convolution behind it (forward) ----------------------------------
+extern "C" int biu_upconv_ok(const biu_act* x, const biu_act* y, int dtype) {
+    return (x && y && !disabled("upconv") && biu_mfma_upconv_ok(x, y, dtype)) ? 1 : 0;
+}
+extern "C" size_t biu_upconv_packed_bytes(int cin, int cout, int dtype) { return biu_mfma_upconv_packed_bytes(cin, cout, dtype); }
+extern "C" int biu_upconv_pack(const float* w, int cin, int cout, int dtype, void* packed, biu_stream stream) {
+    BIU_REQUIRE(w && packed && biu_mfma_upconv_packed_bytes(cin, cout, dtype) > 0, BIU_ERR_SHAPE, "upconv_pack: null pointer or unsupported channels %d -> %d", cin, cout);
+    return biu_mfma_upconv_pack(w, cin, cout, dtype, packed, (hipStream_t)stream);
+}
+extern "C" size_t biu_upconv_fwd_stats_floats(const biu_act* x, const biu_act* y) {
+    return (size_t)biu_mfma_upconv_stat_rows(x, y) * y->c * 2;
+}
+extern "C" int biu_upconv_fwd(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, const biu_act* y,
+                              float* bn_partial, size_t bn_partial_floats, int* bn_nblk, int dtype, biu_stream stream) {
+    BIU_REQUIRE(x && y && packed, BIU_ERR_SHAPE, "upconv_fwd: null pointer");
+    BIU_REQUIRE(biu_mfma_upconv_ok(x, y, dtype), BIU_ERR_UNSUPPORTED, "upconv_fwd: shape %dx%dx%dx%d c%d -> %dx%dx%dx%d c%d is not served by the folded kernel",
+                x->n, x->d, x->h, x->w, x->c, y->n, y->d, y->h, y->w, y->c);
+    if (bn_nblk) *bn_nblk = 0;
+    if (bn_partial) {
+        BIU_REQUIRE(bn_nblk, BIU_ERR_SHAPE, "upconv_fwd: bn_partial without bn_nblk");
+        const int nb = biu_mfma_upconv_stat_rows(x, y);
+        BIU_REQUIRE((size_t)nb * y->c * 2 <= bn_partial_floats, BIU_ERR_WORKSPACE, "upconv_fwd: partial buffer too small (%zu floats, need %zu)",
+                    bn_partial_floats, (size_t)nb * y->c * 2);
+        int rc = biu_mfma_upconv_fwd(x, xf, packed, bias, y, bn_partial, dtype, (hipStream_t)stream);
+        if (rc == BIU_OK) *bn_nblk = nb;
+        return rc;
+    }
+    return biu_mfma_upconv_fwd(x, xf, packed, bias, y, nullptr, dtype, (hipStream_t)stream);
+}
+
 extern "C" int biu_convt_fwd(const biu_act* x, const biu_xform* xf, const float* w, const void* packed, const float* bias,
                              int kd, const biu_act* y, int dtype, biu_stream stream) {
     BIU_REQUIRE(valid_act(x) && valid_act(y) && w && biu_convt_shapes_ok(x, y, kd), BIU_ERR_SHAPE,

@@ -55,6 +55,13 @@ int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int
 
 size_t biu_mfma_convt_packed_bytes(int kind, int cin, int cout, int kd, int dtype);
 int biu_mfma_convt_pack(int kind, const float* w, int cin, int cout, int kd, int dtype, void* packed, hipStream_t st);
+// nearest-neighbour up-sampling folded into the 3x3x3 convolution behind it (forward)
+bool biu_mfma_upconv_ok(const biu_act* x, const biu_act* y, int dtype);
+size_t biu_mfma_upconv_packed_bytes(int cin, int cout, int dtype);
+int biu_mfma_upconv_pack(const float* w, int cin, int cout, int dtype, void* packed, hipStream_t st);
+int biu_mfma_upconv_stat_rows(const biu_act* x, const biu_act* y);
+int biu_mfma_upconv_fwd(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, const biu_act* y, float* bn_partial,
+                        int dtype, hipStream_t st);
 bool biu_mfma_convt_ok(int kind, const biu_act* lo, const biu_act* hi, int kd, int dtype);
 int biu_mfma_convt_fwd(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, const biu_act* y,
                        int dtype, hipStream_t st);

@@ -223,9 +223,14 @@ class ConvBlockNode(Node):
     backward: d a -> d y (BatchNorm + LeakyReLU backward, in place) ; dW, db ; d x.
     """
 
-    def __init__(self, eng, seq: nn.Sequential, xin: Act, yout: Act, dropout_follows: bool = False):
+    def __init__(self, eng, seq: nn.Sequential, xin: Act, yout: Act, dropout_follows: bool = False, fold_src: Optional[Act] = None):
+        """``fold_src``: ``xin`` is the nearest-neighbour up-sampling (x2) of this coarse activation
+        (multi_output_unet3d/multi_output_unet3d.py:138-139).  The forward then runs folded on the coarse tensor
+        (``biu_upconv_fwd``: 8 parity classes x 2x2x2 taps instead of 27 taps, include/biu.h) when the kernel serves the shape; the
+        backward still reads ``xin``."""
         conv, bn = seq[0], seq[1]
         self.conv, self.bn, self.xin, self.y = conv, bn, xin, yout
+        self.fold_src, self.fold_slot = None, None
         # the block's activation as a leaky slope: LeakyReLU(s) -> s, ReLU -> 0 (Unet_v0 / BabyUnet), none or a later
         # non-piecewise-linear one (the attention gate's Sigmoid, applied by GateNode) -> 1
         act = seq[2] if len(seq) > 2 else None
@@ -250,6 +255,11 @@ class ConvBlockNode(Node):
         yout.vec("slope").fill_(self.slope)
         eng.need_partial(cout)
         eng.need_partial_floats(lib.biu_conv_fwd_stats_floats(yout.a(), self.kd))
+        if (fold_src is not None and (self.kd, self.kh, self.kw, self.dil) == (3, 3, 3, 1) and not isinstance(xin, CatAct)
+                and fold_src.c == xin.c and lib.biu_upconv_ok(fold_src.a(), yout.a(), eng.dtype)):
+            self.fold_src = fold_src
+            self.fold_slot = {"buf": torch.empty(lib.biu_upconv_packed_bytes(xin.c, cout, eng.dtype), dtype=torch.uint8, device=dev), "ver": None}
+            eng.need_partial_floats(lib.biu_upconv_fwd_stats_floats(fold_src.a(), yout.a()))
         self.pk_f = eng.packed_slot(0, xin.c, cout, self.kd, self.kh, self.kw, self.dil)
         self.pk_b = eng.packed_slot(1, xin.c, cout, self.kd, self.kh, self.kw, self.dil)
         self.ws_bytes = lib.biu_conv_bwd_weight_workspace(xin.c, cout, self.kd, self.kh, self.kw, eng.dtype)
@@ -269,10 +279,20 @@ class ConvBlockNode(Node):
         bn = self.bn
         scale, shift = self.y.vec("scale"), self.y.vec("shift")
         cat = self.xin.parts if isinstance(self.xin, CatAct) else None
+        folded = None
+        if self.fold_src is not None:                       # up-sampling + conv on the coarse tensor: weights folded once per version
+            ver = (self.conv.weight.data_ptr(), self.conv.weight._version)
+            if self.fold_slot["ver"] != ver:
+                check(lib.biu_upconv_pack(_ptr(w), self.xin.c, self.y.c, eng.dtype, _ptr(self.fold_slot["buf"]), st), "upconv_pack")
+                self.fold_slot["ver"] = ver
+            folded = _ptr(self.fold_slot["buf"])
         if eng.bn_training(bn):
             # convolution + BatchNorm statistics in one call (the MFMA kernel reduces them in its epilogue)
             nblk = C.c_int(0)
-            if cat:
+            if folded:
+                check(lib.biu_upconv_fwd(self.fold_src.a(), self.fold_src.xf(), folded, _ptr(b), self.y.a(), _ptr(eng.partial),
+                                         eng.partial.numel(), C.byref(nblk), eng.dtype, st), "upconv_fwd")
+            elif cat:
                 check(lib.biu_conv_fwd_cat(cat[0].a(), cat[0].xf(), cat[1].a(), cat[1].xf(), _ptr(w), packed, _ptr(b), self.kd,
                                            self.kh, self.kw, self.dil, self.y.a(), _ptr(eng.partial), eng.partial.numel(),
                                            C.byref(nblk), _ptr(eng.ws), eng.ws_bytes, eng.dtype, st), "conv_fwd_cat")
@@ -290,7 +310,10 @@ class ConvBlockNode(Node):
                 eng.nbt_bump.append(bn.num_batches_tracked)
             self.batch_stats = True
         else:
-            if cat:
+            if folded:
+                check(lib.biu_upconv_fwd(self.fold_src.a(), self.fold_src.xf(), folded, _ptr(b), self.y.a(), None, 0, None, eng.dtype, st),
+                      "upconv_fwd")
+            elif cat:
                 check(lib.biu_conv_fwd_cat(cat[0].a(), cat[0].xf(), cat[1].a(), cat[1].xf(), _ptr(w), packed, _ptr(b), self.kd,
                                            self.kh, self.kw, self.dil, self.y.a(), None, 0, None, _ptr(eng.ws), eng.ws_bytes, eng.dtype, st), "conv_fwd_cat")
             else:
@@ -438,9 +461,12 @@ class ResampleNode(Node):
     def __init__(self, eng, kind: str, xin: Act, yout: Act):
         assert kind in ("maxpool", "down", "up", "trilinear")
         self.kind, self.xin, self.y = kind, xin, yout
+        self.only_for_backward = False       # an up-sampling whose only reader folds it into its forward: needed by that reader's backward alone
         xin.consumed()
 
     def fwd(self, eng):
+        if self.only_for_backward and not eng.grad_mode:
+            return
         f = {"maxpool": lib.biu_maxpool_fwd, "down": lib.biu_nearest_down_fwd, "up": lib.biu_nearest_up_fwd,
              "trilinear": lib.biu_trilinear_up_fwd}[self.kind]
         check(f(self.xin.a(), self.xin.xf(), self.y.a(), eng.dtype, _stream()), self.kind + "_fwd")

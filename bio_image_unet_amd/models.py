@@ -357,9 +357,12 @@ class _Body3D(_HipNet):
                 eng.add(E.ConvTNode(eng, getattr(self, f"up{lvl}"), t, u))
             elif up == "nearest_conv":
                 r = eng.new_act(sp, t.c, lazy=False)
-                eng.add(E.ResampleNode(eng, "up", t, r))
+                rs = E.ResampleNode(eng, "up", t, r)
+                eng.add(rs)
                 u = buf.slice(0, up_c[i], lazy=True)
-                eng.add(E.ConvBlockNode(eng, getattr(self, f"up{lvl}_conv"), r, u))
+                blk = E.ConvBlockNode(eng, getattr(self, f"up{lvl}_conv"), r, u, fold_src=t)      # forward folded onto the coarse tensor
+                rs.only_for_backward = blk.fold_src is not None
+                eng.add(blk)
             elif up == "trilinear":                       # F.interpolate(scale_factor=2, mode='trilinear') [unet3d/unet3d.py:82]
                 u = buf.slice(0, up_c[i], lazy=False)
                 assert u.c == t.c

@@ -149,6 +149,32 @@ class InSitu:
             y = (F.conv3d if nd3 else F.conv2d)(x, w, b, padding=dil if w.shape[-1] == 3 else 0, dilation=dil)
         return y if nd3 else y.unsqueeze(2)
 
+    def _fold_conv(self, xc, w32, b):
+        """The folded up-conv as the kernel computes it (include/biu.h: biu_upconv_fwd): per output parity p the taps of the 3x3x3 kernel
+        that read the same coarse voxel are summed in fp32 (ascending tap order, as k_pack_upconv does), rounded to the compute dtype,
+        and applied as a 2x2x2 kernel to the zero-padded coarse tensor xc: y[2v + p] = sum_t W'[p][t] xc[v + t - 1 + p]."""
+        n, c, d, h, w_ = xc.shape
+        cout = w32.shape[0]
+        xp = F.pad(xc, (1, 1, 1, 1, 1, 1))
+        y = torch.zeros(n, cout, 2 * d, 2 * h, 2 * w_, dtype=torch.float64)
+        cls = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}            # (parity, coarse tap) -> fine taps of one axis
+        for pd in range(2):
+            for ph in range(2):
+                for pw in range(2):
+                    k = torch.zeros(cout, c, 2, 2, 2, dtype=torch.float32)
+                    for td in range(2):
+                        for th in range(2):
+                            for tw in range(2):
+                                acc = torch.zeros(cout, c, dtype=torch.float32)
+                                for kd in cls[(pd, td)]:
+                                    for kh in cls[(ph, th)]:
+                                        for kw in cls[(pw, tw)]:
+                                            acc = acc + w32[:, :, kd, kh, kw]
+                                k[:, :, td, th, tw] = acc
+                    k = _r(k, self.bf16).double()
+                    y[:, :, pd::2, ph::2, pw::2] = F.conv3d(xp[:, :, pd:pd + d + 1, ph:ph + h + 1, pw:pw + w_ + 1], k, b)
+        return y
+
     def _parts(self, xin):
         return list(xin.parts) if isinstance(xin, E.CatAct) else [xin]
 
@@ -190,9 +216,16 @@ class InSitu:
         w = nd.conv.weight.detach().cpu().double()
         b = nd.conv.bias.detach().cpu().double() if nd.conv.bias is not None else None
         mf = self._mfma(nd.xin.c, nd.y.c, nd.dil, nd.kw)
-        if self.bf16 and mf:
-            a, w = _r(a.float(), True).double(), _r(w.float(), True).double()
-        want = self._conv(a, w, b, nd.dil)
+        if getattr(nd, "fold_src", None) is not None:
+            # forward folded onto the coarse tensor: same function of the fp32 weights, but the weights are rounded AFTER the fold
+            ac = act_T(nd.fold_src)
+            want = self._fold_conv(_r(ac.float(), self.bf16).double(), nd.conv.weight.detach().cpu().float(), b)
+            if not self.bf16:
+                assert float((want - self._conv(a, w, b, nd.dil)).abs().max()) <= 1e-5 * float(want.abs().max()), "fold emulation != conv of the up-sampled tensor"
+        else:
+            if self.bf16 and mf:
+                a, w = _r(a.float(), True).double(), _r(w.float(), True).double()
+            want = self._conv(a, w, b, nd.dil)
         y = act_raw(nd.y)
         self.close(lab, "conv output y", y, want)
         bn = nd.bn

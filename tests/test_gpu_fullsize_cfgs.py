@@ -146,8 +146,11 @@ def test_bf16_mask_agrees_with_fp32(cfg):
     mf.train()
     with torch.no_grad():
         ob, of = m_out(mb, xs), m_out(mf, xs)
+    # width of the band around the threshold inside which bf16 may decide differently: above the largest bf16-vs-fp32 deviation of the
+    # logits (cfg3 < 0.05 of the logit range; cfg5, 23 bf16 layers deep in 3-D: 0.057-0.067 measured, folded or unfolded up-convs alike)
+    frac = {"cfg5": 0.08}.get(cfg, 0.05)
     for lb, lf in zip(ob, of):
-        band = 0.05 * float(lf.abs().max())
+        band = frac * float(lf.abs().max())
         safe = lf.abs() > band
         assert float(safe.float().mean()) > 0.5
         assert bool(((lb > 0) == (lf > 0))[safe].all())

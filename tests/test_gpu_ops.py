@@ -397,6 +397,59 @@ def test_conv_mfma_fwd_dgrad(case, dtype):
     torch.testing.assert_close(db.cpu(), dyr.sum(dim=[0] + list(range(2, dyr.dim()))), rtol=1e-3, atol=1e-3 * float(dyr.abs().sum() ** 0.5))
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# nearest-neighbour up-sampling folded into the 3x3x3 convolution behind it (forward): 8 parity classes x 2x2x2 taps on the coarse tensor
+# ---------------------------------------------------------------------------------------------------------------
+UPCONV_CASES = [
+    # (N, Cin, Cout, coarse extent)  -- extents off the 4 x 8 x 16 brick, one / two / three output tiles, 16- and 32-channel chunks
+    (1, 32, 32, (4, 8, 16)),
+    (2, 64, 64, (3, 5, 9)),
+    (1, 48, 96, (5, 9, 17)),
+    (1, 16, 24, (2, 3, 20)),
+    (1, 128, 128, (4, 8, 8)),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", UPCONV_CASES)
+def test_upconv_fwd_matches_upsample_then_conv(case, dtype):
+    """biu_upconv_fwd == F.interpolate(scale_factor=2, mode='nearest') + Conv3d(k3, padding=1) on the lazily transformed input
+    (multi_output_unet3d/multi_output_unet3d.py:138-139), with the BatchNorm statistics of the stored output from its epilogue."""
+    n, cin, cout, sp = case
+    code = DT[dtype][1]
+    x = rnd(n, cin, *sp, seed=1)
+    w = rnd(cout, cin, 3, 3, 3, seed=2) * (1.0 / (cin * 27) ** 0.5)
+    b = rnd(cout, seed=3)
+    xf = XF(cin, seed=4)
+    xd = Dev(x, dtype=dtype, pitch=cin + 16, c0=8)
+    hi = tuple(2 * v for v in sp)
+    yd = Dev(shape=(n, cout, *hi), dtype=dtype, pitch=cout + 8, c0=8)
+    assert lib.biu_upconv_ok(xd.a(), yd.a(), code) == 1
+    xa = xf.apply(xd.ref())
+    if dtype == "bf16":
+        xa = xa.bfloat16().float()
+    yref = F.conv3d(F.interpolate(xa, scale_factor=2, mode="nearest"), w, b, padding=1)
+    wd, bd = w.cuda(), b.cuda()
+    pk = torch.empty(lib.biu_upconv_packed_bytes(cin, cout, code), dtype=torch.uint8, device="cuda")
+    check(lib.biu_upconv_pack(ptr(wd), cin, cout, code, ptr(pk), stream()), "upconv_pack")
+    nfl = lib.biu_upconv_fwd_stats_floats(xd.a(), yd.a())
+    part = torch.full((nfl,), float("nan"), device="cuda")
+    nblk = C.c_int(0)
+    check(lib.biu_upconv_fwd(xd.a(), xf.x(), ptr(pk), ptr(bd), yd.a(), ptr(part), nfl, C.byref(nblk), code, stream()), "upconv_fwd")
+    got = yd.get()
+    t = dict(rtol=1e-4, atol=1e-4 * float(yref.abs().max())) if dtype == "f32" else dict(rtol=1e-2, atol=1.5e-2 * float(yref.abs().max()))
+    torch.testing.assert_close(got, yref, **t)
+    assert torch.isnan(yd.buf[..., :8].float()).all()                       # channels outside the slice untouched
+    sums = part[:nblk.value * cout * 2].view(nblk.value, cout, 2).double().sum(0).cpu()
+    gd = got.double()
+    torch.testing.assert_close(sums[:, 0], gd.sum(dim=(0, 2, 3, 4)), rtol=1e-4, atol=1e-4 * float(gd.abs().sum() / cout))
+    torch.testing.assert_close(sums[:, 1], (gd * gd).sum(dim=(0, 2, 3, 4)), rtol=1e-4, atol=1e-6)
+    # without statistics
+    yd2 = Dev(shape=(n, cout, *hi), dtype=dtype)
+    check(lib.biu_upconv_fwd(xd.a(), xf.x(), ptr(pk), ptr(bd), yd2.a(), None, 0, None, code, stream()), "upconv_fwd (no statistics)")
+    assert torch.equal(yd2.get(), got)
+
+
 CONVT_MFMA_CASES = [
     # (nd, N, Cin, Cout, coarse spatial)
     (3, 1, 64, 64, (4, 8, 16)),

@@ -46,6 +46,12 @@ def _run(which, disable, tmp_path):
     ("unet3d_bf16", "wroll", 1e-6, 2.5e-4),
     ("unet3d_bf16", "wroll16", 1e-6, 2.5e-4),             # its form for a 16-channel plain operand (decode6) against the half-empty 32-row tile
     ("unet2d_bf16_n8", "wroll2d", 1e-6, 2.5e-4),            # its 2-D form (a batch of images as the depth axis)
+    # nearest up-sampling + upN_conv forward folded onto the coarse tensor (biu_upconv_fwd) against up-sample + conv (BIU_DISABLE=upconv):
+    # fp32: the same sums in another order; bf16: the folded weights are rounded after the fold, the unfolded ones tap by tap
+    ("mo3d_interp_f32", "upconv", 1e-5, 2e-2),
+    # (this network is the sensitive one of DESIGN section 4 -- nearest down-sampling, 23 bf16 layers: swapping the 16-row kernels on the SAME
+    # probe moves all gradients together by 0.206, the fold by 0.173; logits within 0.017-0.021 either way.  A wrong tap moves them by ~1)
+    ("mo3d_interp_bf16", "upconv", 3e-2, 0.25),
 ])
 def test_variant_matches_the_kernel_it_replaces(which, disable, tol_out, tol_grad, tmp_path):
     on, off = _run(which, None, tmp_path), _run(which, disable, tmp_path)
