@@ -328,10 +328,18 @@ extern "C" int biu_convt_pack(int kind, const float* w, int cin, int cout, int k
 extern "C" int biu_upconv_ok(const biu_act* x, const biu_act* y, int dtype) {
     return (x && y && !disabled("upconv") && biu_mfma_upconv_ok(x, y, dtype)) ? 1 : 0;
 }
-extern "C" size_t biu_upconv_packed_bytes(int cin, int cout, int dtype) { return biu_mfma_upconv_packed_bytes(cin, cout, dtype); }
-extern "C" int biu_upconv_pack(const float* w, int cin, int cout, int dtype, void* packed, biu_stream stream) {
-    BIU_REQUIRE(w && packed && biu_mfma_upconv_packed_bytes(cin, cout, dtype) > 0, BIU_ERR_SHAPE, "upconv_pack: null pointer or unsupported channels %d -> %d", cin, cout);
-    return biu_mfma_upconv_pack(w, cin, cout, dtype, packed, (hipStream_t)stream);
+extern "C" size_t biu_upconv_packed_bytes(int kind, int cin, int cout, int dtype) { return biu_mfma_upconv_packed_bytes(kind, cin, cout, dtype); }
+extern "C" int biu_upconv_pack(int kind, const float* w, int cin, int cout, int dtype, void* packed, biu_stream stream) {
+    BIU_REQUIRE(w && packed && biu_mfma_upconv_packed_bytes(kind, cin, cout, dtype) > 0, BIU_ERR_SHAPE,
+                "upconv_pack: null pointer, kind %d or unsupported channels %d -> %d", kind, cin, cout);
+    return biu_mfma_upconv_pack(kind, w, cin, cout, dtype, packed, (hipStream_t)stream);
+}
+extern "C" int biu_upconv_bwd_data(const biu_act* dy, const void* packed, const biu_act* dx, int accumulate, int dtype, biu_stream stream) {
+    BIU_REQUIRE(dy && dx && packed, BIU_ERR_SHAPE, "upconv_bwd_data: null pointer");
+    BIU_REQUIRE(biu_mfma_upconv_ok(dx, dy, dtype) && biu_mfma_upconv_packed_bytes(1, dx->c, dy->c, dtype) > 0, BIU_ERR_UNSUPPORTED,
+                "upconv_bwd_data: shape %dx%dx%dx%d c%d <- %dx%dx%dx%d c%d is not served by the folded kernel", dx->n, dx->d, dx->h, dx->w, dx->c,
+                dy->n, dy->d, dy->h, dy->w, dy->c);
+    return biu_mfma_upconv_dgrad(dy, packed, dx, accumulate, dtype, (hipStream_t)stream);
 }
 extern "C" size_t biu_upconv_fwd_stats_floats(const biu_act* x, const biu_act* y) {
     return (size_t)biu_mfma_upconv_stat_rows(x, y) * y->c * 2;

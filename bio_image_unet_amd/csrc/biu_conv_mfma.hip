@@ -158,6 +158,10 @@ struct ConvArgs {
     // CUs (the 16 x 16 images of a U-Net bottleneck).
     int ksplit;
     size_t y_zstride, y1_zstride;
+    // k_conv_pipe<T, 2, 2, 1, ...> ("fold"): 0 / 1 = forward of up-sampling + conv on the coarse tensor (parity = blockIdx.z, scattered
+    // store); 2 = its data gradient: the reduction runs over (output parity p, channel chunk) -- 8 x Cin / CK items per brick --, item
+    // (p, chunk) stages the parity-p sub-lattice of the fine tensor x (voxel 2u + p, a stride-2 gather), input voxel = grid voxel + tap - p
+    int fold;
 };
 
 #ifdef BIU_DIAG
@@ -276,7 +280,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     const int r = lane & 31, hf = lane >> 5;
     const bool has_xf = a.xs != nullptr || a.xs1 != nullptr;
     const size_t esz = sizeof(T);
-    const int nchunks = a.Cin / CK;
+    const bool fold_dg = FOLD && a.fold == 2;                  // folded data gradient: 8 parity classes x channel chunks form the reduction
+    const int nchunks_real = a.Cin / CK;
+    const int nchunks = fold_dg ? 8 * nchunks_real : nchunks_real;
     const int ksz = (a.ksplit > 1) ? (int)blockIdx.z : 0;
     const int c_begin = (a.ksplit > 1) ? (ksz * nchunks) / a.ksplit : 0;
     const int c_end = (a.ksplit > 1) ? ((ksz + 1) * nchunks) / a.ksplit : nchunks;
@@ -362,7 +368,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
         const int hh = t % HH;
         const int hd = t / HH;
         xs_[j] = (hv < HV) ? (unsigned)(hd | (hh << 10) | (hw << 20)) : 511u;
-        lvox[j] = (unsigned)((hd * a.IH + hh) * a.IW + hw);
+        lvox[j] = fold_dg ? (unsigned)((hd * 2 * a.IH + hh) * 2 * a.IW + hw)      // (x 2 below: voxel 2u + p of the fine tensor, extents 2 ID x 2 IH x 2 IW)
+                          : (unsigned)((hd * a.IH + hh) * a.IW + hw);
     }
     // weight slab of chunk ch: async global->LDS copy into the buffer the NEXT item reads (or into registers)
     auto issue_wpiece = [&](int ch, bool live, int j) {
@@ -395,10 +402,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
     __amdgpu_buffer_rsrc_t rs;
     auto issue_prep = [&](int brick, int ch, bool live) {
         const Org o = origin(brick);
-        // (fold: parity 0 of an axis reads coarse voxels v - 1, v; parity 1 reads v, v + 1)
-        const int gd0 = o.d0 * SD - PD - (FOLD ? 1 - (int)((blockIdx.z >> 2) & 1) : 0);
-        const int gh0 = o.h0 * S - PHW - (FOLD ? 1 - (int)((blockIdx.z >> 1) & 1) : 0);
-        const int gw0 = o.w0 * S - PHW - (FOLD ? 1 - (int)(blockIdx.z & 1) : 0);
+        // (fold, forward: parity 0 of an axis reads coarse voxels v - 1, v; parity 1 reads v, v + 1.  Data gradient: the item's parity class p
+        //  reads sub-lattice voxels u - p, u - p + 1)
+        const int fpar = fold_dg ? ch / nchunks_real : (int)blockIdx.z;
+        if (fold_dg) ch -= fpar * nchunks_real;
+        const int fpd = (fpar >> 2) & 1, fph = (fpar >> 1) & 1, fpw = fpar & 1;
+        const int gd0 = o.d0 * SD - PD - (FOLD ? (fold_dg ? fpd : 1 - fpd) : 0);
+        const int gh0 = o.h0 * S - PHW - (FOLD ? (fold_dg ? fph : 1 - fph) : 0);
+        const int gw0 = o.w0 * S - PHW - (FOLD ? (fold_dg ? fpw : 1 - fpw) : 0);
         const int lod = max(0, -gd0), loh = max(0, -gh0), low = max(0, -gw0);
         const int hid = min(HD - 1, a.ID - 1 - gd0), hih = min(HH - 1, a.IH - 1 - gh0), hiw = min(HW - 1, a.IW - 1 - gw0);
         c_lo = GBITS - (unsigned)(lod | (loh << 10) | (low << 20));     // x + c_lo keeps a guard bit iff x >= lo
@@ -409,8 +420,15 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv_pipe(ConvArgs a) {
         const char* xbase = s1 ? a.x1 : a.x;
         rowb = (unsigned)((s1 ? a.xpitch1 : a.xpitch) * (int)esz);
         const int cch = ch * CK - (s1 ? a.csplit : 0);
-        brb = (int)(unsigned)((long long)((gd0 * a.IH + gh0) * a.IW + gw0) * rowb + (long long)cch * (int)esz);
-        const size_t sample_bytes = (size_t)a.ID * a.IH * a.IW * rowb;        // < 2^32 - 64 Ki (checked on the host)
+        size_t sample_bytes = (size_t)a.ID * a.IH * a.IW * rowb;              // < 2^32 - 64 Ki (checked on the host)
+        if (fold_dg) {
+            // fine voxel (2 (gd0 + hd) + pd, ...) = 2 * lvox + the brick's base: the row pitch doubles, the base carries the parity
+            brb = (int)(unsigned)((long long)(((2 * gd0 + fpd) * 2 * a.IH + 2 * gh0 + fph) * 2 * a.IW + 2 * gw0 + fpw) * rowb + (long long)cch * (int)esz);
+            sample_bytes *= 8;
+            rowb *= 2;
+        } else {
+            brb = (int)(unsigned)((long long)((gd0 * a.IH + gh0) * a.IW + gw0) * rowb + (long long)cch * (int)esz);
+        }
         // a dead prefetch (nothing follows) reads through an empty descriptor: every piece is zero, nothing is fetched
         rs = __builtin_amdgcn_make_buffer_rsrc((void*)(xbase + (size_t)o.n * sample_bytes), 0, live ? (int)(unsigned)sample_bytes : 0, 0x00020000);
         inb_mask = 0;
@@ -1637,6 +1655,7 @@ static int launch_conv16(ConvArgs a, hipStream_t st) {
 }
 
 static void clear_cat(ConvArgs& a) {
+    a.fold = 0;
     a.ksplit = 1; a.y_zstride = a.y1_zstride = 0;
     a.x1 = nullptr; a.xpitch1 = 0; a.csplit = 0;
     a.xs1 = a.xb1 = a.xl1 = nullptr;
@@ -2069,6 +2088,31 @@ __global__ void k_pack_upconv(const float* __restrict__ w, int cin, int cout, in
     }
 }
 
+// packed image of the folded DATA GRADIENT: rows = input channels ci, reduction index kv = p * Cout + co over the 8 parity classes,
+// tap s = the coarse offset u - p + s it reads: W'[p][co][ci][t = 1 - s per axis].  out[ntile(ci)][kstep(kv)][tap s][lane]
+template <typename T>
+__global__ void k_pack_upconv_dgrad(const float* __restrict__ w, int cin, int cout, int nKSv, int ntiles, uint4* __restrict__ out) {
+    using F = Frag<T>;
+    constexpr int PE = F::PE;
+    const size_t total = (size_t)ntiles * nKSv * 8 * 64;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx % 64);
+        size_t r = idx / 64;
+        const int sidx = (int)(r % 8); r /= 8;
+        const int ks = (int)(r % nKSv);
+        const int nt = (int)(r / nKSv);
+        const int ci = nt * 32 + (lane & 31);
+        float f[PE];
+#pragma unroll
+        for (int e = 0; e < PE; ++e) {
+            const int kv = ks * 2 * PE + (lane >> 5) * PE + e;
+            const int p = kv / cout, co = kv - p * cout;
+            f[e] = (ci < cin && p < 8) ? fold_nearest_weight(w, cin, co, ci, p, 7 - sidx) : 0.f;
+        }
+        out[idx] = F::pack(f);
+    }
+}
+
 bool biu_mfma_upconv_ok(const biu_act* x, const biu_act* y, int dtype) {
     if (dtype != BIU_BF16 && dtype != BIU_F32) return false;
     if (y->n != x->n || y->d != 2 * x->d || y->h != 2 * x->h || y->w != 2 * x->w) return false;
@@ -2077,24 +2121,34 @@ bool biu_mfma_upconv_ok(const biu_act* x, const biu_act* y, int dtype) {
 static size_t upconv_slice16(int cin, int cout, int dtype) {                 // packed fragments (16 B) per parity class
     return (size_t)((cout + 31) / 32) * (cin / ks_of(dtype)) * 8 * 64;
 }
-size_t biu_mfma_upconv_packed_bytes(int cin, int cout, int dtype) {
-    if ((dtype != BIU_BF16 && dtype != BIU_F32) || !chan_ok(cin, cout, dtype)) return 0;
-    return 8 * upconv_slice16(cin, cout, dtype) * 16;
+// kind 0: forward image (8 parity slices);  kind 1: data-gradient image (reduction over 8 x Cout)
+size_t biu_mfma_upconv_packed_bytes(int kind, int cin, int cout, int dtype) {
+    if ((dtype != BIU_BF16 && dtype != BIU_F32) || (kind != 0 && kind != 1)) return 0;
+    if (kind == 0) return chan_ok(cin, cout, dtype) ? 8 * upconv_slice16(cin, cout, dtype) * 16 : 0;
+    if (!chan_ok(cout, cin, dtype)) return 0;
+    return (size_t)((cin + 31) / 32) * (8 * cout / ks_of(dtype)) * 8 * 64 * 16;
 }
-int biu_mfma_upconv_pack(const float* w, int cin, int cout, int dtype, void* packed, hipStream_t st) {
-    const size_t slice = upconv_slice16(cin, cout, dtype);
-    const int ntiles = (cout + 31) / 32, nKS = cin / ks_of(dtype);
-    BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_upconv<T>, dim3(grid_for((i64)slice, 256, 512), 8), dim3(256), 0, st, w, cin, cout, nKS, ntiles,
-                                                 (uint4*)packed));
+int biu_mfma_upconv_pack(int kind, const float* w, int cin, int cout, int dtype, void* packed, hipStream_t st) {
+    if (kind == 0) {
+        const size_t slice = upconv_slice16(cin, cout, dtype);
+        const int ntiles = (cout + 31) / 32, nKS = cin / ks_of(dtype);
+        BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_upconv<T>, dim3(grid_for((i64)slice, 256, 512), 8), dim3(256), 0, st, w, cin, cout, nKS, ntiles,
+                                                     (uint4*)packed));
+    } else {
+        const int ntiles = (cin + 31) / 32, nKSv = 8 * cout / ks_of(dtype);
+        BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_upconv_dgrad<T>, dim3(grid_for((i64)ntiles * nKSv * 8 * 64, 256, 4096)), dim3(256), 0, st, w, cin,
+                                                     cout, nKSv, ntiles, (uint4*)packed));
+    }
     BIU_CHECK_LAUNCH("upconv_pack");
     return BIU_OK;
 }
 template <typename T, int NT, int CKP>
-static int launch_upconv_cfg(const ConvArgs& a, int ntiles, hipStream_t st) { return launch_cfg<T, 2, 2, 1, 4, 8, 16, NT, CKP>(a, ntiles, 8, st); }
+static int launch_upconv_cfg(const ConvArgs& a, int ntiles, hipStream_t st) { return launch_cfg<T, 2, 2, 1, 4, 8, 16, NT, CKP>(a, ntiles, a.fold == 2 ? 1 : 8, st); }
 template <typename T>
 static int launch_upconv(const ConvArgs& a, hipStream_t st) {
     const int ntiles = (a.Cout + 31) / 32, nt = pick_nt(ntiles);
     const int e = 16 / (int)sizeof(T);                                       // channels per 16-byte piece
+    // (a data-gradient chunk must lie in ONE parity class: a.Cin = channels per class there)
     if (a.Cin % (4 * e) == 0) return nt == 1 ? launch_upconv_cfg<T, 1, 4>(a, ntiles, st) : launch_upconv_cfg<T, 2, 4>(a, ntiles, st);
     return nt == 1 ? launch_upconv_cfg<T, 1, 2>(a, ntiles, st) : launch_upconv_cfg<T, 2, 2>(a, ntiles, st);
 }
@@ -2130,6 +2184,33 @@ int biu_mfma_upconv_fwd(const biu_act* x, const biu_xform* xf, const void* packe
     a.accumulate = 0;
     a.diag = nullptr;
     a.nbd = a.nbh = a.nbw = 0;
+    a.fold = 1;
+    if (dtype == BIU_BF16) return launch_upconv<bf16_t>(a, st);
+    return launch_upconv<float>(a, st);
+}
+// data gradient of the folded up-conv: dx[u] (+)= sum_p sum_s W'[p][1 - s]^T . dy[2 (u - p + s) + p]   (dy fine, dx coarse)
+int biu_mfma_upconv_dgrad(const biu_act* dy, const void* packed, const biu_act* dx, int accumulate, int dtype, hipStream_t st) {
+    ConvArgs a;
+    clear_cat(a);
+    a.bn_partial = nullptr;
+    a.red_mode = 0; a.red_y = nullptr; a.red_ypitch = 0;
+    a.red_scale = a.red_shift = a.red_slope = a.red_mean = a.red_invstd = nullptr;
+    a.x = (const char*)dy->p;
+    a.y = (char*)dx->p;
+    a.wpk = (const uint4*)packed;
+    a.bias = nullptr;
+    a.xs = a.xb = a.xl = nullptr;
+    a.xpitch = dy->pitch; a.ypitch = dx->pitch;
+    a.N = dx->n;
+    a.GD = a.OD = a.ID = dx->d; a.GH = a.OH = a.IH = dx->h; a.GW = a.OW = a.IW = dx->w;      // (input extents: those of a parity sub-lattice of dy)
+    a.osd = a.osh = a.osw = 1;
+    a.Cin = dy->c; a.Cout = dx->c;
+    a.nKS = 8 * dy->c / ks_of(dtype);
+    a.wz_stride = 0;
+    a.accumulate = accumulate;
+    a.diag = nullptr;
+    a.nbd = a.nbh = a.nbw = 0;
+    a.fold = 2;
     if (dtype == BIU_BF16) return launch_upconv<bf16_t>(a, st);
     return launch_upconv<float>(a, st);
 }

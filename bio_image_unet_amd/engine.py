@@ -226,11 +226,12 @@ class ConvBlockNode(Node):
     def __init__(self, eng, seq: nn.Sequential, xin: Act, yout: Act, dropout_follows: bool = False, fold_src: Optional[Act] = None):
         """``fold_src``: ``xin`` is the nearest-neighbour up-sampling (x2) of this coarse activation
         (multi_output_unet3d/multi_output_unet3d.py:138-139).  The forward then runs folded on the coarse tensor
-        (``biu_upconv_fwd``: 8 parity classes x 2x2x2 taps instead of 27 taps, include/biu.h) when the kernel serves the shape; the
-        backward still reads ``xin``."""
+        (``biu_upconv_fwd``: 8 parity classes x 2x2x2 taps instead of 27 taps, include/biu.h) when the kernel serves the shape, and
+        the data gradient goes straight to ``fold_src`` (``biu_upconv_bwd_data``; the up-sampling node's backward then has nothing to
+        do); the weight gradient still reads ``xin``."""
         conv, bn = seq[0], seq[1]
         self.conv, self.bn, self.xin, self.y = conv, bn, xin, yout
-        self.fold_src, self.fold_slot = None, None
+        self.fold_src, self.fold_slot, self.fold_dg_slot = None, None, None
         # the block's activation as a leaky slope: LeakyReLU(s) -> s, ReLU -> 0 (Unet_v0 / BabyUnet), none or a later
         # non-piecewise-linear one (the attention gate's Sigmoid, applied by GateNode) -> 1
         act = seq[2] if len(seq) > 2 else None
@@ -258,7 +259,10 @@ class ConvBlockNode(Node):
         if (fold_src is not None and (self.kd, self.kh, self.kw, self.dil) == (3, 3, 3, 1) and not isinstance(xin, CatAct)
                 and fold_src.c == xin.c and lib.biu_upconv_ok(fold_src.a(), yout.a(), eng.dtype)):
             self.fold_src = fold_src
-            self.fold_slot = {"buf": torch.empty(lib.biu_upconv_packed_bytes(xin.c, cout, eng.dtype), dtype=torch.uint8, device=dev), "ver": None}
+            self.fold_slot = {"buf": torch.empty(lib.biu_upconv_packed_bytes(0, xin.c, cout, eng.dtype), dtype=torch.uint8, device=dev), "ver": None}
+            nb1 = lib.biu_upconv_packed_bytes(1, xin.c, cout, eng.dtype)
+            if nb1:
+                self.fold_dg_slot = {"buf": torch.empty(nb1, dtype=torch.uint8, device=dev), "ver": None}
             eng.need_partial_floats(lib.biu_upconv_fwd_stats_floats(fold_src.a(), yout.a()))
         self.pk_f = eng.packed_slot(0, xin.c, cout, self.kd, self.kh, self.kw, self.dil)
         self.pk_b = eng.packed_slot(1, xin.c, cout, self.kd, self.kh, self.kw, self.dil)
@@ -283,7 +287,7 @@ class ConvBlockNode(Node):
         if self.fold_src is not None:                       # up-sampling + conv on the coarse tensor: weights folded once per version
             ver = (self.conv.weight.data_ptr(), self.conv.weight._version)
             if self.fold_slot["ver"] != ver:
-                check(lib.biu_upconv_pack(_ptr(w), self.xin.c, self.y.c, eng.dtype, _ptr(self.fold_slot["buf"]), st), "upconv_pack")
+                check(lib.biu_upconv_pack(0, _ptr(w), self.xin.c, self.y.c, eng.dtype, _ptr(self.fold_slot["buf"]), st), "upconv_pack")
                 self.fold_slot["ver"] = ver
             folded = _ptr(self.fold_slot["buf"])
         if eng.bn_training(bn):
@@ -371,6 +375,15 @@ class ConvBlockNode(Node):
                   "conv_bwd_data_cat")
             cat[0].mark_g()
             cat[1].mark_g()
+        elif self.fold_dg_slot is not None and eng.wants_grad(self.fold_src):
+            # folded: d loss / d (coarse input) in one launch; xin's gradient is never written, so the up-sampling node's backward returns
+            ver = (self.conv.weight.data_ptr(), self.conv.weight._version)
+            if self.fold_dg_slot["ver"] != ver:
+                check(lib.biu_upconv_pack(1, _ptr(self.conv.weight.data), self.xin.c, cout, eng.dtype, _ptr(self.fold_dg_slot["buf"]), st), "upconv_pack")
+                self.fold_dg_slot["ver"] = ver
+            check(lib.biu_upconv_bwd_data(y.g(), _ptr(self.fold_dg_slot["buf"]), self.fold_src.g(), int(self.fold_src.g_written()), eng.dtype, st),
+                  "upconv_bwd_data")
+            self.fold_src.mark_g()
         elif eng.wants_grad(self.xin):
             packed = eng.pack(self.pk_b, 1, self.conv.weight, self.xin.c, cout, self.kd, self.kh, self.kw)
             up = _fusable_producer(self.xin)

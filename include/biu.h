@@ -223,14 +223,17 @@ int biu_nearest_up_bwd(const biu_act* dout, const biu_act* dx, int accumulate, i
  *   y[2v + p] = bias + sum_{t in {0,1}^3} W'[p][t] . T(x)[v + t - 1 + p]      p = output parity per axis, x = the coarse tensor (D,H,W),
  *   W'[p][t] = the sum of the conv's taps that read the same coarse voxel (8 x 8 tap groups instead of 27 taps: 0.30 x the FLOPs),
  * identical to the convolution of the up-sampled tensor up to fp32 summation order (coarse zero padding = fine zero padding).
- * y is (2D, 2H, 2W).  The backward of the block still runs on the up-sampled tensor (biu_nearest_up_fwd + biu_conv_bwd_*).
- * biu_upconv_ok: shapes / channels the folded kernel serves (else: up-sample + biu_conv_fwd).  biu_upconv_pack folds and packs
- * w (Cout, Cin, 3, 3, 3) fp32 into `packed` (biu_upconv_packed_bytes).  bn_partial may be NULL (no statistics); with it,
- * *bn_nblk partial rows of [Cout][2] (sum, sum of squares) are written, as biu_conv_fwd_stats does
- * (biu_upconv_fwd_stats_floats sizes the buffer). */
+ * y is (2D, 2H, 2W).  biu_upconv_bwd_data is the matching data gradient straight onto the coarse tensor (replaces biu_conv_bwd_data +
+ * biu_nearest_up_bwd):   dx[u] (+)= sum_p sum_{s in {0,1}^3} W'[p][1 - s]^T . dy[2 (u - p + s) + p];   the weight gradient of the block
+ * still runs on the up-sampled tensor (biu_nearest_up_fwd + biu_conv_bwd_weight_bn).
+ * biu_upconv_ok: shapes / channels the folded kernels serve (else: up-sample + biu_conv_*).  biu_upconv_pack folds and packs
+ * w (Cout, Cin, 3, 3, 3) fp32 into `packed` (biu_upconv_packed_bytes; kind 0 = forward image, 1 = data-gradient image).
+ * bn_partial may be NULL (no statistics); with it, *bn_nblk partial rows of [Cout][2] (sum, sum of squares) are written, as
+ * biu_conv_fwd_stats does (biu_upconv_fwd_stats_floats sizes the buffer). */
 int    biu_upconv_ok(const biu_act* x, const biu_act* y, int dtype);
-size_t biu_upconv_packed_bytes(int cin, int cout, int dtype);
-int    biu_upconv_pack(const float* w, int cin, int cout, int dtype, void* packed, biu_stream stream);
+size_t biu_upconv_packed_bytes(int kind, int cin, int cout, int dtype);
+int    biu_upconv_pack(int kind, const float* w, int cin, int cout, int dtype, void* packed, biu_stream stream);
+int    biu_upconv_bwd_data(const biu_act* dy, const void* packed, const biu_act* dx, int accumulate, int dtype, biu_stream stream);
 size_t biu_upconv_fwd_stats_floats(const biu_act* x, const biu_act* y);
 int    biu_upconv_fwd(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, const biu_act* y,
                       float* bn_partial, size_t bn_partial_floats, int* bn_nblk, int dtype, biu_stream stream);

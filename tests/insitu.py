@@ -359,6 +359,7 @@ class InSitu:
             return None
         parts = self._parts(nd.xin)
         return dict(da=act_grad(nd.y), gx=[self._gsnap(p) for p in parts],
+                    gfold=self._gsnap(nd.fold_src) if getattr(nd, "fold_dg_slot", None) is not None else None,
                     pg={p: (self.eng.grads[p].detach().cpu().double().clone() if p in self.eng.grads else None) for p in nd.params})
 
     def _pgrad(self, nd, s, p):
@@ -399,7 +400,15 @@ class InSitu:
         self.vec_close(lab, "dW", self._pgrad(nd, s, nd.conv.weight), gw, rel=2e-4, floor=3e-5)
         # data gradient(s)
         parts = self._parts(nd.xin)
-        if any(self.eng.wants_grad(p) if isinstance(p, E.Act) else True for p in parts):
+        if getattr(nd, "fold_dg_slot", None) is not None:
+            # folded: the gradient goes straight to the coarse tensor (biu_upconv_bwd_data); the kernel's weights are the folded ones
+            xc = _r(act_T(nd.fold_src).float(), self.bf16).double().requires_grad_(True)
+            (gc,) = torch.autograd.grad(self._fold_conv(xc, nd.conv.weight.detach().cpu().float(), None), xc, dy_got)
+            if s["gfold"] is not None:
+                gc = gc + s["gfold"]
+            self.close(lab, "dx (coarse, folded)" + (" (accumulated)" if s["gfold"] is not None else ""), act_grad(nd.fold_src), gc)
+            assert not nd.xin.g_written(), "the up-sampled tensor's gradient must stay unwritten when the data gradient is folded"
+        elif any(self.eng.wants_grad(p) if isinstance(p, E.Act) else True for p in parts):
             out2 = self._conv(av, wq, None, nd.dil)
             (gx,) = torch.autograd.grad(out2, av, dy_got)
             o = 0

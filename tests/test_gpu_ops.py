@@ -428,17 +428,18 @@ def test_upconv_fwd_matches_upsample_then_conv(case, dtype):
     xa = xf.apply(xd.ref())
     if dtype == "bf16":
         xa = xa.bfloat16().float()
+    xa.requires_grad_(True)
     yref = F.conv3d(F.interpolate(xa, scale_factor=2, mode="nearest"), w, b, padding=1)
     wd, bd = w.cuda(), b.cuda()
-    pk = torch.empty(lib.biu_upconv_packed_bytes(cin, cout, code), dtype=torch.uint8, device="cuda")
-    check(lib.biu_upconv_pack(ptr(wd), cin, cout, code, ptr(pk), stream()), "upconv_pack")
+    pk = torch.empty(lib.biu_upconv_packed_bytes(0, cin, cout, code), dtype=torch.uint8, device="cuda")
+    check(lib.biu_upconv_pack(0, ptr(wd), cin, cout, code, ptr(pk), stream()), "upconv_pack")
     nfl = lib.biu_upconv_fwd_stats_floats(xd.a(), yd.a())
     part = torch.full((nfl,), float("nan"), device="cuda")
     nblk = C.c_int(0)
     check(lib.biu_upconv_fwd(xd.a(), xf.x(), ptr(pk), ptr(bd), yd.a(), ptr(part), nfl, C.byref(nblk), code, stream()), "upconv_fwd")
     got = yd.get()
     t = dict(rtol=1e-4, atol=1e-4 * float(yref.abs().max())) if dtype == "f32" else dict(rtol=1e-2, atol=1.5e-2 * float(yref.abs().max()))
-    torch.testing.assert_close(got, yref, **t)
+    torch.testing.assert_close(got, yref.detach(), **t)
     assert torch.isnan(yd.buf[..., :8].float()).all()                       # channels outside the slice untouched
     sums = part[:nblk.value * cout * 2].view(nblk.value, cout, 2).double().sum(0).cpu()
     gd = got.double()
@@ -448,6 +449,21 @@ def test_upconv_fwd_matches_upsample_then_conv(case, dtype):
     yd2 = Dev(shape=(n, cout, *hi), dtype=dtype)
     check(lib.biu_upconv_fwd(xd.a(), xf.x(), ptr(pk), ptr(bd), yd2.a(), None, 0, None, code, stream()), "upconv_fwd (no statistics)")
     assert torch.equal(yd2.get(), got)
+    # data gradient straight onto the coarse tensor (= nearest_up_bwd(conv_bwd_data(dy))), plain and accumulated
+    dyd = Dev(rnd(n, cout, *hi, seed=5), dtype=dtype, pitch=cout + 8, c0=0)
+    yref.backward(dyd.ref())
+    if lib.biu_upconv_packed_bytes(1, cin, cout, code) == 0:               # (bf16, Cout = 24: a reduction chunk would straddle two parity classes)
+        assert (cin, cout, dtype) == (16, 24, "bf16")
+        return
+    pk1 = torch.empty(lib.biu_upconv_packed_bytes(1, cin, cout, code), dtype=torch.uint8, device="cuda")
+    check(lib.biu_upconv_pack(1, ptr(wd), cin, cout, code, ptr(pk1), stream()), "upconv_pack (data gradient)")
+    dxd = Dev(shape=(n, cin, *sp), dtype=dtype, pitch=cin + 8, c0=8)
+    check(lib.biu_upconv_bwd_data(dyd.a(), ptr(pk1), dxd.a(), 0, code, stream()), "upconv_bwd_data")
+    t2 = dict(rtol=1e-4, atol=1e-4 * float(xa.grad.abs().max())) if dtype == "f32" else dict(rtol=1e-2, atol=1.5e-2 * float(xa.grad.abs().max()))
+    torch.testing.assert_close(dxd.get(), xa.grad, **t2)
+    check(lib.biu_upconv_bwd_data(dyd.a(), ptr(pk1), dxd.a(), 1, code, stream()), "upconv_bwd_data (accumulate)")
+    torch.testing.assert_close(dxd.get(), 2 * xa.grad, rtol=2 * t2["rtol"], atol=2 * t2["atol"])
+    assert torch.isnan(dxd.buf[..., :8].float()).all()
 
 
 CONVT_MFMA_CASES = [

@@ -39,12 +39,12 @@ for name, n, c, (d, h, w) in (("up3_conv", 1, 128, (64, 128, 128)), ("up2_conv",
     ax, au, ay = biu_act(x.data_ptr(), n, d, h, w, c, c), biu_act(u.data_ptr(), n, 2 * d, 2 * h, 2 * w, c, c), biu_act(y.data_ptr(), n, 2 * d, 2 * h, 2 * w, c, c)
     pk = torch.empty(lib.biu_conv_packed_bytes(0, c, c, 3, 3, 3, 1, code), dtype=torch.uint8, device="cuda")
     check(lib.biu_conv_pack(0, P(wt), c, c, 3, 3, 3, code, P(pk), st))
-    pf = torch.empty(lib.biu_upconv_packed_bytes(c, c, code), dtype=torch.uint8, device="cuda")
+    pf = torch.empty(lib.biu_upconv_packed_bytes(0, c, c, code), dtype=torch.uint8, device="cuda")
     stat = torch.empty(max(lib.biu_conv_fwd_stats_floats(C.byref(ay), 3), lib.biu_upconv_fwd_stats_floats(C.byref(ax), C.byref(ay))), device="cuda")
     nblk = C.c_int(0)
     t_up = timed(lambda: check(lib.biu_nearest_up_fwd(C.byref(ax), C.byref(xf), C.byref(au), code, st)))
     t_cv = timed(lambda: check(lib.biu_conv_fwd_stats(C.byref(au), None, P(wt), P(pk), P(bias), 3, 3, 3, 1, C.byref(ay), P(stat), stat.numel(), C.byref(nblk), None, 0, code, st)))
-    t_pk = timed(lambda: check(lib.biu_upconv_pack(P(wt), c, c, code, P(pf), st)))
+    t_pk = timed(lambda: check(lib.biu_upconv_pack(0, P(wt), c, c, code, P(pf), st)))
     t_fd = timed(lambda: check(lib.biu_upconv_fwd(C.byref(ax), C.byref(xf), P(pf), P(bias), C.byref(ay), P(stat), stat.numel(), C.byref(nblk), code, st)))
     yref = y.clone()                                          # (the timed loop above left the unfolded result in y before the folded one overwrote it?  recompute both)
     check(lib.biu_conv_fwd_stats(C.byref(au), None, P(wt), P(pk), P(bias), 3, 3, 3, 1, C.byref(ay), P(stat), stat.numel(), C.byref(nblk), None, 0, code, st))
