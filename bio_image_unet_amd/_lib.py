@@ -80,6 +80,8 @@ SIGNATURES = {
     "biu_upconv_packed_bytes": (_Z, [_I, _I, _I, _I]),
     "biu_upconv_pack": (_I, [_I, _P, _I, _I, _I, _P, _P]),
     "biu_upconv_bwd_data": (_I, [_A, _P, _A, _I, _I, _P]),
+    "biu_upconv_bwd_weight_workspace": (_Z, [_I, _I, _I]),
+    "biu_upconv_bwd_weight_bn": (_I, [_A, _X, _A, _A, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _P]),
     "biu_upconv_fwd_stats_floats": (_Z, [_A, _A]),
     "biu_upconv_fwd": (_I, [_A, _X, _P, _P, _A, _P, _Z, C.POINTER(C.c_int), _I, _P]),
     "biu_nearest_up_bwd": (_I, [_A, _A, _I, _I, _P]),

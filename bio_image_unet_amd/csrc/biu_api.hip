@@ -334,6 +334,25 @@ extern "C" int biu_upconv_pack(int kind, const float* w, int cin, int cout, int 
                 "upconv_pack: null pointer, kind %d or unsupported channels %d -> %d", kind, cin, cout);
     return biu_mfma_upconv_pack(kind, w, cin, cout, dtype, packed, (hipStream_t)stream);
 }
+extern "C" size_t biu_upconv_bwd_weight_workspace(int cin, int cout, int dtype) { return biu_mfma_upconv_wgrad_workspace(cin, cout, dtype); }
+extern "C" int biu_upconv_bwd_weight_bn(const biu_act* x, const biu_xform* xf, const biu_act* da, const biu_act* y, const float* scale,
+                                        const float* shift, const float* slope, const float* coefA, const float* coefB, const float* coefC,
+                                        float* dw, void* ws, size_t ws_bytes, int dtype, biu_stream stream) {
+    BIU_REQUIRE(x && da && dw && ws, BIU_ERR_SHAPE, "upconv_bwd_weight_bn: null pointer");
+    BIU_REQUIRE(biu_mfma_upconv_ok(x, da, dtype) && biu_mfma_upconv_wgrad_workspace(x->c, da->c, dtype) > 0, BIU_ERR_UNSUPPORTED,
+                "upconv_bwd_weight_bn: shape %dx%dx%dx%d c%d / %dx%dx%dx%d c%d is not served by the folded kernel", x->n, x->d, x->h, x->w, x->c,
+                da->n, da->d, da->h, da->w, da->c);
+    if (y) {
+        BIU_REQUIRE(valid_act(y) && same_space(y, da) && y->c == da->c && scale && shift && coefA && coefB && coefC, BIU_ERR_SHAPE,
+                    "upconv_bwd_weight_bn: y / coefficient vectors do not match da");
+        const size_t es = dsize(dtype);
+        BIU_REQUIRE(((uintptr_t)y->p % 16) == 0 && ((size_t)y->pitch * es) % 16 == 0 && (i64)y->d * y->h * y->w * y->pitch * (i64)es < (1LL << 32) - 65536,
+                    BIU_ERR_UNSUPPORTED, "upconv_bwd_weight_bn: y is not 16-byte aligned or a sample exceeds 4 GB");
+        BnBwdFuse bn{y, scale, shift, slope, coefA, coefB, coefC};
+        return biu_mfma_upconv_wgrad(x, xf, da, dw, ws, ws_bytes, dtype, (hipStream_t)stream, &bn);
+    }
+    return biu_mfma_upconv_wgrad(x, xf, da, dw, ws, ws_bytes, dtype, (hipStream_t)stream, nullptr);
+}
 extern "C" int biu_upconv_bwd_data(const biu_act* dy, const void* packed, const biu_act* dx, int accumulate, int dtype, biu_stream stream) {
     BIU_REQUIRE(dy && dx && packed, BIU_ERR_SHAPE, "upconv_bwd_data: null pointer");
     BIU_REQUIRE(biu_mfma_upconv_ok(dx, dy, dtype) && biu_mfma_upconv_packed_bytes(1, dx->c, dy->c, dtype) > 0, BIU_ERR_UNSUPPORTED,

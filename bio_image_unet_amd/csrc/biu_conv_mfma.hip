@@ -2262,6 +2262,10 @@ struct WgradArgs {
     // ConvTranspose launches (S == 2: the tapped tile holds every fine voxel of the brick exactly once): per-channel sums of the tapped
     // operand (= d bias), accumulated while its pieces are committed to LDS, by the blocks of the first plain-operand tile; zeroed by the host
     float* dbias_out;
+    // k_wgrad_pipe<T, 2, 2, 1, ...> ("fold": weight gradient of nearest up-sampling + conv, one launch per output parity class):
+    // fold_par = -1: off; else p = (pd << 2 | ph << 1 | pw): the plain operand (and y) is the parity-p sub-lattice of a FINE tensor of extents
+    // 2 GD x 2 GH x 2 GW (voxel 2v + p, a stride-2 gather), the tapped operand voxel = grid voxel + tap - (1 - p)
+    int fold_par;
 };
 
 template <typename T, int PE>
@@ -2303,6 +2307,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     constexpr int CTA = CT * NI, PPVA = CTA / PE, RSA = CTA * LES;
     constexpr int PD = (KD == 3) ? 1 : 0;
     constexpr int PHW = (KHW == 3) ? 1 : 0;
+    constexpr bool FOLD = (KD == 2 && KHW == 2 && S == 1);   // up-sampling folded into the conv: one parity class per launch (WgradArgs::fold_par)
     constexpr int SD = (KD == 1) ? 1 : S;
     constexpr int HD = (TD - 1) * SD + KD, HH = (TH - 1) * S + KHW, HW = (TW - 1) * S + KHW;
     constexpr int HV = HD * HH * HW;
@@ -2454,8 +2459,13 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         const unsigned xv = (i < HV * PPV && bpiece_ok) ? (unsigned)((t / HH) | ((t % HH) << 10) | (hw << 20)) : 511u;
         if constexpr (TAB_LDS) ltab[(NA + j) * NTHR + tid] = xv; else xb_[j] = xv;
     }
-    const int rowA = a.apitch * (int)esz, rowY = a.ypitch * (int)esz, rowB = bpitch_ * (int)esz;
-    const size_t sampA = (size_t)a.GD * a.GH * a.GW * rowA, sampY = (size_t)a.GD * a.GH * a.GW * rowY;
+    // (fold: the plain operand is gathered with stride 2 from the fine tensor -- doubled row / plane / voxel strides, parity in the base)
+    const int fgs = FOLD ? 2 : 1;
+    const int fpd = FOLD ? (a.fold_par >> 2) & 1 : 0, fph = FOLD ? (a.fold_par >> 1) & 1 : 0, fpw = FOLD ? a.fold_par & 1 : 0;
+    const unsigned GHa = (unsigned)(a.GH * fgs), GWa = (unsigned)(a.GW * fgs);
+    const int rowA1 = a.apitch * (int)esz, rowY1 = a.ypitch * (int)esz;
+    const int rowA = rowA1 * fgs, rowY = rowY1 * fgs, rowB = bpitch_ * (int)esz;
+    const size_t sampA = (size_t)a.GD * a.GH * a.GW * rowA1 * (FOLD ? 8 : 1), sampY = (size_t)a.GD * a.GH * a.GW * rowY1 * (FOLD ? 8 : 1);
     const size_t sampB = (size_t)a.BD * a.BH * a.BW * rowB;                  // all < 2^31 (checked on the host)
     unsigned ca_hi = 0, cb_lo = 0, cb_hi = 0;
     int brA = 0, brY = 0, brB = 0;
@@ -2468,10 +2478,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         const int n = b / a.nbd;
         const int d0 = bd * TD, h0 = bh * TH, w0 = bw * TW;
         ca_hi = GBITS + (unsigned)(min(TD - 1, a.GD - 1 - d0) | (min(TH - 1, a.GH - 1 - h0) << 10) | (min(TW - 1, a.GW - 1 - w0) << 20));
-        const int va = (d0 * a.GH + h0) * a.GW + w0;
-        brA = (int)(unsigned)((long long)va * rowA + ac0 * (int)esz);          // mod 2^32, see k_conv_pipe
-        brY = (int)(unsigned)((long long)va * rowY + ac0 * (int)esz);
-        const int gd0 = d0 * SD - PD, gh0 = h0 * S - PHW, gw0 = w0 * S - PHW;
+        const int va = FOLD ? (((2 * d0 + fpd) * 2 * a.GH + 2 * h0 + fph) * 2 * a.GW + 2 * w0 + fpw) : (d0 * a.GH + h0) * a.GW + w0;
+        brA = (int)(unsigned)((long long)va * rowA1 + ac0 * (int)esz);         // mod 2^32, see k_conv_pipe
+        brY = (int)(unsigned)((long long)va * rowY1 + ac0 * (int)esz);
+        const int gd0 = d0 * SD - PD - (FOLD ? 1 - fpd : 0), gh0 = h0 * S - PHW - (FOLD ? 1 - fph : 0), gw0 = w0 * S - PHW - (FOLD ? 1 - fpw : 0);
         cb_lo = GBITS - (unsigned)(max(0, -gd0) | (max(0, -gh0) << 10) | (max(0, -gw0) << 20));
         cb_hi = GBITS + (unsigned)(min(HD - 1, a.BD - 1 - gd0) | (min(HH - 1, a.BH - 1 - gh0) << 10) | (min(HW - 1, a.BW - 1 - gw0) << 20));
         brB = (int)(unsigned)((long long)((gd0 * a.BH + gh0) * a.BW + gw0) * rowB + bc_local * (int)esz);
@@ -2488,7 +2498,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     auto issue_a = [&](int j) {
         const unsigned x = TAB_LDS ? ltab[j * NTHR + tid] : xa_[TAB_LDS ? 0 : j];
         const bool ok = ((ca_hi - x) & GBITS) == GBITS;
-        const int v = (int)__umul24(__umul24(x & 511u, (unsigned)a.GH) + ((x >> 10) & 511u), (unsigned)a.GW) + (int)(x >> 20);
+        const int v = (int)__umul24(__umul24(x & 511u, GHa) + ((x >> 10) & 511u), GWa) + (int)(x >> 20);
         pa[j] = ld128(rsA, ok ? (int)(__umul24((unsigned)v, (unsigned)rowA) + (unsigned)brA) : -1);
         if (bn_fused) pyv[j] = ld128(rsY, ok ? (int)(__umul24((unsigned)v, (unsigned)rowY) + (unsigned)brY) : -1);
         amask |= ok ? (1u << j) : 0u;
@@ -2548,7 +2558,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                         if (a.write_back) {                                      // dy replaces da (only in the launch that owns it)
                             typedef unsigned v4u __attribute__((ext_vector_type(4)));
                             const unsigned x = TAB_LDS ? ltab[j * NTHR + tid] : xa_[TAB_LDS ? 0 : j];
-                            const int v = (int)__umul24(__umul24(x & 511u, (unsigned)a.GH) + ((x >> 10) & 511u), (unsigned)a.GW) + (int)(x >> 20);
+                            const int v = (int)__umul24(__umul24(x & 511u, GHa) + ((x >> 10) & 511u), GWa) + (int)(x >> 20);
                             __builtin_amdgcn_raw_buffer_store_b128(v4u{pa[j].x, pa[j].y, pa[j].z, pa[j].w}, rsA, (int)(__umul24((unsigned)v, (unsigned)rowA) + (unsigned)brA), 0, 0);
                         }
                     }
@@ -3684,6 +3694,7 @@ int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int
     a.pa = (const char*)dy->p;  a.apitch = dy->pitch;  a.CA = dy->c;      // plain operand: dy  (rows i = co)
     a.pb = (const char*)x->p;   a.bpitch = x->pitch;   a.CB = x->c;       // tapped operand: x (cols j = ci)
     a.dbias_out = nullptr;
+    a.fold_par = -1;
     a.pb1 = nullptr; a.bpitch1 = 0; a.bsplit = 0; a.bs1_ = a.bb1_ = a.bl1_ = nullptr;
     if (x1) {                                                              // x = concat(x, x1)
         a.pb1 = (const char*)x1->p; a.bpitch1 = x1->pitch; a.bsplit = x->c; a.CB = x->c + x1->c;
@@ -3720,6 +3731,69 @@ int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int
     return BIU_OK;
 }
 
+// ---- weight gradient of nearest up-sampling + 3x3x3 conv on the coarse tensor ("fold") ------------------------------------------
+//   G[p][t][co][ci] = sum_v dy[2v + p][co] * T(x)[v + t - 1 + p][ci]          one launch per output parity class p (k_wgrad_pipe<T, 2, 2, 1>)
+//   dW[co][ci][k]   = sum_p G[p][t_p(k)]                                      t_p(k): the coarse tap the fine tap k reads under parity p
+__global__ void k_upconv_wgrad_unfold(const float* __restrict__ ws, size_t slice_f, int cout, int cin, float* __restrict__ dw) {
+    const size_t total = (size_t)cout * cin * 27;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % 27);
+        const size_t r = idx / 27;
+        const int ci = (int)(r % cin), co = (int)(r / cin);
+        const int kk[3] = {k / 9, (k / 3) % 3, k % 3};
+        float sum = 0.f;
+        for (int p = 0; p < 8; ++p) {
+            int t = 0;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const int pa = (p >> (2 - ax)) & 1;
+                const int ta = pa == 0 ? (kk[ax] >= 1 ? 1 : 0) : (kk[ax] == 2 ? 1 : 0);
+                t |= ta << (2 - ax);
+            }
+            sum += ws[(size_t)p * slice_f + ((size_t)t * cout + co) * cin + ci];
+        }
+        dw[idx] = sum;
+    }
+}
+size_t biu_mfma_upconv_wgrad_workspace(int cin, int cout, int dtype) {
+    if ((dtype != BIU_BF16 && dtype != BIU_F32) || !wgrad_chan_ok(cin, cout)) return 0;
+    return 8 * wgrad_acc_bytes(cout, cin, 8);
+}
+int biu_mfma_upconv_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, float* dw, void* ws, size_t ws_bytes, int dtype,
+                          hipStream_t st, const BnBwdFuse* bn) {
+    WgradArgs a;
+    if (bn) {
+        a.py = (const char*)bn->y->p; a.ypitch = bn->y->pitch;
+        a.bn_scale = bn->scale; a.bn_shift = bn->shift; a.bn_slope = bn->slope;
+        a.bn_cA = bn->cA; a.bn_cB = bn->cB; a.bn_cC = bn->cC;
+    } else {
+        a.py = nullptr; a.ypitch = 0;
+        a.bn_scale = a.bn_shift = a.bn_slope = a.bn_cA = a.bn_cB = a.bn_cC = nullptr;
+    }
+    a.pa = (const char*)dy->p;  a.apitch = dy->pitch;  a.CA = dy->c;      // plain operand: the parity sub-lattice of the FINE dy (rows i = co)
+    a.pb = (const char*)x->p;   a.bpitch = x->pitch;   a.CB = x->c;       // tapped operand: the coarse x (cols j = ci)
+    a.dbias_out = nullptr;
+    a.pb1 = nullptr; a.bpitch1 = 0; a.bsplit = 0; a.bs1_ = a.bb1_ = a.bl1_ = nullptr;
+    a.as_ = a.ab_ = a.al_ = nullptr;
+    int rc = wgrad_xf(xf, &a.bs_, &a.bb_, &a.bl_);
+    if (rc) return rc;
+    a.N = x->n;
+    a.GD = a.BD = x->d; a.GH = a.BH = x->h; a.GW = a.BW = x->w;          // brick grid = the coarse grid
+    const size_t slice = wgrad_acc_bytes(a.CA, a.CB, 8);
+    BIU_REQUIRE(ws_bytes >= 8 * slice, BIU_ERR_WORKSPACE, "upconv_wgrad: workspace %zu too small (need %zu)", ws_bytes, 8 * slice);
+    if (int zr = zero_ws(ws, 8 * slice, nullptr, 0, st)) return zr;
+    for (int p = 0; p < 8; ++p) {
+        a.ws = (float*)((char*)ws + (size_t)p * slice);
+        a.fold_par = p;
+        rc = dtype == BIU_BF16 ? launch_wgrad<bf16_t, 2, 2, 1, 4, 8, 16, 1>(a, st) : launch_wgrad<float, 2, 2, 1, 4, 4, 16, 1>(a, st);
+        if (rc != BIU_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_upconv_wgrad_unfold, dim3(grid_for((i64)a.CA * a.CB * 27, 256, 2048)), dim3(256), 0, st, (const float*)ws, slice / sizeof(float),
+                       a.CA, a.CB, dw);
+    BIU_CHECK_LAUNCH("upconv_wgrad_unfold");
+    return BIU_OK;
+}
+
 int biu_mfma_convt_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, float* dw, float* dbias, void* ws,
                          size_t ws_bytes, int dtype, hipStream_t st) {
     WgradArgs a;
@@ -3727,6 +3801,7 @@ int biu_mfma_convt_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* d
     a.bn_scale = a.bn_shift = a.bn_slope = a.bn_cA = a.bn_cB = a.bn_cC = nullptr;
     a.pa = (const char*)x->p;   a.apitch = x->pitch;   a.CA = x->c;       // plain operand: x on the coarse grid (rows i = ci)
     a.pb = (const char*)dy->p;  a.bpitch = dy->pitch;  a.CB = dy->c;      // tapped operand: dy on the fine grid (cols j = co)
+    a.fold_par = -1;
     a.pb1 = nullptr; a.bpitch1 = 0; a.bsplit = 0; a.bs1_ = a.bb1_ = a.bl1_ = nullptr;
     a.ws = (float*)ws;
     int rc = wgrad_xf(xf, &a.as_, &a.ab_, &a.al_);

@@ -60,6 +60,10 @@ bool biu_mfma_upconv_ok(const biu_act* x, const biu_act* y, int dtype);
 size_t biu_mfma_upconv_packed_bytes(int kind, int cin, int cout, int dtype);
 int biu_mfma_upconv_pack(int kind, const float* w, int cin, int cout, int dtype, void* packed, hipStream_t st);
 int biu_mfma_upconv_dgrad(const biu_act* dy, const void* packed, const biu_act* dx, int accumulate, int dtype, hipStream_t st);
+struct BnBwdFuse;
+size_t biu_mfma_upconv_wgrad_workspace(int cin, int cout, int dtype);
+int biu_mfma_upconv_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, float* dw, void* ws, size_t ws_bytes, int dtype,
+                          hipStream_t st, const BnBwdFuse* bn);
 int biu_mfma_upconv_stat_rows(const biu_act* x, const biu_act* y);
 int biu_mfma_upconv_fwd(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, const biu_act* y, float* bn_partial,
                         int dtype, hipStream_t st);

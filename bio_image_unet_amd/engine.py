@@ -227,11 +227,12 @@ class ConvBlockNode(Node):
         """``fold_src``: ``xin`` is the nearest-neighbour up-sampling (x2) of this coarse activation
         (multi_output_unet3d/multi_output_unet3d.py:138-139).  The forward then runs folded on the coarse tensor
         (``biu_upconv_fwd``: 8 parity classes x 2x2x2 taps instead of 27 taps, include/biu.h) when the kernel serves the shape, and
-        the data gradient goes straight to ``fold_src`` (``biu_upconv_bwd_data``; the up-sampling node's backward then has nothing to
-        do); the weight gradient still reads ``xin``."""
+        the data gradient goes straight to ``fold_src`` (``biu_upconv_bwd_data``) and the weight gradient reads ``fold_src``
+        (``biu_upconv_bwd_weight_bn``): with all three (``fold_all``) the up-sampled tensor ``xin`` is never needed and the up-sampling
+        node is skipped."""
         conv, bn = seq[0], seq[1]
         self.conv, self.bn, self.xin, self.y = conv, bn, xin, yout
-        self.fold_src, self.fold_slot, self.fold_dg_slot = None, None, None
+        self.fold_src, self.fold_slot, self.fold_dg_slot, self.fold_wg, self.fold_all = None, None, None, False, False
         # the block's activation as a leaky slope: LeakyReLU(s) -> s, ReLU -> 0 (Unet_v0 / BabyUnet), none or a later
         # non-piecewise-linear one (the attention gate's Sigmoid, applied by GateNode) -> 1
         act = seq[2] if len(seq) > 2 else None
@@ -263,6 +264,11 @@ class ConvBlockNode(Node):
             nb1 = lib.biu_upconv_packed_bytes(1, xin.c, cout, eng.dtype)
             if nb1:
                 self.fold_dg_slot = {"buf": torch.empty(nb1, dtype=torch.uint8, device=dev), "ver": None}
+            wsf = lib.biu_upconv_bwd_weight_workspace(xin.c, cout, eng.dtype)
+            if wsf:
+                self.fold_wg = True
+                eng.need_ws(wsf)
+            self.fold_all = self.fold_dg_slot is not None and self.fold_wg
             eng.need_partial_floats(lib.biu_upconv_fwd_stats_floats(fold_src.a(), yout.a()))
         self.pk_f = eng.packed_slot(0, xin.c, cout, self.kd, self.kh, self.kw, self.dil)
         self.pk_b = eng.packed_slot(1, xin.c, cout, self.kd, self.kh, self.kw, self.dil)
@@ -359,6 +365,9 @@ class ConvBlockNode(Node):
             check(lib.biu_conv_bwd_weight_cat(cat[0].a(), cat[0].xf(), cat[1].a(), cat[1].xf(), y.g(), y.a(), scale, shift, slope,
                                               _ptr(A), _ptr(B), _ptr(Cc), self.kd, self.kh, self.kw, self.dil, _ptr(dw), _ptr(eng.ws),
                                               eng.ws_bytes, eng.dtype, st), "conv_bwd_weight_cat")
+        elif self.fold_wg:
+            check(lib.biu_upconv_bwd_weight_bn(self.fold_src.a(), self.fold_src.xf(), y.g(), y.a(), scale, shift, slope, _ptr(A), _ptr(B),
+                                               _ptr(Cc), _ptr(dw), _ptr(eng.ws), eng.ws_bytes, eng.dtype, st), "upconv_bwd_weight_bn")
         else:
             check(lib.biu_conv_bwd_weight_bn(self.xin.a(), self.xin.xf(), y.g(), y.a(), scale, shift, slope, _ptr(A), _ptr(B),
                                              _ptr(Cc), self.kd, self.kh, self.kw, self.dil, _ptr(dw), _ptr(eng.ws), eng.ws_bytes,
@@ -475,10 +484,11 @@ class ResampleNode(Node):
         assert kind in ("maxpool", "down", "up", "trilinear")
         self.kind, self.xin, self.y = kind, xin, yout
         self.only_for_backward = False       # an up-sampling whose only reader folds it into its forward: needed by that reader's backward alone
+        self.skip = False                    # ... and whose reader folds its backward too: the up-sampled tensor is never needed
         xin.consumed()
 
     def fwd(self, eng):
-        if self.only_for_backward and not eng.grad_mode:
+        if self.skip or (self.only_for_backward and not eng.grad_mode):
             return
         f = {"maxpool": lib.biu_maxpool_fwd, "down": lib.biu_nearest_down_fwd, "up": lib.biu_nearest_up_fwd,
              "trilinear": lib.biu_trilinear_up_fwd}[self.kind]

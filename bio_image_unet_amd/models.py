@@ -362,6 +362,7 @@ class _Body3D(_HipNet):
                 u = buf.slice(0, up_c[i], lazy=True)
                 blk = E.ConvBlockNode(eng, getattr(self, f"up{lvl}_conv"), r, u, fold_src=t)      # forward folded onto the coarse tensor
                 rs.only_for_backward = blk.fold_src is not None
+                rs.skip = blk.fold_all                                                            # (forward, data and weight gradient folded)
                 eng.add(blk)
             elif up == "trilinear":                       # F.interpolate(scale_factor=2, mode='trilinear') [unet3d/unet3d.py:82]
                 u = buf.slice(0, up_c[i], lazy=False)

@@ -224,8 +224,11 @@ int biu_nearest_up_bwd(const biu_act* dout, const biu_act* dx, int accumulate, i
  *   W'[p][t] = the sum of the conv's taps that read the same coarse voxel (8 x 8 tap groups instead of 27 taps: 0.30 x the FLOPs),
  * identical to the convolution of the up-sampled tensor up to fp32 summation order (coarse zero padding = fine zero padding).
  * y is (2D, 2H, 2W).  biu_upconv_bwd_data is the matching data gradient straight onto the coarse tensor (replaces biu_conv_bwd_data +
- * biu_nearest_up_bwd):   dx[u] (+)= sum_p sum_{s in {0,1}^3} W'[p][1 - s]^T . dy[2 (u - p + s) + p];   the weight gradient of the block
- * still runs on the up-sampled tensor (biu_nearest_up_fwd + biu_conv_bwd_weight_bn).
+ * biu_nearest_up_bwd):   dx[u] (+)= sum_p sum_{s in {0,1}^3} W'[p][1 - s]^T . dy[2 (u - p + s) + p].
+ * biu_upconv_bwd_weight_bn is the weight gradient, with the block's BatchNorm+LeakyReLU backward in its loader exactly as
+ * biu_conv_bwd_weight_bn has it (da -> dy in place; y = NULL: da already is dy): per parity class
+ *   G[p][t] = sum_v dy[2v + p] (x) T(x)[v + t - 1 + p],   dw[k] = sum_p G[p][t_p(k)]   (t_p(k): the coarse tap fine tap k reads under parity p);
+ * with all three the up-sampled tensor is never materialised (no biu_nearest_up_fwd / _bwd).
  * biu_upconv_ok: shapes / channels the folded kernels serve (else: up-sample + biu_conv_*).  biu_upconv_pack folds and packs
  * w (Cout, Cin, 3, 3, 3) fp32 into `packed` (biu_upconv_packed_bytes; kind 0 = forward image, 1 = data-gradient image).
  * bn_partial may be NULL (no statistics); with it, *bn_nblk partial rows of [Cout][2] (sum, sum of squares) are written, as
@@ -234,6 +237,10 @@ int    biu_upconv_ok(const biu_act* x, const biu_act* y, int dtype);
 size_t biu_upconv_packed_bytes(int kind, int cin, int cout, int dtype);
 int    biu_upconv_pack(int kind, const float* w, int cin, int cout, int dtype, void* packed, biu_stream stream);
 int    biu_upconv_bwd_data(const biu_act* dy, const void* packed, const biu_act* dx, int accumulate, int dtype, biu_stream stream);
+size_t biu_upconv_bwd_weight_workspace(int cin, int cout, int dtype);
+int    biu_upconv_bwd_weight_bn(const biu_act* x, const biu_xform* xf, const biu_act* da, const biu_act* y, const float* scale,
+                                const float* shift, const float* slope, const float* coefA, const float* coefB, const float* coefC,
+                                float* dw, void* ws, size_t ws_bytes, int dtype, biu_stream stream);
 size_t biu_upconv_fwd_stats_floats(const biu_act* x, const biu_act* y);
 int    biu_upconv_fwd(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, const biu_act* y,
                       float* bn_partial, size_t bn_partial_floats, int* bn_nblk, int dtype, biu_stream stream);

@@ -212,7 +212,7 @@ class InSitu:
 
     def fwd_ConvBlockNode_post(self, nd, s):
         lab = nd.label + ":fwd"
-        a = self._T_cat(nd.xin)
+        a = F.interpolate(act_T(nd.fold_src), scale_factor=2, mode="nearest") if getattr(nd, "fold_all", False) else self._T_cat(nd.xin)
         w = nd.conv.weight.detach().cpu().double()
         b = nd.conv.bias.detach().cpu().double() if nd.conv.bias is not None else None
         mf = self._mfma(nd.xin.c, nd.y.c, nd.dil, nd.kw)
@@ -270,6 +270,8 @@ class InSitu:
         return F.interpolate(a, scale_factor=sf, mode="trilinear", align_corners=False)
 
     def fwd_ResampleNode_post(self, nd, s):
+        if getattr(nd, "skip", False):             # its reader folds forward and backward onto the coarse tensor: nothing was computed
+            return
         want = self._resample(nd.kind, act_T(nd.xin), nd.y.space)
         # stored result: one rounding of the exact value (the pool compares unrounded fp32 values)
         self.close(nd.label + ":fwd", nd.kind, act_raw(nd.y), want, rel=2.0 ** -8 if self.bf16 else 1e-6)
@@ -387,7 +389,10 @@ class InSitu:
         # the result is a difference of nearly equal terms where |dy| << |dz|: tolerance relative to the operands
         self.close(lab, "dy (BN+LReLU bwd)", dy_got, dy, abs_frac=(2.0 ** -8 if self.bf16 else 1e-5) * float(dz.pow(2).mean().sqrt() * gis.abs().max() / (dy.pow(2).mean().sqrt() + 1e-30) + 1.0), ignore=near)
         # weight gradient from the dy the engine actually stored
-        a = self._T_cat(nd.xin)
+        if getattr(nd, "fold_all", False):          # the up-sampled tensor was never materialised: rebuild it from the coarse one
+            a = F.interpolate(act_T(nd.fold_src), scale_factor=2, mode="nearest")
+        else:
+            a = self._T_cat(nd.xin)
         wgrad_mfma = nd.xin.c >= 16 and nd.xin.c % 8 == 0 and nd.y.c >= 16 and nd.y.c % 8 == 0 and nd.dil == 1 and nd.kw == 3
         if self.bf16 and wgrad_mfma:
             a = _r(a.float(), True).double()

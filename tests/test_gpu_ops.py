@@ -466,6 +466,49 @@ def test_upconv_fwd_matches_upsample_then_conv(case, dtype):
     assert torch.isnan(dxd.buf[..., :8].float()).all()
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(1, 32, 32, (4, 8, 16)), (2, 64, 32, (3, 5, 9)), (1, 96, 64, (5, 9, 17)), (1, 16, 24, (2, 3, 20))])
+def test_upconv_bwd_weight_matches_the_unfolded_weight_gradient(case, dtype):
+    """biu_upconv_bwd_weight_bn (coarse x, fine da / y) == biu_nearest_up_fwd + biu_conv_bwd_weight_bn on the up-sampled tensor: the same dy
+    written back over da, the same dW up to the order of the fp32 sums; y = NULL: the plain weight gradient of a finished dy."""
+    n, cin, cout, sp = case
+    code = DT[dtype][1]
+    hi = tuple(2 * v for v in sp)
+    x = Dev(rnd(n, cin, *sp, seed=1), dtype=dtype, pitch=cin + 8, c0=0)
+    xf = XF(cin, seed=2)
+    y = Dev(rnd(n, cout, *hi, seed=3), dtype=dtype)
+    da0 = rnd(n, cout, *hi, seed=4)
+    yxf = XF(cout, seed=5)
+    cA, cB, cC = (rnd(cout, seed=6) * 0.3 + 1.0), rnd(cout, seed=7) * 0.05, rnd(cout, seed=8) * 0.05
+    coef = [t.cuda() for t in (cA, cB, cC)]
+    # reference: materialise the up-sampled (transformed) tensor, then the unfolded BatchNorm-fused weight gradient
+    up = Dev(shape=(n, cin, *hi), dtype=dtype)
+    check(lib.biu_nearest_up_fwd(x.a(), xf.x(), up.a(), code, stream()), "nearest_up_fwd")
+    ws0 = torch.empty(max(lib.biu_conv_bwd_weight_workspace(cin, cout, 3, 3, 3, code), 16), dtype=torch.uint8, device="cuda")
+    da_ref = Dev(da0, dtype=dtype)
+    dw_ref = torch.full((cout, cin, 3, 3, 3), float("nan"), device="cuda")
+    check(lib.biu_conv_bwd_weight_bn(up.a(), None, da_ref.a(), y.a(), ptr(yxf.d[0]), ptr(yxf.d[1]), ptr(yxf.d[2]), ptr(coef[0]), ptr(coef[1]),
+                                     ptr(coef[2]), 3, 3, 3, 1, ptr(dw_ref), ptr(ws0), ws0.numel(), code, stream()), "conv_bwd_weight_bn")
+    wsz = lib.biu_upconv_bwd_weight_workspace(cin, cout, code)
+    assert wsz > 0
+    ws = torch.empty(wsz, dtype=torch.uint8, device="cuda")
+    scale = float(dw_ref.abs().max())
+    t2 = dict(rtol=1e-3, atol=2e-4 * scale) if dtype == "f32" else dict(rtol=2e-2, atol=2e-2 * scale)
+    for rep in range(2):
+        da = Dev(da0, dtype=dtype)
+        dw = torch.full((cout, cin, 3, 3, 3), float("nan"), device="cuda")
+        check(lib.biu_upconv_bwd_weight_bn(x.a(), xf.x(), da.a(), y.a(), ptr(yxf.d[0]), ptr(yxf.d[1]), ptr(yxf.d[2]), ptr(coef[0]), ptr(coef[1]),
+                                           ptr(coef[2]), ptr(dw), ptr(ws), ws.numel(), code, stream()), "upconv_bwd_weight_bn")
+        t = dict(rtol=1e-5, atol=1e-5) if dtype == "f32" else dict(rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(da.get(), da_ref.get(), **t)                 # dy written back over da, every parity class its own voxels
+        torch.testing.assert_close(dw.cpu(), dw_ref.cpu(), **t2)
+    # plain form on the finished dy
+    dw2 = torch.full((cout, cin, 3, 3, 3), float("nan"), device="cuda")
+    check(lib.biu_upconv_bwd_weight_bn(x.a(), xf.x(), da_ref.a(), None, None, None, None, None, None, None, ptr(dw2), ptr(ws), ws.numel(), code, stream()),
+          "upconv_bwd_weight (plain)")
+    torch.testing.assert_close(dw2.cpu(), dw_ref.cpu(), **t2)
+
+
 CONVT_MFMA_CASES = [
     # (nd, N, Cin, Cout, coarse spatial)
     (3, 1, 64, 64, (4, 8, 16)),

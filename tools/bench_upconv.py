@@ -54,6 +54,24 @@ for name, n, c, (d, h, w) in (("up3_conv", 1, 128, (64, 128, 128)), ("up2_conv",
     diff = (yf - yref).abs()
     print(f"   folded vs unfolded: max |diff| {float(diff.max()):.4f}, mean {float(diff.mean()):.5f}, max |y| {float(yref.abs().max()):.3f}, rms y {float(yref.pow(2).mean().sqrt()):.3f}; "
           f"worst voxel {tuple(int(v) for v in torch.unravel_index(diff.amax(-1).argmax(), diff.shape[:-1]))}", flush=True)
+    # backward: data gradient (+ nearest_up_bwd) and BatchNorm-fused weight gradient, unfolded on the up-sampled tensor against folded
+    dy = torch.randn(n, 2 * d, 2 * h, 2 * w, c, device="cuda").to(tdt)
+    du = torch.empty_like(u)
+    dx = torch.empty_like(x)
+    ady, adu, adx = biu_act(dy.data_ptr(), n, 2 * d, 2 * h, 2 * w, c, c), biu_act(du.data_ptr(), n, 2 * d, 2 * h, 2 * w, c, c), biu_act(dx.data_ptr(), n, d, h, w, c, c)
+    pk1 = torch.empty(lib.biu_conv_packed_bytes(1, c, c, 3, 3, 3, 1, code), dtype=torch.uint8, device="cuda")
+    check(lib.biu_conv_pack(1, P(wt), c, c, 3, 3, 3, code, P(pk1), st))
+    pf1 = torch.empty(lib.biu_upconv_packed_bytes(1, c, c, code), dtype=torch.uint8, device="cuda")
+    check(lib.biu_upconv_pack(1, P(wt), c, c, code, P(pf1), st))
+    t_dg = timed(lambda: check(lib.biu_conv_bwd_data(C.byref(ady), P(wt), P(pk1), 3, 3, 3, 1, C.byref(adu), 0, None, 0, code, st)))
+    t_ub = timed(lambda: check(lib.biu_nearest_up_bwd(C.byref(adu), C.byref(adx), 0, code, st)))
+    t_fdg = timed(lambda: check(lib.biu_upconv_bwd_data(C.byref(ady), P(pf1), C.byref(adx), 0, code, st)))
+    kv = [torch.ones(c, device="cuda"), torch.zeros(c, device="cuda"), torch.full((c,), 0.1, device="cuda"), torch.ones(c, device="cuda"), torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")]
+    ws = torch.empty(max(lib.biu_conv_bwd_weight_workspace(c, c, 3, 3, 3, code), lib.biu_upconv_bwd_weight_workspace(c, c, code)), dtype=torch.uint8, device="cuda")
+    dw = torch.empty_like(wt)
+    t_wg = timed(lambda: check(lib.biu_conv_bwd_weight_bn(C.byref(au), None, C.byref(ady), C.byref(ay), P(kv[0]), P(kv[1]), P(kv[2]), P(kv[3]), P(kv[4]), P(kv[5]), 3, 3, 3, 1, P(dw), P(ws), ws.numel(), code, st)))
+    t_fwg = timed(lambda: check(lib.biu_upconv_bwd_weight_bn(C.byref(ax), C.byref(xf), C.byref(ady), C.byref(ay), P(kv[0]), P(kv[1]), P(kv[2]), P(kv[3]), P(kv[4]), P(kv[5]), P(dw), P(ws), ws.numel(), code, st)))
+    print(f"   data gradient: conv {t_dg:.3f} + nearest_up_bwd {t_ub:.3f} ms  |  folded {t_fdg:.3f} ms      weight gradient (BatchNorm-fused): unfolded {t_wg:.3f} ms  |  folded {t_fwg:.3f} ms", flush=True)
     fl27 = 2.0 * n * 8 * d * h * w * 27 * c * c
     print(f"{name} {c}->{c} coarse {(d, h, w)}: up-sample {t_up:.3f} ms + conv {t_cv:.3f} ms ({fl27 / t_cv / 1e9:.0f} TF/s)  |  folded {t_fd:.3f} ms "
           f"({fl27 * 8 / 27 / t_fd / 1e9:.0f} TF/s of its own 8-tap work) + fold/pack {t_pk:.3f} ms", flush=True)
