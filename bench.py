@@ -135,6 +135,11 @@ def call_cost(eng, api, label):
         taps = node.kd * node.kh * node.kw
         v = node.y.nvox
         return 2.0 * v * taps * node.xin.c * node.y.c, float(v) * (node.xin.c + node.y.c) * esz
+    if isinstance(node, E.ConvBlockNode) and api.startswith("biu_upconv") and api != "biu_upconv_pack":
+        # up-sampling folded into the conv: 8 parity classes x 8 coarse taps per FINE voxel instead of 27 fine taps (the work the kernel does);
+        # bytes: the coarse input instead of the up-sampled one
+        v = node.y.nvox
+        return 2.0 * v * 8 * node.xin.c * node.y.c, float(v) * (node.xin.c / 8.0 + node.y.c) * esz
     if isinstance(node, E.ConvTNode) and api.startswith("biu_convt"):
         v = node.xin.nvox
         taps = node.kd * 4
