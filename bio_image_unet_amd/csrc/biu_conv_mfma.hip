@@ -2326,12 +2326,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     char* at = (char*)lds;                           // [NPL][BV][CT]
     char* bt = at + NPL * BV * RSA;                  // [NPL][HV][CT]
-    float* lxf = (float*)(bt + NPL * HV * RS);       // [3][CTA] transform of A, [3][CT] transform of B, [6][CT] BN-bwd (NI == 1)
+    float* lxf = (float*)(bt + NPL * HV * RS);       // [3][CTA] transform of A, [3][CT] transform of B, [6][CTA] BN-bwd
     constexpr int LA = 0, LB = 3 * CTA, LBN = 3 * CTA + 3 * CT;
     // packed piece coordinates of every thread (brick-invariant): in LDS [NA + NB][NTHR] when they fit next to the tiles
     // (the big-tile kernels have no registers to spare), else in registers
     constexpr bool TAB_LDS = wgrad_tab_in_lds((size_t)NPL * ((size_t)HV * RS + (size_t)BV * RSA), NA + NB);
-    unsigned* ltab = (unsigned*)(lxf + LBN + 6 * CT);
+    unsigned* ltab = (unsigned*)(lxf + LBN + 6 * CTA);
     unsigned xa_[TAB_LDS ? 1 : NA], xb_[TAB_LDS ? 1 : NB];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2350,15 +2350,15 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     const float* bl_ = b_src1 ? a.bl1_ : a.bl_;
     const bool a_xf = a.as_ != nullptr, b_xf = bs_ != nullptr;
     const bool bn_fused = a.py != nullptr;
-    if (tid < CT && bn_fused) {
+    if (tid < CTA && bn_fused) {                         // (all NI tiles of the plain operand: [6][CTA])
         const int ca = it * CTA + tid;
         const bool ok = ca < a.CA;
-        lxf[LBN + 0 * CT + tid] = ok ? a.bn_scale[ca] : 1.f;
-        lxf[LBN + 1 * CT + tid] = ok ? a.bn_shift[ca] : 0.f;
-        lxf[LBN + 2 * CT + tid] = (ok && a.bn_slope) ? a.bn_slope[ca] : 1.f;
-        lxf[LBN + 3 * CT + tid] = ok ? a.bn_cA[ca] : 0.f;
-        lxf[LBN + 4 * CT + tid] = ok ? a.bn_cB[ca] : 0.f;
-        lxf[LBN + 5 * CT + tid] = ok ? a.bn_cC[ca] : 0.f;
+        lxf[LBN + 0 * CTA + tid] = ok ? a.bn_scale[ca] : 1.f;
+        lxf[LBN + 1 * CTA + tid] = ok ? a.bn_shift[ca] : 0.f;
+        lxf[LBN + 2 * CTA + tid] = (ok && a.bn_slope) ? a.bn_slope[ca] : 1.f;
+        lxf[LBN + 3 * CTA + tid] = ok ? a.bn_cA[ca] : 0.f;
+        lxf[LBN + 4 * CTA + tid] = ok ? a.bn_cB[ca] : 0.f;
+        lxf[LBN + 5 * CTA + tid] = ok ? a.bn_cC[ca] : 0.f;
     }
     if (tid < CTA) {
         const int ca = it * CTA + tid;
@@ -2529,7 +2529,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
             {
                 float ks[PE], kh[PE], kl[PE];
 #pragma unroll
-                for (int e = 0; e < PE; ++e) { ks[e] = lxf[LBN + piece * PE + e]; kh[e] = lxf[LBN + CT + piece * PE + e]; kl[e] = lxf[LBN + 2 * CT + piece * PE + e]; }
+                for (int e = 0; e < PE; ++e) { ks[e] = lxf[LBN + pieceA * PE + e]; kh[e] = lxf[LBN + CTA + pieceA * PE + e]; kl[e] = lxf[LBN + 2 * CTA + pieceA * PE + e]; }
 #pragma unroll
                 for (int j = 0; j < NA; ++j) {
                     if ((amask >> j) & 1u) {
@@ -2545,7 +2545,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
             {
                 float ka[PE], kb[PE], kc[PE];
 #pragma unroll
-                for (int e = 0; e < PE; ++e) { ka[e] = lxf[LBN + 3 * CT + piece * PE + e]; kb[e] = lxf[LBN + 4 * CT + piece * PE + e]; kc[e] = lxf[LBN + 5 * CT + piece * PE + e]; }
+                for (int e = 0; e < PE; ++e) { ka[e] = lxf[LBN + 3 * CTA + pieceA * PE + e]; kb[e] = lxf[LBN + 4 * CTA + pieceA * PE + e]; kc[e] = lxf[LBN + 5 * CTA + pieceA * PE + e]; }
 #pragma unroll
                 for (int j = 0; j < NA; ++j) {
                     if ((amask >> j) & 1u) {
@@ -3625,7 +3625,7 @@ static int launch_wgrad(WgradArgs a, hipStream_t st) {
     constexpr int PPV_ = 32 / (16 / (int)sizeof(T));
     constexpr int NA_ = (BV * PPV_ * NI + 511) / 512, NB_ = (HV * PPV_ + 511) / 512;
     const size_t tile_bytes = (size_t)(HV + BV * NI) * 32 * (SplitOf<T>::parts ? 2 * SplitOf<T>::parts : sizeof(T));    // split products: one bf16 plane per part
-    const size_t lds_bytes = tile_bytes + (9 + 3 * NI) * 32 * sizeof(float) + (wgrad_tab_in_lds(tile_bytes, NA_ + NB_) ? (size_t)(NA_ + NB_) * 512 * sizeof(unsigned) : 0);
+    const size_t lds_bytes = tile_bytes + (3 + 9 * NI) * 32 * sizeof(float) + (wgrad_tab_in_lds(tile_bytes, NA_ + NB_) ? (size_t)(NA_ + NB_) * 512 * sizeof(unsigned) : 0);
     a.nbd = (a.GD + TD - 1) / TD;
     a.nbh = (a.GH + TH - 1) / TH;
     a.nbw = (a.GW + TW - 1) / TW;
@@ -3785,7 +3785,9 @@ int biu_mfma_upconv_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* 
     for (int p = 0; p < 8; ++p) {
         a.ws = (float*)((char*)ws + (size_t)p * slice);
         a.fold_par = p;
-        rc = dtype == BIU_BF16 ? launch_wgrad<bf16_t, 2, 2, 1, 4, 8, 16, 1>(a, st) : launch_wgrad<float, 2, 2, 1, 4, 4, 16, 1>(a, st);
+        // two 32-wide tiles of dy's channels per block when it has them: twice the MFMA work per staged tile of the coarse operand
+        if (a.CA > 32) rc = dtype == BIU_BF16 ? launch_wgrad<bf16_t, 2, 2, 1, 4, 8, 16, 1, 2>(a, st) : launch_wgrad<float, 2, 2, 1, 4, 4, 16, 1, 2>(a, st);
+        else rc = dtype == BIU_BF16 ? launch_wgrad<bf16_t, 2, 2, 1, 4, 8, 16, 1>(a, st) : launch_wgrad<float, 2, 2, 1, 4, 4, 16, 1>(a, st);
         if (rc != BIU_OK) return rc;
     }
     hipLaunchKernelGGL(k_upconv_wgrad_unfold, dim3(grid_for((i64)a.CA * a.CB * 27, 256, 2048)), dim3(256), 0, st, (const float*)ws, slice / sizeof(float),
