@@ -104,6 +104,11 @@ SIGNATURES = {
     "biu_conv_bwd_weight_cat": (_I, [_A, _X, _A, _X, _A, _A, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _Z, _I, _P]),
     "biu_convt_packed_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "biu_convt_pack": (_I, [_I, _P, _I, _I, _I, _I, _P, _P]),
+    "biu_foldt_ok": (_I, [_A, _A, _A, _I]),
+    "biu_foldt_packed_bytes": (_Z, [_I, _I, _I, _I]),
+    "biu_foldt_pack": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "biu_foldt_fwd_stats_floats": (_Z, [_A, _A]),
+    "biu_foldt_fwd": (_I, [_A, _X, _A, _X, _P, _A, _P, _Z, C.POINTER(C.c_int), _I, _P]),
     "biu_convt_fwd": (_I, [_A, _X, _P, _P, _P, _I, _A, _I, _P]),
     "biu_convt_bwd_data": (_I, [_A, _P, _P, _I, _A, _I, _I, _P]),
     "biu_convt_bwd_weight_workspace": (_Z, [_I, _I, _I, _I]),

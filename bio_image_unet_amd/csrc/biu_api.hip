@@ -381,6 +381,33 @@ extern "C" int biu_upconv_fwd(const biu_act* x, const biu_xform* xf, const void*
     return biu_mfma_upconv_fwd(x, xf, packed, bias, y, nullptr, dtype, (hipStream_t)stream);
 }
 
+// ---- ConvTranspose(k2, s2) + concat + 3x3x3 conv of a decoder level, the up half folded onto the coarse tensor -------------------------
+extern "C" int biu_foldt_ok(const biu_act* x_low, const biu_act* skip, const biu_act* y, int dtype) {
+    return (x_low && skip && y && !disabled("foldt") && biu_mfma_foldt_ok(x_low, skip, y, dtype)) ? 1 : 0;
+}
+extern "C" size_t biu_foldt_packed_bytes(int cin_low, int cskip, int cout, int dtype) { return biu_mfma_foldt_packed_bytes(cin_low, cskip, cout, dtype); }
+extern "C" int biu_foldt_pack(const float* w_conv, const float* b_conv, const float* w_t, const float* b_t, int cin_low, int cup, int cskip, int cout,
+                              int dtype, void* packed, biu_stream stream) {
+    BIU_REQUIRE(w_conv && w_t && packed && cin_low > 0 && cup > 0 && cskip > 0 && cout > 0, BIU_ERR_SHAPE, "foldt_pack: null pointer or empty shape");
+    return biu_mfma_foldt_pack(w_conv, b_conv, w_t, b_t, cin_low, cup, cskip, cout, dtype, packed, (hipStream_t)stream);
+}
+extern "C" size_t biu_foldt_fwd_stats_floats(const biu_act* x_low, const biu_act* y) { return (size_t)biu_mfma_foldt_stat_rows(x_low, y) * y->c * 2; }
+extern "C" int biu_foldt_fwd(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const void* packed,
+                             const biu_act* y, float* bn_partial, size_t bn_partial_floats, int* bn_nblk, int dtype, biu_stream stream) {
+    BIU_REQUIRE(x_low && skip && y && packed, BIU_ERR_SHAPE, "foldt_fwd: null pointer");
+    BIU_REQUIRE(biu_mfma_foldt_ok(x_low, skip, y, dtype), BIU_ERR_UNSUPPORTED, "foldt_fwd: shapes are not served by the folded kernels");
+    if (bn_nblk) *bn_nblk = 0;
+    if (bn_partial) {
+        BIU_REQUIRE(bn_nblk, BIU_ERR_SHAPE, "foldt_fwd: bn_partial without bn_nblk");
+        const int nb = biu_mfma_foldt_stat_rows(x_low, y);
+        BIU_REQUIRE((size_t)nb * y->c * 2 <= bn_partial_floats, BIU_ERR_WORKSPACE, "foldt_fwd: partial buffer too small");
+        int rc = biu_mfma_foldt_fwd(x_low, xf_low, skip, xf_skip, packed, y, bn_partial, dtype, (hipStream_t)stream);
+        if (rc == BIU_OK) *bn_nblk = nb;
+        return rc;
+    }
+    return biu_mfma_foldt_fwd(x_low, xf_low, skip, xf_skip, packed, y, nullptr, dtype, (hipStream_t)stream);
+}
+
 extern "C" int biu_convt_fwd(const biu_act* x, const biu_xform* xf, const float* w, const void* packed, const float* bias,
                              int kd, const biu_act* y, int dtype, biu_stream stream) {
     BIU_REQUIRE(valid_act(x) && valid_act(y) && w && biu_convt_shapes_ok(x, y, kd), BIU_ERR_SHAPE,

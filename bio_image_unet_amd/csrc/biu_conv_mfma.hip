@@ -1401,20 +1401,25 @@ size_t biu_mfma_packed_bytes(int kind, int cin, int cout, int kd, int kh, int kw
     return b;
 }
 
-int biu_mfma_pack(int kind, const float* w, int cin, int cout, int kd, int kh, int kw, int dtype, void* packed, hipStream_t st) {
+// w: (Cout, cin_stride, taps) with the layer's `cin` input channels starting at w (a channel slice of a wider weight tensor: pass
+// w + first_channel * taps and the full tensor's channel count as cin_stride)
+static int mfma_pack_strided(int kind, const float* w, int cin_stride, int cin, int cout, int kd, int kh, int kw, int dtype, void* packed, hipStream_t st) {
     const int K = kind == 0 ? cin : cout, Nn = kind == 0 ? cout : cin;
     const int taps = kd * kh * kw, ntiles = (Nn + 31) / 32, nKS = nks_of(K, kd, dtype);
     const size_t total = (size_t)ntiles * nKS * taps * 64;
-    BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_weights<T>, dim3(grid_for((i64)total, 256, 4096)), dim3(256), 0, st, w, cin,
+    BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_weights<T>, dim3(grid_for((i64)total, 256, 4096)), dim3(256), 0, st, w, cin_stride,
                                                  cout, taps, kind, K, Nn, nKS, ntiles, (uint4*)packed, x3_ok(K, kd, dtype)));
     BIU_CHECK_LAUNCH("pack_weights");
     if (m16_chan_ok(K, Nn, dtype)) {
         const size_t total16 = m16_packed_bytes(K, Nn, taps, dtype) / 16;
-        hipLaunchKernelGGL(k_pack_weights16, dim3(grid_for((i64)total16, 256, 4096)), dim3(256), 0, st, w, cin, cout, taps, kind, K, Nn,
+        hipLaunchKernelGGL(k_pack_weights16, dim3(grid_for((i64)total16, 256, 4096)), dim3(256), 0, st, w, cin_stride, cout, taps, kind, K, Nn,
                            m16_mtl(K, Nn, dtype), (uint4*)((char*)packed + regular_packed_bytes(K, Nn, taps, dtype)));
         BIU_CHECK_LAUNCH("pack_weights16");
     }
     return BIU_OK;
+}
+int biu_mfma_pack(int kind, const float* w, int cin, int cout, int kd, int kh, int kw, int dtype, void* packed, hipStream_t st) {
+    return mfma_pack_strided(kind, w, cin, cin, cout, kd, kh, kw, dtype, packed, st);
 }
 
 bool biu_mfma_conv_ok(const biu_act* x, const biu_act* y, int kd, int kh, int kw, int dilation, int dtype) {
@@ -2064,8 +2069,9 @@ __device__ __forceinline__ float fold_nearest_weight(const float* __restrict__ w
     return sum;
 }
 // packed image of the 8 folded kernels: out[parity = blockIdx.y][ntile][kstep][tap t][lane], fragment layout of k_pack_weights
+// (wf != nullptr: explicit folded weights [p][co][ci][t] -- the composed ones of a ConvTranspose decoder -- instead of the tap sums of w)
 template <typename T>
-__global__ void k_pack_upconv(const float* __restrict__ w, int cin, int cout, int nKS, int ntiles, uint4* __restrict__ out) {
+__global__ void k_pack_upconv(const float* __restrict__ w, int cin, int cout, int nKS, int ntiles, uint4* __restrict__ out, const float* __restrict__ wf = nullptr) {
     using F = Frag<T>;
     constexpr int PE = F::PE;
     const int p = (int)blockIdx.y;
@@ -2082,7 +2088,7 @@ __global__ void k_pack_upconv(const float* __restrict__ w, int cin, int cout, in
 #pragma unroll
         for (int e = 0; e < PE; ++e) {
             const int ci = ks * 2 * PE + (lane >> 5) * PE + e;
-            f[e] = (co < cout && ci < cin) ? fold_nearest_weight(w, cin, co, ci, p, t) : 0.f;
+            f[e] = (co < cout && ci < cin) ? (wf ? wf[(((size_t)p * cout + co) * cin + ci) * 8 + t] : fold_nearest_weight(w, cin, co, ci, p, t)) : 0.f;
         }
         out[idx] = F::pack(f);
     }
@@ -2091,7 +2097,7 @@ __global__ void k_pack_upconv(const float* __restrict__ w, int cin, int cout, in
 // packed image of the folded DATA GRADIENT: rows = input channels ci, reduction index kv = p * Cout + co over the 8 parity classes,
 // tap s = the coarse offset u - p + s it reads: W'[p][co][ci][t = 1 - s per axis].  out[ntile(ci)][kstep(kv)][tap s][lane]
 template <typename T>
-__global__ void k_pack_upconv_dgrad(const float* __restrict__ w, int cin, int cout, int nKSv, int ntiles, uint4* __restrict__ out) {
+__global__ void k_pack_upconv_dgrad(const float* __restrict__ w, int cin, int cout, int nKSv, int ntiles, uint4* __restrict__ out, const float* __restrict__ wf = nullptr) {
     using F = Frag<T>;
     constexpr int PE = F::PE;
     const size_t total = (size_t)ntiles * nKSv * 8 * 64;
@@ -2107,7 +2113,7 @@ __global__ void k_pack_upconv_dgrad(const float* __restrict__ w, int cin, int co
         for (int e = 0; e < PE; ++e) {
             const int kv = ks * 2 * PE + (lane >> 5) * PE + e;
             const int p = kv / cout, co = kv - p * cout;
-            f[e] = (ci < cin && p < 8) ? fold_nearest_weight(w, cin, co, ci, p, 7 - sidx) : 0.f;
+            f[e] = (ci < cin && p < 8) ? (wf ? wf[(((size_t)p * cout + co) * cin + ci) * 8 + (7 - sidx)] : fold_nearest_weight(w, cin, co, ci, p, 7 - sidx)) : 0.f;
         }
         out[idx] = F::pack(f);
     }
@@ -2128,16 +2134,16 @@ size_t biu_mfma_upconv_packed_bytes(int kind, int cin, int cout, int dtype) {
     if (!chan_ok(cout, cin, dtype)) return 0;
     return (size_t)((cin + 31) / 32) * (8 * cout / ks_of(dtype)) * 8 * 64 * 16;
 }
-int biu_mfma_upconv_pack(int kind, const float* w, int cin, int cout, int dtype, void* packed, hipStream_t st) {
+int biu_mfma_upconv_pack(int kind, const float* w, int cin, int cout, int dtype, void* packed, hipStream_t st, const float* wf) {
     if (kind == 0) {
         const size_t slice = upconv_slice16(cin, cout, dtype);
         const int ntiles = (cout + 31) / 32, nKS = cin / ks_of(dtype);
         BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_upconv<T>, dim3(grid_for((i64)slice, 256, 512), 8), dim3(256), 0, st, w, cin, cout, nKS, ntiles,
-                                                     (uint4*)packed));
+                                                     (uint4*)packed, wf));
     } else {
         const int ntiles = (cin + 31) / 32, nKSv = 8 * cout / ks_of(dtype);
         BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_pack_upconv_dgrad<T>, dim3(grid_for((i64)ntiles * nKSv * 8 * 64, 256, 4096)), dim3(256), 0, st, w, cin,
-                                                     cout, nKSv, ntiles, (uint4*)packed));
+                                                     cout, nKSv, ntiles, (uint4*)packed, wf));
     }
     BIU_CHECK_LAUNCH("upconv_pack");
     return BIU_OK;
@@ -2161,7 +2167,7 @@ int biu_mfma_upconv_stat_rows(const biu_act* x, const biu_act* y) {
     return 8 * g;
 }
 int biu_mfma_upconv_fwd(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, const biu_act* y, float* bn_partial,
-                        int dtype, hipStream_t st) {
+                        int dtype, hipStream_t st, int accumulate) {
     ConvArgs a;
     clear_cat(a);
     a.bn_partial = bn_partial;
@@ -2181,7 +2187,7 @@ int biu_mfma_upconv_fwd(const biu_act* x, const biu_xform* xf, const void* packe
     a.Cin = x->c; a.Cout = y->c;
     a.nKS = x->c / ks_of(dtype);
     a.wz_stride = (int)upconv_slice16(x->c, y->c, dtype);
-    a.accumulate = 0;
+    a.accumulate = accumulate;
     a.diag = nullptr;
     a.nbd = a.nbh = a.nbw = 0;
     a.fold = 1;
@@ -2213,6 +2219,146 @@ int biu_mfma_upconv_dgrad(const biu_act* dy, const void* packed, const biu_act* 
     a.fold = 2;
     if (dtype == BIU_BF16) return launch_upconv<bf16_t>(a, st);
     return launch_upconv<float>(a, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ConvTranspose(k2, s2) + concat + 3x3x3 conv of a decoder level, with the up half folded onto the coarse tensor ("foldt"):
+//   y = conv(concat(up, skip)),  up = convT(T(x_low)) + b_T        (unet3d/unet3d.py:52-58,84-90: no non-linearity between the two)
+//     = conv_skip(T(skip)) + b_conv + sum_{k inside} Wb[k]  +  fold(T(x_low); W')                       Wb[k] = W_conv[:, up, k] . b_T
+//   W'[p][t][ci][co] = sum_{k in class(p, t)} sum_c W_conv[co][c][k] * W_T[ci][c][q(p, k)]              q = (p + k + 1) & 1 per axis: the
+// sub-position inside its coarse cell of the fine voxel tap k reads.  A tap that falls outside the fine tensor drops both its x term (coarse
+// zero padding does that) and its bias term (the 27-state border table below).  Blob prepared once per weight version (biu_foldt_pack):
+//   [fold forward image | fold data-gradient image | skip forward image | skip data-gradient image | W' fp32 | Wb | border fix table | bias sum]
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fold_class(int p, int t, int& lo, int& hi) {          // fine taps of one axis that read coarse tap t under parity p
+    lo = p == 0 ? (t ? 1 : 0) : (t ? 2 : 0);
+    hi = p == 0 ? (t ? 2 : 0) : (t ? 2 : 1);
+}
+__global__ void k_foldt_compose(const float* __restrict__ wc, int ccat, int c0, int cup, int cout, const float* __restrict__ wt, int cin_low,
+                                float* __restrict__ wfold) {
+    const size_t total = (size_t)8 * cout * cin_low * 8;                     // wfold[p][co][ci][t]
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(idx % 8);
+        size_t r = idx / 8;
+        const int ci = (int)(r % cin_low); r /= cin_low;
+        const int co = (int)(r % cout);
+        const int p = (int)(r / cout);
+        int lo[3], hi[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) fold_class((p >> (2 - ax)) & 1, (t >> (2 - ax)) & 1, lo[ax], hi[ax]);
+        float sum = 0.f;
+        for (int kd = lo[0]; kd <= hi[0]; ++kd)
+            for (int kh = lo[1]; kh <= hi[1]; ++kh)
+                for (int kw = lo[2]; kw <= hi[2]; ++kw) {
+                    const int k = (kd * 3 + kh) * 3 + kw;
+                    const int q = ((((p >> 2) & 1) + kd + 1) & 1) * 4 + ((((p >> 1) & 1) + kh + 1) & 1) * 2 + (((p & 1) + kw + 1) & 1);
+                    const float* a = wc + ((size_t)co * ccat + c0) * 27 + k;                 // W_conv[co][c0 + c][k], stride 27 over c
+                    const float* b = wt + (size_t)ci * cup * 8 + q;                          // W_T[ci][c][q],         stride 8 over c
+                    float acc = 0.f;
+                    for (int c = 0; c < cup; ++c) acc = fmaf(a[(size_t)c * 27], b[(size_t)c * 8], acc);
+                    sum += acc;
+                }
+        wfold[idx] = sum;
+    }
+}
+// Wb[k][co] = sum_c W_conv[co][c0 + c][k] b_T[c];  fix[state][co] = sum of Wb[k] over the taps OUTSIDE the tensor for a voxel in border state
+// (per axis 0 = first, 1 = interior, 2 = last coordinate);  bias_sum[co] = b_conv[co] + sum_k Wb[k][co]
+__global__ void k_foldt_bias(const float* __restrict__ wc, int ccat, int c0, int cup, int cout, const float* __restrict__ bt, const float* __restrict__ bconv,
+                             float* __restrict__ wb, float* __restrict__ fix, float* __restrict__ bias_sum) {
+    const int co = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (co >= cout) return;
+    float all = 0.f;
+    for (int k = 0; k < 27; ++k) {
+        float acc = 0.f;
+        if (bt)
+            for (int c = 0; c < cup; ++c) acc = fmaf(wc[((size_t)co * ccat + c0 + c) * 27 + k], bt[c], acc);
+        wb[k * cout + co] = acc;
+        all += acc;
+    }
+    bias_sum[co] = (bconv ? bconv[co] : 0.f) + all;
+    for (int s = 0; s < 27; ++s) {
+        const int sd = s / 9, sh = (s / 3) % 3, sw = s % 3;
+        float out = 0.f;
+        for (int k = 0; k < 27; ++k) {
+            const int kd = k / 9, kh = (k / 3) % 3, kw = k % 3;
+            const bool outside = (kd == 0 && sd == 0) || (kd == 2 && sd == 2) || (kh == 0 && sh == 0) || (kh == 2 && sh == 2) || (kw == 0 && sw == 0) || (kw == 2 && sw == 2);
+            if (outside) out += wb[k * cout + co];
+        }
+        fix[s * cout + co] = out;
+    }
+}
+// y[o][co] -= fix[state(o)][co] on the border shell (one thread per voxel; interior voxels leave at once).  A 1-voxel axis is both first and last:
+// its state would need both corrections -- such tensors do not take this path (biu_mfma_foldt_ok: every extent >= 2).
+template <typename T>
+__global__ void k_foldt_border_fix(char* __restrict__ y, int n, int d, int h, int w, int c, int pitch, const float* __restrict__ fix) {
+    const long nv = (long)n * d * h * w;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(v % w), yy = (int)((v / w) % h), z = (int)((v / ((long)w * h)) % d);
+        const int sd = z == 0 ? 0 : (z == d - 1 ? 2 : 1), sh = yy == 0 ? 0 : (yy == h - 1 ? 2 : 1), sw = x == 0 ? 0 : (x == w - 1 ? 2 : 1);
+        if (sd == 1 && sh == 1 && sw == 1) continue;
+        const float* f = fix + (size_t)((sd * 3 + sh) * 3 + sw) * c;
+        T* row = (T*)y + (size_t)v * pitch;
+        for (int cc = 0; cc < c; ++cc) row[cc] = (T)((float)row[cc] - f[cc]);
+    }
+}
+
+struct FoldtBlob { size_t fwd, dg, sfwd, sdg, wfold, wb, fix, bias, total; };
+static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+static FoldtBlob foldt_blob(int cin_low, int cskip, int cout, int dtype) {
+    FoldtBlob b;
+    size_t o = 0;
+    b.fwd = o;   o += al256(biu_mfma_upconv_packed_bytes(0, cin_low, cout, dtype));
+    b.dg = o;    o += al256(biu_mfma_upconv_packed_bytes(1, cin_low, cout, dtype));
+    b.sfwd = o;  o += al256(biu_mfma_packed_bytes(0, cskip, cout, 3, 3, 3, 1, dtype));
+    b.sdg = o;   o += al256(biu_mfma_packed_bytes(1, cskip, cout, 3, 3, 3, 1, dtype));
+    b.wfold = o; o += al256((size_t)8 * cout * cin_low * 8 * sizeof(float));
+    b.wb = o;    o += al256((size_t)27 * cout * sizeof(float));
+    b.fix = o;   o += al256((size_t)27 * cout * sizeof(float));
+    b.bias = o;  o += al256((size_t)cout * sizeof(float));
+    b.total = o;
+    return b;
+}
+// forward (and data gradient, when the channel counts allow its 8-class reduction) served by the folded kernels
+bool biu_mfma_foldt_ok(const biu_act* x_low, const biu_act* skip, const biu_act* y, int dtype) {
+    if (dtype != BIU_BF16 && dtype != BIU_F32) return false;
+    if (!biu_mfma_upconv_ok(x_low, y, dtype) || x_low->d < 1 || y->d < 2 || y->h < 2 || y->w < 2) return false;
+    if (skip->n != y->n || skip->d != y->d || skip->h != y->h || skip->w != y->w) return false;
+    if (!biu_mfma_conv_ok(skip, y, 3, 3, 3, 1, dtype)) return false;
+    return biu_mfma_upconv_packed_bytes(1, x_low->c, y->c, dtype) > 0 && biu_mfma_packed_bytes(1, skip->c, y->c, 3, 3, 3, 1, dtype) > 0;
+}
+size_t biu_mfma_foldt_packed_bytes(int cin_low, int cskip, int cout, int dtype) { return foldt_blob(cin_low, cskip, cout, dtype).total; }
+// w_conv: (Cout, cup + cskip, 3, 3, 3), concat order (up | skip) [unet3d/unet3d.py:86: torch.cat([up, skip])]; w_t: (Cin_low, cup, 2, 2, 2)
+int biu_mfma_foldt_pack(const float* w_conv, const float* b_conv, const float* w_t, const float* b_t, int cin_low, int cup, int cskip, int cout, int dtype,
+                        void* packed, hipStream_t st) {
+    const FoldtBlob b = foldt_blob(cin_low, cskip, cout, dtype);
+    char* base = (char*)packed;
+    float* wfold = (float*)(base + b.wfold);
+    const int ccat = cup + cskip;
+    hipLaunchKernelGGL(k_foldt_compose, dim3(grid_for((i64)8 * cout * cin_low * 8, 256, 4096)), dim3(256), 0, st, w_conv, ccat, 0, cup, cout, w_t, cin_low, wfold);
+    hipLaunchKernelGGL(k_foldt_bias, dim3((cout + 63) / 64), dim3(64), 0, st, w_conv, ccat, 0, cup, cout, b_t, b_conv, (float*)(base + b.wb), (float*)(base + b.fix),
+                       (float*)(base + b.bias));
+    BIU_CHECK_LAUNCH("foldt_compose");
+    int rc = biu_mfma_upconv_pack(0, nullptr, cin_low, cout, dtype, base + b.fwd, st, wfold);
+    if (rc == BIU_OK) rc = biu_mfma_upconv_pack(1, nullptr, cin_low, cout, dtype, base + b.dg, st, wfold);
+    if (rc == BIU_OK) rc = mfma_pack_strided(0, w_conv + (size_t)cup * 27, ccat, cskip, cout, 3, 3, 3, dtype, base + b.sfwd, st);
+    if (rc == BIU_OK) rc = mfma_pack_strided(1, w_conv + (size_t)cup * 27, ccat, cskip, cout, 3, 3, 3, dtype, base + b.sdg, st);
+    return rc;
+}
+int biu_mfma_foldt_stat_rows(const biu_act* x_low, const biu_act* y) { return biu_mfma_upconv_stat_rows(x_low, y); }
+int biu_mfma_foldt_fwd(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const void* packed, const biu_act* y,
+                       float* bn_partial, int dtype, hipStream_t st) {
+    const FoldtBlob b = foldt_blob(x_low->c, skip->c, y->c, dtype);
+    const char* base = (const char*)packed;
+    // 1. skip half + both biases (the full 27-tap ConvT-bias sum; the border shell is corrected next)
+    int rc = biu_mfma_conv(skip, xf_skip, base + b.sfwd, (const float*)(base + b.bias), 3, 3, 3, y, 0, nullptr, dtype, st, nullptr, nullptr, nullptr, 0);
+    if (rc != BIU_OK) return rc;
+    // 2. taps that fall outside the tensor carry no ConvT bias
+    const long nv = (long)y->n * y->d * y->h * y->w;
+    BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_foldt_border_fix<T>, dim3(grid_for((i64)nv, 256, 8192)), dim3(256), 0, st, (char*)y->p, y->n, y->d, y->h, y->w,
+                                                 y->c, y->pitch, (const float*)(base + b.fix)));
+    BIU_CHECK_LAUNCH("foldt_border_fix");
+    // 3. the up half on the coarse tensor, accumulated; BatchNorm statistics of the finished output from this launch's epilogue
+    return biu_mfma_upconv_fwd(x_low, xf_low, base + b.fwd, nullptr, y, bn_partial, dtype, st, 1);
 }
 
 // ===============================================================================================================

@@ -58,7 +58,7 @@ int biu_mfma_convt_pack(int kind, const float* w, int cin, int cout, int kd, int
 // nearest-neighbour up-sampling folded into the 3x3x3 convolution behind it (forward)
 bool biu_mfma_upconv_ok(const biu_act* x, const biu_act* y, int dtype);
 size_t biu_mfma_upconv_packed_bytes(int kind, int cin, int cout, int dtype);
-int biu_mfma_upconv_pack(int kind, const float* w, int cin, int cout, int dtype, void* packed, hipStream_t st);
+int biu_mfma_upconv_pack(int kind, const float* w, int cin, int cout, int dtype, void* packed, hipStream_t st, const float* wf = nullptr);
 int biu_mfma_upconv_dgrad(const biu_act* dy, const void* packed, const biu_act* dx, int accumulate, int dtype, hipStream_t st);
 struct BnBwdFuse;
 size_t biu_mfma_upconv_wgrad_workspace(int cin, int cout, int dtype);
@@ -66,7 +66,15 @@ int biu_mfma_upconv_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* 
                           hipStream_t st, const BnBwdFuse* bn);
 int biu_mfma_upconv_stat_rows(const biu_act* x, const biu_act* y);
 int biu_mfma_upconv_fwd(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, const biu_act* y, float* bn_partial,
-                        int dtype, hipStream_t st);
+                        int dtype, hipStream_t st, int accumulate = 0);
+// ConvTranspose + concat + 3x3x3 conv of a decoder level with the up half folded onto the coarse tensor
+bool biu_mfma_foldt_ok(const biu_act* x_low, const biu_act* skip, const biu_act* y, int dtype);
+size_t biu_mfma_foldt_packed_bytes(int cin_low, int cskip, int cout, int dtype);
+int biu_mfma_foldt_pack(const float* w_conv, const float* b_conv, const float* w_t, const float* b_t, int cin_low, int cup, int cskip, int cout, int dtype,
+                        void* packed, hipStream_t st);
+int biu_mfma_foldt_stat_rows(const biu_act* x_low, const biu_act* y);
+int biu_mfma_foldt_fwd(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const void* packed, const biu_act* y,
+                       float* bn_partial, int dtype, hipStream_t st);
 bool biu_mfma_convt_ok(int kind, const biu_act* lo, const biu_act* hi, int kd, int dtype);
 int biu_mfma_convt_fwd(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, const biu_act* y,
                        int dtype, hipStream_t st);

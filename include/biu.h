@@ -333,6 +333,23 @@ size_t biu_convt_bwd_weight_workspace(int cin, int cout, int kd, int dtype);
 int biu_convt_bwd_weight(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, float* dw, float* dbias,
                          void* ws, size_t ws_bytes, int dtype, biu_stream stream);
 
+/* ConvTranspose(k2, s2) + concat + 3x3x3 convolution of a decoder level as ONE op, the up half folded onto the coarse tensor.
+ * replaces self.upN (nn.ConvTranspose3d) + torch.cat + the first conv of the decode block: unet3d/unet3d.py:40-42,84-90
+ * (multi_output_unet3d/multi_output_unet3d.py with use_interpolation=False likewise); no non-linearity sits between the two.
+ *   y = conv(concat(convT(T(x_low)) + b_T, T(skip))) + b_conv
+ *     = conv_skip(T(skip)) + b_conv + sum_{taps k inside} Wb[k] + sum_{t in {0,1}^3} W'[p][t] . T(x_low)[v + t - 1 + p]        at y[2v + p],
+ *   W'[p][t][ci][co] = sum_{k in class(p,t)} sum_c W_conv[co][c][k] W_T[ci][c][q(p,k)],  Wb[k][co] = sum_c W_conv[co][c][k] b_T[c]:
+ * the same function of the four parameter tensors (the up-sampled tensor is not materialised, 8 x 8 instead of 27 taps on its channels).
+ * w_conv (Cout, cup + cskip, 3,3,3) with the concat order (up | skip); w_t (Cin_low, cup, 2,2,2); packed: biu_foldt_packed_bytes, refreshed
+ * by biu_foldt_pack whenever one of the four tensors changes.  bn_partial as in biu_upconv_fwd (biu_foldt_fwd_stats_floats). */
+int    biu_foldt_ok(const biu_act* x_low, const biu_act* skip, const biu_act* y, int dtype);
+size_t biu_foldt_packed_bytes(int cin_low, int cskip, int cout, int dtype);
+int    biu_foldt_pack(const float* w_conv, const float* b_conv, const float* w_t, const float* b_t, int cin_low, int cup, int cskip, int cout,
+                      int dtype, void* packed, biu_stream stream);
+size_t biu_foldt_fwd_stats_floats(const biu_act* x_low, const biu_act* y);
+int    biu_foldt_fwd(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const void* packed,
+                     const biu_act* y, float* bn_partial, size_t bn_partial_floats, int* bn_nblk, int dtype, biu_stream stream);
+
 /* ------------------------------------------------------------------------------------------------
  * 1x1(x1) head + activation                                                             [K9]
  * replaces final Conv + torch.sigmoid: unet/unet.py:51,103-104, unet3d/unet3d.py:50,98-99,

@@ -509,6 +509,57 @@ def test_upconv_bwd_weight_matches_the_unfolded_weight_gradient(case, dtype):
     torch.testing.assert_close(dw2.cpu(), dw_ref.cpu(), **t2)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# ConvTranspose(k2, s2) + concat + 3x3x3 conv of a decoder level, the up half folded onto the coarse tensor
+# ---------------------------------------------------------------------------------------------------------------
+FOLDT_CASES = [
+    # (N, Cin_low, Cup, Cskip, Cout, coarse extent)
+    (1, 64, 64, 32, 32, (4, 8, 16)),          # decode5 of UNet3D(n_filter = 32)
+    (2, 32, 32, 16, 32, (3, 5, 9)),
+    (1, 128, 128, 64, 64, (2, 4, 8)),         # decode3
+    (1, 48, 32, 32, 64, (5, 3, 7)),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", FOLDT_CASES)
+def test_foldt_fwd_matches_convT_concat_conv(case, dtype):
+    """biu_foldt_fwd == ConvTranspose3d(k2, s2) -> torch.cat([up, skip], 1) -> Conv3d(k3, padding=1) (unet3d/unet3d.py:84-90), both inputs
+    lazily transformed, ConvT bias included (its border behaviour is the point of the 27-state table), BatchNorm statistics from the epilogue."""
+    n, cl, cup, cs, cout, sp = case
+    code = DT[dtype][1]
+    hi = tuple(2 * v for v in sp)
+    xl = Dev(rnd(n, cl, *sp, seed=1), dtype=dtype, pitch=cl + 8, c0=0)
+    sk = Dev(rnd(n, cs, *hi, seed=2), dtype=dtype, pitch=cs + 16, c0=8)
+    xfl, xfs = XF(cl, seed=3), XF(cs, seed=4)
+    wt = rnd(cl, cup, 2, 2, 2, seed=5) * (1.0 / cl ** 0.5)
+    bt = rnd(cup, seed=6)
+    wc = rnd(cout, cup + cs, 3, 3, 3, seed=7) * (1.0 / ((cup + cs) * 27) ** 0.5)
+    bc = rnd(cout, seed=8)
+    yd = Dev(shape=(n, cout, *hi), dtype=dtype, pitch=cout + 8, c0=8)
+    assert lib.biu_foldt_ok(xl.a(), sk.a(), yd.a(), code) == 1
+    xa, sa = xfl.apply(xl.ref()), xfs.apply(sk.ref())
+    if dtype == "bf16":
+        xa, sa = xa.bfloat16().float(), sa.bfloat16().float()
+    up = F.conv_transpose3d(xa, wt, bt, stride=2)
+    yref = F.conv3d(torch.cat([up, sa], 1), wc, bc, padding=1)
+    dev = [t.cuda() for t in (wc, bc, wt, bt)]
+    pk = torch.empty(lib.biu_foldt_packed_bytes(cl, cs, cout, code), dtype=torch.uint8, device="cuda")
+    check(lib.biu_foldt_pack(ptr(dev[0]), ptr(dev[1]), ptr(dev[2]), ptr(dev[3]), cl, cup, cs, cout, code, ptr(pk), stream()), "foldt_pack")
+    nfl = lib.biu_foldt_fwd_stats_floats(xl.a(), yd.a())
+    part = torch.full((nfl,), float("nan"), device="cuda")
+    nblk = C.c_int(0)
+    check(lib.biu_foldt_fwd(xl.a(), xfl.x(), sk.a(), xfs.x(), ptr(pk), yd.a(), ptr(part), nfl, C.byref(nblk), code, stream()), "foldt_fwd")
+    got = yd.get()
+    t = dict(rtol=1e-4, atol=1e-4 * float(yref.abs().max())) if dtype == "f32" else dict(rtol=1e-2, atol=2e-2 * float(yref.abs().max()))
+    torch.testing.assert_close(got, yref, **t)
+    assert torch.isnan(yd.buf[..., :8].float()).all()
+    sums = part[:nblk.value * cout * 2].view(nblk.value, cout, 2).double().sum(0).cpu()
+    gd = got.double()
+    torch.testing.assert_close(sums[:, 0], gd.sum(dim=(0, 2, 3, 4)), rtol=1e-4, atol=1e-4 * float(gd.abs().sum() / cout))
+    torch.testing.assert_close(sums[:, 1], (gd * gd).sum(dim=(0, 2, 3, 4)), rtol=1e-4, atol=1e-6)
+
+
 CONVT_MFMA_CASES = [
     # (nd, N, Cin, Cout, coarse spatial)
     (3, 1, 64, 64, (4, 8, 16)),
