@@ -408,6 +408,43 @@ extern "C" int biu_foldt_fwd(const biu_act* x_low, const biu_xform* xf_low, cons
     return biu_mfma_foldt_fwd(x_low, xf_low, skip, xf_skip, packed, y, nullptr, dtype, (hipStream_t)stream);
 }
 
+extern "C" size_t biu_foldt_bwd_data_bnred_floats(const biu_act* dx_low) { return (size_t)biu_mfma_upconv_dgrad_rows(dx_low) * dx_low->c * 2; }
+extern "C" int biu_foldt_bwd_data(const biu_act* dy, const void* packed, const biu_act* dx_low, int acc_low, const biu_act* dskip, int acc_skip,
+                                  const biu_act* y_low, const float* scale, const float* shift, const float* slope, const float* mean,
+                                  const float* invstd, float* partial, size_t partial_floats, int* nblk, void* ws, size_t ws_bytes, int dtype,
+                                  biu_stream stream) {
+    BIU_REQUIRE(dy && packed && dx_low && dskip, BIU_ERR_SHAPE, "foldt_bwd_data: null pointer");
+    BIU_REQUIRE(biu_mfma_foldt_ok(dx_low, dskip, dy, dtype), BIU_ERR_UNSUPPORTED, "foldt_bwd_data: shapes are not served by the folded kernels");
+    if (nblk) *nblk = 0;
+    if (y_low) {                  // BatchNorm-backward sums of x_low's producer from the epilogue (x_low's gradient is complete after this write)
+        BIU_REQUIRE(!acc_low && valid_act(y_low) && same_space(y_low, dx_low) && y_low->c == dx_low->c && scale && shift && mean && invstd && partial && nblk,
+                    BIU_ERR_SHAPE, "foldt_bwd_data: fused reduction needs acc_low = 0, y_low like dx_low and its vectors");
+        const int nb = biu_mfma_upconv_dgrad_rows(dx_low);
+        BIU_REQUIRE((size_t)nb * dx_low->c * 2 <= partial_floats, BIU_ERR_WORKSPACE, "foldt_bwd_data: partial buffer too small");
+        BnRedFuse red{y_low, scale, shift, slope, mean, invstd};
+        int rc = biu_mfma_foldt_dgrad(dy, packed, dx_low, 0, dskip, acc_skip, dtype, (hipStream_t)stream, partial, &red, ws, ws_bytes);
+        if (rc == BIU_OK) *nblk = nb;
+        return rc;
+    }
+    return biu_mfma_foldt_dgrad(dy, packed, dx_low, acc_low, dskip, acc_skip, dtype, (hipStream_t)stream, nullptr, nullptr, ws, ws_bytes);
+}
+extern "C" size_t biu_foldt_bwd_weight_workspace(int cin_low, int cskip, int cout, int dtype) { return biu_mfma_foldt_wgrad_workspace(cin_low, cskip, cout, dtype); }
+extern "C" int biu_foldt_bwd_weight_bn(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const biu_act* da,
+                                       const biu_act* y, const float* scale, const float* shift, const float* slope, const float* coefA,
+                                       const float* coefB, const float* coefC, const float* w_conv, const float* w_t, const float* b_t, int cup,
+                                       float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes, int dtype, biu_stream stream) {
+    BIU_REQUIRE(x_low && skip && da && w_conv && w_t && dw_conv && dw_t && ws && cup > 0, BIU_ERR_SHAPE, "foldt_bwd_weight_bn: null pointer");
+    BIU_REQUIRE(biu_mfma_foldt_ok(x_low, skip, da, dtype) && biu_mfma_wgrad_ok(skip, da, 3, 3, 3, 1, dtype), BIU_ERR_UNSUPPORTED,
+                "foldt_bwd_weight_bn: shapes are not served by the folded kernels");
+    if (y) {
+        BIU_REQUIRE(valid_act(y) && same_space(y, da) && y->c == da->c && scale && shift && coefA && coefB && coefC, BIU_ERR_SHAPE,
+                    "foldt_bwd_weight_bn: y / coefficient vectors do not match da");
+        BnBwdFuse bn{y, scale, shift, slope, coefA, coefB, coefC};
+        return biu_mfma_foldt_wgrad(x_low, xf_low, skip, xf_skip, da, &bn, w_conv, w_t, b_t, cup, dw_conv, dw_t, db_t, ws, ws_bytes, dtype, (hipStream_t)stream);
+    }
+    return biu_mfma_foldt_wgrad(x_low, xf_low, skip, xf_skip, da, nullptr, w_conv, w_t, b_t, cup, dw_conv, dw_t, db_t, ws, ws_bytes, dtype, (hipStream_t)stream);
+}
+
 extern "C" int biu_convt_fwd(const biu_act* x, const biu_xform* xf, const float* w, const void* packed, const float* bias,
                              int kd, const biu_act* y, int dtype, biu_stream stream) {
     BIU_REQUIRE(valid_act(x) && valid_act(y) && w && biu_convt_shapes_ok(x, y, kd), BIU_ERR_SHAPE,

@@ -1494,7 +1494,7 @@ static int launch_cfg_r(const ConvArgs& a0, int ntiles, int nz, hipStream_t st) 
 template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int NT, int CKP, int NW = 8>
 static int launch_cfg(const ConvArgs& a, int ntiles, int nz, hipStream_t st) {
     // the BatchNorm-backward epilogue only exists for stride-1 3x3(x3) data gradients and stride-2 ConvT data gradients
-    if constexpr ((S == 1 && KHW == 3) || S == 2) {
+    if constexpr ((S == 1 && KHW == 3) || S == 2 || (KD == 2 && KHW == 2 && S == 1)) {
         if (a.red_mode) return launch_cfg_r<T, KD, KHW, S, TD, TH, TW, NT, CKP, true, NW>(a, ntiles, nz, st);
     } else {
         if (a.red_mode) return biu_fail(BIU_ERR_UNSUPPORTED, "conv_pipe: no fused BatchNorm-backward epilogue for this kernel shape");
@@ -2195,12 +2195,24 @@ int biu_mfma_upconv_fwd(const biu_act* x, const biu_xform* xf, const void* packe
     return launch_upconv<float>(a, st);
 }
 // data gradient of the folded up-conv: dx[u] (+)= sum_p sum_s W'[p][1 - s]^T . dy[2 (u - p + s) + p]   (dy fine, dx coarse)
-int biu_mfma_upconv_dgrad(const biu_act* dy, const void* packed, const biu_act* dx, int accumulate, int dtype, hipStream_t st) {
+// BatchNorm-backward partial rows of the folded data gradient with the fused reduction (one per block; mirrors launch_cfg_r)
+int biu_mfma_upconv_dgrad_rows(const biu_act* dx) {
+    const int ntiles = (dx->c + 31) / 32, gy = ntiles / pick_nt(ntiles);
+    int g = grid_per_column(num_cus(), gy);
+    const int nbricks = dx->n * ((dx->d + 3) / 4) * ((dx->h + 7) / 8) * ((dx->w + 15) / 16);
+    return g > nbricks ? nbricks : g;
+}
+int biu_mfma_upconv_dgrad(const biu_act* dy, const void* packed, const biu_act* dx, int accumulate, int dtype, hipStream_t st, float* bn_partial,
+                          const BnRedFuse* red) {
     ConvArgs a;
     clear_cat(a);
-    a.bn_partial = nullptr;
+    a.bn_partial = red ? bn_partial : nullptr;
     a.red_mode = 0; a.red_y = nullptr; a.red_ypitch = 0;
     a.red_scale = a.red_shift = a.red_slope = a.red_mean = a.red_invstd = nullptr;
+    if (red) {
+        a.red_mode = 1; a.red_y = (const char*)red->y->p; a.red_ypitch = red->y->pitch;
+        a.red_scale = red->scale; a.red_shift = red->shift; a.red_slope = red->slope; a.red_mean = red->mean; a.red_invstd = red->invstd;
+    }
     a.x = (const char*)dy->p;
     a.y = (char*)dx->p;
     a.wpk = (const uint4*)packed;
@@ -3706,14 +3718,16 @@ static int launch_wgrad_roll(WgradArgs a, hipStream_t st, bool k2d = false) {
 }
 
 // ws[tap][i][j] -> dw[i][j][tap]
-__global__ void k_wgrad_finalize(const float* __restrict__ ws, int rows, int cols, int taps, float* __restrict__ dw) {
+// (ld_cols > 0: dw is a channel slice [c_off, c_off + cols) of a (rows, ld_cols, taps) tensor)
+__global__ void k_wgrad_finalize(const float* __restrict__ ws, int rows, int cols, int taps, float* __restrict__ dw, int ld_cols = 0, int c_off = 0) {
     const size_t total = (size_t)rows * cols * taps;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int tap = (int)(i % taps);
         const size_t r = i / taps;
         const int c = (int)(r % cols);
         const int rr = (int)(r / cols);
-        dw[i] = ws[((size_t)tap * rows + rr) * cols + c];
+        const size_t o = ld_cols > 0 ? ((size_t)rr * ld_cols + c_off + c) * taps + tap : i;
+        dw[o] = ws[((size_t)tap * rows + rr) * cols + c];
     }
 }
 
@@ -3826,7 +3840,8 @@ static int wgrad_xf(const biu_xform* xf, const float** s, const float** b, const
 }
 
 int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, int kh, int kw, float* dw, float* dbias,
-                   void* ws, size_t ws_bytes, int dtype, hipStream_t st, const BnBwdFuse* bn, const biu_act* x1, const biu_xform* xf1) {
+                   void* ws, size_t ws_bytes, int dtype, hipStream_t st, const BnBwdFuse* bn, const biu_act* x1, const biu_xform* xf1,
+                   int dw_ld_cols, int dw_c_off) {
     WgradArgs a;
     int rc_ = BIU_OK;
     if (bn) {
@@ -3871,7 +3886,7 @@ int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int
     else rc = (kd == 3) ? launch_wgrad<float, 3, 3, 1, 4, 4, 16, 1>(a, st) : launch_wgrad<float, 1, 3, 1, 1, 16, 16, 4>(a, st);
     if (rc != BIU_OK) return rc;
     hipLaunchKernelGGL(k_wgrad_finalize, dim3(grid_for((i64)a.CA * a.CB * taps, 256, 2048)), dim3(256), 0, st, (const float*)ws,
-                       a.CA, a.CB, taps, dw);
+                       a.CA, a.CB, taps, dw, dw_ld_cols, dw_c_off);
     BIU_CHECK_LAUNCH("wgrad_finalize");
     if (dbias) return biu_chan_sum_vec(dy, dbias, (char*)ws + need, dtype, st);
     return BIU_OK;
@@ -3936,9 +3951,163 @@ int biu_mfma_upconv_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* 
         else rc = dtype == BIU_BF16 ? launch_wgrad<bf16_t, 2, 2, 1, 4, 8, 16, 1>(a, st) : launch_wgrad<float, 2, 2, 1, 4, 4, 16, 1>(a, st);
         if (rc != BIU_OK) return rc;
     }
+    if (!dw) return BIU_OK;                              // (foldt: the caller turns G[p][t][co][ci] in ws into the gradients of both weight tensors)
     hipLaunchKernelGGL(k_upconv_wgrad_unfold, dim3(grid_for((i64)a.CA * a.CB * 27, 256, 2048)), dim3(256), 0, st, (const float*)ws, slice / sizeof(float),
                        a.CA, a.CB, dw);
     BIU_CHECK_LAUNCH("upconv_wgrad_unfold");
+    return BIU_OK;
+}
+
+// ---- foldt backward ------------------------------------------------------------------------------------------------------------
+// data gradients: d skip through the channel-sliced data-gradient image of the conv, d x_low through the composed fold (optionally with the
+// BatchNorm-backward sums of x_low's producer from its epilogue)
+int biu_mfma_foldt_dgrad(const biu_act* dy, const void* packed, const biu_act* dx_low, int acc_low, const biu_act* dskip, int acc_skip, int dtype,
+                         hipStream_t st, float* bn_partial_low, const BnRedFuse* red_low, void* ws, size_t ws_bytes) {
+    const FoldtBlob b = foldt_blob(dx_low->c, dskip->c, dy->c, dtype);
+    const char* base = (const char*)packed;
+    int rc = biu_mfma_conv(dy, nullptr, base + b.sdg, nullptr, 3, 3, 3, dskip, acc_skip, nullptr, dtype, st, nullptr, nullptr, ws, ws_bytes);
+    if (rc != BIU_OK) return rc;
+    return biu_mfma_upconv_dgrad(dy, base + b.dg, dx_low, acc_low, dtype, st, bn_partial_low, red_low);
+}
+// border sums of dy: R[state][co] = sum of dy over the voxels of border state (sd, sh, sw) != interior (fp32 atomics into a zeroed table;
+// only shell voxels are touched)
+template <typename T>
+__global__ void k_foldt_border_sums(const char* __restrict__ dy, int n, int d, int h, int w, int c, int pitch, float* __restrict__ R) {
+    const long nv = (long)n * d * h * w;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(v % w), yy = (int)((v / w) % h), z = (int)((v / ((long)w * h)) % d);
+        const int sd = z == 0 ? 0 : (z == d - 1 ? 2 : 1), sh = yy == 0 ? 0 : (yy == h - 1 ? 2 : 1), sw = x == 0 ? 0 : (x == w - 1 ? 2 : 1);
+        if (sd == 1 && sh == 1 && sw == 1) continue;
+        float* r = R + (size_t)((sd * 3 + sh) * 3 + sw) * c;
+        const T* row = (const T*)dy + (size_t)v * pitch;
+        for (int cc = 0; cc < c; ++cc) atomicAdd(r + cc, (float)row[cc]);
+    }
+}
+// chain rule from G[p][t][co][ci] (ws, parity slices `slice_f` floats apart) to the gradients of both weight tensors and the ConvT bias:
+//   dW_conv[co][c][k] = sum_p sum_ci W_T[ci][c][q(p,k)] G[p][t_p(k)][co][ci]                          (c < cup: the up half of the concat)
+//   dW_T[ci][c][q]    = sum_{(p,k): q(p,k) = q} sum_co W_conv[co][c][k] G[p][t_p(k)][co][ci]
+//   db_T[c]           = sum_k sum_co W_conv[co][c][k] S_k[co],  S_k = sum of dy over the voxels where tap k stays inside = -(sum over the
+//                       border states where it does not): sum_v dy = 0 exactly behind a train-mode BatchNorm
+__device__ __forceinline__ void foldt_tq(int p, int k, int& t, int& q) {
+    const int kk[3] = {k / 9, (k / 3) % 3, k % 3};
+    t = 0; q = 0;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const int pa = (p >> (2 - ax)) & 1;
+        const int ta = pa == 0 ? (kk[ax] >= 1 ? 1 : 0) : (kk[ax] == 2 ? 1 : 0);
+        t |= ta << (2 - ax);
+        q |= ((pa + kk[ax] + 1) & 1) << (2 - ax);
+    }
+}
+// S_k[co] = sum of dy over the voxels whose tap k stays inside = -(sum of R over the border states where it does not)
+__global__ void k_foldt_inside_sums(const float* __restrict__ R, int cout, float* __restrict__ Sk) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= 27 * cout) return;
+    const int k = i / cout, co = i % cout;
+    const int kd = k / 9, kh = (k / 3) % 3, kw = k % 3;
+    float sum = 0.f;
+    for (int s = 0; s < 27; ++s) {
+        if (s == 13) continue;
+        const int sd = s / 9, sh = (s / 3) % 3, sw = s % 3;
+        const bool outside = (kd == 0 && sd == 0) || (kd == 2 && sd == 2) || (kh == 0 && sh == 0) || (kh == 2 && sh == 2) || (kw == 0 && sw == 0) || (kw == 2 && sw == 2);
+        if (outside) sum -= R[s * cout + co];
+    }
+    Sk[i] = sum;
+}
+// (the ConvT bias is part of `up`: dW_conv[co][c][k] also gets b_T[c] S_k[co])
+__global__ void k_foldt_chain_wconv(const float* __restrict__ G, size_t slice_f, const float* __restrict__ wt, int cin_low, int cup, int cout, int ccat,
+                                    float* __restrict__ dwc, const float* __restrict__ bt, const float* __restrict__ Sk) {
+    const size_t total = (size_t)cout * cup * 27;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % 27);
+        const size_t r = idx / 27;
+        const int c = (int)(r % cup), co = (int)(r / cup);
+        float sum = 0.f;
+        for (int p = 0; p < 8; ++p) {
+            int t, q;
+            foldt_tq(p, k, t, q);
+            const float* g = G + (size_t)p * slice_f + ((size_t)t * cout + co) * cin_low;
+            const float* b = wt + (size_t)c * 8 + q;
+            float acc = 0.f;
+            for (int ci = 0; ci < cin_low; ++ci) acc = fmaf(b[(size_t)ci * cup * 8], g[ci], acc);
+            sum += acc;
+        }
+        if (bt) sum = fmaf(bt[c], Sk[k * cout + co], sum);
+        dwc[((size_t)co * ccat + c) * 27 + k] = sum;
+    }
+}
+__global__ void k_foldt_chain_wt(const float* __restrict__ G, size_t slice_f, const float* __restrict__ wc, int cin_low, int cup, int cout, int ccat,
+                                 float* __restrict__ dwt) {
+    const size_t total = (size_t)cin_low * cup * 8;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % 8);
+        const size_t r = idx / 8;
+        const int c = (int)(r % cup), ci = (int)(r / cup);
+        float sum = 0.f;
+        for (int p = 0; p < 8; ++p)
+            for (int k = 0; k < 27; ++k) {
+                int t, qq;
+                foldt_tq(p, k, t, qq);
+                if (qq != q) continue;
+                const float* g = G + (size_t)p * slice_f + (size_t)t * cout * cin_low + ci;
+                const float* a = wc + (size_t)c * 27 + k;
+                float acc = 0.f;
+                for (int co = 0; co < cout; ++co) acc = fmaf(a[(size_t)co * ccat * 27], g[(size_t)co * cin_low], acc);
+                sum += acc;
+            }
+        dwt[idx] = sum;
+    }
+}
+__global__ void k_foldt_chain_bt(const float* __restrict__ Sk, const float* __restrict__ wc, int cup, int cout, int ccat, float* __restrict__ dbt) {
+    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (c >= cup) return;
+    float sum = 0.f;
+    for (int k = 0; k < 27; ++k) {
+        float acc = 0.f;
+        for (int co = 0; co < cout; ++co) acc = fmaf(wc[((size_t)co * ccat + c) * 27 + k], Sk[k * cout + co], acc);
+        sum += acc;
+    }
+    dbt[c] = sum;
+}
+size_t biu_mfma_foldt_wgrad_workspace(int cin_low, int cskip, int cout, int dtype) {
+    if (!wgrad_chan_ok(cin_low, cout) || !wgrad_chan_ok(cskip, cout)) return 0;
+    const size_t g = 8 * wgrad_acc_bytes(cout, cin_low, 8), sk = biu_mfma_wgrad_workspace(cskip, cout, 3, 3, 3, dtype);
+    return (g > sk ? g : sk) + 2 * al256((size_t)27 * cout * sizeof(float));
+}
+// da -> dy in place (BatchNorm + LeakyReLU backward in the loader of the skip half's weight gradient, which runs first); then G on the finished dy
+int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const biu_act* da, const BnBwdFuse* bn,
+                         const float* w_conv, const float* w_t, const float* b_t, int cup, float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes,
+                         int dtype, hipStream_t st) {
+    const int cin_low = x_low->c, cskip = skip->c, cout = da->c, ccat = cup + cskip;
+    const size_t need = biu_mfma_foldt_wgrad_workspace(cin_low, cskip, cout, dtype);
+    BIU_REQUIRE(need > 0 && ws_bytes >= need, BIU_ERR_WORKSPACE, "foldt_wgrad: workspace %zu too small (need %zu)", ws_bytes, need);
+    const size_t rbytes = al256((size_t)27 * cout * sizeof(float)), main_bytes = need - 2 * rbytes;
+    float* R = (float*)((char*)ws + main_bytes);
+    float* Sk = (float*)((char*)ws + main_bytes + rbytes);
+    // 1. skip half of dW_conv (its slice of the channel axis), BatchNorm backward in the loader: da becomes dy
+    int rc = biu_mfma_wgrad(skip, xf_skip, da, 3, 3, 3, dw_conv, nullptr, ws, main_bytes, dtype, st, bn, nullptr, nullptr, ccat, cup);
+    if (rc != BIU_OK) return rc;
+    // 2. G[p][t] on the finished dy
+    rc = biu_mfma_upconv_wgrad(x_low, xf_low, da, nullptr, ws, main_bytes, dtype, st, nullptr);
+    if (rc != BIU_OK) return rc;
+    // 3. the ConvT bias: border sums of dy -> S_k (taps inside), needed by dW_conv (b_T is part of `up`) and by db_T
+    const bool has_bias = b_t != nullptr || db_t != nullptr;
+    if (has_bias) {
+        if (int zr = zero_ws(R, rbytes, nullptr, 0, st)) return zr;
+        const long nv = (long)da->n * da->d * da->h * da->w;
+        BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_foldt_border_sums<T>, dim3(grid_for((i64)nv, 256, 8192)), dim3(256), 0, st, (const char*)da->p, da->n, da->d,
+                                                     da->h, da->w, da->c, da->pitch, R));
+        hipLaunchKernelGGL(k_foldt_inside_sums, dim3((27 * cout + 127) / 128), dim3(128), 0, st, (const float*)R, cout, Sk);
+        BIU_CHECK_LAUNCH("foldt_border_sums");
+    }
+    // 4. chain rule to the up half of dW_conv, to dW_T and to db_T
+    const size_t slice_f = wgrad_acc_bytes(cout, cin_low, 8) / sizeof(float);
+    hipLaunchKernelGGL(k_foldt_chain_wconv, dim3(grid_for((i64)cout * cup * 27, 128, 4096)), dim3(128), 0, st, (const float*)ws, slice_f, w_t, cin_low, cup, cout, ccat,
+                       dw_conv, b_t, (const float*)Sk);
+    hipLaunchKernelGGL(k_foldt_chain_wt, dim3(grid_for((i64)cin_low * cup * 8, 128, 4096)), dim3(128), 0, st, (const float*)ws, slice_f, w_conv, cin_low, cup, cout, ccat,
+                       dw_t);
+    if (db_t) hipLaunchKernelGGL(k_foldt_chain_bt, dim3((cup + 63) / 64), dim3(64), 0, st, (const float*)Sk, w_conv, cup, cout, ccat, db_t);
+    BIU_CHECK_LAUNCH("foldt_chain");
     return BIU_OK;
 }
 

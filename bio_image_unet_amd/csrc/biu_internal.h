@@ -51,7 +51,7 @@ struct BnBwdFuse {            // BatchNorm(+LeakyReLU) backward fused into the w
 };
 int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, int kh, int kw, float* dw,
                    float* dbias, void* ws, size_t ws_bytes, int dtype, hipStream_t st, const BnBwdFuse* bn = nullptr,
-                   const biu_act* x1 = nullptr, const biu_xform* xf1 = nullptr);
+                   const biu_act* x1 = nullptr, const biu_xform* xf1 = nullptr, int dw_ld_cols = 0, int dw_c_off = 0);
 
 size_t biu_mfma_convt_packed_bytes(int kind, int cin, int cout, int kd, int dtype);
 int biu_mfma_convt_pack(int kind, const float* w, int cin, int cout, int kd, int dtype, void* packed, hipStream_t st);
@@ -59,7 +59,9 @@ int biu_mfma_convt_pack(int kind, const float* w, int cin, int cout, int kd, int
 bool biu_mfma_upconv_ok(const biu_act* x, const biu_act* y, int dtype);
 size_t biu_mfma_upconv_packed_bytes(int kind, int cin, int cout, int dtype);
 int biu_mfma_upconv_pack(int kind, const float* w, int cin, int cout, int dtype, void* packed, hipStream_t st, const float* wf = nullptr);
-int biu_mfma_upconv_dgrad(const biu_act* dy, const void* packed, const biu_act* dx, int accumulate, int dtype, hipStream_t st);
+int biu_mfma_upconv_dgrad_rows(const biu_act* dx);
+int biu_mfma_upconv_dgrad(const biu_act* dy, const void* packed, const biu_act* dx, int accumulate, int dtype, hipStream_t st, float* bn_partial = nullptr,
+                          const BnRedFuse* red = nullptr);
 struct BnBwdFuse;
 size_t biu_mfma_upconv_wgrad_workspace(int cin, int cout, int dtype);
 int biu_mfma_upconv_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, float* dw, void* ws, size_t ws_bytes, int dtype,
@@ -75,6 +77,12 @@ int biu_mfma_foldt_pack(const float* w_conv, const float* b_conv, const float* w
 int biu_mfma_foldt_stat_rows(const biu_act* x_low, const biu_act* y);
 int biu_mfma_foldt_fwd(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const void* packed, const biu_act* y,
                        float* bn_partial, int dtype, hipStream_t st);
+int biu_mfma_foldt_dgrad(const biu_act* dy, const void* packed, const biu_act* dx_low, int acc_low, const biu_act* dskip, int acc_skip, int dtype,
+                         hipStream_t st, float* bn_partial_low, const BnRedFuse* red_low, void* ws, size_t ws_bytes);
+size_t biu_mfma_foldt_wgrad_workspace(int cin_low, int cskip, int cout, int dtype);
+int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const biu_act* da, const BnBwdFuse* bn,
+                         const float* w_conv, const float* w_t, const float* b_t, int cup, float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes,
+                         int dtype, hipStream_t st);
 bool biu_mfma_convt_ok(int kind, const biu_act* lo, const biu_act* hi, int kd, int dtype);
 int biu_mfma_convt_fwd(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, const biu_act* y,
                        int dtype, hipStream_t st);

@@ -349,6 +349,24 @@ int    biu_foldt_pack(const float* w_conv, const float* b_conv, const float* w_t
 size_t biu_foldt_fwd_stats_floats(const biu_act* x_low, const biu_act* y);
 int    biu_foldt_fwd(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const void* packed,
                      const biu_act* y, float* bn_partial, size_t bn_partial_floats, int* bn_nblk, int dtype, biu_stream stream);
+/* backward of the same op.  biu_foldt_bwd_data: d skip (the conv's data gradient restricted to the skip channels) and d x_low (the composed fold
+ * transposed: replaces biu_conv_bwd_data_cat's up half + biu_convt_bwd_data); y_low != NULL additionally emits the BatchNorm-backward sums of
+ * x_low's producer as biu_convt_bwd_data_bnred does (acc_low must be 0; biu_foldt_bwd_data_bnred_floats sizes `partial`).
+ * biu_foldt_bwd_weight_bn: BatchNorm+LeakyReLU backward of the block in the loader (da -> dy in place; y = NULL: da already is dy), then
+ *   dw_conv (Cout, cup + cskip, 27) in full, dw_t (Cin_low, cup, 8) and db_t (cup; may be NULL) by the chain rule from
+ *   G[p][t] = sum_v dy[2v + p] (x) T(x_low)[v + t - 1 + p]:  dw_conv[.., c < cup, k] = sum_p W_T[., c, q(p,k)] . G[p][t_p(k)] + b_T[c] S_k,
+ *   dw_t[ci, c, q] = sum_{(p,k): q(p,k) = q} W_conv[., c, k] . G[p][t_p(k)][., ci],  db_t[c] = sum_k W_conv[., c, k] . S_k with S_k the sum of dy over
+ *   the voxels whose tap k stays inside the tensor (border sums; sum_v dy = 0 behind a train-mode BatchNorm). */
+size_t biu_foldt_bwd_data_bnred_floats(const biu_act* dx_low);
+int    biu_foldt_bwd_data(const biu_act* dy, const void* packed, const biu_act* dx_low, int acc_low, const biu_act* dskip, int acc_skip,
+                          const biu_act* y_low, const float* scale, const float* shift, const float* slope, const float* mean,
+                          const float* invstd, float* partial, size_t partial_floats, int* nblk, void* ws, size_t ws_bytes, int dtype,
+                          biu_stream stream);
+size_t biu_foldt_bwd_weight_workspace(int cin_low, int cskip, int cout, int dtype);
+int    biu_foldt_bwd_weight_bn(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const biu_act* da,
+                               const biu_act* y, const float* scale, const float* shift, const float* slope, const float* coefA,
+                               const float* coefB, const float* coefC, const float* w_conv, const float* w_t, const float* b_t, int cup,
+                               float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes, int dtype, biu_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 1x1(x1) head + activation                                                             [K9]

@@ -541,9 +541,11 @@ def test_foldt_fwd_matches_convT_concat_conv(case, dtype):
     xa, sa = xfl.apply(xl.ref()), xfs.apply(sk.ref())
     if dtype == "bf16":
         xa, sa = xa.bfloat16().float(), sa.bfloat16().float()
+    xa.requires_grad_(True); sa.requires_grad_(True)
+    wt, bt, wc = wt.requires_grad_(True), bt.requires_grad_(True), wc.requires_grad_(True)
     up = F.conv_transpose3d(xa, wt, bt, stride=2)
     yref = F.conv3d(torch.cat([up, sa], 1), wc, bc, padding=1)
-    dev = [t.cuda() for t in (wc, bc, wt, bt)]
+    dev = [t.detach().cuda() for t in (wc, bc, wt, bt)]
     pk = torch.empty(lib.biu_foldt_packed_bytes(cl, cs, cout, code), dtype=torch.uint8, device="cuda")
     check(lib.biu_foldt_pack(ptr(dev[0]), ptr(dev[1]), ptr(dev[2]), ptr(dev[3]), cl, cup, cs, cout, code, ptr(pk), stream()), "foldt_pack")
     nfl = lib.biu_foldt_fwd_stats_floats(xl.a(), yd.a())
@@ -552,12 +554,39 @@ def test_foldt_fwd_matches_convT_concat_conv(case, dtype):
     check(lib.biu_foldt_fwd(xl.a(), xfl.x(), sk.a(), xfs.x(), ptr(pk), yd.a(), ptr(part), nfl, C.byref(nblk), code, stream()), "foldt_fwd")
     got = yd.get()
     t = dict(rtol=1e-4, atol=1e-4 * float(yref.abs().max())) if dtype == "f32" else dict(rtol=1e-2, atol=2e-2 * float(yref.abs().max()))
-    torch.testing.assert_close(got, yref, **t)
+    torch.testing.assert_close(got, yref.detach(), **t)
     assert torch.isnan(yd.buf[..., :8].float()).all()
     sums = part[:nblk.value * cout * 2].view(nblk.value, cout, 2).double().sum(0).cpu()
     gd = got.double()
     torch.testing.assert_close(sums[:, 0], gd.sum(dim=(0, 2, 3, 4)), rtol=1e-4, atol=1e-4 * float(gd.abs().sum() / cout))
     torch.testing.assert_close(sums[:, 1], (gd * gd).sum(dim=(0, 2, 3, 4)), rtol=1e-4, atol=1e-6)
+    # ---- backward: a dy whose per-channel sum is zero (what a train-mode BatchNorm hands back; the ConvT-bias gradient relies on it) ----
+    dy0 = rnd(n, cout, *hi, seed=9)
+    dy0 = dy0 - dy0.mean(dim=(0, 2, 3, 4), keepdim=True)
+    dyd = Dev(dy0, dtype=dtype, pitch=cout + 8, c0=0)
+    dyr = dyd.ref()
+    if dtype == "bf16":                                 # the stored bf16 dy no longer sums to zero exactly: its residue goes into the db_T tolerance
+        pass
+    yref.backward(dyr)
+    dxl = Dev(shape=(n, cl, *sp), dtype=dtype, pitch=cl + 8, c0=8)
+    dsk = Dev(shape=(n, cs, *hi), dtype=dtype)
+    wsd = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    check(lib.biu_foldt_bwd_data(dyd.a(), ptr(pk), dxl.a(), 0, dsk.a(), 0, None, None, None, None, None, None, None, 0, None, ptr(wsd), wsd.numel(), code,
+                                 stream()), "foldt_bwd_data")
+    tg = lambda ref: dict(rtol=1e-4, atol=1e-4 * float(ref.abs().max())) if dtype == "f32" else dict(rtol=1e-2, atol=2e-2 * float(ref.abs().max()))  # noqa: E731
+    torch.testing.assert_close(dxl.get(), xa.grad, **tg(xa.grad))
+    torch.testing.assert_close(dsk.get(), sa.grad, **tg(sa.grad))
+    wsz = lib.biu_foldt_bwd_weight_workspace(cl, cs, cout, code)
+    assert wsz > 0
+    ws = torch.empty(wsz, dtype=torch.uint8, device="cuda")
+    dwc, dwt, dbt = (torch.full(t_.shape, float("nan"), device="cuda") for t_ in (wc, wt, bt))
+    check(lib.biu_foldt_bwd_weight_bn(xl.a(), xfl.x(), sk.a(), xfs.x(), dyd.a(), None, None, None, None, None, None, None, ptr(dev[0]), ptr(dev[2]), ptr(dev[3]), cup,
+                                      ptr(dwc), ptr(dwt), ptr(dbt), ptr(ws), ws.numel(), code, stream()), "foldt_bwd_weight")
+    tw = lambda ref: dict(rtol=1e-3, atol=2e-4 * float(ref.abs().max())) if dtype == "f32" else dict(rtol=2e-2, atol=2e-2 * float(ref.abs().max()))  # noqa: E731
+    torch.testing.assert_close(dwc.cpu(), wc.grad, **tw(wc.grad))
+    torch.testing.assert_close(dwt.cpu(), wt.grad, **tw(wt.grad))
+    resid = float(dyr.sum(dim=(0, 2, 3, 4)).abs().max()) * float(wc.detach().abs().sum(dim=(0, 2, 3, 4)).max())       # |sum dy| x |W_conv|: the zero-sum assumption
+    torch.testing.assert_close(dbt.cpu(), bt.grad, rtol=1e-3 if dtype == "f32" else 2e-2, atol=(2e-4 if dtype == "f32" else 2e-2) * float(bt.grad.abs().max()) + resid)
 
 
 CONVT_MFMA_CASES = [
