@@ -223,7 +223,8 @@ class ConvBlockNode(Node):
     backward: d a -> d y (BatchNorm + LeakyReLU backward, in place) ; dW, db ; d x.
     """
 
-    def __init__(self, eng, seq: nn.Sequential, xin: Act, yout: Act, dropout_follows: bool = False, fold_src: Optional[Act] = None):
+    def __init__(self, eng, seq: nn.Sequential, xin: Act, yout: Act, dropout_follows: bool = False, fold_src: Optional[Act] = None,
+                 convt: Optional["ConvTNode"] = None):
         """``fold_src``: ``xin`` is the nearest-neighbour up-sampling (x2) of this coarse activation
         (multi_output_unet3d/multi_output_unet3d.py:138-139).  The forward then runs folded on the coarse tensor
         (``biu_upconv_fwd``: 8 parity classes x 2x2x2 taps instead of 27 taps, include/biu.h) when the kernel serves the shape, and
@@ -233,6 +234,10 @@ class ConvBlockNode(Node):
         conv, bn = seq[0], seq[1]
         self.conv, self.bn, self.xin, self.y = conv, bn, xin, yout
         self.fold_src, self.fold_slot, self.fold_dg_slot, self.fold_wg, self.fold_all = None, None, None, False, False
+        # ``convt``: xin = concat(convt's output, skip) (unet3d/unet3d.py:84-90).  ConvTranspose + concat + this conv then run as ONE op with the up
+        # half folded onto convt's coarse input (include/biu.h: biu_foldt_*), forward and backward; the ConvT node is skipped altogether and
+        # this node delivers the gradients of its parameters too.
+        self.foldt, self.foldt_blob, self.foldt_ver = None, None, None
         # the block's activation as a leaky slope: LeakyReLU(s) -> s, ReLU -> 0 (Unet_v0 / BabyUnet), none or a later
         # non-piecewise-linear one (the attention gate's Sigmoid, applied by GateNode) -> 1
         act = seq[2] if len(seq) > 2 else None
@@ -257,6 +262,16 @@ class ConvBlockNode(Node):
         yout.vec("slope").fill_(self.slope)
         eng.need_partial(cout)
         eng.need_partial_floats(lib.biu_conv_fwd_stats_floats(yout.a(), self.kd))
+        if (convt is not None and isinstance(xin, CatAct) and len(xin.parts) == 2 and xin.parts[0] is convt.y and convt.kd == 2
+                and (self.kd, self.kh, self.kw, self.dil) == (3, 3, 3, 1) and convt.up.bias is not None
+                and lib.biu_foldt_ok(convt.xin.a(), xin.parts[1].a(), yout.a(), eng.dtype)
+                and lib.biu_foldt_bwd_weight_workspace(convt.xin.c, xin.parts[1].c, cout, eng.dtype) > 0):
+            self.foldt = convt
+            lo, skip = convt.xin, xin.parts[1]
+            self.foldt_blob = torch.empty(lib.biu_foldt_packed_bytes(lo.c, skip.c, cout, eng.dtype), dtype=torch.uint8, device=dev)
+            eng.need_partial_floats(lib.biu_foldt_fwd_stats_floats(lo.a(), yout.a()))
+            eng.need_ws(lib.biu_foldt_bwd_weight_workspace(lo.c, skip.c, cout, eng.dtype))
+            self.params = [conv.weight, conv.bias, bn.weight, bn.bias]
         if (fold_src is not None and (self.kd, self.kh, self.kw, self.dil) == (3, 3, 3, 1) and not isinstance(xin, CatAct)
                 and fold_src.c == xin.c and lib.biu_upconv_ok(fold_src.a(), yout.a(), eng.dtype)):
             self.fold_src = fold_src
@@ -289,6 +304,8 @@ class ConvBlockNode(Node):
         bn = self.bn
         scale, shift = self.y.vec("scale"), self.y.vec("shift")
         cat = self.xin.parts if isinstance(self.xin, CatAct) else None
+        if self.foldt is not None:
+            return self._fwd_foldt(eng, st)
         folded = None
         if self.fold_src is not None:                       # up-sampling + conv on the coarse tensor: weights folded once per version
             ver = (self.conv.weight.data_ptr(), self.conv.weight._version)
@@ -333,6 +350,69 @@ class ConvBlockNode(Node):
                                          _ptr(bn.running_var), bn.eps, _ptr(scale), _ptr(shift), st), "bn_eval_affine")
             self.batch_stats = False
 
+    def _foldt_packed(self, st):
+        ct = self.foldt
+        ps = (self.conv.weight, self.conv.bias, ct.up.weight, ct.up.bias)
+        ver = tuple((p.data_ptr(), p._version) for p in ps if p is not None)
+        if self.foldt_ver != ver:
+            check(lib.biu_foldt_pack(_ptr(self.conv.weight.data), _ptr(self.conv.bias.data) if self.conv.bias is not None else None,
+                                     _ptr(ct.up.weight.data), _ptr(ct.up.bias.data), ct.xin.c, ct.y.c, self.xin.parts[1].c, self.y.c, self._dtype,
+                                     _ptr(self.foldt_blob), st), "foldt_pack")
+            self.foldt_ver = ver
+        return _ptr(self.foldt_blob)
+
+    def _fwd_foldt(self, eng, st):
+        self._dtype = eng.dtype
+        ct, skip, bn = self.foldt, self.xin.parts[1], self.bn
+        blob = self._foldt_packed(st)
+        scale, shift = self.y.vec("scale"), self.y.vec("shift")
+        if eng.bn_training(bn):
+            nblk = C.c_int(0)
+            check(lib.biu_foldt_fwd(ct.xin.a(), ct.xin.xf(), skip.a(), skip.xf(), blob, self.y.a(), _ptr(eng.partial), eng.partial.numel(), C.byref(nblk),
+                                    eng.dtype, st), "foldt_fwd")
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            track = bn.track_running_stats and bn.running_mean is not None
+            check(lib.biu_bn_finalize(_ptr(eng.partial), nblk.value, self.y.c, float(self.y.nvox), _ptr(bn.weight.data),
+                                      _ptr(bn.bias.data), _ptr(bn.running_mean) if track else None,
+                                      _ptr(bn.running_var) if track else None, mom, bn.eps, _ptr(scale), _ptr(shift),
+                                      _ptr(self.save_mean), _ptr(self.save_invstd), st), "bn_finalize")
+            if track and bn.num_batches_tracked is not None:
+                eng.nbt_bump.append(bn.num_batches_tracked)
+            self.batch_stats = True
+        else:
+            check(lib.biu_foldt_fwd(ct.xin.a(), ct.xin.xf(), skip.a(), skip.xf(), blob, self.y.a(), None, 0, None, eng.dtype, st), "foldt_fwd")
+            check(lib.biu_bn_eval_affine(self.y.c, _ptr(bn.weight.data), _ptr(bn.bias.data), _ptr(bn.running_mean),
+                                         _ptr(bn.running_var), bn.eps, _ptr(scale), _ptr(shift), st), "bn_eval_affine")
+            self.batch_stats = False
+
+    def _bwd_foldt(self, eng, st, scale, shift, slope, A, B, Cc, dw):
+        ct, skip, y = self.foldt, self.xin.parts[1], self.y
+        lo = ct.xin
+        dwt, dbt = eng.new_grad(ct.up.weight), eng.new_grad(ct.up.bias)
+        check(lib.biu_foldt_bwd_weight_bn(lo.a(), lo.xf(), skip.a(), skip.xf(), y.g(), y.a(), scale, shift, slope, _ptr(A), _ptr(B), _ptr(Cc),
+                                          _ptr(self.conv.weight.data), _ptr(ct.up.weight.data), _ptr(ct.up.bias.data), ct.y.c, _ptr(dw), _ptr(dwt),
+                                          _ptr(dbt), _ptr(eng.ws), eng.ws_bytes, eng.dtype, st), "foldt_bwd_weight_bn")
+        eng.add_grad(ct.up.weight, dwt)
+        eng.add_grad(ct.up.bias, dbt)
+        blob = self._foldt_packed(st)
+        want_lo = eng.wants_grad(lo)
+        up = _fusable_producer(lo) if want_lo else None
+        if not want_lo:
+            raise NotImplementedError("foldt: the coarse input of a decoder level always wants its gradient")
+        if up is not None:
+            need = lib.biu_foldt_bwd_data_bnred_floats(lo.a())
+            if up.red_partial is None or up.red_partial.numel() < need:
+                up.red_partial = torch.empty(need, dtype=torch.float32, device=eng.device)
+            n_up = C.c_int(0)
+            check(lib.biu_foldt_bwd_data(y.g(), blob, lo.g(), 0, skip.g(), int(skip.g_written()), lo.a(), *up.red_coeffs(), _ptr(up.red_partial),
+                                         up.red_partial.numel(), C.byref(n_up), _ptr(eng.ws), eng.ws_bytes, eng.dtype, st), "foldt_bwd_data")
+            up.red_nblk = n_up.value
+        else:
+            check(lib.biu_foldt_bwd_data(y.g(), blob, lo.g(), int(lo.g_written()), skip.g(), int(skip.g_written()), None, None, None, None, None, None,
+                                         None, 0, None, _ptr(eng.ws), eng.ws_bytes, eng.dtype, st), "foldt_bwd_data")
+        lo.mark_g()
+        skip.mark_g()
+
     def bwd(self, eng):
         if not self.y.g_written():
             return            # no gradient reaches this block (e.g. Siam 'control' branch)
@@ -361,6 +441,14 @@ class ConvBlockNode(Node):
         db = eng.zero_like_bias(self.conv.bias) if self.conv.bias is not None else None
         # BatchNorm+LeakyReLU backward (da -> dy, in place) rides inside the weight-gradient kernel's tile loader
         cat = self.xin.parts if isinstance(self.xin, CatAct) else None
+        if self.foldt is not None:
+            self._bwd_foldt(eng, st, scale, shift, slope, A, B, Cc, dw)
+            eng.add_grad(self.conv.weight, dw)
+            if db is not None:
+                eng.add_grad(self.conv.bias, db)
+            eng.add_grad(self.bn.weight, dgamma)
+            eng.add_grad(self.bn.bias, dbeta)
+            return
         if cat:
             check(lib.biu_conv_bwd_weight_cat(cat[0].a(), cat[0].xf(), cat[1].a(), cat[1].xf(), y.g(), y.a(), scale, shift, slope,
                                               _ptr(A), _ptr(B), _ptr(Cc), self.kd, self.kh, self.kw, self.dil, _ptr(dw), _ptr(eng.ws),
@@ -443,17 +531,20 @@ class ConvTNode(Node):
         self.kd = 2 if w.dim() == 5 else 1
         assert tuple(w.shape[:2]) == (xin.c, yout.c)
         self.params = [up.weight, up.bias]
+        self.folded_into = None              # the ConvBlockNode that computes ConvT + concat + conv as one op (biu_foldt_*): this node then does nothing
         self.pk_f = eng.packed_slot_convt(0, xin.c, yout.c, self.kd)
         self.pk_b = eng.packed_slot_convt(1, xin.c, yout.c, self.kd)
         eng.need_ws(lib.biu_convt_bwd_weight_workspace(xin.c, yout.c, self.kd, eng.dtype))
 
     def fwd(self, eng):
+        if self.folded_into is not None:
+            return
         packed = eng.pack_convt(self.pk_f, 0, self.up.weight, self.xin.c, self.y.c, self.kd)
         check(lib.biu_convt_fwd(self.xin.a(), self.xin.xf(), _ptr(self.up.weight.data), packed, _ptr(self.up.bias.data),
                                 self.kd, self.y.a(), eng.dtype, _stream()), "convt_fwd")
 
     def bwd(self, eng):
-        if not self.y.g_written():
+        if self.folded_into is not None or not self.y.g_written():
             return
         st = _stream()
         dw, db = eng.new_grad(self.up.weight), eng.new_grad(self.up.bias)

@@ -352,9 +352,11 @@ class _Body3D(_HipNet):
         for i, lvl in enumerate((1, 2, 3)):
             buf = cat_bufs[i]
             sp = spaces[3 - lvl]
+            ctn = None
             if up == "convT":
                 u = buf.slice(0, up_c[i], lazy=False)
-                eng.add(E.ConvTNode(eng, getattr(self, f"up{lvl}"), t, u))
+                ctn = E.ConvTNode(eng, getattr(self, f"up{lvl}"), t, u)
+                eng.add(ctn)
             elif up == "nearest_conv":
                 r = eng.new_act(sp, t.c, lazy=False)
                 rs = E.ResampleNode(eng, "up", t, r)
@@ -373,7 +375,10 @@ class _Body3D(_HipNet):
             cat = buf.full()
             b1, b2 = getattr(self, f"decode{2 * lvl - 1}"), getattr(self, f"decode{2 * lvl}")
             a = eng.new_act(sp, b1[0].out_channels, lazy=True)
-            eng.add(E.ConvBlockNode(eng, b1, cat, a))
+            blk1 = E.ConvBlockNode(eng, b1, cat, a, convt=ctn)       # ConvT + concat + conv as one op when the folded kernels serve the level
+            if ctn is not None and blk1.foldt is not None:
+                ctn.folded_into = blk1
+            eng.add(blk1)
             t = eng.new_act(sp, b2[0].out_channels, lazy=True)
             eng.add(E.ConvBlockNode(eng, b2, a, t))
         return t

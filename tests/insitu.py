@@ -175,6 +175,59 @@ class InSitu:
                     y[:, :, pd::2, ph::2, pw::2] = F.conv3d(xp[:, :, pd:pd + d + 1, ph:ph + h + 1, pw:pw + w_ + 1], k, b)
         return y
 
+    def _foldt_fwd(self, nd):
+        """ConvTranspose + concat + conv as biu_foldt_fwd computes it: composed weights W'[p][t] = sum_k sum_c W_conv[.][c][k] W_T[.][c][q(p,k)]
+        (fp32, rounded to the compute dtype once), the skip half + biases first (stored), the border shell corrected (stored), the fold
+        accumulated on top (stored)."""
+        ct = nd.foldt
+        lo, skip = ct.xin, nd.xin.parts[1]
+        cup = ct.y.c
+        wc = nd.conv.weight.detach().cpu().float()
+        wt = ct.up.weight.detach().cpu().float()
+        bt = ct.up.bias.detach().cpu().double()
+        bc = nd.conv.bias.detach().cpu().double() if nd.conv.bias is not None else torch.zeros(wc.shape[0], dtype=torch.float64)
+        xl = _r(act_T(lo).float(), self.bf16).double()
+        xs = _r(act_T(skip).float(), self.bf16).double()
+        cout, cl = wc.shape[0], wt.shape[0]
+        wb = torch.einsum("ocdhw,c->odhw", wc[:, :cup].double(), bt)                       # Wb[co][k]
+        y1 = F.conv3d(xs, _r(wc[:, cup:], self.bf16).double(), (bc + wb.sum(dim=(1, 2, 3))).float().double(), padding=1)
+        y1 = _r(y1.float(), self.bf16).double()
+        # taps outside the tensor carry no ConvT bias: subtract them on the border shell
+        n, _, d2, h2, w2 = y1.shape
+        ones = torch.ones(1, 1, d2, h2, w2, dtype=torch.float64)
+        inside = torch.stack([F.conv3d(ones, torch.eye(27, dtype=torch.float64)[k].view(1, 1, 3, 3, 3), padding=1)[0, 0] for k in range(27)])   # [27][d][h][w]
+        fix = torch.einsum("ok,kdhw->odhw", wb.reshape(cout, 27), 1.0 - inside)
+        y1 = _r((y1 - fix.unsqueeze(0)).float(), self.bf16).double()
+        cls = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}
+        xp = F.pad(xl, (1, 1, 1, 1, 1, 1))
+        d, h, w_ = xl.shape[2:]
+        fold = torch.zeros_like(y1)
+        wtv = wt.reshape(cl, cup, 8)
+        for pd in range(2):
+            for ph in range(2):
+                for pw in range(2):
+                    k8 = torch.zeros(cout, cl, 2, 2, 2, dtype=torch.float32)
+                    for td in range(2):
+                        for th in range(2):
+                            for tw in range(2):
+                                acc = torch.zeros(cout, cl, dtype=torch.float32)
+                                for kd in cls[(pd, td)]:
+                                    for kh in cls[(ph, th)]:
+                                        for kw in cls[(pw, tw)]:
+                                            q = ((pd + kd + 1) & 1) * 4 + ((ph + kh + 1) & 1) * 2 + ((pw + kw + 1) & 1)
+                                            acc = acc + wc[:, :cup, kd, kh, kw] @ wtv[:, :, q].t()
+                                k8[:, :, td, th, tw] = acc
+                    fold[:, :, pd::2, ph::2, pw::2] = F.conv3d(xp[:, :, pd:pd + d + 1, ph:ph + h + 1, pw:pw + w_ + 1], _r(k8, self.bf16).double())
+        return y1 + fold
+
+    def _foldt_cat(self, nd, round_inputs):
+        """The concat the folded op never materialises: (convT(T(x_low)) + b_T | T(skip)), the up half NOT rounded to the storage type."""
+        ct = nd.foldt
+        xl, xs = act_T(ct.xin), act_T(nd.xin.parts[1])
+        if round_inputs:
+            xl, xs = _r(xl.float(), True).double(), _r(xs.float(), True).double()
+        return xl, xs
+
     def _parts(self, xin):
         return list(xin.parts) if isinstance(xin, E.CatAct) else [xin]
 
@@ -212,6 +265,18 @@ class InSitu:
 
     def fwd_ConvBlockNode_post(self, nd, s):
         lab = nd.label + ":fwd"
+        if getattr(nd, "foldt", None) is not None:
+            want = self._foldt_fwd(nd)
+            if not self.bf16:            # the folded op is the same function as ConvT -> concat -> conv
+                ct = nd.foldt
+                up = F.conv_transpose3d(act_T(ct.xin), ct.up.weight.detach().cpu().double(), ct.up.bias.detach().cpu().double(), stride=2)
+                ref = F.conv3d(torch.cat([up, act_T(nd.xin.parts[1])], 1), nd.conv.weight.detach().cpu().double(),
+                               nd.conv.bias.detach().cpu().double() if nd.conv.bias is not None else None, padding=1)
+                assert float((want - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), "foldt emulation != ConvT -> concat -> conv"
+            y = act_raw(nd.y)
+            self.close(lab, "conv output y (ConvT + concat + conv folded)", y, want)
+            self._check_bn_fwd(nd, s, y, lab)
+            return
         a = F.interpolate(act_T(nd.fold_src), scale_factor=2, mode="nearest") if getattr(nd, "fold_all", False) else self._T_cat(nd.xin)
         w = nd.conv.weight.detach().cpu().double()
         b = nd.conv.bias.detach().cpu().double() if nd.conv.bias is not None else None
@@ -228,6 +293,9 @@ class InSitu:
             want = self._conv(a, w, b, nd.dil)
         y = act_raw(nd.y)
         self.close(lab, "conv output y", y, want)
+        self._check_bn_fwd(nd, s, y, lab)
+
+    def _check_bn_fwd(self, nd, s, y, lab):
         bn = nd.bn
         cnt = y.numel() / y.shape[1]
         if nd.batch_stats:
@@ -250,6 +318,8 @@ class InSitu:
             self.vec_close(lab, "BN shift (eval)", nd.y.vec("shift").cpu(), be - bn.running_mean.detach().cpu().double() * g * invstd, rel=2e-6, floor=2e-6)
 
     def fwd_ConvTNode_post(self, nd, s):
+        if getattr(nd, "folded_into", None) is not None:       # ConvT + concat + conv run as one op (biu_foldt_*): checked at that conv block
+            return
         a = act_T(nd.xin)
         w = nd.up.weight.detach().cpu().double()
         if self.bf16 and self._mfma(nd.xin.c, nd.y.c):
@@ -360,6 +430,10 @@ class InSitu:
         if not nd.y.g_written():
             return None
         parts = self._parts(nd.xin)
+        extra = list(nd.foldt.params) if getattr(nd, "foldt", None) is not None else []
+        if extra:                   # folded ConvT + concat + conv: gradients go to the ConvT's coarse input and to the skip tensor
+            return dict(da=act_grad(nd.y), gx=[self._gsnap(nd.foldt.xin), self._gsnap(parts[1])],
+                        pg={p: (self.eng.grads[p].detach().cpu().double().clone() if p in self.eng.grads else None) for p in list(nd.params) + extra})
         return dict(da=act_grad(nd.y), gx=[self._gsnap(p) for p in parts],
                     gfold=self._gsnap(nd.fold_src) if getattr(nd, "fold_dg_slot", None) is not None else None,
                     pg={p: (self.eng.grads[p].detach().cpu().double().clone() if p in self.eng.grads else None) for p in nd.params})
@@ -388,6 +462,9 @@ class InSitu:
         dy_got = act_grad(nd.y)
         # the result is a difference of nearly equal terms where |dy| << |dz|: tolerance relative to the operands
         self.close(lab, "dy (BN+LReLU bwd)", dy_got, dy, abs_frac=(2.0 ** -8 if self.bf16 else 1e-5) * float(dz.pow(2).mean().sqrt() * gis.abs().max() / (dy.pow(2).mean().sqrt() + 1e-30) + 1.0), ignore=near)
+        if getattr(nd, "foldt", None) is not None:
+            self._bwd_foldt_check(nd, s, lab, dy_got)
+            return
         # weight gradient from the dy the engine actually stored
         if getattr(nd, "fold_all", False):          # the up-sampled tensor was never materialised: rebuild it from the coarse one
             a = F.interpolate(act_T(nd.fold_src), scale_factor=2, mode="nearest")
@@ -428,8 +505,74 @@ class InSitu:
                 self._check_red(p, lab)
                 o += p.c
 
+    def _bwd_foldt_check(self, nd, s, lab, dy_got):
+        """Gradients of the folded ConvT + concat + conv from the dy the engine stored: autograd through the unfolded expression with the
+        operands as the kernels see them (inputs in the storage type, the up-sampled tensor never rounded, weights fp32 in the chain rule;
+        the data gradients use the packed -- rounded -- weights)."""
+        ct = nd.foldt
+        lo, skip = ct.xin, nd.xin.parts[1]
+        cup = ct.y.c
+        xl, xs = self._foldt_cat(nd, self.bf16)
+        xl, xs = xl.clone().requires_grad_(True), xs.clone().requires_grad_(True)
+        wc = nd.conv.weight.detach().cpu().double().requires_grad_(True)
+        wt = ct.up.weight.detach().cpu().double().requires_grad_(True)
+        bt = ct.up.bias.detach().cpu().double().requires_grad_(True)
+        out = F.conv3d(torch.cat([F.conv_transpose3d(xl, wt, bt, stride=2), xs], 1), wc, None, padding=1)
+        gwc, gwt, gbt = torch.autograd.grad(out, (wc, wt, bt), dy_got)
+        # the ConvT bias reaches dW_conv (b_T[c] S_k) and db_T (W_conv . S_k) through S_k = sum of dy over the voxels whose tap k stays inside,
+        # which the kernel takes as MINUS the border sums: sum_v dy = 0 exactly behind a train-mode BatchNorm.  The STORED dy carries its
+        # rounding (bf16: |sum_v dy| ~ sqrt(N) 2^-9 |dy|), which autograd on the stored dy includes and the kernel -- closer to the fp32
+        # reference there -- does not: that residue is allowed for
+        tot = float(dy_got.sum(dim=(0, 2, 3, 4)).abs().max())
+        resid_w = tot * float(bt.detach().abs().max())
+        self.vec_close(lab, "dW (conv, folded)", self._pgrad(nd, s, nd.conv.weight), gwc, rel=2e-4, floor=3e-5 + resid_w / (float(gwc.abs().max()) + 1e-30))
+        self.vec_close(lab, "dW (ConvT, folded)", self._pgrad(nd, s, ct.up.weight), gwt, rel=2e-4, floor=3e-5)
+        resid = tot * float(wc.detach()[:, :cup].abs().sum(dim=(0, 2, 3, 4)).max())
+        self.vec_close(lab, "dbias (ConvT, folded)", self._pgrad(nd, s, ct.up.bias), gbt, rel=2e-4, floor=3e-5 + resid / (float(gbt.abs().max()) + 1e-30))
+        # data gradients: the packed (rounded) composed / sliced weights
+        out2 = self._foldt_fwd_lin(nd, xl, xs)
+        gl, gs = torch.autograd.grad(out2, (xl, xs), dy_got)
+        for act, g, before, name in ((lo, gl, s["gx"][0], "dx (coarse, folded)"), (skip, gs, s["gx"][1], "dx (skip)")):
+            want = g + before if before is not None else g
+            self.close(lab, name + (" (accumulated)" if before is not None else ""), act_grad(act), want)
+            self._check_red(act, lab)
+        assert not ct.y.g_written(), "the ConvT output's gradient must stay unwritten when the op is folded"
+
+    def _foldt_fwd_lin(self, nd, xl, xs):
+        """Linear part of _foldt_fwd (no biases, no intermediate rounding) with the rounded weights, differentiable in (xl, xs)."""
+        ct = nd.foldt
+        cup = ct.y.c
+        wc = nd.conv.weight.detach().cpu().float()
+        wtv = ct.up.weight.detach().cpu().float().reshape(ct.xin.c, cup, 8)
+        cout, cl = wc.shape[0], wtv.shape[0]
+        y = F.conv3d(xs, _r(wc[:, cup:], self.bf16).double(), None, padding=1)
+        cls = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}
+        xp = F.pad(xl, (1, 1, 1, 1, 1, 1))
+        d, h, w_ = xl.shape[2:]
+        parts = {}
+        for pd in range(2):
+            for ph in range(2):
+                for pw in range(2):
+                    k8 = torch.zeros(cout, cl, 2, 2, 2, dtype=torch.float32)
+                    for td in range(2):
+                        for th in range(2):
+                            for tw in range(2):
+                                acc = torch.zeros(cout, cl, dtype=torch.float32)
+                                for kd in cls[(pd, td)]:
+                                    for kh in cls[(ph, th)]:
+                                        for kw in cls[(pw, tw)]:
+                                            q = ((pd + kd + 1) & 1) * 4 + ((ph + kh + 1) & 1) * 2 + ((pw + kw + 1) & 1)
+                                            acc = acc + wc[:, :cup, kd, kh, kw] @ wtv[:, :, q].t()
+                                k8[:, :, td, th, tw] = acc
+                    parts[(pd, ph, pw)] = F.conv3d(xp[:, :, pd:pd + d + 1, ph:ph + h + 1, pw:pw + w_ + 1], _r(k8, self.bf16).double())
+        n = xl.shape[0]
+        # interleave the 8 parity classes: [n][c][d][2][h][2][w][2]
+        st = torch.stack([torch.stack([torch.stack([parts[(pd, ph, pw)] for pw in range(2)], -1) for ph in range(2)], -3) for pd in range(2)], -5)
+        fold = st.reshape(n, cout, 2 * d, 2 * h, 2 * w_)
+        return y + fold
+
     def bwd_ConvTNode_pre(self, nd):
-        if not nd.y.g_written():
+        if getattr(nd, "folded_into", None) is not None or not nd.y.g_written():
             return None
         return dict(gx=self._gsnap(nd.xin), pg={p: (self.eng.grads[p].detach().cpu().double().clone() if p in self.eng.grads else None) for p in nd.params})
 
