@@ -382,8 +382,12 @@ extern "C" int biu_upconv_fwd(const biu_act* x, const biu_xform* xf, const void*
 }
 
 // ---- ConvTranspose(k2, s2) + concat + 3x3x3 conv of a decoder level, the up half folded onto the coarse tensor -------------------------
+// 1: the folded kernels serve the level AND it is large enough for the fold to pay (BIU_FOLDT=always: wherever they serve it -- the tests)
 extern "C" int biu_foldt_ok(const biu_act* x_low, const biu_act* skip, const biu_act* y, int dtype) {
-    return (x_low && skip && y && !disabled("foldt") && biu_mfma_foldt_ok(x_low, skip, y, dtype)) ? 1 : 0;
+    static int always = -1;
+    if (always < 0) { const char* e = getenv("BIU_FOLDT"); always = (e && strstr(e, "always")) ? 1 : 0; }
+    if (!(x_low && skip && y) || disabled("foldt") || !biu_mfma_foldt_ok(x_low, skip, y, dtype)) return 0;
+    return (always || biu_mfma_foldt_worth(x_low, y)) ? 1 : 0;
 }
 extern "C" size_t biu_foldt_packed_bytes(int cin_low, int cskip, int cout, int dtype) { return biu_mfma_foldt_packed_bytes(cin_low, cskip, cout, dtype); }
 extern "C" int biu_foldt_pack(const float* w_conv, const float* b_conv, const float* w_t, const float* b_t, int cin_low, int cup, int cskip, int cout,

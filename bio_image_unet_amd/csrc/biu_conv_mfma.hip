@@ -2246,71 +2246,150 @@ __device__ __forceinline__ void fold_class(int p, int t, int& lo, int& hi) {    
     lo = p == 0 ? (t ? 1 : 0) : (t ? 2 : 0);
     hi = p == 0 ? (t ? 2 : 0) : (t ? 2 : 1);
 }
-__global__ void k_foldt_compose(const float* __restrict__ wc, int ccat, int c0, int cup, int cout, const float* __restrict__ wt, int cin_low,
-                                float* __restrict__ wfold) {
-    const size_t total = (size_t)8 * cout * cin_low * 8;                     // wfold[p][co][ci][t]
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int t = (int)(idx % 8);
-        size_t r = idx / 8;
-        const int ci = (int)(r % cin_low); r /= cin_low;
-        const int co = (int)(r % cout);
-        const int p = (int)(r / cout);
-        int lo[3], hi[3];
+// Weight-space products of the fold are sums of small fp32 GEMMs: one 32 x 32 output tile per block (256 threads, 2 x 2 outputs each), the
+// reduction in chunks of 16 through LDS.  Term `term` multiplies the strided views A = pa + offA[term] (element (m, kk) at m * sa_m + kk * sa_k)
+// and B = pb + offB[term] (element (kk, nn) at kk * sb_k + nn * sb_n); M, N, K bound the views (reads outside return 0).
+struct SgView { const float* p; long s0, s1; };
+__device__ __forceinline__ void small_gemm_tile(int nterms, int M, int N, int K, int m0, int n0, SgView A, const long* offA, SgView B, const long* offB,
+                                                float (&acc)[2][2]) {
+    __shared__ float As[32][17];
+    __shared__ float Bs[16][33];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    for (int term = 0; term < nterms; ++term) {
+        const float* pa = A.p + offA[term];
+        const float* pb = B.p + offB[term];
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            for (int i = tid; i < 32 * 16; i += 256) {
+                const int r = i >> 4, c = i & 15;
+                As[r][c] = (m0 + r < M && k0 + c < K) ? pa[(long)(m0 + r) * A.s0 + (long)(k0 + c) * A.s1] : 0.f;
+            }
+            for (int i = tid; i < 16 * 32; i += 256) {
+                const int r = i >> 5, c = i & 31;
+                Bs[r][c] = (k0 + r < K && n0 + c < N) ? pb[(long)(k0 + r) * B.s0 + (long)(n0 + c) * B.s1] : 0.f;
+            }
+            __syncthreads();
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) fold_class((p >> (2 - ax)) & 1, (t >> (2 - ax)) & 1, lo[ax], hi[ax]);
-        float sum = 0.f;
-        for (int kd = lo[0]; kd <= hi[0]; ++kd)
-            for (int kh = lo[1]; kh <= hi[1]; ++kh)
-                for (int kw = lo[2]; kw <= hi[2]; ++kw) {
-                    const int k = (kd * 3 + kh) * 3 + kw;
-                    const int q = ((((p >> 2) & 1) + kd + 1) & 1) * 4 + ((((p >> 1) & 1) + kh + 1) & 1) * 2 + (((p & 1) + kw + 1) & 1);
-                    const float* a = wc + ((size_t)co * ccat + c0) * 27 + k;                 // W_conv[co][c0 + c][k], stride 27 over c
-                    const float* b = wt + (size_t)ci * cup * 8 + q;                          // W_T[ci][c][q],         stride 8 over c
-                    float acc = 0.f;
-                    for (int c = 0; c < cup; ++c) acc = fmaf(a[(size_t)c * 27], b[(size_t)c * 8], acc);
-                    sum += acc;
-                }
-        wfold[idx] = sum;
-    }
-}
-// Wb[k][co] = sum_c W_conv[co][c0 + c][k] b_T[c];  fix[state][co] = sum of Wb[k] over the taps OUTSIDE the tensor for a voxel in border state
-// (per axis 0 = first, 1 = interior, 2 = last coordinate);  bias_sum[co] = b_conv[co] + sum_k Wb[k][co]
-__global__ void k_foldt_bias(const float* __restrict__ wc, int ccat, int c0, int cup, int cout, const float* __restrict__ bt, const float* __restrict__ bconv,
-                             float* __restrict__ wb, float* __restrict__ fix, float* __restrict__ bias_sum) {
-    const int co = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (co >= cout) return;
-    float all = 0.f;
-    for (int k = 0; k < 27; ++k) {
-        float acc = 0.f;
-        if (bt)
-            for (int c = 0; c < cup; ++c) acc = fmaf(wc[((size_t)co * ccat + c0 + c) * 27 + k], bt[c], acc);
-        wb[k * cout + co] = acc;
-        all += acc;
-    }
-    bias_sum[co] = (bconv ? bconv[co] : 0.f) + all;
-    for (int s = 0; s < 27; ++s) {
-        const int sd = s / 9, sh = (s / 3) % 3, sw = s % 3;
-        float out = 0.f;
-        for (int k = 0; k < 27; ++k) {
-            const int kd = k / 9, kh = (k / 3) % 3, kw = k % 3;
-            const bool outside = (kd == 0 && sd == 0) || (kd == 2 && sd == 2) || (kh == 0 && sh == 0) || (kh == 2 && sh == 2) || (kw == 0 && sw == 0) || (kw == 2 && sw == 2);
-            if (outside) out += wb[k * cout + co];
+            for (int kk = 0; kk < 16; ++kk) {
+                const float a0 = As[2 * ty][kk], a1 = As[2 * ty + 1][kk], b0 = Bs[kk][2 * tx], b1 = Bs[kk][2 * tx + 1];
+                acc[0][0] = fmaf(a0, b0, acc[0][0]); acc[0][1] = fmaf(a0, b1, acc[0][1]);
+                acc[1][0] = fmaf(a1, b0, acc[1][0]); acc[1][1] = fmaf(a1, b1, acc[1][1]);
+            }
+            __syncthreads();
         }
-        fix[s * cout + co] = out;
     }
 }
-// y[o][co] -= fix[state(o)][co] on the border shell (one thread per voxel; interior voxels leave at once).  A 1-voxel axis is both first and last:
-// its state would need both corrections -- such tensors do not take this path (biu_mfma_foldt_ok: every extent >= 2).
+__device__ __forceinline__ void foldt_tq(int p, int k, int& t, int& q) {                // coarse tap and sub-position of fine tap k under parity class p
+    const int kk[3] = {k / 9, (k / 3) % 3, k % 3};
+    t = 0; q = 0;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const int pa = (p >> (2 - ax)) & 1;
+        const int ta = pa == 0 ? (kk[ax] >= 1 ? 1 : 0) : (kk[ax] == 2 ? 1 : 0);
+        t |= ta << (2 - ax);
+        q |= ((pa + kk[ax] + 1) & 1) << (2 - ax);
+    }
+}
+// wfold[p][co][ci][t] = sum_{k in class(p, t)} sum_c W_conv[co][c0 + c][k] W_T[ci][c][q(p, k)]      grid (Cin_low / 32, Cout / 32, 64 = (p, t))
+__global__ __launch_bounds__(256) void k_foldt_compose(const float* __restrict__ wc, int ccat, int c0, int cup, int cout, const float* __restrict__ wt,
+                                                       int cin_low, float* __restrict__ wfold) {
+    __shared__ long offA[8], offB[8];
+    __shared__ int nterms_s;
+    const int p = (int)blockIdx.z >> 3, t = (int)blockIdx.z & 7;
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int k = 0; k < 27; ++k) {
+            int tt, q;
+            foldt_tq(p, k, tt, q);
+            if (tt == t) { offA[n] = (long)c0 * 27 + k; offB[n] = q; ++n; }
+        }
+        nterms_s = n;
+    }
+    __syncthreads();
+    const int m0 = (int)blockIdx.y * 32, n0 = (int)blockIdx.x * 32;          // rows co, cols ci
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    small_gemm_tile(nterms_s, cout, cin_low, cup, m0, n0, SgView{wc, (long)ccat * 27, 27}, offA, SgView{wt, 8, (long)cup * 8}, offB, acc);
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = m0 + 2 * ty + i, ci = n0 + 2 * tx + j;
+            if (co < cout && ci < cin_low) wfold[(((size_t)p * cout + co) * cin_low + ci) * 8 + t] = acc[i][j];
+        }
+}
+// Wb[k][co] = sum_c W_conv[co][c0 + c][k] b_T[c]                                                  (one thread per (k, co))
+__global__ void k_foldt_wb(const float* __restrict__ wc, int ccat, int c0, int cup, int cout, const float* __restrict__ bt, float* __restrict__ wb) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= 27 * cout) return;
+    const int k = i / cout, co = i % cout;
+    float acc = 0.f;
+    if (bt)
+        for (int c = 0; c < cup; ++c) acc = fmaf(wc[((size_t)co * ccat + c0 + c) * 27 + k], bt[c], acc);
+    wb[i] = acc;
+}
+__device__ __forceinline__ bool tap_outside(int k, int s) {       // tap k falls outside the tensor for a voxel in border state s (per axis 0 first, 1 interior, 2 last)
+    const int kd = k / 9, kh = (k / 3) % 3, kw = k % 3, sd = s / 9, sh = (s / 3) % 3, sw = s % 3;
+    return (kd == 0 && sd == 0) || (kd == 2 && sd == 2) || (kh == 0 && sh == 0) || (kh == 2 && sh == 2) || (kw == 0 && sw == 0) || (kw == 2 && sw == 2);
+}
+// fix[state][co] = sum of Wb[k] over the taps OUTSIDE the tensor in that border state;  bias_sum[co] = b_conv[co] + sum_k Wb[k][co]   (thread per (state, co))
+__global__ void k_foldt_fix(const float* __restrict__ wb, int cout, const float* __restrict__ bconv, float* __restrict__ fix, float* __restrict__ bias_sum) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= 27 * cout) return;
+    const int s_ = i / cout, co = i % cout;
+    float out = 0.f, all = 0.f;
+    for (int k = 0; k < 27; ++k) {
+        const float v = wb[k * cout + co];
+        all += v;
+        if (tap_outside(k, s_)) out += v;
+    }
+    fix[i] = out;
+    if (s_ == 13) bias_sum[co] = (bconv ? bconv[co] : 0.f) + all;
+}
+// The border shell of an (n, d, h, w) tensor as three disjoint regular index spaces: A = {d on a face}, B = {d inside, h on a face},
+// C = {d, h inside, w on a face}.  shell_voxel maps a flat index to its voxel and border state.
+struct ShellDims { int n, d, h, w; long nA, nB, nC; };
+__host__ __device__ inline ShellDims shell_dims(int n, int d, int h, int w) {
+    ShellDims s{n, d, h, w, 0, 0, 0};
+    const long fd = d >= 2 ? 2 : 1, fh = h >= 2 ? 2 : 1, fw = w >= 2 ? 2 : 1, id = d > 2 ? d - 2 : 0, ih = h > 2 ? h - 2 : 0;
+    s.nA = (long)n * fd * h * w;
+    s.nB = (long)n * id * fh * w;
+    s.nC = (long)n * id * ih * fw;
+    return s;
+}
+__device__ __forceinline__ void shell_voxel(const ShellDims& s, long i, long& vox, int& state) {
+    int nn, z, y, x;
+    if (i < s.nA) {
+        x = (int)(i % s.w); i /= s.w; y = (int)(i % s.h); i /= s.h;
+        const int f = (int)(i % (s.d >= 2 ? 2 : 1)); nn = (int)(i / (s.d >= 2 ? 2 : 1));
+        z = f ? s.d - 1 : 0;
+    } else if (i < s.nA + s.nB) {
+        i -= s.nA;
+        x = (int)(i % s.w); i /= s.w;
+        const int f = (int)(i % 2); i /= 2;
+        z = 1 + (int)(i % (s.d - 2)); nn = (int)(i / (s.d - 2));
+        y = f ? s.h - 1 : 0;
+    } else {
+        i -= s.nA + s.nB;
+        const int f = (int)(i % 2); i /= 2;
+        y = 1 + (int)(i % (s.h - 2)); i /= (s.h - 2);
+        z = 1 + (int)(i % (s.d - 2)); nn = (int)(i / (s.d - 2));
+        x = f ? s.w - 1 : 0;
+    }
+    const int sd = z == 0 ? 0 : (z == s.d - 1 ? 2 : 1), sh = y == 0 ? 0 : (y == s.h - 1 ? 2 : 1), sw = x == 0 ? 0 : (x == s.w - 1 ? 2 : 1);
+    state = (sd * 3 + sh) * 3 + sw;
+    vox = (((long)nn * s.d + z) * s.h + y) * s.w + x;
+}
+// y[o][co] -= fix[state(o)][co] on the border shell (one thread per shell voxel and channel).  Extents >= 2 (biu_mfma_foldt_ok): a 1-voxel axis
+// would be first and last at once.
 template <typename T>
-__global__ void k_foldt_border_fix(char* __restrict__ y, int n, int d, int h, int w, int c, int pitch, const float* __restrict__ fix) {
-    const long nv = (long)n * d * h * w;
-    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(v % w), yy = (int)((v / w) % h), z = (int)((v / ((long)w * h)) % d);
-        const int sd = z == 0 ? 0 : (z == d - 1 ? 2 : 1), sh = yy == 0 ? 0 : (yy == h - 1 ? 2 : 1), sw = x == 0 ? 0 : (x == w - 1 ? 2 : 1);
-        if (sd == 1 && sh == 1 && sw == 1) continue;
-        const float* f = fix + (size_t)((sd * 3 + sh) * 3 + sw) * c;
-        T* row = (T*)y + (size_t)v * pitch;
-        for (int cc = 0; cc < c; ++cc) row[cc] = (T)((float)row[cc] - f[cc]);
+__global__ void k_foldt_border_fix(char* __restrict__ y, ShellDims sd, int c, int pitch, const float* __restrict__ fix) {
+    const long total = (sd.nA + sd.nB + sd.nC) * c;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % c);
+        long vox; int st;
+        shell_voxel(sd, i / c, vox, st);
+        T* e = (T*)y + (size_t)vox * pitch + cc;
+        *e = (T)((float)*e - fix[st * c + cc]);
     }
 }
 
@@ -2336,7 +2415,14 @@ bool biu_mfma_foldt_ok(const biu_act* x_low, const biu_act* skip, const biu_act*
     if (!biu_mfma_upconv_ok(x_low, y, dtype) || x_low->d < 1 || y->d < 2 || y->h < 2 || y->w < 2) return false;
     if (skip->n != y->n || skip->d != y->d || skip->h != y->h || skip->w != y->w) return false;
     if (!biu_mfma_conv_ok(skip, y, 3, 3, 3, 1, dtype)) return false;
+
     return biu_mfma_upconv_packed_bytes(1, x_low->c, y->c, dtype) > 0 && biu_mfma_packed_bytes(1, skip->c, y->c, 3, 3, 3, 1, dtype) > 0;
+}
+// The composed weights and the chain rule cost 3 x 216 small fp32 GEMMs of Cout x Cup x Cin_low per step, whatever the volume: the fold pays only
+// where the voxel-space work it saves ((27 - 8) Cup Cout per fine voxel) dwarfs them (UNet3D(32) at 4 x 128^3: decode5 and decode3, not the 32^3 level)
+bool biu_mfma_foldt_worth(const biu_act* x_low, const biu_act* y) {
+    const double vox = (double)y->n * y->d * y->h * y->w;
+    return vox * 19.0 >= 64.0 * 648.0 * x_low->c;
 }
 size_t biu_mfma_foldt_packed_bytes(int cin_low, int cskip, int cout, int dtype) { return foldt_blob(cin_low, cskip, cout, dtype).total; }
 // w_conv: (Cout, cup + cskip, 3, 3, 3), concat order (up | skip) [unet3d/unet3d.py:86: torch.cat([up, skip])]; w_t: (Cin_low, cup, 2, 2, 2)
@@ -2346,8 +2432,9 @@ int biu_mfma_foldt_pack(const float* w_conv, const float* b_conv, const float* w
     char* base = (char*)packed;
     float* wfold = (float*)(base + b.wfold);
     const int ccat = cup + cskip;
-    hipLaunchKernelGGL(k_foldt_compose, dim3(grid_for((i64)8 * cout * cin_low * 8, 256, 4096)), dim3(256), 0, st, w_conv, ccat, 0, cup, cout, w_t, cin_low, wfold);
-    hipLaunchKernelGGL(k_foldt_bias, dim3((cout + 63) / 64), dim3(64), 0, st, w_conv, ccat, 0, cup, cout, b_t, b_conv, (float*)(base + b.wb), (float*)(base + b.fix),
+    hipLaunchKernelGGL(k_foldt_compose, dim3((cin_low + 31) / 32, (cout + 31) / 32, 64), dim3(256), 0, st, w_conv, ccat, 0, cup, cout, w_t, cin_low, wfold);
+    hipLaunchKernelGGL(k_foldt_wb, dim3((27 * cout + 127) / 128), dim3(128), 0, st, w_conv, ccat, 0, cup, cout, b_t, (float*)(base + b.wb));
+    hipLaunchKernelGGL(k_foldt_fix, dim3((27 * cout + 127) / 128), dim3(128), 0, st, (const float*)(base + b.wb), cout, b_conv, (float*)(base + b.fix),
                        (float*)(base + b.bias));
     BIU_CHECK_LAUNCH("foldt_compose");
     int rc = biu_mfma_upconv_pack(0, nullptr, cin_low, cout, dtype, base + b.fwd, st, wfold);
@@ -2365,9 +2452,9 @@ int biu_mfma_foldt_fwd(const biu_act* x_low, const biu_xform* xf_low, const biu_
     int rc = biu_mfma_conv(skip, xf_skip, base + b.sfwd, (const float*)(base + b.bias), 3, 3, 3, y, 0, nullptr, dtype, st, nullptr, nullptr, nullptr, 0);
     if (rc != BIU_OK) return rc;
     // 2. taps that fall outside the tensor carry no ConvT bias
-    const long nv = (long)y->n * y->d * y->h * y->w;
-    BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_foldt_border_fix<T>, dim3(grid_for((i64)nv, 256, 8192)), dim3(256), 0, st, (char*)y->p, y->n, y->d, y->h, y->w,
-                                                 y->c, y->pitch, (const float*)(base + b.fix)));
+    const ShellDims sh = shell_dims(y->n, y->d, y->h, y->w);
+    BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_foldt_border_fix<T>, dim3(grid_for((i64)((sh.nA + sh.nB + sh.nC) * y->c), 256, 4096)), dim3(256), 0, st, (char*)y->p,
+                                                 sh, y->c, y->pitch, (const float*)(base + b.fix)));
     BIU_CHECK_LAUNCH("foldt_border_fix");
     // 3. the up half on the coarse tensor, accumulated; BatchNorm statistics of the finished output from this launch's epilogue
     return biu_mfma_upconv_fwd(x_low, xf_low, base + b.fwd, nullptr, y, bn_partial, dtype, st, 1);
@@ -3969,34 +4056,47 @@ int biu_mfma_foldt_dgrad(const biu_act* dy, const void* packed, const biu_act* d
     if (rc != BIU_OK) return rc;
     return biu_mfma_upconv_dgrad(dy, base + b.dg, dx_low, acc_low, dtype, st, bn_partial_low, red_low);
 }
-// border sums of dy: R[state][co] = sum of dy over the voxels of border state (sd, sh, sw) != interior (fp32 atomics into a zeroed table;
-// only shell voxels are touched)
+// border sums of dy: R[state][co] = sum of dy over the voxels of border state (sd, sh, sw) != interior.  One thread per shell voxel and channel
+// (lanes run over channels: the LDS atomics of a wave hit distinct addresses); every block writes its own table -- no global atomics,
+// the sum over blocks (k_foldt_inside_sums) runs in a fixed order
+constexpr int FOLDT_SUM_BLOCKS = 256;
 template <typename T>
-__global__ void k_foldt_border_sums(const char* __restrict__ dy, int n, int d, int h, int w, int c, int pitch, float* __restrict__ R) {
-    const long nv = (long)n * d * h * w;
-    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(v % w), yy = (int)((v / w) % h), z = (int)((v / ((long)w * h)) % d);
-        const int sd = z == 0 ? 0 : (z == d - 1 ? 2 : 1), sh = yy == 0 ? 0 : (yy == h - 1 ? 2 : 1), sw = x == 0 ? 0 : (x == w - 1 ? 2 : 1);
-        if (sd == 1 && sh == 1 && sw == 1) continue;
-        float* r = R + (size_t)((sd * 3 + sh) * 3 + sw) * c;
-        const T* row = (const T*)dy + (size_t)v * pitch;
-        for (int cc = 0; cc < c; ++cc) atomicAdd(r + cc, (float)row[cc]);
+__global__ __launch_bounds__(256) void k_foldt_border_sums(const char* __restrict__ dy, ShellDims sd, int c, int pitch, float* __restrict__ partial) {
+    extern __shared__ float tab[];                        // [27][c]
+    for (int i = threadIdx.x; i < 27 * c; i += 256) tab[i] = 0.f;
+    __syncthreads();
+    const long total = (sd.nA + sd.nB + sd.nC) * c;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % c);
+        long vox; int st;
+        shell_voxel(sd, i / c, vox, st);
+        atomicAdd(tab + st * c + cc, (float)((const T*)dy)[(size_t)vox * pitch + cc]);
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 27 * c; i += 256) partial[(size_t)blockIdx.x * 27 * c + i] = tab[i];
 }
 // chain rule from G[p][t][co][ci] (ws, parity slices `slice_f` floats apart) to the gradients of both weight tensors and the ConvT bias:
 //   dW_conv[co][c][k] = sum_p sum_ci W_T[ci][c][q(p,k)] G[p][t_p(k)][co][ci]                          (c < cup: the up half of the concat)
 //   dW_T[ci][c][q]    = sum_{(p,k): q(p,k) = q} sum_co W_conv[co][c][k] G[p][t_p(k)][co][ci]
 //   db_T[c]           = sum_k sum_co W_conv[co][c][k] S_k[co],  S_k = sum of dy over the voxels where tap k stays inside = -(sum over the
 //                       border states where it does not): sum_v dy = 0 exactly behind a train-mode BatchNorm
-__device__ __forceinline__ void foldt_tq(int p, int k, int& t, int& q) {
-    const int kk[3] = {k / 9, (k / 3) % 3, k % 3};
-    t = 0; q = 0;
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-        const int pa = (p >> (2 - ax)) & 1;
-        const int ta = pa == 0 ? (kk[ax] >= 1 ? 1 : 0) : (kk[ax] == 2 ? 1 : 0);
-        t |= ta << (2 - ax);
-        q |= ((pa + kk[ax] + 1) & 1) << (2 - ax);
+// R[state][co] = sum over the blocks' tables (fixed order): one block per state, threads over (part of the blocks, channel), LDS tree over the parts
+__global__ __launch_bounds__(256) void k_foldt_reduce_tables(const float* __restrict__ partial, int nblocks, int cout, float* __restrict__ R) {
+    __shared__ float red[256];
+    const int s_ = (int)blockIdx.x;
+    for (int c0 = 0; c0 < cout; c0 += 32) {                               // 32 channels x 8 parts per pass
+        const int co = c0 + (int)(threadIdx.x & 31), part = (int)(threadIdx.x >> 5);
+        float sum = 0.f;
+        if (co < cout)
+            for (int b = part; b < nblocks; b += 8) sum += partial[((size_t)b * 27 + s_) * cout + co];
+        red[threadIdx.x] = sum;
+        __syncthreads();
+        if (threadIdx.x < 32 && co < cout) {
+            float t = 0.f;
+            for (int pp = 0; pp < 8; ++pp) t += red[pp * 32 + threadIdx.x];
+            R[s_ * cout + co] = t;
+        }
+        __syncthreads();
     }
 }
 // S_k[co] = sum of dy over the voxels whose tap k stays inside = -(sum of R over the border states where it does not)
@@ -4004,75 +4104,87 @@ __global__ void k_foldt_inside_sums(const float* __restrict__ R, int cout, float
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= 27 * cout) return;
     const int k = i / cout, co = i % cout;
-    const int kd = k / 9, kh = (k / 3) % 3, kw = k % 3;
     float sum = 0.f;
-    for (int s = 0; s < 27; ++s) {
-        if (s == 13) continue;
-        const int sd = s / 9, sh = (s / 3) % 3, sw = s % 3;
-        const bool outside = (kd == 0 && sd == 0) || (kd == 2 && sd == 2) || (kh == 0 && sh == 0) || (kh == 2 && sh == 2) || (kw == 0 && sw == 0) || (kw == 2 && sw == 2);
-        if (outside) sum -= R[s * cout + co];
-    }
+    for (int s_ = 0; s_ < 27; ++s_)
+        if (s_ != 13 && tap_outside(k, s_)) sum -= R[s_ * cout + co];
     Sk[i] = sum;
 }
 // (the ConvT bias is part of `up`: dW_conv[co][c][k] also gets b_T[c] S_k[co])
-__global__ void k_foldt_chain_wconv(const float* __restrict__ G, size_t slice_f, const float* __restrict__ wt, int cin_low, int cup, int cout, int ccat,
-                                    float* __restrict__ dwc, const float* __restrict__ bt, const float* __restrict__ Sk) {
-    const size_t total = (size_t)cout * cup * 27;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int k = (int)(idx % 27);
-        const size_t r = idx / 27;
-        const int c = (int)(r % cup), co = (int)(r / cup);
-        float sum = 0.f;
-        for (int p = 0; p < 8; ++p) {
-            int t, q;
-            foldt_tq(p, k, t, q);
-            const float* g = G + (size_t)p * slice_f + ((size_t)t * cout + co) * cin_low;
-            const float* b = wt + (size_t)c * 8 + q;
-            float acc = 0.f;
-            for (int ci = 0; ci < cin_low; ++ci) acc = fmaf(b[(size_t)ci * cup * 8], g[ci], acc);
-            sum += acc;
+// dW_conv[co][c][k] = sum_p sum_ci G[p][t_p(k)][co][ci] W_T[ci][c][q(p,k)]  (+ b_T[c] S_k[co])          grid (cup / 32, Cout / 32, 27 = k)
+__global__ __launch_bounds__(256) void k_foldt_chain_wconv(const float* __restrict__ G, size_t slice_f, const float* __restrict__ wt, int cin_low, int cup, int cout,
+                                                           int ccat, float* __restrict__ dwc, const float* __restrict__ bt, const float* __restrict__ Sk) {
+    __shared__ long offA[8], offB[8];
+    const int k = (int)blockIdx.z;
+    if (threadIdx.x < 8) {
+        int t, q;
+        foldt_tq((int)threadIdx.x, k, t, q);
+        offA[threadIdx.x] = (long)threadIdx.x * (long)slice_f + (long)t * cout * cin_low;
+        offB[threadIdx.x] = q;
+    }
+    __syncthreads();
+    const int m0 = (int)blockIdx.y * 32, n0 = (int)blockIdx.x * 32;             // rows co, cols c; reduction ci
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    small_gemm_tile(8, cout, cup, cin_low, m0, n0, SgView{G, cin_low, 1}, offA, SgView{wt, (long)cup * 8, 8}, offB, acc);
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = m0 + 2 * ty + i, c = n0 + 2 * tx + j;
+            if (co < cout && c < cup) dwc[((size_t)co * ccat + c) * 27 + k] = bt ? fmaf(bt[c], Sk[k * cout + co], acc[i][j]) : acc[i][j];
         }
-        if (bt) sum = fmaf(bt[c], Sk[k * cout + co], sum);
-        dwc[((size_t)co * ccat + c) * 27 + k] = sum;
-    }
 }
-__global__ void k_foldt_chain_wt(const float* __restrict__ G, size_t slice_f, const float* __restrict__ wc, int cin_low, int cup, int cout, int ccat,
-                                 float* __restrict__ dwt) {
-    const size_t total = (size_t)cin_low * cup * 8;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int q = (int)(idx % 8);
-        const size_t r = idx / 8;
-        const int c = (int)(r % cup), ci = (int)(r / cup);
-        float sum = 0.f;
-        for (int p = 0; p < 8; ++p)
-            for (int k = 0; k < 27; ++k) {
-                int t, qq;
-                foldt_tq(p, k, t, qq);
-                if (qq != q) continue;
-                const float* g = G + (size_t)p * slice_f + (size_t)t * cout * cin_low + ci;
-                const float* a = wc + (size_t)c * 27 + k;
-                float acc = 0.f;
-                for (int co = 0; co < cout; ++co) acc = fmaf(a[(size_t)co * ccat * 27], g[(size_t)co * cin_low], acc);
-                sum += acc;
-            }
-        dwt[idx] = sum;
+// dW_T[ci][c][q] = sum_{(p,k): q(p,k) = q} sum_co G[p][t_p(k)][co][ci] W_conv[co][c][k]                    grid (cup / 32, Cin_low / 32, 8 = q)
+// (for every fine tap k exactly one parity class has sub-position q: p = (q + k + 1) & 1 per axis)
+__global__ __launch_bounds__(256) void k_foldt_chain_wt(const float* __restrict__ G, size_t slice_f, const float* __restrict__ wc, int cin_low, int cup, int cout,
+                                                        int ccat, float* __restrict__ dwt) {
+    __shared__ long offA[27], offB[27];
+    const int q = (int)blockIdx.z;
+    if (threadIdx.x < 27) {
+        const int k = (int)threadIdx.x, kk[3] = {k / 9, (k / 3) % 3, k % 3};
+        int p = 0, t = 0;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const int qa = (q >> (2 - ax)) & 1, pa = (qa + kk[ax] + 1) & 1;
+            const int ta = pa == 0 ? (kk[ax] >= 1 ? 1 : 0) : (kk[ax] == 2 ? 1 : 0);
+            p |= pa << (2 - ax); t |= ta << (2 - ax);
+        }
+        offA[k] = (long)p * (long)slice_f + (long)t * cout * cin_low;
+        offB[k] = k;
     }
+    __syncthreads();
+    const int m0 = (int)blockIdx.y * 32, n0 = (int)blockIdx.x * 32;             // rows ci, cols c; reduction co
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    small_gemm_tile(27, cin_low, cup, cout, m0, n0, SgView{G, 1, cin_low}, offA, SgView{wc, (long)ccat * 27, 27}, offB, acc);
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ci = m0 + 2 * ty + i, c = n0 + 2 * tx + j;
+            if (ci < cin_low && c < cup) dwt[((size_t)ci * cup + c) * 8 + q] = acc[i][j];
+        }
 }
-__global__ void k_foldt_chain_bt(const float* __restrict__ Sk, const float* __restrict__ wc, int cup, int cout, int ccat, float* __restrict__ dbt) {
-    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (c >= cup) return;
+__global__ __launch_bounds__(256) void k_foldt_chain_bt(const float* __restrict__ Sk, const float* __restrict__ wc, int cup, int cout, int ccat, float* __restrict__ dbt) {
+    __shared__ float red[256];
+    const int c = (int)blockIdx.x;                       // one block per ConvT output channel, threads over (co, k)
     float sum = 0.f;
-    for (int k = 0; k < 27; ++k) {
-        float acc = 0.f;
-        for (int co = 0; co < cout; ++co) acc = fmaf(wc[((size_t)co * ccat + c) * 27 + k], Sk[k * cout + co], acc);
-        sum += acc;
+    for (int i = threadIdx.x; i < cout * 27; i += 256) {
+        const int co = i / 27, k = i % 27;
+        sum = fmaf(wc[((size_t)co * ccat + c) * 27 + k], Sk[k * cout + co], sum);
     }
-    dbt[c] = sum;
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dbt[c] = red[0];
 }
 size_t biu_mfma_foldt_wgrad_workspace(int cin_low, int cskip, int cout, int dtype) {
     if (!wgrad_chan_ok(cin_low, cout) || !wgrad_chan_ok(cskip, cout)) return 0;
     const size_t g = 8 * wgrad_acc_bytes(cout, cin_low, 8), sk = biu_mfma_wgrad_workspace(cskip, cout, 3, 3, 3, dtype);
-    return (g > sk ? g : sk) + 2 * al256((size_t)27 * cout * sizeof(float));
+    return (g > sk ? g : sk) + al256((size_t)FOLDT_SUM_BLOCKS * 27 * cout * sizeof(float)) + al256((size_t)2 * 27 * cout * sizeof(float));
 }
 // da -> dy in place (BatchNorm + LeakyReLU backward in the loader of the skip half's weight gradient, which runs first); then G on the finished dy
 int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const biu_act* da, const BnBwdFuse* bn,
@@ -4081,9 +4193,10 @@ int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const bi
     const int cin_low = x_low->c, cskip = skip->c, cout = da->c, ccat = cup + cskip;
     const size_t need = biu_mfma_foldt_wgrad_workspace(cin_low, cskip, cout, dtype);
     BIU_REQUIRE(need > 0 && ws_bytes >= need, BIU_ERR_WORKSPACE, "foldt_wgrad: workspace %zu too small (need %zu)", ws_bytes, need);
-    const size_t rbytes = al256((size_t)27 * cout * sizeof(float)), main_bytes = need - 2 * rbytes;
-    float* R = (float*)((char*)ws + main_bytes);
-    float* Sk = (float*)((char*)ws + main_bytes + rbytes);
+    const size_t pbytes = al256((size_t)FOLDT_SUM_BLOCKS * 27 * cout * sizeof(float)), sbytes = al256((size_t)2 * 27 * cout * sizeof(float));
+    const size_t main_bytes = need - pbytes - sbytes;
+    float* R = (float*)((char*)ws + main_bytes);                    // per-block border tables
+    float* Sk = (float*)((char*)ws + main_bytes + pbytes);
     // 1. skip half of dW_conv (its slice of the channel axis), BatchNorm backward in the loader: da becomes dy
     int rc = biu_mfma_wgrad(skip, xf_skip, da, 3, 3, 3, dw_conv, nullptr, ws, main_bytes, dtype, st, bn, nullptr, nullptr, ccat, cup);
     if (rc != BIU_OK) return rc;
@@ -4093,20 +4206,21 @@ int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const bi
     // 3. the ConvT bias: border sums of dy -> S_k (taps inside), needed by dW_conv (b_T is part of `up`) and by db_T
     const bool has_bias = b_t != nullptr || db_t != nullptr;
     if (has_bias) {
-        if (int zr = zero_ws(R, rbytes, nullptr, 0, st)) return zr;
-        const long nv = (long)da->n * da->d * da->h * da->w;
-        BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_foldt_border_sums<T>, dim3(grid_for((i64)nv, 256, 8192)), dim3(256), 0, st, (const char*)da->p, da->n, da->d,
-                                                     da->h, da->w, da->c, da->pitch, R));
-        hipLaunchKernelGGL(k_foldt_inside_sums, dim3((27 * cout + 127) / 128), dim3(128), 0, st, (const float*)R, cout, Sk);
+        const ShellDims sh = shell_dims(da->n, da->d, da->h, da->w);
+        BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_foldt_border_sums<T>, dim3(FOLDT_SUM_BLOCKS), dim3(256), (size_t)27 * cout * sizeof(float), st,
+                                                     (const char*)da->p, sh, da->c, da->pitch, R));
+        float* Rsum = Sk + 27 * cout;                                   // (second half of the Sk region)
+        hipLaunchKernelGGL(k_foldt_reduce_tables, dim3(27), dim3(256), 0, st, (const float*)R, FOLDT_SUM_BLOCKS, cout, Rsum);
+        hipLaunchKernelGGL(k_foldt_inside_sums, dim3((27 * cout + 127) / 128), dim3(128), 0, st, (const float*)Rsum, cout, Sk);
         BIU_CHECK_LAUNCH("foldt_border_sums");
     }
     // 4. chain rule to the up half of dW_conv, to dW_T and to db_T
     const size_t slice_f = wgrad_acc_bytes(cout, cin_low, 8) / sizeof(float);
-    hipLaunchKernelGGL(k_foldt_chain_wconv, dim3(grid_for((i64)cout * cup * 27, 128, 4096)), dim3(128), 0, st, (const float*)ws, slice_f, w_t, cin_low, cup, cout, ccat,
+    hipLaunchKernelGGL(k_foldt_chain_wconv, dim3((cup + 31) / 32, (cout + 31) / 32, 27), dim3(256), 0, st, (const float*)ws, slice_f, w_t, cin_low, cup, cout, ccat,
                        dw_conv, b_t, (const float*)Sk);
-    hipLaunchKernelGGL(k_foldt_chain_wt, dim3(grid_for((i64)cin_low * cup * 8, 128, 4096)), dim3(128), 0, st, (const float*)ws, slice_f, w_conv, cin_low, cup, cout, ccat,
+    hipLaunchKernelGGL(k_foldt_chain_wt, dim3((cup + 31) / 32, (cin_low + 31) / 32, 8), dim3(256), 0, st, (const float*)ws, slice_f, w_conv, cin_low, cup, cout, ccat,
                        dw_t);
-    if (db_t) hipLaunchKernelGGL(k_foldt_chain_bt, dim3((cup + 63) / 64), dim3(64), 0, st, (const float*)Sk, w_conv, cup, cout, ccat, db_t);
+    if (db_t) hipLaunchKernelGGL(k_foldt_chain_bt, dim3(cup), dim3(256), 0, st, (const float*)Sk, w_conv, cup, cout, ccat, db_t);
     BIU_CHECK_LAUNCH("foldt_chain");
     return BIU_OK;
 }

@@ -71,6 +71,7 @@ int biu_mfma_upconv_fwd(const biu_act* x, const biu_xform* xf, const void* packe
                         int dtype, hipStream_t st, int accumulate = 0);
 // ConvTranspose + concat + 3x3x3 conv of a decoder level with the up half folded onto the coarse tensor
 bool biu_mfma_foldt_ok(const biu_act* x_low, const biu_act* skip, const biu_act* y, int dtype);
+bool biu_mfma_foldt_worth(const biu_act* x_low, const biu_act* y);
 size_t biu_mfma_foldt_packed_bytes(int cin_low, int cskip, int cout, int dtype);
 int biu_mfma_foldt_pack(const float* w_conv, const float* b_conv, const float* w_t, const float* b_t, int cin_low, int cup, int cskip, int cout, int dtype,
                         void* packed, hipStream_t st);

@@ -341,7 +341,8 @@ int biu_convt_bwd_weight(const biu_act* x, const biu_xform* xf, const biu_act* d
  *   W'[p][t][ci][co] = sum_{k in class(p,t)} sum_c W_conv[co][c][k] W_T[ci][c][q(p,k)],  Wb[k][co] = sum_c W_conv[co][c][k] b_T[c]:
  * the same function of the four parameter tensors (the up-sampled tensor is not materialised, 8 x 8 instead of 27 taps on its channels).
  * w_conv (Cout, cup + cskip, 3,3,3) with the concat order (up | skip); w_t (Cin_low, cup, 2,2,2); packed: biu_foldt_packed_bytes, refreshed
- * by biu_foldt_pack whenever one of the four tensors changes.  bn_partial as in biu_upconv_fwd (biu_foldt_fwd_stats_floats). */
+ * by biu_foldt_pack whenever one of the four tensors changes.  biu_foldt_ok: the kernels serve the level and it is large enough to pay for the
+ * weight-space work of every step (3 x 216 small GEMMs of Cout x cup x Cin_low; BIU_FOLDT=always in the environment drops the size test).  bn_partial as in biu_upconv_fwd (biu_foldt_fwd_stats_floats). */
 int    biu_foldt_ok(const biu_act* x_low, const biu_act* skip, const biu_act* y, int dtype);
 size_t biu_foldt_packed_bytes(int cin_low, int cskip, int cout, int dtype);
 int    biu_foldt_pack(const float* w_conv, const float* b_conv, const float* w_t, const float* b_t, int cin_low, int cup, int cskip, int cout,

@@ -6,6 +6,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The folded ConvTranspose + concat + conv op (include/biu.h: biu_foldt_*) is taken only where a decoder level is large enough for it to pay;
+# the test networks are small: take it wherever the kernels serve the shapes, so that every parity test exercises it (the library reads the
+# variable once, at its first biu_foldt_ok call; the size rule itself is what bench.py and a default process run)
+os.environ.setdefault("BIU_FOLDT", "always")
 
 
 def pytest_configure(config):

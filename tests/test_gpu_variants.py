@@ -48,6 +48,9 @@ def _run(which, disable, tmp_path):
     ("unet2d_bf16_n8", "wroll2d", 1e-6, 2.5e-4),            # its 2-D form (a batch of images as the depth axis)
     # nearest up-sampling + upN_conv forward folded onto the coarse tensor (biu_upconv_fwd) against up-sample + conv (BIU_DISABLE=upconv):
     # fp32: the same sums in another order; bf16: the folded weights are rounded after the fold, the unfolded ones tap by tap
+    # ConvTranspose + concat + conv of the decoder levels as one folded op (biu_foldt_*) against the three separate ops (BIU_DISABLE=foldt)
+    ("unet3d_f32", "foldt", 1e-5, 2e-2),
+    ("unet3d_bf16", "foldt", 2e-2, 6e-2),
     ("mo3d_interp_f32", "upconv", 1e-5, 2e-2),
     # (this network is the sensitive one of DESIGN section 4 -- nearest down-sampling, 23 bf16 layers: swapping the 16-row kernels on the SAME
     # probe moves all gradients together by 0.206, the fold by 0.173; logits within 0.017-0.021 either way.  A wrong tap moves them by ~1)

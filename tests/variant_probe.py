@@ -13,10 +13,11 @@ from oracle import unet_oracle as O  # noqa: E402
 which, out = sys.argv[1], sys.argv[2]
 torch.manual_seed(0)
 g = torch.Generator().manual_seed(5)
-if which == "unet3d_bf16":            # UNet3D(n_filter=32): decode6 forward and encode2 data gradient take the 16-row MFMA kernel
+if which in ("unet3d_bf16", "unet3d_f32"):   # UNet3D(n_filter=32): decode6 forward and encode2 data gradient take the 16-row MFMA kernel
     m = B.UNet3D(1, 1, 32).cuda()
     m.load_state_dict(O.init_unet3d(1, 1, 32, seed=7))
-    m.set_compute_dtype(torch.bfloat16)
+    if which.endswith("bf16"):
+        m.set_compute_dtype(torch.bfloat16)
     shape = (2, 1, 16, 32, 32)
 elif which == "unet2d_bf16_n8":       # Unet(n_filter=32) bf16 on 8 images: the 64^2 and 32^2 levels take the 2-D form of the rolling-window weight gradient
     m = B.Unet(1, 1, 32).cuda()
