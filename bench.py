@@ -135,6 +135,12 @@ def call_cost(eng, api, label):
         taps = node.kd * node.kh * node.kw
         v = node.y.nvox
         return 2.0 * v * taps * node.xin.c * node.y.c, float(v) * (node.xin.c + node.y.c) * esz
+    if isinstance(node, E.ConvBlockNode) and api in ("biu_foldt_fwd", "biu_foldt_bwd_data", "biu_foldt_bwd_weight_bn") and node.foldt is not None:
+        # ConvTranspose + concat + conv as one op: 27 taps on the skip channels, 8 parity classes x 8 coarse taps on the ConvT's input channels
+        # (the work the kernels do; the unfolded op would be 27 taps on all concat channels plus the ConvT); bytes: coarse input, skip, output
+        v = node.y.nvox
+        lo, skip = node.foldt.xin, node.xin.parts[1]
+        return 2.0 * v * node.y.c * (27 * skip.c + 8 * lo.c), float(v) * (lo.c / 8.0 + skip.c + node.y.c) * esz
     if isinstance(node, E.ConvBlockNode) and api.startswith("biu_upconv") and api != "biu_upconv_pack":
         # up-sampling folded into the conv: 8 parity classes x 8 coarse taps per FINE voxel instead of 27 fine taps (the work the kernel does);
         # bytes: the coarse input instead of the up-sampled one
