@@ -2356,23 +2356,27 @@ __host__ __device__ inline ShellDims shell_dims(int n, int d, int h, int w) {
     s.nC = (long)n * id * ih * fw;
     return s;
 }
-__device__ __forceinline__ void shell_voxel(const ShellDims& s, long i, long& vox, int& state) {
+// (shell voxel counts stay below 2^31 -- the tensors' voxel counts do, biu_mfma_conv_ok --: 32-bit divisions)
+__device__ __forceinline__ void shell_voxel(const ShellDims& s, long i64_, long& vox, int& state) {
     int nn, z, y, x;
-    if (i < s.nA) {
-        x = (int)(i % s.w); i /= s.w; y = (int)(i % s.h); i /= s.h;
-        const int f = (int)(i % (s.d >= 2 ? 2 : 1)); nn = (int)(i / (s.d >= 2 ? 2 : 1));
+    unsigned i = (unsigned)i64_;
+    const unsigned nA = (unsigned)s.nA, nB = (unsigned)s.nB;
+    if (i < nA) {
+        x = (int)(i % (unsigned)s.w); i /= (unsigned)s.w; y = (int)(i % (unsigned)s.h); i /= (unsigned)s.h;
+        const unsigned fd = s.d >= 2 ? 2u : 1u;
+        const int f = (int)(i % fd); nn = (int)(i / fd);
         z = f ? s.d - 1 : 0;
-    } else if (i < s.nA + s.nB) {
-        i -= s.nA;
-        x = (int)(i % s.w); i /= s.w;
-        const int f = (int)(i % 2); i /= 2;
-        z = 1 + (int)(i % (s.d - 2)); nn = (int)(i / (s.d - 2));
+    } else if (i < nA + nB) {
+        i -= nA;
+        x = (int)(i % (unsigned)s.w); i /= (unsigned)s.w;
+        const int f = (int)(i & 1u); i >>= 1;
+        z = 1 + (int)(i % (unsigned)(s.d - 2)); nn = (int)(i / (unsigned)(s.d - 2));
         y = f ? s.h - 1 : 0;
     } else {
-        i -= s.nA + s.nB;
-        const int f = (int)(i % 2); i /= 2;
-        y = 1 + (int)(i % (s.h - 2)); i /= (s.h - 2);
-        z = 1 + (int)(i % (s.d - 2)); nn = (int)(i / (s.d - 2));
+        i -= nA + nB;
+        const int f = (int)(i & 1u); i >>= 1;
+        y = 1 + (int)(i % (unsigned)(s.h - 2)); i /= (unsigned)(s.h - 2);
+        z = 1 + (int)(i % (unsigned)(s.d - 2)); nn = (int)(i / (unsigned)(s.d - 2));
         x = f ? s.w - 1 : 0;
     }
     const int sd = z == 0 ? 0 : (z == s.d - 1 ? 2 : 1), sh = y == 0 ? 0 : (y == s.h - 1 ? 2 : 1), sw = x == 0 ? 0 : (x == s.w - 1 ? 2 : 1);
@@ -2383,14 +2387,17 @@ __device__ __forceinline__ void shell_voxel(const ShellDims& s, long i, long& vo
 // would be first and last at once.
 template <typename T>
 __global__ void k_foldt_border_fix(char* __restrict__ y, ShellDims sd, int c, int pitch, const float* __restrict__ fix) {
-    const long total = (sd.nA + sd.nB + sd.nC) * c;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cc = (int)(i % c);
-        long vox; int st;
-        shell_voxel(sd, i / c, vox, st);
-        T* e = (T*)y + (size_t)vox * pitch + cc;
-        *e = (T)((float)*e - fix[st * c + cc]);
-    }
+    const int lanes_c = c < 256 ? c : 256, slots = 256 / lanes_c;
+    const int cc0 = (int)threadIdx.x % lanes_c, slot = (int)threadIdx.x / lanes_c;
+    const long nsv = sd.nA + sd.nB + sd.nC;
+    if (slot < slots)
+        for (long v = (long)blockIdx.x * slots + slot; v < nsv; v += (long)gridDim.x * slots) {
+            long vox; int st;
+            shell_voxel(sd, v, vox, st);
+            T* row = (T*)y + (size_t)vox * pitch;
+            const float* f = fix + st * c;
+            for (int cc = cc0; cc < c; cc += lanes_c) row[cc] = (T)((float)row[cc] - f[cc]);
+        }
 }
 
 struct FoldtBlob { size_t fwd, dg, sfwd, sdg, wfold, wb, fix, bias, total; };
@@ -2453,7 +2460,7 @@ int biu_mfma_foldt_fwd(const biu_act* x_low, const biu_xform* xf_low, const biu_
     if (rc != BIU_OK) return rc;
     // 2. taps that fall outside the tensor carry no ConvT bias
     const ShellDims sh = shell_dims(y->n, y->d, y->h, y->w);
-    BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_foldt_border_fix<T>, dim3(grid_for((i64)((sh.nA + sh.nB + sh.nC) * y->c), 256, 4096)), dim3(256), 0, st, (char*)y->p,
+    BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_foldt_border_fix<T>, dim3(2048), dim3(256), 0, st, (char*)y->p,
                                                  sh, y->c, y->pitch, (const float*)(base + b.fix)));
     BIU_CHECK_LAUNCH("foldt_border_fix");
     // 3. the up half on the coarse tensor, accumulated; BatchNorm statistics of the finished output from this launch's epilogue
@@ -4059,19 +4066,24 @@ int biu_mfma_foldt_dgrad(const biu_act* dy, const void* packed, const biu_act* d
 // border sums of dy: R[state][co] = sum of dy over the voxels of border state (sd, sh, sw) != interior.  One thread per shell voxel and channel
 // (lanes run over channels: the LDS atomics of a wave hit distinct addresses); every block writes its own table -- no global atomics,
 // the sum over blocks (k_foldt_inside_sums) runs in a fixed order
-constexpr int FOLDT_SUM_BLOCKS = 256;
+constexpr int FOLDT_SUM_BLOCKS = 1024;
 template <typename T>
 __global__ __launch_bounds__(256) void k_foldt_border_sums(const char* __restrict__ dy, ShellDims sd, int c, int pitch, float* __restrict__ partial) {
     extern __shared__ float tab[];                        // [27][c]
     for (int i = threadIdx.x; i < 27 * c; i += 256) tab[i] = 0.f;
     __syncthreads();
-    const long total = (sd.nA + sd.nB + sd.nC) * c;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cc = (int)(i % c);
-        long vox; int st;
-        shell_voxel(sd, i / c, vox, st);
-        atomicAdd(tab + st * c + cc, (float)((const T*)dy)[(size_t)vox * pitch + cc]);
-    }
+    // threads = (voxel slot, channel): one shell_voxel per voxel and thread, channels in the low bits so that a wave's LDS atomics spread
+    const int lanes_c = c < 256 ? c : 256, slots = 256 / lanes_c;
+    const int cc0 = (int)threadIdx.x % lanes_c, slot = (int)threadIdx.x / lanes_c;
+    const long nsv = sd.nA + sd.nB + sd.nC;
+    if (slot < slots)
+        for (long v = (long)blockIdx.x * slots + slot; v < nsv; v += (long)gridDim.x * slots) {
+            long vox; int st;
+            shell_voxel(sd, v, vox, st);
+            const T* p = (const T*)dy + (size_t)vox * pitch;
+            float* r = tab + st * c;
+            for (int cc = cc0; cc < c; cc += lanes_c) atomicAdd(r + cc, (float)p[cc]);
+        }
     __syncthreads();
     for (int i = threadIdx.x; i < 27 * c; i += 256) partial[(size_t)blockIdx.x * 27 * c + i] = tab[i];
 }

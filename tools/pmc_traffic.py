@@ -12,7 +12,7 @@ def total(d, counter, sub):
     f = glob.glob(d + "/*counter_collection.csv")[0]
     tot, n = 0.0, 0
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == counter and sub in r["Kernel_Name"]:
+        if r["Counter_Name"] == counter and any(x in r["Kernel_Name"] for x in sub.split("|")):       # sub: one or several substrings, '|'-separated
             tot += float(r["Counter_Value"])
             n += 1
     return tot, n

@@ -6,18 +6,21 @@
 # tools/summarize_profile.py and tools/pmc_traffic.py turn them into profiles/<tag>_cfg4_summary.md and profiles/pmc_traffic_cfg4.json.
 set -e
 TAG=${1:-r03}
-LEG=${2:-dg_cat,wg_cat,fwd_cat}
+LEG=${2:-wg,fwd,dg}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O -o cfg4 --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_profiler.json 2> $O/bench_under_profiler.err
 echo "trace done" >> $O/progress.txt
-for L in ${LEG//,/ }; do          # one pair of counter passes per leg (dg_cat, wg_cat, fwd_cat ...): bench.py's dominant call is one of them
+# one pair of counter passes per leg of the folded decode5 op (tools/bench_foldt.py: wg = biu_foldt_bwd_weight_bn, fwd, dg): bench.py's dominant
+# call is one of them (before the fold: tools/bench_conv.py cfg4 bf16 decode5 with BENCH_LEGS=dg_cat | wg_cat | fwd_cat)
+export BENCH_REPS=20
+for L in ${LEG//,/ }; do
     export BENCH_LEGS=$L
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch_$L -o p --output-format csv -- python3 $R/tools/bench_conv.py cfg4 bf16 decode5 > $O/pmc_fetch_$L.log 2>&1
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch_$L -o p --output-format csv -- python3 $R/tools/bench_foldt.py bf16 decode5 > $O/pmc_fetch_$L.log 2>&1
     echo "fetch $L done" >> $O/progress.txt
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write_$L -o p --output-format csv -- python3 $R/tools/bench_conv.py cfg4 bf16 decode5 > $O/pmc_write_$L.log 2>&1
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write_$L -o p --output-format csv -- python3 $R/tools/bench_foldt.py bf16 decode5 > $O/pmc_write_$L.log 2>&1
     echo "write $L done" >> $O/progress.txt
 done
 find $O -name "*.csv" | head -20
