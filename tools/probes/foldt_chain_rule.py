@@ -1,3 +1,4 @@
+"""CPU derivation check (fp64) of the chain rule of the folded ConvTranspose + concat + conv op: dW_conv, dW_T from the per-parity G[p][t],\nand the ConvT-bias term b_T[c] S_k of dW_conv, against torch autograd.      python tools/probes/foldt_chain_rule.py"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.getcwd())
 import torch, torch.nn.functional as F
