@@ -122,8 +122,10 @@ def make_step(wl, device, graph=False):
     return model, step, fwd, nvox, avg
 
 
-def call_cost(eng, api, label):
-    """Algorithmic FLOPs and bytes (SURVEY.md 8d convention) of one C-ABI call, from the node's shapes."""
+def call_cost(eng, api, label, executed=False):
+    """Algorithmic FLOPs and bytes (SURVEY.md 8d convention: the work of the reference ops the call stands for) of one C-ABI call, from the
+    node's shapes.  ``executed=True``: the FLOPs the kernels actually issue -- fewer for the folded decoder ops, which compute
+    the same function with 8 parity classes x 8 coarse taps instead of 27 fine taps on the up-sampled channels."""
     from bio_image_unet_amd import engine as E
     esz = 2 if eng.tdtype == torch.bfloat16 else 4
     node = next((n for n in eng.nodes if n.label == label.split(":")[0]), None)
@@ -139,13 +141,18 @@ def call_cost(eng, api, label):
         # ConvTranspose + concat + conv as one op: 27 taps on the skip channels, 8 parity classes x 8 coarse taps on the ConvT's input channels
         # (the work the kernels do; the unfolded op would be 27 taps on all concat channels plus the ConvT); bytes: coarse input, skip, output
         v = node.y.nvox
-        lo, skip = node.foldt.xin, node.xin.parts[1]
-        return 2.0 * v * node.y.c * (27 * skip.c + 8 * lo.c), float(v) * (lo.c / 8.0 + skip.c + node.y.c) * esz
+        lo, skip, cup = node.foldt.xin, node.xin.parts[1], node.foldt.y.c
+        by = float(v) * (lo.c / 8.0 + skip.c + node.y.c) * esz
+        if executed:
+            return 2.0 * v * node.y.c * (27 * skip.c + 8 * lo.c), by
+        # the reference ops it replaces: Conv3d(k3) on all concat channels + ConvTranspose3d(k2, s2) (one tap per fine voxel)
+        return 2.0 * v * node.y.c * 27 * (skip.c + cup) + 2.0 * v * lo.c * cup, by
     if isinstance(node, E.ConvBlockNode) and api.startswith("biu_upconv") and api != "biu_upconv_pack":
         # up-sampling folded into the conv: 8 parity classes x 8 coarse taps per FINE voxel instead of 27 fine taps (the work the kernel does);
         # bytes: the coarse input instead of the up-sampled one
         v = node.y.nvox
-        return 2.0 * v * 8 * node.xin.c * node.y.c, float(v) * (node.xin.c / 8.0 + node.y.c) * esz
+        by = float(v) * (node.xin.c / 8.0 + node.y.c) * esz
+        return 2.0 * v * (8 if executed else 27) * node.xin.c * node.y.c, by          # reference: Conv3d(k3) on the up-sampled tensor
     if isinstance(node, E.ConvTNode) and api.startswith("biu_convt"):
         v = node.xin.nvox
         taps = node.kd * 4
@@ -306,6 +313,8 @@ def main():
     if args.breakdown and rank == 0:
         with open(args.breakdown, "w") as f:
             f.write(f"# per-launch HIP-event times of one profiled step, workload {args.workload}; sum = {total_kernel_ms:.3f} ms\n")
+            f.write("# TFLOP/s and GB/s: algorithmic work (SURVEY 8d) of the reference ops a call stands for -- the folded decoder calls (biu_foldt_*, biu_upconv_*) "
+                    "issue fewer FLOPs for the same function (DESIGN.md 3.5)\n")
             for ms, (api, label) in rows:
                 fl, by = call_cost(eng, api, label)
                 f.write(f"{ms:9.4f} ms  {api:26s} {label:22s} {fl / ms / 1e9 if ms else 0:9.1f} TFLOP/s {by / ms / 1e6 if ms else 0:9.1f} GB/s\n")
@@ -389,6 +398,13 @@ def main():
     else:
         roof = {"bound": "hbm", "achieved": by / (dom_launch_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
+    fl_exec, _ = call_cost(eng, *dom_key, executed=True)
+    if fl_exec != fl and fl > 0:
+        # a folded decoder op: `achieved` counts the reference ops the call replaces (SURVEY 8d's algorithmic work, what the step-level figures
+        # count too); the kernels issue fewer FLOPs for the same function -- stated beside it
+        roof["executed"] = {"TFLOP_per_call": fl_exec / 1e12, "TFLOPps": fl_exec / (dom_launch_ms * 1e-3) / 1e12, "frac_of_peak": fl_exec / (dom_launch_ms * 1e-3) / mfma_peak,
+                            "note": "folded op (DESIGN.md 3.5): 8 parity classes x 2x2x2 coarse taps instead of 27 fine taps on the up-sampled channels; "
+                                    "`achieved` = FLOPs of the reference ops it replaces / time"}
     roof["traffic"] = None          # HBM bytes per launch from PMC counters (tools/pmc_traffic.py), when measured for this call
     tr_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"pmc_traffic_{args.workload}.json")
     if os.path.exists(tr_file):
