@@ -587,6 +587,28 @@ def test_foldt_fwd_matches_convT_concat_conv(case, dtype):
     torch.testing.assert_close(dwt.cpu(), wt.grad, **tw(wt.grad))
     resid = float(dyr.sum(dim=(0, 2, 3, 4)).abs().max()) * float(wc.detach().abs().sum(dim=(0, 2, 3, 4)).max())       # |sum dy| x |W_conv|: the zero-sum assumption
     torch.testing.assert_close(dbt.cpu(), bt.grad, rtol=1e-3 if dtype == "f32" else 2e-2, atol=(2e-4 if dtype == "f32" else 2e-2) * float(bt.grad.abs().max()) + resid)
+    # the engine's form: BatchNorm + LeakyReLU backward of the block in the loader (da -> dy written back), against bn_bwd_apply + the plain form
+    yv = Dev(rnd(n, cout, *hi, seed=10), dtype=dtype)
+    yxf = XF(cout, seed=11)
+    cA, cB, cC = (rnd(cout, seed=12) * 0.3 + 1.0), rnd(cout, seed=13) * 0.05, rnd(cout, seed=14) * 0.05
+    coef = [t_.cuda() for t_ in (cA, cB, cC)]
+    da0 = rnd(n, cout, *hi, seed=15)
+    da_ref = Dev(da0, dtype=dtype)
+    check(lib.biu_bn_bwd_apply(da_ref.a(), yv.a(), ptr(yxf.d[0]), ptr(yxf.d[1]), ptr(yxf.d[2]), ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), da_ref.a(), code,
+                               stream()), "bn_bwd_apply")
+    ref3 = [torch.full(t_.shape, float("nan"), device="cuda") for t_ in (wc, wt, bt)]
+    check(lib.biu_foldt_bwd_weight_bn(xl.a(), xfl.x(), sk.a(), xfs.x(), da_ref.a(), None, None, None, None, None, None, None, ptr(dev[0]), ptr(dev[2]), ptr(dev[3]),
+                                      cup, ptr(ref3[0]), ptr(ref3[1]), ptr(ref3[2]), ptr(ws), ws.numel(), code, stream()), "foldt_bwd_weight (plain, reference)")
+    da = Dev(da0, dtype=dtype)
+    got3 = [torch.full(t_.shape, float("nan"), device="cuda") for t_ in (wc, wt, bt)]
+    check(lib.biu_foldt_bwd_weight_bn(xl.a(), xfl.x(), sk.a(), xfs.x(), da.a(), yv.a(), ptr(yxf.d[0]), ptr(yxf.d[1]), ptr(yxf.d[2]), ptr(coef[0]), ptr(coef[1]),
+                                      ptr(coef[2]), ptr(dev[0]), ptr(dev[2]), ptr(dev[3]), cup, ptr(got3[0]), ptr(got3[1]), ptr(got3[2]), ptr(ws), ws.numel(), code,
+                                      stream()), "foldt_bwd_weight_bn")
+    tb = dict(rtol=1e-5, atol=1e-5) if dtype == "f32" else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(da.get(), da_ref.get(), **tb)                     # dy written back over da
+    for g_, r_ in zip(got3, ref3):
+        sc = float(r_.abs().max())
+        torch.testing.assert_close(g_.cpu(), r_.cpu(), rtol=1e-3 if dtype == "f32" else 3e-2, atol=(2e-4 if dtype == "f32" else 3e-2) * sc)
 
 
 CONVT_MFMA_CASES = [
