@@ -2247,35 +2247,55 @@ __device__ __forceinline__ void fold_class(int p, int t, int& lo, int& hi) {    
     hi = p == 0 ? (t ? 2 : 0) : (t ? 2 : 1);
 }
 // Weight-space products of the fold are sums of small fp32 GEMMs: one 32 x 32 output tile per block (256 threads, 2 x 2 outputs each), the
-// reduction in chunks of 16 through LDS.  Term `term` multiplies the strided views A = pa + offA[term] (element (m, kk) at m * sa_m + kk * sa_k)
-// and B = pb + offB[term] (element (kk, nn) at kk * sb_k + nn * sb_n); M, N, K bound the views (reads outside return 0).
+// reduction in chunks of 32 through LDS.  Term `term` multiplies the strided views A = pa + offA[term] (element (m, kk) at m * sa_m + kk * sa_k)
+// and B = pb + offB[term] (element (kk, nn) at kk * sb_k + nn * sb_n); M, N, K bound the views (reads outside return 0).  The grids are small
+// (a few hundred blocks), so a block's time is its chain of dependent global loads: the (term, chunk) steps run as ONE loop with the next
+// step's eight loads per thread in flight under the current step's FMAs, and the lanes of a load run along the view's smaller stride.
 struct SgView { const float* p; long s0, s1; };
 __device__ __forceinline__ void small_gemm_tile(int nterms, int M, int N, int K, int m0, int n0, SgView A, const long* offA, SgView B, const long* offB,
                                                 float (&acc)[2][2]) {
-    __shared__ float As[32][17];
-    __shared__ float Bs[16][33];
+    constexpr int KC = 32;
+    __shared__ float As[32][KC + 1];
+    __shared__ float Bs[KC][33];
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    for (int term = 0; term < nterms; ++term) {
+    const bool a_m = A.s0 < A.s1, b_k = B.s0 < B.s1;               // lanes along m (else k) of A, along k (else n) of B
+    const int nchunks = (K + KC - 1) / KC, nsteps = nterms * nchunks;
+    float ra0[4], rb0[4], ra1[4], rb1[4];                          // two steps of loads in flight
+    auto fetch = [&](int step, float (&ra)[4], float (&rb)[4]) {
+        const int term = step / nchunks, k0 = (step % nchunks) * KC;
         const float* pa = A.p + offA[term];
         const float* pb = B.p + offB[term];
-        for (int k0 = 0; k0 < K; k0 += 16) {
-            for (int i = tid; i < 32 * 16; i += 256) {
-                const int r = i >> 4, c = i & 15;
-                As[r][c] = (m0 + r < M && k0 + c < K) ? pa[(long)(m0 + r) * A.s0 + (long)(k0 + c) * A.s1] : 0.f;
-            }
-            for (int i = tid; i < 16 * 32; i += 256) {
-                const int r = i >> 5, c = i & 31;
-                Bs[r][c] = (k0 + r < K && n0 + c < N) ? pb[(long)(k0 + r) * B.s0 + (long)(n0 + c) * B.s1] : 0.f;
-            }
-            __syncthreads();
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-                const float a0 = As[2 * ty][kk], a1 = As[2 * ty + 1][kk], b0 = Bs[kk][2 * tx], b1 = Bs[kk][2 * tx + 1];
-                acc[0][0] = fmaf(a0, b0, acc[0][0]); acc[0][1] = fmaf(a0, b1, acc[0][1]);
-                acc[1][0] = fmaf(a1, b0, acc[1][0]); acc[1][1] = fmaf(a1, b1, acc[1][1]);
-            }
-            __syncthreads();
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + j * 256;
+            const int r = a_m ? (i & 31) : (i >> 5), c = a_m ? (i >> 5) : (i & 31);
+            ra[j] = (m0 + r < M && k0 + c < K) ? pa[(long)(m0 + r) * A.s0 + (long)(k0 + c) * A.s1] : 0.f;
+            const int rk = b_k ? (i & 31) : (i >> 5), cn = b_k ? (i >> 5) : (i & 31);
+            rb[j] = (k0 + rk < K && n0 + cn < N) ? pb[(long)(k0 + rk) * B.s0 + (long)(n0 + cn) * B.s1] : 0.f;
         }
+    };
+    auto one = [&](int step, float (&ra)[4], float (&rb)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + j * 256;
+            As[a_m ? (i & 31) : (i >> 5)][a_m ? (i >> 5) : (i & 31)] = ra[j];
+            Bs[b_k ? (i & 31) : (i >> 5)][b_k ? (i >> 5) : (i & 31)] = rb[j];
+        }
+        __syncthreads();
+        if (step + 2 < nsteps) fetch(step + 2, ra, rb);
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            const float a0 = As[2 * ty][kk], a1 = As[2 * ty + 1][kk], b0 = Bs[kk][2 * tx], b1 = Bs[kk][2 * tx + 1];
+            acc[0][0] = fmaf(a0, b0, acc[0][0]); acc[0][1] = fmaf(a0, b1, acc[0][1]);
+            acc[1][0] = fmaf(a1, b0, acc[1][0]); acc[1][1] = fmaf(a1, b1, acc[1][1]);
+        }
+        __syncthreads();
+    };
+    if (nsteps > 0) fetch(0, ra0, rb0);
+    if (nsteps > 1) fetch(1, ra1, rb1);
+    for (int step = 0; step < nsteps; step += 2) {
+        one(step, ra0, rb0);
+        if (step + 1 < nsteps) one(step + 1, ra1, rb1);
     }
 }
 __device__ __forceinline__ void foldt_tq(int p, int k, int& t, int& q) {                // coarse tap and sub-position of fine tap k under parity class p
@@ -2422,7 +2442,7 @@ bool biu_mfma_foldt_ok(const biu_act* x_low, const biu_act* skip, const biu_act*
     if (!biu_mfma_upconv_ok(x_low, y, dtype) || x_low->d < 1 || y->d < 2 || y->h < 2 || y->w < 2) return false;
     if (skip->n != y->n || skip->d != y->d || skip->h != y->h || skip->w != y->w) return false;
     if (!biu_mfma_conv_ok(skip, y, 3, 3, 3, 1, dtype)) return false;
-
+    if (y->c > 512) return false;                          // (k_foldt_border_sums: 27 x Cout floats of LDS per block)
     return biu_mfma_upconv_packed_bytes(1, x_low->c, y->c, dtype) > 0 && biu_mfma_packed_bytes(1, skip->c, y->c, 3, 3, 3, 1, dtype) > 0;
 }
 // The composed weights and the chain rule cost 3 x 216 small fp32 GEMMs of Cout x Cup x Cin_low per step, whatever the volume: the fold pays only
@@ -2518,6 +2538,7 @@ struct WgradArgs {
     // fold_par = -1: off; else p = (pd << 2 | ph << 1 | pw): the plain operand (and y) is the parity-p sub-lattice of a FINE tensor of extents
     // 2 GD x 2 GH x 2 GW (voxel 2v + p, a stride-2 gather), the tapped operand voxel = grid voxel + tap - (1 - p)
     int fold_par;
+    size_t fold_slice_f;      // all-parity form (k_wgrad_pipe<..., FALL>): floats between the G slices of two parity classes in ws
 };
 
 template <typename T, int PE>
@@ -2542,7 +2563,11 @@ constexpr bool wgrad_tab_in_lds(size_t tile_bytes, int pieces) { return tile_byt
 
 // NI = 32-wide tiles of the plain operand's channels a block owns (its A tile is NI * 32 channels wide): with NI = 2 the tapped
 // operand -- the large fine-grid tensor of a ConvTranspose weight gradient -- is read half as often.
-template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int KSPLIT, int NI, bool RR16 = false>
+// FALL (fold, all parity classes in one block; KD = KHW = 2, S = 1, KSPLIT = 8): the A region holds EIGHT tiles -- the parity sub-lattices of the
+// fine plain operand over the brick's coarse voxels -- and wave w owns parity class w with all 8 coarse taps; the tapped (coarse) operand is
+// staged ONCE per brick with a one-voxel halo on both sides and read at offset tap + parity.  One launch instead of eight, the coarse operand
+// fetched once instead of eight times (the per-class launches were bound by that traffic: 2.7 GB per decode5 call at 4.4 TB/s).
+template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int KSPLIT, int NI, bool RR16 = false, bool FALL = false>
 __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     using F = Frag<T>;
     constexpr int NTHR = 512, NWAVE = 8;
@@ -2561,9 +2586,11 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     constexpr int PHW = (KHW == 3) ? 1 : 0;
     constexpr bool FOLD = (KD == 2 && KHW == 2 && S == 1);   // up-sampling folded into the conv: one parity class per launch (WgradArgs::fold_par)
     constexpr int SD = (KD == 1) ? 1 : S;
-    constexpr int HD = (TD - 1) * SD + KD, HH = (TH - 1) * S + KHW, HW = (TW - 1) * S + KHW;
+    static_assert(!FALL || (FOLD && KSPLIT == 8 && NI == 1 && sizeof(T) == 2), "the all-parity form: bf16 fold, one wave per parity class");
+    constexpr int HD = (TD - 1) * SD + (FALL ? 3 : KD), HH = (TH - 1) * S + (FALL ? 3 : KHW), HW = (TW - 1) * S + (FALL ? 3 : KHW);
     constexpr int HV = HD * HH * HW;
-    constexpr int BV = TD * TH * TW;
+    constexpr int BVR = TD * TH * TW;                      // voxels of the brick
+    constexpr int BV = FALL ? 8 * BVR : BVR;               // rows of the A region (FALL: 8 parity tiles)
     constexpr int TAPS = KD * KHW * KHW;
     constexpr int WPQ = NWAVE / KSPLIT;                    // waves per K split
     constexpr int IPW = (TAPS + WPQ - 1) / WPQ;            // taps per wave
@@ -2654,6 +2681,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         tap %= TAPS;
         const int ta = tap / (KHW * KHW), tb = (tap / KHW) % KHW, tc = tap % KHW;
         tapoff[t] = ((ta * HH + tb) * HW + tc) * RS;
+        if constexpr (FALL) tapoff[t] += ((((wave >> 2) & 1) * HH + ((wave >> 1) & 1)) * HW + (wave & 1)) * RS;     // wave = parity class: coarse voxel v + t - 1 + p of a tile whose halo starts at v - 1
     }
 
     // rr16 (RR kernels, tapped operand with 16 channels -- encode2 of UNet3D(n_filter = 32)): a 32-wide B tile would be half zeros.
@@ -2696,7 +2724,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
         const int i = tid + NTHR * j;
-        const int q = i / PPVA;
+        static_assert(!FALL || BVR * PPVA == NTHR, "all-parity form: piece j of a thread is its voxel in parity tile j");
+        const int q = FALL ? (i / PPVA) % BVR : i / PPVA;
         const int lw = q % TW;
         const int t = q / TW;
         const unsigned xv = (i < BV * PPVA && apiece_ok) ? (unsigned)((t / TH) | ((t % TH) << 10) | (lw << 20)) : 511u;
@@ -2730,10 +2759,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         const int n = b / a.nbd;
         const int d0 = bd * TD, h0 = bh * TH, w0 = bw * TW;
         ca_hi = GBITS + (unsigned)(min(TD - 1, a.GD - 1 - d0) | (min(TH - 1, a.GH - 1 - h0) << 10) | (min(TW - 1, a.GW - 1 - w0) << 20));
-        const int va = FOLD ? (((2 * d0 + fpd) * 2 * a.GH + 2 * h0 + fph) * 2 * a.GW + 2 * w0 + fpw) : (d0 * a.GH + h0) * a.GW + w0;
+        // (FALL: parity 0's base here; piece j adds its own parity's fine-voxel offset in issue_a)
+        const int va = FOLD ? (((2 * d0 + (FALL ? 0 : fpd)) * 2 * a.GH + 2 * h0 + (FALL ? 0 : fph)) * 2 * a.GW + 2 * w0 + (FALL ? 0 : fpw)) : (d0 * a.GH + h0) * a.GW + w0;
         brA = (int)(unsigned)((long long)va * rowA1 + ac0 * (int)esz);         // mod 2^32, see k_conv_pipe
         brY = (int)(unsigned)((long long)va * rowY1 + ac0 * (int)esz);
-        const int gd0 = d0 * SD - PD - (FOLD ? 1 - fpd : 0), gh0 = h0 * S - PHW - (FOLD ? 1 - fph : 0), gw0 = w0 * S - PHW - (FOLD ? 1 - fpw : 0);
+        const int gd0 = d0 * SD - PD - (FOLD ? (FALL ? 1 : 1 - fpd) : 0), gh0 = h0 * S - PHW - (FOLD ? (FALL ? 1 : 1 - fph) : 0),
+                  gw0 = w0 * S - PHW - (FOLD ? (FALL ? 1 : 1 - fpw) : 0);
         cb_lo = GBITS - (unsigned)(max(0, -gd0) | (max(0, -gh0) << 10) | (max(0, -gw0) << 20));
         cb_hi = GBITS + (unsigned)(min(HD - 1, a.BD - 1 - gd0) | (min(HH - 1, a.BH - 1 - gh0) << 10) | (min(HW - 1, a.BW - 1 - gw0) << 20));
         brB = (int)(unsigned)((long long)((gd0 * a.BH + gh0) * a.BW + gw0) * rowB + bc_local * (int)esz);
@@ -2751,8 +2782,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         const unsigned x = TAB_LDS ? ltab[j * NTHR + tid] : xa_[TAB_LDS ? 0 : j];
         const bool ok = ((ca_hi - x) & GBITS) == GBITS;
         const int v = (int)__umul24(__umul24(x & 511u, GHa) + ((x >> 10) & 511u), GWa) + (int)(x >> 20);
-        pa[j] = ld128(rsA, ok ? (int)(__umul24((unsigned)v, (unsigned)rowA) + (unsigned)brA) : -1);
-        if (bn_fused) pyv[j] = ld128(rsY, ok ? (int)(__umul24((unsigned)v, (unsigned)rowY) + (unsigned)brY) : -1);
+        // (FALL: piece j lives in parity tile j = (pd, ph, pw): fine voxel + (pd * 2 GH + ph) * 2 GW + pw)
+        const unsigned pvo = FALL ? (unsigned)((((j >> 2) & 1) * 2 * a.GH + ((j >> 1) & 1)) * 2 * a.GW + (j & 1)) : 0u;
+        pa[j] = ld128(rsA, ok ? (int)(__umul24((unsigned)v, (unsigned)rowA) + (unsigned)brA + pvo * (unsigned)rowA1) : -1);
+        if (bn_fused) pyv[j] = ld128(rsY, ok ? (int)(__umul24((unsigned)v, (unsigned)rowY) + (unsigned)brY + pvo * (unsigned)rowY1) : -1);
         amask |= ok ? (1u << j) : 0u;
     };
     auto issue_b = [&](int j) {
@@ -2811,7 +2844,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                             typedef unsigned v4u __attribute__((ext_vector_type(4)));
                             const unsigned x = TAB_LDS ? ltab[j * NTHR + tid] : xa_[TAB_LDS ? 0 : j];
                             const int v = (int)__umul24(__umul24(x & 511u, GHa) + ((x >> 10) & 511u), GWa) + (int)(x >> 20);
-                            __builtin_amdgcn_raw_buffer_store_b128(v4u{pa[j].x, pa[j].y, pa[j].z, pa[j].w}, rsA, (int)(__umul24((unsigned)v, (unsigned)rowA) + (unsigned)brA), 0, 0);
+                            const unsigned pvo = FALL ? (unsigned)((((j >> 2) & 1) * 2 * a.GH + ((j >> 1) & 1)) * 2 * a.GW + (j & 1)) : 0u;
+                            __builtin_amdgcn_raw_buffer_store_b128(v4u{pa[j].x, pa[j].y, pa[j].z, pa[j].w}, rsA,
+                                                                   (int)(__umul24((unsigned)v, (unsigned)rowA) + (unsigned)brA + pvo * (unsigned)rowA1), 0, 0);
                         }
                     }
                 }
@@ -2911,7 +2946,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                 const int lw0 = q0 % TW;
                 const int t = q0 / TW;
                 const int lh = t % TH;
-                const int ld = t / TH;
+                const int ld = FALL ? (t / TH) % TD : t / TH;            // (FALL: row q0 of the A region = voxel q0 % BVR of parity tile q0 / BVR)
                 const int hbase = ((ld * SD * HH + lh * S) * HW + lw0 * S) * RS;
                 if constexpr (BFM) {
                     typedef bf16x4 __attribute__((address_space(3))) * lp;
@@ -3017,8 +3052,47 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
+            // all-parity form: 8 accumulators per wave leave no room for a second fragment set -- the A fragment of a k-group and the B
+            // fragments two taps at a time, the other wave of the SIMD covers the LDS latency
+            auto mfma_phase_all = [&]() {
+                if constexpr (FALL && BFM) {
+                    typedef bf16x4 __attribute__((address_space(3))) * lp;
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                        for (int j = pf_lo(g, NA, NG); j < pf_lo(g + 1, NA, NG); ++j) issue_a(j);
+#pragma unroll
+                        for (int j = pf_lo(g, NB, NG); j < pf_lo(g + 1, NB, NG); ++j) issue_b(j);
+#pragma unroll
+                        for (int kk = 0; kk < KPG; ++kk) {
+                            const int q0 = (wq * KPW + g * KPG + kk) * KUNIT;
+                            const int t = q0 / TW;
+                            const int hbase = ((((t / TH) % TD) * SD * HH + (t % TH) * S) * HW + (q0 % TW) * S) * RS;
+                            const char* ap = at + q0 * RSA + a_lane;
+                            const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap));
+                            const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(ap + 4 * RSA));
+                            const bf16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                            for (int t2 = 0; t2 < IPW; t2 += 2) {
+                                bf16x8 bfr[2];
+#pragma unroll
+                                for (int u = 0; u < 2; ++u) {
+                                    const char* bp = bt + hbase + tapoff[t2 + u] + b_lane;
+                                    const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp));
+                                    const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(bp + 4 * S * RS));
+                                    bfr[u] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                                }
+                                acc[t2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[0], acc[t2][0], 0, 0, 0);
+                                acc[t2 + 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[1], acc[t2 + 1][0], 0, 0, 0);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            };
             auto mfma_phase = [&](auto ntap_c) {
             constexpr int NTAP = decltype(ntap_c)::value;
+            if constexpr (FALL) { mfma_phase_all(); return; }
 #ifndef BIU_WGRAD_SPLIT_STEPPED
 #define BIU_WGRAD_SPLIT_STEPPED 1
 #endif
@@ -3187,6 +3261,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
         return;
     }
     const int jj = jt * CT + (lane & 31);
+    float* wsp = a.ws + (FALL ? (size_t)wave * a.fold_slice_f : (size_t)0);       // (all-parity form: wave = parity class = its own G slice)
     if (jj < a.CB) {
 #pragma unroll
         for (int t2 = 0; t2 < IPW; ++t2) {
@@ -3197,7 +3272,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int ii = it * CTA + ni * CT + (e & 3) + 8 * (e >> 2) + 4 * hf;
-                        if (ii < a.CA) atomicAdd(a.ws + ((size_t)tap * a.CA + ii) * a.CB + jj, acc[t2][ni][e]);
+                        if (ii < a.CA) atomicAdd(wsp + ((size_t)tap * a.CA + ii) * a.CB + jj, acc[t2][ni][e]);
                     }
             }
         }
@@ -3871,11 +3946,11 @@ bool biu_mfma_convt_wgrad_ok(const biu_act* x, const biu_act* dy, int kd, int dt
     return (kd == 1 || kd == 2) && wgrad_chan_ok(x->c, dy->c) && wgrad_ptrs_ok(x, dy, dtype);
 }
 
-template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int KSPLIT, int NI = 1, bool RR16 = false>
+template <typename T, int KD, int KHW, int S, int TD, int TH, int TW, int KSPLIT, int NI = 1, bool RR16 = false, bool FALL = false>
 static int launch_wgrad(WgradArgs a, hipStream_t st) {
     constexpr int SD = (KD == 1) ? 1 : S;
-    constexpr int HV = ((TD - 1) * SD + KD) * ((TH - 1) * S + KHW) * ((TW - 1) * S + KHW);
-    constexpr int BV = TD * TH * TW;
+    constexpr int HV = ((TD - 1) * SD + (FALL ? 3 : KD)) * ((TH - 1) * S + (FALL ? 3 : KHW)) * ((TW - 1) * S + (FALL ? 3 : KHW));     // must mirror k_wgrad_pipe
+    constexpr int BV = (FALL ? 8 : 1) * TD * TH * TW;
     constexpr int PPV_ = 32 / (16 / (int)sizeof(T));
     constexpr int NA_ = (BV * PPV_ * NI + 511) / 512, NB_ = (HV * PPV_ + 511) / 512;
     const size_t tile_bytes = (size_t)(HV + BV * NI) * 32 * (SplitOf<T>::parts ? 2 * SplitOf<T>::parts : sizeof(T));    // split products: one bf16 plane per part
@@ -3887,7 +3962,7 @@ static int launch_wgrad(WgradArgs a, hipStream_t st) {
     const int nit = (a.CA + 32 * NI - 1) / (32 * NI);
     a.njt = (a.CB + 31) / 32;
     a.bricks_per_block = 0;
-    auto kern = k_wgrad_pipe<T, KD, KHW, S, TD, TH, TW, KSPLIT, NI, RR16>;
+    auto kern = k_wgrad_pipe<T, KD, KHW, S, TD, TH, TW, KSPLIT, NI, RR16, FALL>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
@@ -4037,6 +4112,18 @@ int biu_mfma_upconv_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* 
     const size_t slice = wgrad_acc_bytes(a.CA, a.CB, 8);
     BIU_REQUIRE(ws_bytes >= 8 * slice, BIU_ERR_WORKSPACE, "upconv_wgrad: workspace %zu too small (need %zu)", ws_bytes, 8 * slice);
     if (int zr = zero_ws(ws, 8 * slice, nullptr, 0, st)) return zr;
+    a.fold_slice_f = slice / sizeof(float);
+    static int fall_off = -1;
+    if (fall_off < 0) { const char* e = getenv("BIU_DISABLE"); fall_off = (e && strstr(e, "foldall")) ? 1 : 0; }
+    if (dtype == BIU_BF16 && a.CA <= 32 && !fall_off) {
+        // all eight parity classes in one launch: wave = class, the coarse operand staged once per 2 x 4 x 16 brick (k_wgrad_pipe<..., FALL>).
+        // Only where dy is ONE 32-channel tile: the per-class launches below stage two tiles of a wider dy per block, this form would re-read
+        // the operands once per tile (cfg5's 64..512-channel levels: 69.0 against 63.2 ms per step, same box).  cfg4 decode5: 608 -> 556 us.
+        a.ws = (float*)ws;
+        a.fold_par = 8;
+        rc = launch_wgrad<bf16_t, 2, 2, 1, 2, 4, 16, 8, 1, false, true>(a, st);
+        if (rc != BIU_OK) return rc;
+    } else
     for (int p = 0; p < 8; ++p) {
         a.ws = (float*)((char*)ws + (size_t)p * slice);
         a.fold_par = p;
@@ -4063,63 +4150,104 @@ int biu_mfma_foldt_dgrad(const biu_act* dy, const void* packed, const biu_act* d
     if (rc != BIU_OK) return rc;
     return biu_mfma_upconv_dgrad(dy, base + b.dg, dx_low, acc_low, dtype, st, bn_partial_low, red_low);
 }
-// border sums of dy: R[state][co] = sum of dy over the voxels of border state (sd, sh, sw) != interior.  One thread per shell voxel and channel
-// (lanes run over channels: the LDS atomics of a wave hit distinct addresses); every block writes its own table -- no global atomics,
-// the sum over blocks (k_foldt_inside_sums) runs in a fixed order
+// border sums of dy: R[state][co] = sum of dy over the voxels of border state (sd, sh, sw) != interior.  Threads = (voxel slot, channel); every
+// slot keeps its OWN [27][c] table in LDS, so each table entry has one owner thread: plain read-modify-write, no atomics (most shell voxels share
+// one of six face states -- one shared table had every wave of the block queueing on the same 32 addresses: 77 us at decode5).  Every block writes
+// the sum of its slots' tables -- no global atomics, the sum over blocks (k_foldt_reduce_tables) runs in a fixed order
 constexpr int FOLDT_SUM_BLOCKS = 1024;
+inline size_t foldt_sum_lds(int c) { return (size_t)27 * (c > 256 ? c : 256) * sizeof(float); }
 template <typename T>
 __global__ __launch_bounds__(256) void k_foldt_border_sums(const char* __restrict__ dy, ShellDims sd, int c, int pitch, float* __restrict__ partial) {
-    extern __shared__ float tab[];                        // [27][c]
-    for (int i = threadIdx.x; i < 27 * c; i += 256) tab[i] = 0.f;
-    __syncthreads();
-    // threads = (voxel slot, channel): one shell_voxel per voxel and thread, channels in the low bits so that a wave's LDS atomics spread
+    extern __shared__ float tab[];                        // [slots][27][c]
     const int lanes_c = c < 256 ? c : 256, slots = 256 / lanes_c;
+    for (int i = threadIdx.x; i < slots * 27 * c; i += 256) tab[i] = 0.f;
+    __syncthreads();
     const int cc0 = (int)threadIdx.x % lanes_c, slot = (int)threadIdx.x / lanes_c;
     const long nsv = sd.nA + sd.nB + sd.nC;
-    if (slot < slots)
-        for (long v = (long)blockIdx.x * slots + slot; v < nsv; v += (long)gridDim.x * slots) {
-            long vox; int st;
-            shell_voxel(sd, v, vox, st);
-            const T* p = (const T*)dy + (size_t)vox * pitch;
-            float* r = tab + st * c;
-            for (int cc = cc0; cc < c; cc += lanes_c) atomicAdd(r + cc, (float)p[cc]);
+    // (a thread's voxels are a chain of dependent gathers: four of them in flight at a time)
+    const long stride = (long)gridDim.x * slots;
+    if (slot < slots) {
+        float* mine = tab + (size_t)slot * 27 * c;
+        for (long v = (long)blockIdx.x * slots + slot; v < nsv; v += 4 * stride) {
+            const T* p[4]; float* r[4]; bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long vv = v + u * stride;
+                ok[u] = vv < nsv;
+                long vox = 0; int st = 0;
+                if (ok[u]) shell_voxel(sd, vv, vox, st);
+                p[u] = (const T*)dy + (size_t)vox * pitch;
+                r[u] = mine + st * c;
+            }
+            for (int cc = cc0; cc < c; cc += lanes_c) {
+                float val[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) val[u] = ok[u] ? (float)p[u][cc] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (ok[u]) r[u][cc] += val[u];
+            }
         }
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < 27 * c; i += 256) partial[(size_t)blockIdx.x * 27 * c + i] = tab[i];
+    for (int i = threadIdx.x; i < 27 * c; i += 256) {
+        float t = 0.f;
+        for (int sl = 0; sl < slots; ++sl) t += tab[(size_t)sl * 27 * c + i];
+        partial[(size_t)blockIdx.x * 27 * c + i] = t;
+    }
 }
 // chain rule from G[p][t][co][ci] (ws, parity slices `slice_f` floats apart) to the gradients of both weight tensors and the ConvT bias:
 //   dW_conv[co][c][k] = sum_p sum_ci W_T[ci][c][q(p,k)] G[p][t_p(k)][co][ci]                          (c < cup: the up half of the concat)
 //   dW_T[ci][c][q]    = sum_{(p,k): q(p,k) = q} sum_co W_conv[co][c][k] G[p][t_p(k)][co][ci]
 //   db_T[c]           = sum_k sum_co W_conv[co][c][k] S_k[co],  S_k = sum of dy over the voxels where tap k stays inside = -(sum over the
 //                       border states where it does not): sum_v dy = 0 exactly behind a train-mode BatchNorm
-// R[state][co] = sum over the blocks' tables (fixed order): one block per state, threads over (part of the blocks, channel), LDS tree over the parts
+// R[split][state][co] = sum over a contiguous share of the blocks' tables (fixed order): grid (27 states, FOLDT_RED_SPLIT), threads over (part of the
+// share, channel) with four independent loads in flight, LDS tree over the parts; k_foldt_inside_sums adds the shares
+constexpr int FOLDT_RED_SPLIT = 8;
 __global__ __launch_bounds__(256) void k_foldt_reduce_tables(const float* __restrict__ partial, int nblocks, int cout, float* __restrict__ R) {
     __shared__ float red[256];
-    const int s_ = (int)blockIdx.x;
+    const int s_ = (int)blockIdx.x, per = (nblocks + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int b0 = (int)blockIdx.y * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
     for (int c0 = 0; c0 < cout; c0 += 32) {                               // 32 channels x 8 parts per pass
         const int co = c0 + (int)(threadIdx.x & 31), part = (int)(threadIdx.x >> 5);
-        float sum = 0.f;
-        if (co < cout)
-            for (int b = part; b < nblocks; b += 8) sum += partial[((size_t)b * 27 + s_) * cout + co];
-        red[threadIdx.x] = sum;
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (co < cout) {
+            int b = b0 + part;
+            for (; b + 24 < b1; b += 32)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s4[u] += partial[((size_t)(b + 8 * u) * 27 + s_) * cout + co];
+            for (; b < b1; b += 8) s4[0] += partial[((size_t)b * 27 + s_) * cout + co];
+        }
+        red[threadIdx.x] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
         __syncthreads();
         if (threadIdx.x < 32 && co < cout) {
             float t = 0.f;
             for (int pp = 0; pp < 8; ++pp) t += red[pp * 32 + threadIdx.x];
-            R[s_ * cout + co] = t;
+            R[((size_t)blockIdx.y * 27 + s_) * cout + co] = t;
         }
         __syncthreads();
     }
 }
-// S_k[co] = sum of dy over the voxels whose tap k stays inside = -(sum of R over the border states where it does not)
-__global__ void k_foldt_inside_sums(const float* __restrict__ R, int cout, float* __restrict__ Sk) {
-    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i >= 27 * cout) return;
-    const int k = i / cout, co = i % cout;
+// S_k[co] = sum of dy over the voxels whose tap k stays inside = -(sum of R over the border states where it does not), summed over the shares of
+// k_foldt_reduce_tables.  grid (27 taps, Cout / 32), threads over (share, channel): 27 unconditional loads each, LDS tree over the shares
+__global__ __launch_bounds__(256) void k_foldt_inside_sums(const float* __restrict__ R, int nsplit, int cout, float* __restrict__ Sk) {
+    __shared__ float red[256];
+    const int k = (int)blockIdx.x, co = (int)blockIdx.y * 32 + (int)(threadIdx.x & 31), part = (int)(threadIdx.x >> 5);
     float sum = 0.f;
-    for (int s_ = 0; s_ < 27; ++s_)
-        if (s_ != 13 && tap_outside(k, s_)) sum -= R[s_ * cout + co];
-    Sk[i] = sum;
+    if (co < cout)
+        for (int sp = part; sp < nsplit; sp += 8) {
+#pragma unroll 9
+            for (int s_ = 0; s_ < 27; ++s_) {
+                const float v = R[((size_t)sp * 27 + s_) * cout + co];
+                sum -= (s_ != 13 && tap_outside(k, s_)) ? v : 0.f;
+            }
+        }
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x < 32 && co < cout) {
+        float t = 0.f;
+        for (int pp = 0; pp < 8; ++pp) t += red[pp * 32 + threadIdx.x];
+        Sk[k * cout + co] = t;
+    }
 }
 // (the ConvT bias is part of `up`: dW_conv[co][c][k] also gets b_T[c] S_k[co])
 // dW_conv[co][c][k] = sum_p sum_ci G[p][t_p(k)][co][ci] W_T[ci][c][q(p,k)]  (+ b_T[c] S_k[co])          grid (cup / 32, Cout / 32, 27 = k)
@@ -4196,7 +4324,7 @@ __global__ __launch_bounds__(256) void k_foldt_chain_bt(const float* __restrict_
 size_t biu_mfma_foldt_wgrad_workspace(int cin_low, int cskip, int cout, int dtype) {
     if (!wgrad_chan_ok(cin_low, cout) || !wgrad_chan_ok(cskip, cout)) return 0;
     const size_t g = 8 * wgrad_acc_bytes(cout, cin_low, 8), sk = biu_mfma_wgrad_workspace(cskip, cout, 3, 3, 3, dtype);
-    return (g > sk ? g : sk) + al256((size_t)FOLDT_SUM_BLOCKS * 27 * cout * sizeof(float)) + al256((size_t)2 * 27 * cout * sizeof(float));
+    return (g > sk ? g : sk) + al256((size_t)FOLDT_SUM_BLOCKS * 27 * cout * sizeof(float)) + al256((size_t)(1 + FOLDT_RED_SPLIT) * 27 * cout * sizeof(float));
 }
 // da -> dy in place (BatchNorm + LeakyReLU backward in the loader of the skip half's weight gradient, which runs first); then G on the finished dy
 int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const biu_act* da, const BnBwdFuse* bn,
@@ -4205,7 +4333,7 @@ int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const bi
     const int cin_low = x_low->c, cskip = skip->c, cout = da->c, ccat = cup + cskip;
     const size_t need = biu_mfma_foldt_wgrad_workspace(cin_low, cskip, cout, dtype);
     BIU_REQUIRE(need > 0 && ws_bytes >= need, BIU_ERR_WORKSPACE, "foldt_wgrad: workspace %zu too small (need %zu)", ws_bytes, need);
-    const size_t pbytes = al256((size_t)FOLDT_SUM_BLOCKS * 27 * cout * sizeof(float)), sbytes = al256((size_t)2 * 27 * cout * sizeof(float));
+    const size_t pbytes = al256((size_t)FOLDT_SUM_BLOCKS * 27 * cout * sizeof(float)), sbytes = al256((size_t)(1 + FOLDT_RED_SPLIT) * 27 * cout * sizeof(float));
     const size_t main_bytes = need - pbytes - sbytes;
     float* R = (float*)((char*)ws + main_bytes);                    // per-block border tables
     float* Sk = (float*)((char*)ws + main_bytes + pbytes);
@@ -4219,11 +4347,11 @@ int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const bi
     const bool has_bias = b_t != nullptr || db_t != nullptr;
     if (has_bias) {
         const ShellDims sh = shell_dims(da->n, da->d, da->h, da->w);
-        BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_foldt_border_sums<T>, dim3(FOLDT_SUM_BLOCKS), dim3(256), (size_t)27 * cout * sizeof(float), st,
+        BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_foldt_border_sums<T>, dim3(FOLDT_SUM_BLOCKS), dim3(256), foldt_sum_lds(cout), st,
                                                      (const char*)da->p, sh, da->c, da->pitch, R));
-        float* Rsum = Sk + 27 * cout;                                   // (second half of the Sk region)
-        hipLaunchKernelGGL(k_foldt_reduce_tables, dim3(27), dim3(256), 0, st, (const float*)R, FOLDT_SUM_BLOCKS, cout, Rsum);
-        hipLaunchKernelGGL(k_foldt_inside_sums, dim3((27 * cout + 127) / 128), dim3(128), 0, st, (const float*)Rsum, cout, Sk);
+        float* Rsum = Sk + 27 * cout;                                   // (rest of the Sk region: FOLDT_RED_SPLIT tables)
+        hipLaunchKernelGGL(k_foldt_reduce_tables, dim3(27, FOLDT_RED_SPLIT), dim3(256), 0, st, (const float*)R, FOLDT_SUM_BLOCKS, cout, Rsum);
+        hipLaunchKernelGGL(k_foldt_inside_sums, dim3(27, (cout + 31) / 32), dim3(256), 0, st, (const float*)Rsum, FOLDT_RED_SPLIT, cout, Sk);
         BIU_CHECK_LAUNCH("foldt_border_sums");
     }
     // 4. chain rule to the up half of dW_conv, to dW_T and to db_T
