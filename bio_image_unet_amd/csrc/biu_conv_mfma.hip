@@ -2628,7 +2628,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_pipe(WgradArgs a) {
     const float* bb_ = b_src1 ? a.bb1_ : a.bb_;
     const float* bl_ = b_src1 ? a.bl1_ : a.bl_;
     const bool a_xf = a.as_ != nullptr, b_xf = bs_ != nullptr;
-    const bool bn_fused = a.py != nullptr;
+    const bool bn_fused = !FALL && a.py != nullptr;     // (the all-parity form has no registers left for the staged y pieces: plain dy only)
     if (tid < CTA && bn_fused) {                         // (all NI tiles of the plain operand: [6][CTA])
         const int ca = it * CTA + tid;
         const bool ok = ca < a.CA;
@@ -4115,7 +4115,7 @@ int biu_mfma_upconv_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* 
     a.fold_slice_f = slice / sizeof(float);
     static int fall_off = -1;
     if (fall_off < 0) { const char* e = getenv("BIU_DISABLE"); fall_off = (e && strstr(e, "foldall")) ? 1 : 0; }
-    if (dtype == BIU_BF16 && a.CA <= 32 && !fall_off) {
+    if (dtype == BIU_BF16 && a.CA <= 32 && bn == nullptr && !fall_off) {
         // all eight parity classes in one launch: wave = class, the coarse operand staged once per 2 x 4 x 16 brick (k_wgrad_pipe<..., FALL>).
         // Only where dy is ONE 32-channel tile: the per-class launches below stage two tiles of a wider dy per block, this form would re-read
         // the operands once per tile (cfg5's 64..512-channel levels: 69.0 against 63.2 ms per step, same box).  cfg4 decode5: 608 -> 556 us.
