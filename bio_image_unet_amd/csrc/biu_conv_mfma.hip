@@ -4115,10 +4115,13 @@ int biu_mfma_upconv_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* 
     a.fold_slice_f = slice / sizeof(float);
     static int fall_off = -1;
     if (fall_off < 0) { const char* e = getenv("BIU_DISABLE"); fall_off = (e && strstr(e, "foldall")) ? 1 : 0; }
-    if (dtype == BIU_BF16 && a.CA <= 32 && bn == nullptr && !fall_off) {
-        // all eight parity classes in one launch: wave = class, the coarse operand staged once per 2 x 4 x 16 brick (k_wgrad_pipe<..., FALL>).
-        // Only where dy is ONE 32-channel tile: the per-class launches below stage two tiles of a wider dy per block, this form would re-read
-        // the operands once per tile (cfg5's 64..512-channel levels: 69.0 against 63.2 ms per step, same box).  cfg4 decode5: 608 -> 556 us.
+    static int fall_ca = -1;                               // (BIU_FALL_MAXCA moves the rule below for A/B runs)
+    if (fall_ca < 0) { const char* e = getenv("BIU_FALL_MAXCA"); fall_ca = e ? atoi(e) : 64; }
+    if (dtype == BIU_BF16 && a.CA <= fall_ca && bn == nullptr && !fall_off) {
+        // all eight parity classes in one launch: wave = class, the coarse operand staged once per 2 x 4 x 16 brick (k_wgrad_pipe<..., FALL>);
+        // plain dy only (no registers left for the y pieces of a fused BatchNorm backward).  Same-box: decode5 (dy 32 ch) 608 -> 410 us,
+        // cfg4 step 12.69 -> 12.46 ms; with decode3 (dy 64 ch: two tiles, operands staged per tile) 12.30 ms.  Wider dy stays on the
+        // per-class launches below, which stage two dy tiles per block.
         a.ws = (float*)ws;
         a.fold_par = 8;
         rc = launch_wgrad<bf16_t, 2, 2, 1, 2, 4, 16, 8, 1, false, true>(a, st);
