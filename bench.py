@@ -97,17 +97,13 @@ def make_step(wl, device, graph=False):
         loss.backward()
         avg.average()                              # (a no-op at N = 1) -- BEFORE the clip: buckets that left during backward are not re-read
         if wl["model"] == "MultiOutputUnet3D":     # multi_output_unet3d/train.py:201, on the global-batch gradient
-            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+            opt.clip_grad_norm_(1.0)
         opt.step()
         return loss
 
-    if graph and wl["model"] == "MultiOutputUnet3D":
-        print("bench: --graph ignored for the multi-head workload (its step clips the gradient norm between backward and Adam; that "
-              "capture is not among the verified ones -- tests/test_gpu_graph.py covers multi-head steps without the clip)", file=sys.stderr)
-        graph = False
     if graph:
         from bio_image_unet_amd.graph import GraphedTrainStep
-        clip = (lambda: torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)) if wl["model"] == "MultiOutputUnet3D" else None
+        clip = (lambda: opt.clip_grad_norm_(1.0)) if wl["model"] == "MultiOutputUnet3D" else None
         ins = [x, px] if px is not None else [x]
         gstep = GraphedTrainStep(model, lambda outs: loss_of(outs), opt, ins, [], after_backward=clip)
         eager_step = step

@@ -138,6 +138,8 @@ SIGNATURES = {
     "biu_adam_step": (_I, [_I, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _F, _P]),
     "biu_adam_set_hyper": (_I, [_P, _F, _F, _F, _F, _I, _F, _P]),
     "biu_adam_step_hyper": (_I, [_I, _P, _P, _P, _P, _P, _P, _P]),
+    "biu_grad_clip_scratch_floats": (_Z, [_I]),
+    "biu_grad_clip": (_I, [_I, _P, _P, _F, _P, _Z, _P, _P]),
 }
 
 

@@ -1304,3 +1304,81 @@ extern "C" int biu_adam_step_hyper(int n, float* const* params, const float* con
     BIU_CHECK_LAUNCH("adam_step_hyper");
     return BIU_OK;
 }
+
+// =====================================================================================================
+// gradient-norm clipping over a table of tensors (torch.nn.utils.clip_grad_norm_(params, max_norm), multi_output_unet3d/train.py:201):
+//   total = sqrt(sum_i |g_i|^2),  coef = min(1, max_norm / (total + 1e-6)),  g_i *= coef in place.
+// Three launches whatever the number of tensors, every sum in a fixed order (no atomics): per-(tensor, block) partial sums of squares,
+// one block folding them (double accumulators) into {total, coef}, and the in-place scaling -- which returns at once when coef == 1
+// (torch multiplies by 1.0 then: the same values).
+// =====================================================================================================
+constexpr int CLIP_BX = 32;
+__global__ __launch_bounds__(256) void k_grad_sumsq(int n, const float* const* grads, const int64_t* numel, float* __restrict__ partial) {
+    __shared__ float red[256];
+    const int t = blockIdx.y;
+    const float* g = grads[t];
+    const i64 cnt = numel[t];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const bool vec = ((uintptr_t)g & 15) == 0;
+    const i64 nv = vec ? cnt / 4 : 0;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (i64)gridDim.x * blockDim.x) {
+        const float4 v = ((const float4*)g)[i];
+        s0 = fmaf(v.x, v.x, s0); s1 = fmaf(v.y, v.y, s1); s2 = fmaf(v.z, v.z, s2); s3 = fmaf(v.w, v.w, s3);
+    }
+    for (i64 i = nv * 4 + (i64)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (i64)gridDim.x * blockDim.x) s0 = fmaf(g[i], g[i], s0);
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(size_t)t * CLIP_BX + blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void k_grad_clip_coef(int nparts, const float* __restrict__ partial, float max_norm, float* __restrict__ out2,
+                                                        float* __restrict__ total_norm) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += (double)partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float total = (float)sqrt(red[0]);
+        const float coef = max_norm / (total + 1e-6f);
+        out2[0] = total;
+        out2[1] = coef < 1.f ? coef : 1.f;
+        if (total_norm) *total_norm = total;
+    }
+}
+__global__ __launch_bounds__(256) void k_grad_scale(int n, float* const* grads, const int64_t* numel, const float* __restrict__ coef) {
+    const float c = *coef;
+    if (c >= 1.f) return;
+    const int t = blockIdx.y;
+    float* g = grads[t];
+    const i64 cnt = numel[t];
+    const bool vec = ((uintptr_t)g & 15) == 0;
+    const i64 nv = vec ? cnt / 4 : 0;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (i64)gridDim.x * blockDim.x) {
+        float4 v = ((float4*)g)[i];
+        v.x *= c; v.y *= c; v.z *= c; v.w *= c;
+        ((float4*)g)[i] = v;
+    }
+    for (i64 i = nv * 4 + (i64)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (i64)gridDim.x * blockDim.x) g[i] *= c;
+}
+extern "C" size_t biu_grad_clip_scratch_floats(int n) { return n > 0 ? (size_t)n * CLIP_BX + 2 : 0; }
+extern "C" int biu_grad_clip(int n, float* const* grads, const int64_t* numel, float max_norm, float* scratch, size_t scratch_floats, float* total_norm,
+                             biu_stream stream) {
+    BIU_REQUIRE(n > 0 && grads && numel && scratch && max_norm > 0.f, BIU_ERR_SHAPE, "grad_clip: bad arguments");
+    BIU_REQUIRE(scratch_floats >= biu_grad_clip_scratch_floats(n), BIU_ERR_WORKSPACE, "grad_clip: scratch %zu floats too small (need %zu)", scratch_floats,
+                biu_grad_clip_scratch_floats(n));
+    hipStream_t st = (hipStream_t)stream;
+    float* out2 = scratch + (size_t)n * CLIP_BX;
+    hipLaunchKernelGGL(k_grad_sumsq, dim3(CLIP_BX, n), dim3(256), 0, st, n, (const float* const*)grads, numel, scratch);
+    hipLaunchKernelGGL(k_grad_clip_coef, dim3(1), dim3(256), 0, st, n * CLIP_BX, (const float*)scratch, max_norm, out2, total_norm);
+    hipLaunchKernelGGL(k_grad_scale, dim3(CLIP_BX, n), dim3(256), 0, st, n, grads, numel, (const float*)(out2 + 1));
+    BIU_CHECK_LAUNCH("grad_clip");
+    return BIU_OK;
+}

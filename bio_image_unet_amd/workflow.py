@@ -405,7 +405,7 @@ class TrainerMo3d:
                     loss = self._total_loss(batch, validating=False)
                     self.optimizer.zero_grad()
                     loss.backward()
-                    torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=1.0)
+                    self.optimizer.clip_grad_norm_(1.0)          # multi_output_unet3d/train.py:201, as three launches (biu_grad_clip)
                     self.optimizer.step()
             return None
         losses = []

@@ -459,6 +459,17 @@ int biu_adam_set_hyper(float* hyper, float lr, float beta1, float beta2, float e
 int biu_adam_step_hyper(int n, float* const* params, const float* const* grads, float* const* exp_avg,
                         float* const* exp_avg_sq, const int64_t* numel, const float* hyper, biu_stream stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Gradient-norm clipping over a table of fp32 tensors                                     [K14b]
+ * replaces torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0): multi_output_unet3d/train.py:201.
+ *   total = sqrt(sum_i |g_i|^2), coef = min(1, max_norm / (total + 1e-6)), g_i *= coef in place (three launches, sums in a fixed order).
+ * grads / numel: device arrays as for biu_adam_step; scratch: biu_grad_clip_scratch_floats(n) floats of device memory;
+ * total_norm: one device float receiving the norm before clipping, or NULL.
+ * ---------------------------------------------------------------------------------------------- */
+size_t biu_grad_clip_scratch_floats(int n);
+int biu_grad_clip(int n, float* const* grads, const int64_t* numel, float max_norm, float* scratch, size_t scratch_floats, float* total_norm,
+                  biu_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

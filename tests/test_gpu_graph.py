@@ -117,9 +117,12 @@ def test_eager_forward_after_a_replay_sees_the_updated_weights():
     torch.testing.assert_close(after, want, rtol=1e-5, atol=1e-5)
 
 
-def test_multi_head_step_replays_like_the_eager_step():
+@pytest.mark.parametrize("clip", [None, 0.05])
+def test_multi_head_step_replays_like_the_eager_step(clip):
     """The stacked heads of MultiOutputUnet3D put device-to-device copy nodes into the captured step; copy nodes replay correctly on this
-    runtime (test_memset_nodes_are_the_ones_that_break), so the step is captured and must train like its eager twin."""
+    runtime (test_memset_nodes_are_the_ones_that_break), so the step is captured and must train like its eager twin.  clip: the step of
+    multi_output_unet3d/train.py:198-202 with its clip_grad_norm_ between backward and Adam (Adam.clip_grad_norm_ = biu_grad_clip inside the
+    capture; 0.05 is below the gradient norm of this case, so the scaling is active)."""
     heads = {"a": {"channels": 1, "activation": "sigmoid"}, "b": {"channels": 2, "activation": None}}
     m, twin = B.MultiOutputUnet3D(1, heads, n_filter=4).cuda().train(), B.MultiOutputUnet3D(1, heads, n_filter=4).cuda().train()
     m.load_state_dict(O.init_mo3d(1, heads, 4, True, seed=6))
@@ -129,13 +132,15 @@ def test_multi_head_step_replays_like_the_eager_step():
     g = torch.Generator().manual_seed(3)
     data = [(torch.rand(1, 1, 8, 16, 16, generator=g).cuda(), torch.rand(1, 1, 8, 16, 16, generator=g).cuda(), torch.rand(1, 2, 8, 16, 16, generator=g).cuda())
             for _ in range(4)]
-    gstep = GraphedTrainStep(m, lossf, opt, [data[0][0]], [data[0][1], data[0][2]])
+    gstep = GraphedTrainStep(m, lossf, opt, [data[0][0]], [data[0][1], data[0][2]], after_backward=(lambda: opt.clip_grad_norm_(clip)) if clip else None)
     assert gstep.node_kinds.get("memcpy", 0) > 0 and gstep.node_kinds.get("memset", 0) == 0, gstep.node_kinds
     for x, ya, yb in data:
         lg = float(gstep([x], [ya, yb]))
         le = lossf(twin(x), ya, yb)
         topt.zero_grad(set_to_none=True)
         le.backward()
+        if clip:
+            assert float(topt.clip_grad_norm_(clip)) > clip                 # (the clip is active in this case)
         topt.step()
         assert abs(lg - float(le)) <= 1e-5 * max(1.0, abs(float(le)))
     for (n, p), (_, q) in zip(m.named_parameters(), twin.named_parameters()):

@@ -85,10 +85,11 @@ def test_golden_train_step_fp32(case):
     # kernel on the engine's gradients against the parameters the reference's torch.optim.Adam produced ------------------------
     from bio_image_unet_amd.optim import Adam
     m.train()
+    opt = Adam(m.parameters(), lr=1e-3)
     if g["gradnorm"] is not None:
-        norm = torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=1.0)
+        norm = opt.clip_grad_norm_(1.0)                  # biu_grad_clip against the norm the reference's clip_grad_norm_ returned
         assert abs(float(norm) - float(g["gradnorm"])) < REL * float(g["gradnorm"]), (float(norm), float(g["gradnorm"]))
-    Adam(m.parameters(), lr=1e-3).step()
+    opt.step()
     torch.cuda.synchronize()
     for k, p in m.named_parameters():
         want, g0 = g["adam1"][k], g["grad"][k]

@@ -295,6 +295,35 @@ def test_adam_matches_torch():
         torch.testing.assert_close(p.cpu(), r.detach(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("max_norm", [1.0, 1e-2, 1e6])
+def test_grad_clip_matches_torch(max_norm):
+    """biu_grad_clip against torch.nn.utils.clip_grad_norm_ (multi_output_unet3d/train.py:201): the returned norm, the scaled gradients, and
+    gradients left bit for bit alone when the norm is below max_norm.  Sizes off the 16-byte path and an unaligned view included."""
+    torch.manual_seed(3)
+    flat = torch.randn(1000, device="cuda")
+    gs = [torch.randn(s, device="cuda") for s in [(7,), (3, 5), (64, 3, 3, 3), (1,), (4096, 33)]] + [flat[1:602]]     # (last: 4-byte aligned only)
+    ref = [g.clone().cpu().requires_grad_(True) for g in gs]
+    for r, g in zip(ref, gs):
+        r.grad = g.clone().cpu()
+    want_norm = torch.nn.utils.clip_grad_norm_(ref, max_norm=max_norm)
+    before = [g.clone() for g in gs]
+    n = len(gs)
+    table = torch.tensor([g.data_ptr() for g in gs], dtype=torch.int64, device="cuda")
+    numel = torch.tensor([g.numel() for g in gs], dtype=torch.int64, device="cuda")
+    need = int(lib.biu_grad_clip_scratch_floats(n))
+    scratch = torch.empty(need, device="cuda")
+    total = torch.zeros(1, device="cuda")
+    check(lib.biu_grad_clip(n, ptr(table), ptr(numel), max_norm, ptr(scratch), need, ptr(total), stream()), "grad_clip")
+    torch.cuda.synchronize()
+    assert abs(float(total) - float(want_norm)) <= 2e-6 * float(want_norm), (float(total), float(want_norm))
+    for g, r, b in zip(gs, ref, before):
+        if float(want_norm) + 1e-6 <= max_norm:
+            assert torch.equal(g, b)                                           # coefficient clamped to 1: untouched
+        torch.testing.assert_close(g.cpu(), r.grad, rtol=3e-6, atol=0.0)
+    # too small a scratch is reported, not overrun
+    assert lib.biu_grad_clip(n, ptr(table), ptr(numel), max_norm, ptr(scratch), need - 1, None, stream()) != 0
+
+
 def test_shape_errors_are_reported_not_thrown():
     x = Dev(rnd(1, 4, 1, 8, 8), dtype="f32")
     y = Dev(shape=(1, 4, 1, 4, 8), dtype="f32")

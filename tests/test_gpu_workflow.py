@@ -306,7 +306,7 @@ def test_mo3d_trainer_and_predict(tmp_path):
     tr.optimizer.zero_grad()
     loss.backward()
     q = _engine_decisions(tr.model)
-    norm = torch.nn.utils.clip_grad_norm_(tr.model.parameters(), max_norm=1.0)
+    norm = tr.optimizer.clip_grad_norm_(1.0)             # (what Trainer.iterate calls: biu_grad_clip)
     clipped = {k: p.grad.detach().cpu().clone() for k, p in tr.model.named_parameters()}
     tr.optimizer.step()
     torch.cuda.synchronize()
