@@ -2188,7 +2188,11 @@ int biu_mfma_upconv_fwd(const biu_act* x, const biu_xform* xf, const void* packe
     a.nKS = x->c / ks_of(dtype);
     a.wz_stride = (int)upconv_slice16(x->c, y->c, dtype);
     a.accumulate = accumulate;
+#ifdef BIU_DIAG
+    a.diag = biu_diag_buffer;                              // (tools/diag_fold.py: in-kernel stamps of the fold forward)
+#else
     a.diag = nullptr;
+#endif
     a.nbd = a.nbh = a.nbw = 0;
     a.fold = 1;
     if (dtype == BIU_BF16) return launch_upconv<bf16_t>(a, st);
