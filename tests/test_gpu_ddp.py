@@ -63,7 +63,8 @@ m.zero_grad(set_to_none=True)
 O.bce_dice_loss(m(x)[1], y).backward()
 local_g = {k: p.grad.clone() for k, p in m.named_parameters()}
 avg.average()
-torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=1e-3)
+from bio_image_unet_amd.optim import Adam
+Adam(m.parameters(), lr=1e-3).clip_grad_norm_(1e-3)        # (biu_grad_clip on the bucket views average() left in p.grad: what bench.py's step does)
 mean_g = {}
 for k in local_g:
     parts = [torch.zeros_like(local_g[k]) for _ in range(world)]
