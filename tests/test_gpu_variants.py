@@ -1,5 +1,5 @@
 """The kernel variants a launch can take must agree with the kernels they replace: the 16-row MFMA kernel (BIU_DISABLE=m16 falls back to
-the 32-row one), the paired-tap weight gradient of a 16-channel input (BIU_DISABLE=rr16), the rolling-window weight gradient (BIU_DISABLE=wroll), the input-channel split of small fp32 launches (BIU_DISABLE=ksplit) and the opt-in bf16x3 products of the fp32 2-D kernels
+the 32-row one), the paired-tap weight gradient of a 16-channel input (BIU_DISABLE=rr16), the rolling-window weight gradient (BIU_DISABLE=wroll), the one-launch folded weight gradient (BIU_DISABLE=foldall), the input-channel split of small fp32 launches (BIU_DISABLE=ksplit) and the opt-in bf16x3 products of the fp32 2-D kernels
 (BIU_FP32_PRODUCTS=bf16x3) against the exact fp32 MFMA.  The switches are read once per process, so
 each side runs in its own subprocess (tests/variant_probe.py)."""
 import os
@@ -51,6 +51,9 @@ def _run(which, disable, tmp_path):
     # ConvTranspose + concat + conv of the decoder levels as one folded op (biu_foldt_*) against the three separate ops (BIU_DISABLE=foldt)
     ("unet3d_f32", "foldt", 1e-5, 2e-2),
     ("unet3d_bf16", "foldt", 2e-2, 6e-2),
+    # the folded weight gradient's G for all eight parity classes in one launch (k_wgrad_pipe<..., FALL>) against one launch per class
+    # (BIU_DISABLE=foldall): the same operands, only the order of the fp32 sums over voxels differs
+    ("unet3d_bf16", "foldall", 1e-6, 2.5e-4),
     ("mo3d_interp_f32", "upconv", 1e-5, 2e-2),
     # (this network is the sensitive one of DESIGN section 4 -- nearest down-sampling, 23 bf16 layers: swapping the 16-row kernels on the SAME
     # probe moves all gradients together by 0.206, the fold by 0.173; logits within 0.017-0.021 either way.  A wrong tap moves them by ~1)
