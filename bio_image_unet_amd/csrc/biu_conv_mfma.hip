@@ -2155,6 +2155,12 @@ static int launch_upconv(const ConvArgs& a, hipStream_t st) {
     const int ntiles = (a.Cout + 31) / 32, nt = pick_nt(ntiles);
     const int e = 16 / (int)sizeof(T);                                       // channels per 16-byte piece
     // (a data-gradient chunk must lie in ONE parity class: a.Cin = channels per class there)
+    // one output tile (decode5 of UNet3D(32)): 64-channel chunks -- half the items per brick, each with twice the MFMAs behind its two barriers;
+    // the 98 KiB tile leaves room for one weight slab (decode5 forward call 1.217 -> 1.183 ms, same box; BIU_DISABLE=foldck8 for the A/B)
+    static int ck8 = -1;
+    if (ck8 < 0) { const char* e8 = getenv("BIU_DISABLE"); ck8 = (e8 && strstr(e8, "foldck8")) ? 0 : 1; }
+    if constexpr (sizeof(T) == 2)
+        if (ck8 && nt == 1 && a.Cin % (8 * e) == 0) return launch_upconv_cfg<T, 1, 8>(a, ntiles, st);
     if (a.Cin % (4 * e) == 0) return nt == 1 ? launch_upconv_cfg<T, 1, 4>(a, ntiles, st) : launch_upconv_cfg<T, 2, 4>(a, ntiles, st);
     return nt == 1 ? launch_upconv_cfg<T, 1, 2>(a, ntiles, st) : launch_upconv_cfg<T, 2, 2>(a, ntiles, st);
 }

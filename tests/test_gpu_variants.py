@@ -54,6 +54,9 @@ def _run(which, disable, tmp_path):
     # the folded weight gradient's G for all eight parity classes in one launch (k_wgrad_pipe<..., FALL>) against one launch per class
     # (BIU_DISABLE=foldall): the same operands, only the order of the fp32 sums over voxels differs
     ("unet3d_bf16", "foldall", 1e-6, 2.5e-4),
+    # 64-channel chunks of the folded forward where the output is one 32-channel tile (decode5) against 32-channel chunks (BIU_DISABLE=foldck8):
+    # the same products summed in the same order (chunk by chunk, tap by tap inside a chunk differs) -- outputs may round differently
+    ("unet3d_bf16", "foldck8", 2e-2, 6e-2),
     ("mo3d_interp_f32", "upconv", 1e-5, 2e-2),
     # (this network is the sensitive one of DESIGN section 4 -- nearest down-sampling, 23 bf16 layers: swapping the 16-row kernels on the SAME
     # probe moves all gradients together by 0.206, the fold by 0.173; logits within 0.017-0.021 either way.  A wrong tap moves them by ~1)
