@@ -306,14 +306,20 @@ def main():
     rows = sorted(((sum(v), k) for k, v in agg.items()), reverse=True)
     total_kernel_ms = sum(r[0] for r in rows)
     dom_ms, dom_key = rows[0]
+    step_exec_flop = sum(call_cost(eng, api, label, executed=True)[0] * len(agg[(api, label)]) for api, label in agg)
     if args.breakdown and rank == 0:
         with open(args.breakdown, "w") as f:
             f.write(f"# per-launch HIP-event times of one profiled step, workload {args.workload}; sum = {total_kernel_ms:.3f} ms\n")
-            f.write("# TFLOP/s and GB/s: algorithmic work (SURVEY 8d) of the reference ops a call stands for -- the folded decoder calls (biu_foldt_*, biu_upconv_*) "
-                    "issue fewer FLOPs for the same function (DESIGN.md 3.5)\n")
+            f.write("# TFLOP/s (executed) and GB/s: the FLOPs the kernels of the call ISSUE and its algorithmic bytes (SURVEY 8d) -- hardware utilisation; "
+                    "'alg': the FLOPs of the reference ops the call stands for (larger for the folded decoder calls biu_foldt_*, biu_upconv_*: DESIGN.md 3.5); "
+                    "'roof': max(executed FLOP / MFMA peak, bytes / 8 TB/s) / time\n")
             for ms, (api, label) in rows:
                 fl, by = call_cost(eng, api, label)
-                f.write(f"{ms:9.4f} ms  {api:26s} {label:22s} {fl / ms / 1e9 if ms else 0:9.1f} TFLOP/s {by / ms / 1e6 if ms else 0:9.1f} GB/s\n")
+                fx, _ = call_cost(eng, api, label, executed=True)
+                pk = MFMA_PEAK["bf16" if eng.tdtype == torch.bfloat16 else "f32"]
+                t_roof = max(fx / pk, by / HBM_PEAK) * 1e3
+                f.write(f"{ms:9.4f} ms  {api:26s} {label:22s} {fx / ms / 1e9 if ms else 0:9.1f} TFLOP/s {by / ms / 1e6 if ms else 0:9.1f} GB/s   "
+                        f"alg {fl / ms / 1e9 if ms else 0:7.1f}  roof {t_roof / ms if ms else 0:5.2f}\n")
 
     # ---- timed region --------------------------------------------------------------------------------------------------
     lib.watch, lib.watched = dom_key, []
@@ -382,7 +388,10 @@ def main():
             torch.distributed.destroy_process_group()
         return
     dom_launch_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in watched) / max(len(watched), 1)
-    fl, by = call_cost(eng, *dom_key)
+    # utilisation figures are taken on the FLOPs the kernels of the call issue (`executed`); for the folded decoder ops the FLOPs of the
+    # reference ops they replace (SURVEY 8d's algorithmic convention, larger) are reported beside them as `algorithmic_equivalent`
+    fl_alg, by = call_cost(eng, *dom_key)
+    fl, _ = call_cost(eng, *dom_key, executed=True)
     dt_name = wl["dtype"]
     x3 = dt_name == "f32" and wl["model"] in ("Unet", "Siam_UNet") and args.fp32_products != "exact"
     nterms = {"bf16x3": 3, "bf16x6": 6}.get(args.fp32_products, 1)
@@ -394,13 +403,11 @@ def main():
     else:
         roof = {"bound": "hbm", "achieved": by / (dom_launch_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
-    fl_exec, _ = call_cost(eng, *dom_key, executed=True)
-    if fl_exec != fl and fl > 0:
-        # a folded decoder op: `achieved` counts the reference ops the call replaces (SURVEY 8d's algorithmic work, what the step-level figures
-        # count too); the kernels issue fewer FLOPs for the same function -- stated beside it
-        roof["executed"] = {"TFLOP_per_call": fl_exec / 1e12, "TFLOPps": fl_exec / (dom_launch_ms * 1e-3) / 1e12, "frac_of_peak": fl_exec / (dom_launch_ms * 1e-3) / mfma_peak,
-                            "note": "folded op (DESIGN.md 3.5): 8 parity classes x 2x2x2 coarse taps instead of 27 fine taps on the up-sampled channels; "
-                                    "`achieved` = FLOPs of the reference ops it replaces / time"}
+    if fl_alg != fl and fl > 0:
+        roof["algorithmic_equivalent"] = {"TFLOP_per_call": fl_alg / 1e12, "TFLOPps": fl_alg / (dom_launch_ms * 1e-3) / 1e12,
+                                          "note": "folded op (DESIGN.md 3.5): the kernels issue 8 parity classes x 2x2x2 coarse taps instead of 27 fine taps on the "
+                                                  "up-sampled channels; `achieved` / `frac` count the issued FLOPs, this entry the FLOPs of the reference ops "
+                                                  "(Conv3d on all concat channels + ConvTranspose3d) the call replaces -- not a utilisation figure"}
     roof["traffic"] = None          # HBM bytes per launch from PMC counters (tools/pmc_traffic.py), when measured for this call
     tr_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"pmc_traffic_{args.workload}.json")
     if os.path.exists(tr_file):
@@ -427,7 +434,10 @@ def main():
                                "train step = forward + reference loss + backward + Adam", "parallelism": f"dp{world}"},
         "fwd_only": {"value": nvox / (fwd_ms * 1e-3) * world, "unit": "voxels/s", "ms": fwd_ms},
         "step_roofline": {"hbm_frac_algorithmic": vps_gpu * per_vox[1] / HBM_PEAK, "algorithmic_GBps": vps_gpu * per_vox[1] / 1e9,
-                          "algorithmic_TFLOPps": vps_gpu * per_vox[0] / 1e12, "mfma_frac": vps_gpu * per_vox[0] / mfma_peak,
+                          "algorithmic_TFLOPps": vps_gpu * per_vox[0] / 1e12, "mfma_frac_algorithmic": vps_gpu * per_vox[0] / mfma_peak,
+                          "executed_TFLOPps": step_exec_flop / (ms_per_step * 1e-3) / 1e12, "mfma_frac": step_exec_flop / (ms_per_step * 1e-3) / mfma_peak,
+                          "note": "mfma_frac = FLOPs the step's kernels issue / time / peak (utilisation); *_algorithmic = SURVEY 8d's per-voxel figures of the "
+                                  "reference ops (what `value` x 1.316 MFLOP is), larger where decoder levels run folded",
                           "kernel_time_ms_one_step": total_kernel_ms},
         "roofline": roof,
     }

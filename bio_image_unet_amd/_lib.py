@@ -69,6 +69,7 @@ SIGNATURES = {
     "biu_xform_apply": (_I, [_A, _X, _A, _I, _P]),
     "biu_bn_bwd_reduce": (_I, [_A, _A, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_int), _I, _P]),
     "biu_bn_bwd_finalize": (_I, [_P, _I, _I, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "biu_bn_bwd_finalize_eval": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "biu_bn_bwd_apply": (_I, [_A, _A, _P, _P, _P, _P, _P, _P, _A, _I, _P]),
     "biu_maxpool_fwd": (_I, [_A, _X, _A, _I, _P]),
     "biu_maxpool_bwd": (_I, [_A, _X, _A, _A, _I, _I, _P]),
@@ -112,7 +113,7 @@ SIGNATURES = {
     "biu_foldt_bwd_data_bnred_floats": (_Z, [_A]),
     "biu_foldt_bwd_data": (_I, [_A, _P, _A, _I, _A, _I, _A, _P, _P, _P, _P, _P, _P, _Z, C.POINTER(C.c_int), _P, _Z, _I, _P]),
     "biu_foldt_bwd_weight_workspace": (_Z, [_I, _I, _I, _I]),
-    "biu_foldt_bwd_weight_bn": (_I, [_A, _X, _A, _X, _A, _A, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _I, _P]),
+    "biu_foldt_bwd_weight_bn": (_I, [_A, _X, _A, _X, _A, _A, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _I, _P]),
     "biu_convt_fwd": (_I, [_A, _X, _P, _P, _P, _I, _A, _I, _P]),
     "biu_convt_bwd_data": (_I, [_A, _P, _P, _I, _A, _I, _I, _P]),
     "biu_convt_bwd_weight_workspace": (_Z, [_I, _I, _I, _I]),

@@ -384,9 +384,18 @@ extern "C" int biu_upconv_fwd(const biu_act* x, const biu_xform* xf, const void*
 // ---- ConvTranspose(k2, s2) + concat + 3x3x3 conv of a decoder level, the up half folded onto the coarse tensor -------------------------
 // 1: the folded kernels serve the level AND it is large enough for the fold to pay (BIU_FOLDT=always: wherever they serve it -- the tests)
 extern "C" int biu_foldt_ok(const biu_act* x_low, const biu_act* skip, const biu_act* y, int dtype) {
-    static int always = -1;
-    if (always < 0) { const char* e = getenv("BIU_FOLDT"); always = (e && strstr(e, "always")) ? 1 : 0; }
+    // BIU_FOLDT=always: wherever the kernels serve the level (the tests); BIU_FOLDT=cmax:N: exactly the levels whose coarse input has at
+    // most N channels -- reproduces at test extents the pattern the size rule picks at a benchmark's extents (cfg4: cmax:128 = decode5 and
+    // decode3 folded, decode1 through the 3-D ConvT + two-source kernels; tests/test_gpu_bench_dispatch.py)
+    static int always = -1, cmax = 0;
+    if (always < 0) {
+        const char* e = getenv("BIU_FOLDT");
+        const char* c = e ? strstr(e, "cmax:") : nullptr;
+        cmax = c ? atoi(c + 5) : 0;
+        always = (e && strstr(e, "always")) ? 1 : 0;
+    }
     if (!(x_low && skip && y) || disabled("foldt") || !biu_mfma_foldt_ok(x_low, skip, y, dtype)) return 0;
+    if (cmax > 0) return x_low->c <= cmax ? 1 : 0;
     return (always || biu_mfma_foldt_worth(x_low, y)) ? 1 : 0;
 }
 extern "C" size_t biu_foldt_packed_bytes(int cin_low, int cskip, int cout, int dtype) { return biu_mfma_foldt_packed_bytes(cin_low, cskip, cout, dtype); }
@@ -435,18 +444,31 @@ extern "C" int biu_foldt_bwd_data(const biu_act* dy, const void* packed, const b
 extern "C" size_t biu_foldt_bwd_weight_workspace(int cin_low, int cskip, int cout, int dtype) { return biu_mfma_foldt_wgrad_workspace(cin_low, cskip, cout, dtype); }
 extern "C" int biu_foldt_bwd_weight_bn(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const biu_act* da,
                                        const biu_act* y, const float* scale, const float* shift, const float* slope, const float* coefA,
-                                       const float* coefB, const float* coefC, const float* w_conv, const float* w_t, const float* b_t, int cup,
-                                       float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes, int dtype, biu_stream stream) {
+                                       const float* coefB, const float* coefC, const float* dy_sum, const float* w_conv, const float* w_t, const float* b_t,
+                                       int cup, float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes, int dtype, biu_stream stream) {
     BIU_REQUIRE(x_low && skip && da && w_conv && w_t && dw_conv && dw_t && ws && cup > 0, BIU_ERR_SHAPE, "foldt_bwd_weight_bn: null pointer");
     BIU_REQUIRE(biu_mfma_foldt_ok(x_low, skip, da, dtype) && biu_mfma_wgrad_ok(skip, da, 3, 3, 3, 1, dtype), BIU_ERR_UNSUPPORTED,
                 "foldt_bwd_weight_bn: shapes are not served by the folded kernels");
+    // S_k (the sum of dy over the voxels whose tap k stays inside) = sum_v dy - (border sums): without dy_sum the total is taken as zero, which
+    // holds only for the dy of a train-mode BatchNorm -- a plain dy (y = NULL) has no such guarantee
+    BIU_REQUIRE(y || dy_sum || !(b_t || db_t), BIU_ERR_UNSUPPORTED,
+                "foldt_bwd_weight_bn: a plain dy (y = NULL) needs dy_sum, its per-channel sum over all voxels (it is zero only behind a train-mode BatchNorm)");
     if (y) {
         BIU_REQUIRE(valid_act(y) && same_space(y, da) && y->c == da->c && scale && shift && coefA && coefB && coefC, BIU_ERR_SHAPE,
                     "foldt_bwd_weight_bn: y / coefficient vectors do not match da");
+        const size_t es = dsize(dtype);
+        const bool yok = ((uintptr_t)y->p % 16) == 0 && ((size_t)y->pitch * es) % 16 == 0 &&
+                         (i64)y->d * y->h * y->w * y->pitch * (i64)es < (1LL << 32) - 65536;
+        if (!yok) {                                      // the BatchNorm-fused loader reads y in 16-byte pieces through a 32-bit descriptor: apply first
+            int rc = biu_bn_bwd_apply(da, y, scale, shift, slope, coefA, coefB, coefC, da, dtype, stream);
+            if (rc != BIU_OK) return rc;
+            return biu_mfma_foldt_wgrad(x_low, xf_low, skip, xf_skip, da, nullptr, dy_sum, w_conv, w_t, b_t, cup, dw_conv, dw_t, db_t, ws, ws_bytes, dtype,
+                                        (hipStream_t)stream);
+        }
         BnBwdFuse bn{y, scale, shift, slope, coefA, coefB, coefC};
-        return biu_mfma_foldt_wgrad(x_low, xf_low, skip, xf_skip, da, &bn, w_conv, w_t, b_t, cup, dw_conv, dw_t, db_t, ws, ws_bytes, dtype, (hipStream_t)stream);
+        return biu_mfma_foldt_wgrad(x_low, xf_low, skip, xf_skip, da, &bn, dy_sum, w_conv, w_t, b_t, cup, dw_conv, dw_t, db_t, ws, ws_bytes, dtype, (hipStream_t)stream);
     }
-    return biu_mfma_foldt_wgrad(x_low, xf_low, skip, xf_skip, da, nullptr, w_conv, w_t, b_t, cup, dw_conv, dw_t, db_t, ws, ws_bytes, dtype, (hipStream_t)stream);
+    return biu_mfma_foldt_wgrad(x_low, xf_low, skip, xf_skip, da, nullptr, dy_sum, w_conv, w_t, b_t, cup, dw_conv, dw_t, db_t, ws, ws_bytes, dtype, (hipStream_t)stream);
 }
 
 extern "C" int biu_convt_fwd(const biu_act* x, const biu_xform* xf, const float* w, const void* packed, const float* bias,

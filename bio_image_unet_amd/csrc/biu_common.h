@@ -13,7 +13,7 @@ typedef long long i64;
 // ---------------------------------------------------------------------------------------------------
 // host-side error plumbing
 // ---------------------------------------------------------------------------------------------------
-extern thread_local char biu_errbuf[512];
+extern __attribute__((visibility("hidden"))) thread_local char biu_errbuf[512];
 int biu_fail(int code, const char* fmt, ...);
 
 #define BIU_REQUIRE(cond, code, ...)                       \

@@ -4240,12 +4240,13 @@ __global__ __launch_bounds__(256) void k_foldt_reduce_tables(const float* __rest
         __syncthreads();
     }
 }
-// S_k[co] = sum of dy over the voxels whose tap k stays inside = -(sum of R over the border states where it does not), summed over the shares of
+// S_k[co] = sum of dy over the voxels whose tap k stays inside = total - (sum of R over the border states where it does not), summed over the shares of
 // k_foldt_reduce_tables.  grid (27 taps, Cout / 32), threads over (share, channel): 27 unconditional loads each, LDS tree over the shares
-__global__ __launch_bounds__(256) void k_foldt_inside_sums(const float* __restrict__ R, int nsplit, int cout, float* __restrict__ Sk) {
+// (total = per-channel sum of dy over ALL voxels, or NULL when it is identically zero: dy behind a train-mode BatchNorm)
+__global__ __launch_bounds__(256) void k_foldt_inside_sums(const float* __restrict__ R, int nsplit, int cout, float* __restrict__ Sk, const float* __restrict__ total) {
     __shared__ float red[256];
     const int k = (int)blockIdx.x, co = (int)blockIdx.y * 32 + (int)(threadIdx.x & 31), part = (int)(threadIdx.x >> 5);
-    float sum = 0.f;
+    float sum = (total && part == 0 && co < cout) ? total[co] : 0.f;
     if (co < cout)
         for (int sp = part; sp < nsplit; sp += 8) {
 #pragma unroll 9
@@ -4341,7 +4342,7 @@ size_t biu_mfma_foldt_wgrad_workspace(int cin_low, int cskip, int cout, int dtyp
 }
 // da -> dy in place (BatchNorm + LeakyReLU backward in the loader of the skip half's weight gradient, which runs first); then G on the finished dy
 int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const biu_act* da, const BnBwdFuse* bn,
-                         const float* w_conv, const float* w_t, const float* b_t, int cup, float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes,
+                         const float* dy_sum, const float* w_conv, const float* w_t, const float* b_t, int cup, float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes,
                          int dtype, hipStream_t st) {
     const int cin_low = x_low->c, cskip = skip->c, cout = da->c, ccat = cup + cskip;
     const size_t need = biu_mfma_foldt_wgrad_workspace(cin_low, cskip, cout, dtype);
@@ -4364,7 +4365,7 @@ int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const bi
                                                      (const char*)da->p, sh, da->c, da->pitch, R));
         float* Rsum = Sk + 27 * cout;                                   // (rest of the Sk region: FOLDT_RED_SPLIT tables)
         hipLaunchKernelGGL(k_foldt_reduce_tables, dim3(27, FOLDT_RED_SPLIT), dim3(256), 0, st, (const float*)R, FOLDT_SUM_BLOCKS, cout, Rsum);
-        hipLaunchKernelGGL(k_foldt_inside_sums, dim3(27, (cout + 31) / 32), dim3(256), 0, st, (const float*)Rsum, FOLDT_RED_SPLIT, cout, Sk);
+        hipLaunchKernelGGL(k_foldt_inside_sums, dim3(27, (cout + 31) / 32), dim3(256), 0, st, (const float*)Rsum, FOLDT_RED_SPLIT, cout, Sk, dy_sum);
         BIU_CHECK_LAUNCH("foldt_border_sums");
     }
     // 4. chain rule to the up half of dW_conv, to dW_T and to db_T

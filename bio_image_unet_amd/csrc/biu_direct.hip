@@ -330,6 +330,32 @@ __global__ void k_bn_bwd_finalize(const float* __restrict__ partial, int nblk, i
     }
 }
 
+// eval-mode BatchNorm: the statistics are constants, dy = scale * dz
+__global__ void k_bn_bwd_finalize_eval(const float* __restrict__ partial, int nblk, int C, const float* scale, float* dgamma, float* dbeta,
+                                       float* dbias, float* A, float* B, float* Cc) {
+    __shared__ double d0[TPB], d1[TPB];
+    int c = blockIdx.x;
+    double a0 = 0, a1 = 0;
+    for (int b = threadIdx.x; b < nblk; b += TPB) {
+        a0 += partial[((i64)b * C + c) * 2 + 0];
+        a1 += partial[((i64)b * C + c) * 2 + 1];
+    }
+    d0[threadIdx.x] = a0; d1[threadIdx.x] = a1;
+    __syncthreads();
+    for (int s = TPB / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { d0[threadIdx.x] += d0[threadIdx.x + s]; d1[threadIdx.x] += d1[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (dbeta) dbeta[c] = (float)d0[0];
+        if (dgamma) dgamma[c] = (float)d1[0];
+        if (dbias) dbias[c] = (float)((double)scale[c] * d0[0]);
+        A[c] = scale[c];
+        B[c] = 0.f;
+        Cc[c] = 0.f;
+    }
+}
+
 template <typename T, int G>
 __global__ void k_bn_bwd_apply(DAct da, DAct y, DXf xf, const float* __restrict__ A, const float* __restrict__ B,
                                const float* __restrict__ Cc, DAct dy) {
@@ -858,7 +884,7 @@ __global__ void k_adam(int n, float* const* params, const float* const* grads, f
 
 template <typename T> constexpr int vecg() { return 16 / sizeof(T); }
 
-extern "C" int biu_conv_fwd_direct(const biu_act* x, const biu_xform* xf, const float* w, const float* bias,
+extern "C" BIU_HIDDEN int biu_conv_fwd_direct(const biu_act* x, const biu_xform* xf, const float* w, const float* bias,
                                    int kd, int kh, int kw, int dil, const biu_act* y, int dtype, hipStream_t st) {
     i64 total = nvox(y) * y->c;
     BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_conv_fwd_direct<T>, dim3(grid_for(total, TPB)), dim3(TPB), 0, st,
@@ -866,7 +892,7 @@ extern "C" int biu_conv_fwd_direct(const biu_act* x, const biu_xform* xf, const 
     BIU_CHECK_LAUNCH("conv_fwd_direct");
     return BIU_OK;
 }
-extern "C" int biu_conv_bwd_data_direct(const biu_act* dy, const float* w, int kd, int kh, int kw, int dil,
+extern "C" BIU_HIDDEN int biu_conv_bwd_data_direct(const biu_act* dy, const float* w, int kd, int kh, int kw, int dil,
                                         const biu_act* dx, int accumulate, int dtype, hipStream_t st) {
     i64 total = nvox(dx) * dx->c;
     BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_conv_dgrad_direct<T>, dim3(grid_for(total, TPB)), dim3(TPB), 0, st,
@@ -874,7 +900,7 @@ extern "C" int biu_conv_bwd_data_direct(const biu_act* dy, const float* w, int k
     BIU_CHECK_LAUNCH("conv_dgrad_direct");
     return BIU_OK;
 }
-extern "C" int biu_conv_bwd_weight_direct(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, int kh,
+extern "C" BIU_HIDDEN int biu_conv_bwd_weight_direct(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, int kh,
                                           int kw, int dil, float* dw, float* dbias, int dtype, hipStream_t st) {
     int outs = dy->c * x->c * kd * kh * kw;
     BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_conv_wgrad_direct<T>, dim3(outs), dim3(TPB), 0, st, dact(x), dxf(xf),
@@ -977,6 +1003,15 @@ extern "C" int biu_bn_bwd_finalize(const float* partial, int nblk, int c, double
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(c), dim3(TPB), 0, (hipStream_t)stream, partial, nblk, c, count, scale,
                        save_mean, save_invstd, dgamma, dbeta, coefA, coefB, coefC);
     BIU_CHECK_LAUNCH("bn_bwd_finalize");
+    return BIU_OK;
+}
+
+extern "C" int biu_bn_bwd_finalize_eval(const float* partial, int nblk, int c, const float* scale, float* dgamma, float* dbeta, float* dbias,
+                                        float* coefA, float* coefB, float* coefC, biu_stream stream) {
+    BIU_REQUIRE(partial && nblk > 0 && c > 0 && scale && coefA && coefB && coefC, BIU_ERR_SHAPE, "bn_bwd_finalize_eval: bad arguments");
+    hipLaunchKernelGGL(k_bn_bwd_finalize_eval, dim3(c), dim3(TPB), 0, (hipStream_t)stream, partial, nblk, c, scale, dgamma, dbeta, dbias, coefA, coefB,
+                       coefC);
+    BIU_CHECK_LAUNCH("bn_bwd_finalize_eval");
     return BIU_OK;
 }
 
@@ -1105,7 +1140,7 @@ extern "C" int biu_nearest_up_bwd(const biu_act* dout, const biu_act* dx, int ac
 static bool convt_shapes(const biu_act* lo, const biu_act* hi, int kd) {
     return lo->n == hi->n && hi->h == 2 * lo->h && hi->w == 2 * lo->w && hi->d == kd * lo->d && (kd == 1 || kd == 2);
 }
-extern "C" int biu_convt_fwd_direct(const biu_act* x, const biu_xform* xf, const float* w, const float* bias, int kd,
+extern "C" BIU_HIDDEN int biu_convt_fwd_direct(const biu_act* x, const biu_xform* xf, const float* w, const float* bias, int kd,
                                     const biu_act* y, int dtype, hipStream_t st) {
     i64 total = nvox(y) * y->c;
     BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_convt_fwd_direct<T>, dim3(grid_for(total, TPB)), dim3(TPB), 0, st,
@@ -1113,7 +1148,7 @@ extern "C" int biu_convt_fwd_direct(const biu_act* x, const biu_xform* xf, const
     BIU_CHECK_LAUNCH("convt_fwd_direct");
     return BIU_OK;
 }
-extern "C" int biu_convt_bwd_data_direct(const biu_act* dy, const float* w, int kd, const biu_act* dx, int accumulate,
+extern "C" BIU_HIDDEN int biu_convt_bwd_data_direct(const biu_act* dy, const float* w, int kd, const biu_act* dx, int accumulate,
                                          int dtype, hipStream_t st) {
     i64 total = nvox(dx) * dx->c;
     BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_convt_dgrad_direct<T>, dim3(grid_for(total, TPB)), dim3(TPB), 0, st,
@@ -1121,7 +1156,7 @@ extern "C" int biu_convt_bwd_data_direct(const biu_act* dy, const float* w, int 
     BIU_CHECK_LAUNCH("convt_dgrad_direct");
     return BIU_OK;
 }
-extern "C" int biu_convt_bwd_weight_direct(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, float* dw,
+extern "C" BIU_HIDDEN int biu_convt_bwd_weight_direct(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, float* dw,
                                            float* dbias, int dtype, hipStream_t st) {
     int outs = x->c * dy->c * kd * 4;
     BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_convt_wgrad_direct<T>, dim3(outs), dim3(TPB), 0, st, dact(x), dxf(xf),

@@ -2,18 +2,19 @@
 #pragma once
 #include "biu_common.h"
 
-// biu_direct.hip
-extern "C" int biu_conv_fwd_direct(const biu_act* x, const biu_xform* xf, const float* w, const float* bias, int kd,
+// biu_direct.hip (C linkage, hidden: these cross translation units of the library, they are not part of include/biu.h)
+#define BIU_HIDDEN __attribute__((visibility("hidden")))
+extern "C" BIU_HIDDEN int biu_conv_fwd_direct(const biu_act* x, const biu_xform* xf, const float* w, const float* bias, int kd,
                                    int kh, int kw, int dil, const biu_act* y, int dtype, hipStream_t st);
-extern "C" int biu_conv_bwd_data_direct(const biu_act* dy, const float* w, int kd, int kh, int kw, int dil,
+extern "C" BIU_HIDDEN int biu_conv_bwd_data_direct(const biu_act* dy, const float* w, int kd, int kh, int kw, int dil,
                                         const biu_act* dx, int accumulate, int dtype, hipStream_t st);
-extern "C" int biu_conv_bwd_weight_direct(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, int kh,
+extern "C" BIU_HIDDEN int biu_conv_bwd_weight_direct(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, int kh,
                                           int kw, int dil, float* dw, float* dbias, int dtype, hipStream_t st);
-extern "C" int biu_convt_fwd_direct(const biu_act* x, const biu_xform* xf, const float* w, const float* bias, int kd,
+extern "C" BIU_HIDDEN int biu_convt_fwd_direct(const biu_act* x, const biu_xform* xf, const float* w, const float* bias, int kd,
                                     const biu_act* y, int dtype, hipStream_t st);
-extern "C" int biu_convt_bwd_data_direct(const biu_act* dy, const float* w, int kd, const biu_act* dx, int accumulate,
+extern "C" BIU_HIDDEN int biu_convt_bwd_data_direct(const biu_act* dy, const float* w, int kd, const biu_act* dx, int accumulate,
                                          int dtype, hipStream_t st);
-extern "C" int biu_convt_bwd_weight_direct(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, float* dw,
+extern "C" BIU_HIDDEN int biu_convt_bwd_weight_direct(const biu_act* x, const biu_xform* xf, const biu_act* dy, int kd, float* dw,
                                            float* dbias, int dtype, hipStream_t st);
 int biu_chan_sum(const biu_act* a, float* out, int dtype, hipStream_t st);
 bool biu_convt_shapes_ok(const biu_act* lo, const biu_act* hi, int kd);
@@ -82,7 +83,7 @@ int biu_mfma_foldt_dgrad(const biu_act* dy, const void* packed, const biu_act* d
                          hipStream_t st, float* bn_partial_low, const BnRedFuse* red_low, void* ws, size_t ws_bytes);
 size_t biu_mfma_foldt_wgrad_workspace(int cin_low, int cskip, int cout, int dtype);
 int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const biu_act* da, const BnBwdFuse* bn,
-                         const float* w_conv, const float* w_t, const float* b_t, int cup, float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes,
+                         const float* dy_sum, const float* w_conv, const float* w_t, const float* b_t, int cup, float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes,
                          int dtype, hipStream_t st);
 bool biu_mfma_convt_ok(int kind, const biu_act* lo, const biu_act* hi, int kd, int dtype);
 int biu_mfma_convt_fwd(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, const biu_act* y,

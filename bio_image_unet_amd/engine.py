@@ -348,7 +348,17 @@ class ConvBlockNode(Node):
                                        self.dil, self.y.a(), _ptr(eng.ws), eng.ws_bytes, eng.dtype, st), "conv_fwd")
             check(lib.biu_bn_eval_affine(self.y.c, _ptr(bn.weight.data), _ptr(bn.bias.data), _ptr(bn.running_mean),
                                          _ptr(bn.running_var), bn.eps, _ptr(scale), _ptr(shift), st), "bn_eval_affine")
+            self._eval_saved(eng)
             self.batch_stats = False
+
+    def _eval_saved(self, eng):
+        """Eval-mode forward under autograd (``model.eval(); loss.backward()``: frozen-BatchNorm fine-tuning, which the reference's plain
+        nn.BatchNorm allows, unet/unet.py:54-60): the running statistics play the part of the saved batch statistics in the backward's
+        (sum dz, sum dz * yhat).  Two C-sized vector ops, only when a backward can follow."""
+        if eng.grad_mode:
+            bn = self.bn
+            self.save_mean.copy_(bn.running_mean)
+            torch.rsqrt(bn.running_var.float() + bn.eps, out=self.save_invstd)
 
     def _foldt_packed(self, st):
         ct = self.foldt
@@ -383,13 +393,14 @@ class ConvBlockNode(Node):
             check(lib.biu_foldt_fwd(ct.xin.a(), ct.xin.xf(), skip.a(), skip.xf(), blob, self.y.a(), None, 0, None, eng.dtype, st), "foldt_fwd")
             check(lib.biu_bn_eval_affine(self.y.c, _ptr(bn.weight.data), _ptr(bn.bias.data), _ptr(bn.running_mean),
                                          _ptr(bn.running_var), bn.eps, _ptr(scale), _ptr(shift), st), "bn_eval_affine")
+            self._eval_saved(eng)
             self.batch_stats = False
 
-    def _bwd_foldt(self, eng, st, scale, shift, slope, A, B, Cc, dw):
+    def _bwd_foldt(self, eng, st, scale, shift, slope, A, B, Cc, dw, dy_sum=None):
         ct, skip, y = self.foldt, self.xin.parts[1], self.y
         lo = ct.xin
         dwt, dbt = eng.new_grad(ct.up.weight), eng.new_grad(ct.up.bias)
-        check(lib.biu_foldt_bwd_weight_bn(lo.a(), lo.xf(), skip.a(), skip.xf(), y.g(), y.a(), scale, shift, slope, _ptr(A), _ptr(B), _ptr(Cc),
+        check(lib.biu_foldt_bwd_weight_bn(lo.a(), lo.xf(), skip.a(), skip.xf(), y.g(), y.a(), scale, shift, slope, _ptr(A), _ptr(B), _ptr(Cc), _ptr(dy_sum),
                                           _ptr(self.conv.weight.data), _ptr(ct.up.weight.data), _ptr(ct.up.bias.data), ct.y.c, _ptr(dw), _ptr(dwt),
                                           _ptr(dbt), _ptr(eng.ws), eng.ws_bytes, eng.dtype, st), "foldt_bwd_weight_bn")
         eng.add_grad(ct.up.weight, dwt)
@@ -416,8 +427,6 @@ class ConvBlockNode(Node):
     def bwd(self, eng):
         if not self.y.g_written():
             return            # no gradient reaches this block (e.g. Siam 'control' branch)
-        if not self.batch_stats:
-            raise NotImplementedError("backward through eval-mode BatchNorm is not on the reference hot path")
         st = _stream()
         y, cout = self.y, self.y.c
         scale, shift, slope = _ptr(y.vec("scale")), _ptr(y.vec("shift")), _ptr(y.vec("slope"))
@@ -431,18 +440,27 @@ class ConvBlockNode(Node):
                                         _ptr(partial), C.byref(nblk), eng.dtype, st), "bn_bwd_reduce")
         dgamma, dbeta = eng.new_grad(self.bn.weight), eng.new_grad(self.bn.bias)
         A, B, Cc = eng.coef[0][:cout], eng.coef[1][:cout], eng.coef[2][:cout]
-        check(lib.biu_bn_bwd_finalize(_ptr(partial), nblk.value, cout, float(y.nvox), scale, _ptr(self.save_mean),
-                                      _ptr(self.save_invstd), _ptr(dgamma), _ptr(dbeta), _ptr(A), _ptr(B), _ptr(Cc), st),
-              "bn_bwd_finalize")
         dw = eng.new_grad(self.conv.weight)
-        # d loss / d conv-bias: the bias is removed again by the batch mean, so sum_v dy == 0 identically
-        # (A*S1 + B*M*mean + C*M cancels term by term); the reference's value is pure rounding noise (~1e-8).
-        # Emit the exact zero instead of spending a pass over dy on it.
-        db = eng.zero_like_bias(self.conv.bias) if self.conv.bias is not None else None
+        dy_sum = None
+        if self.batch_stats:
+            check(lib.biu_bn_bwd_finalize(_ptr(partial), nblk.value, cout, float(y.nvox), scale, _ptr(self.save_mean),
+                                          _ptr(self.save_invstd), _ptr(dgamma), _ptr(dbeta), _ptr(A), _ptr(B), _ptr(Cc), st),
+                  "bn_bwd_finalize")
+            # d loss / d conv-bias: the bias is removed again by the batch mean, so sum_v dy == 0 identically
+            # (A*S1 + B*M*mean + C*M cancels term by term); the reference's value is pure rounding noise (~1e-8).
+            # Emit the exact zero instead of spending a pass over dy on it.
+            db = eng.zero_like_bias(self.conv.bias) if self.conv.bias is not None else None
+        else:
+            # eval-mode BatchNorm: constants instead of statistics -- dy = scale * dz, and the conv bias gradient sum_v dy = scale * sum dz
+            # is a real number again (it is also what the folded decoder's ConvT-bias chain rule needs: biu_foldt_bwd_weight_bn, dy_sum)
+            dy_sum = eng.new_grad(self.bn.bias)
+            check(lib.biu_bn_bwd_finalize_eval(_ptr(partial), nblk.value, cout, scale, _ptr(dgamma), _ptr(dbeta), _ptr(dy_sum), _ptr(A), _ptr(B),
+                                               _ptr(Cc), st), "bn_bwd_finalize_eval")
+            db = dy_sum if self.conv.bias is not None else None
         # BatchNorm+LeakyReLU backward (da -> dy, in place) rides inside the weight-gradient kernel's tile loader
         cat = self.xin.parts if isinstance(self.xin, CatAct) else None
         if self.foldt is not None:
-            self._bwd_foldt(eng, st, scale, shift, slope, A, B, Cc, dw)
+            self._bwd_foldt(eng, st, scale, shift, slope, A, B, Cc, dw, dy_sum)
             eng.add_grad(self.conv.weight, dw)
             if db is not None:
                 eng.add_grad(self.conv.bias, db)
@@ -888,6 +906,14 @@ class Engine:
         ``Tensor._version``)."""
         for s in self._slots:
             s["ver"] = None
+        # the folded decoder levels keep their composed weights outside the slot list (biu_upconv_pack / biu_foldt_pack images)
+        for nd_ in self.nodes:
+            for name in ("fold_slot", "fold_dg_slot"):
+                s = getattr(nd_, name, None)
+                if s is not None:
+                    s["ver"] = None
+            if getattr(nd_, "foldt_ver", None) is not None:
+                nd_.foldt_ver = None
 
     # ---- build helpers -------------------------------------------------------------------------------
     def new_buf(self, n, d, h, w, c) -> Buf:

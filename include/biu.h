@@ -193,6 +193,13 @@ int biu_bn_bwd_finalize(const float* partial, int nblk, int c, double count,
                         const float* scale, const float* save_mean, const float* save_invstd,
                         float* dgamma, float* dbeta, float* coefA, float* coefB, float* coefC,
                         biu_stream stream);
+/* The same for a BatchNorm in EVAL mode (running statistics are constants: model.eval(); loss.backward(), the frozen-BatchNorm
+ * fine-tuning the reference's plain nn.BatchNorm allows, unet/unet.py:54-60).  `partial` from biu_bn_bwd_reduce called with
+ * save_mean = running_mean and save_invstd = 1 / sqrt(running_var + eps):  dgamma = sum dz*yhat, dbeta = sum dz, dy = scale * dz, i.e.
+ * (A, B, C) = (scale, 0, 0), and the conv bias gradient dbias = sum_v dy = scale * sum dz is no longer zero (dbias may be NULL).          */
+int biu_bn_bwd_finalize_eval(const float* partial, int nblk, int c, const float* scale,
+                             float* dgamma, float* dbeta, float* dbias, float* coefA, float* coefB, float* coefC,
+                             biu_stream stream);
 int biu_bn_bwd_apply(const biu_act* da, const biu_act* y, const float* scale, const float* shift,
                      const float* slope, const float* coefA, const float* coefB, const float* coefC,
                      const biu_act* dy, int dtype, biu_stream stream);
@@ -357,7 +364,9 @@ int    biu_foldt_fwd(const biu_act* x_low, const biu_xform* xf_low, const biu_ac
  *   dw_conv (Cout, cup + cskip, 27) in full, dw_t (Cin_low, cup, 8) and db_t (cup; may be NULL) by the chain rule from
  *   G[p][t] = sum_v dy[2v + p] (x) T(x_low)[v + t - 1 + p]:  dw_conv[.., c < cup, k] = sum_p W_T[., c, q(p,k)] . G[p][t_p(k)] + b_T[c] S_k,
  *   dw_t[ci, c, q] = sum_{(p,k): q(p,k) = q} W_conv[., c, k] . G[p][t_p(k)][., ci],  db_t[c] = sum_k W_conv[., c, k] . S_k with S_k the sum of dy over
- *   the voxels whose tap k stays inside the tensor (border sums; sum_v dy = 0 behind a train-mode BatchNorm). */
+ *   the voxels whose tap k stays inside the tensor = dy_sum - (border sums).  dy_sum (Cout floats) = sum_v dy per channel; NULL = identically
+ *   zero, which holds behind a train-mode BatchNorm only: a plain dy (y = NULL) or an eval-mode BatchNorm (coefB = coefC = 0, see
+ *   biu_bn_bwd_finalize_eval) must pass it (BIU_ERR_UNSUPPORTED otherwise when the ConvT has a bias). */
 size_t biu_foldt_bwd_data_bnred_floats(const biu_act* dx_low);
 int    biu_foldt_bwd_data(const biu_act* dy, const void* packed, const biu_act* dx_low, int acc_low, const biu_act* dskip, int acc_skip,
                           const biu_act* y_low, const float* scale, const float* shift, const float* slope, const float* mean,
@@ -366,8 +375,8 @@ int    biu_foldt_bwd_data(const biu_act* dy, const void* packed, const biu_act* 
 size_t biu_foldt_bwd_weight_workspace(int cin_low, int cskip, int cout, int dtype);
 int    biu_foldt_bwd_weight_bn(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const biu_act* da,
                                const biu_act* y, const float* scale, const float* shift, const float* slope, const float* coefA,
-                               const float* coefB, const float* coefC, const float* w_conv, const float* w_t, const float* b_t, int cup,
-                               float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes, int dtype, biu_stream stream);
+                               const float* coefB, const float* coefC, const float* dy_sum, const float* w_conv, const float* w_t, const float* b_t,
+                               int cup, float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes, int dtype, biu_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 1x1(x1) head + activation                                                             [K9]

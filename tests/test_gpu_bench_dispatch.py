@@ -1,0 +1,68 @@
+"""The parity suite must run the dispatch the benchmark runs.  tests/conftest.py sets BIU_FOLDT=always so that the small test networks
+fold every decoder level; bench.py and a default process take the library's size rule instead, which at cfg4 (UNet3D(1,1,32), 4 x 128^3)
+folds decode5 and decode3 and leaves the 32^3 level (decode1) on the 3-D ConvTranspose MFMA kernels (`up1`) + the two-source conv kernels
+(`biu_conv_*_cat` behind a ConvT).  Here that exact composition goes through the teacher-forced in-situ checker, the mid-size oracle
+comparisons and the full-size property tests:
+
+* at test extents the size rule would fold nothing, so BIU_FOLDT=cmax:128 (include/biu.h, biu_foldt_ok) reproduces cfg4's pattern
+  by channel count -- coarse inputs of <= 128 channels (decode5: 64, decode3: 128) fold, decode1 (256) does not;
+* at full size (tests/test_gpu_fullsize.py: 4 x 128^3) the variable is removed: the size rule itself decides, as in bench.py.
+
+The library reads BIU_FOLDT once per process, so each leg is one child pytest process (one at a time)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _child(env_foldt, args, timeout):
+    env = dict(os.environ)
+    env.pop("BIU_DISABLE", None)
+    if env_foldt is None:
+        env["BIU_FOLDT"] = "size"          # (anything without 'always' / 'cmax:': the size rule; conftest's setdefault leaves it alone)
+    else:
+        env["BIU_FOLDT"] = env_foldt
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider"] + args, env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=timeout)
+    tail = (r.stdout or "")[-4000:] + (r.stderr or "")[-2000:]
+    assert r.returncode == 0, tail
+    return r.stdout
+
+
+@pytest.mark.timeout(900)
+def test_fold_pattern_probe_matches_cfg4():
+    """cmax:128 at the test extent picks exactly the levels the size rule picks at 4 x 128^3 (decode5, decode3 folded; decode1 not)."""
+    code = r"""
+import torch, bio_image_unet_amd as B
+from bio_image_unet_amd import engine as E
+import sys
+shape = tuple(int(v) for v in sys.argv[1].split(','))
+m = B.UNet3D(1, 1, 32).cuda(); m.set_compute_dtype(torch.bfloat16); m.train()
+eng = m._engine_for(torch.empty(shape, device='cuda'))
+print('FOLDED', ','.join(n.label for n in eng.nodes if isinstance(n, E.ConvBlockNode) and n.foldt is not None))
+"""
+    def folded(env_foldt, shape):
+        env = dict(os.environ, BIU_FOLDT=env_foldt)
+        r = subprocess.run([sys.executable, "-c", code, shape], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return [ln for ln in r.stdout.splitlines() if ln.startswith("FOLDED")][-1]
+
+    small = folded("cmax:128", "2,1,16,32,32")
+    full = folded("size", "4,1,128,128,128")
+    assert small == full == "FOLDED decode3,decode5", (small, full)
+
+
+@pytest.mark.timeout(1500)
+def test_insitu_and_midsize_parity_under_the_benchmarked_fold_pattern():
+    out = _child("cmax:128", ["tests/test_gpu_insitu.py", "tests/test_gpu_models.py", "-m", "gpu", "-k", "cfg4_unet3d_f32"], 1400)
+    assert " passed" in out and "failed" not in out, out[-2000:]
+
+
+@pytest.mark.timeout(1500)
+def test_fullsize_properties_under_the_size_rule():
+    out = _child(None, ["tests/test_gpu_fullsize.py", "-m", "gpu"], 1400)
+    assert " passed" in out and "failed" not in out, out[-2000:]

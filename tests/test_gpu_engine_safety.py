@@ -98,6 +98,49 @@ def test_data_write_needs_invalidate_and_inplace_op_does_not():
         assert float((got.cpu() - want).abs().max()) < 1e-3 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("kind", ["foldt", "upconv"])
+def test_data_write_and_invalidate_reach_the_folded_decoder_levels(kind):
+    """The composed weights of the folded decoder levels (biu_foldt_pack / biu_upconv_pack images) are cached outside the engine's
+    slot list: ``invalidate_packed()`` after a raw ``.data`` write must drop them too (ddp.GradAverager calls it after its broadcast).
+    Compared with a FRESH model holding the written parameters -- forward, and the gradients of the folded level's parameters."""
+    torch.manual_seed(4)
+    heads = {"seg": {"channels": 1, "activation": None}}
+    if kind == "foldt":
+        mk = lambda: B.UNet3D(1, 1, 32).cuda()
+        sd = O.init_unet3d(1, 1, 32, seed=21)
+    else:
+        mk = lambda: B.MultiOutputUnet3D(1, heads, 32, True).cuda()
+        sd = O.init_mo3d(1, heads, 32, True, seed=22)
+    x = torch.rand(2, 1, 16, 32, 32).cuda()
+
+    def logits_of(o):
+        return o["seg"] if isinstance(o, dict) else o[1]
+
+    m = mk()
+    m.load_state_dict(sd)
+    m.train()
+    logits_of(m(x)).square().mean().backward()          # packs every image, folded ones included, forward and backward
+    m.zero_grad()
+    g = torch.Generator().manual_seed(9)
+    new = {k: (v + 0.05 * torch.randn(v.shape, generator=g) if v.is_floating_point() and v.dim() > 1 else v) for k, v in sd.items()}
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            p.data.copy_(new[k].to(p.device))            # raw .data write: no version bump
+    m.invalidate_packed()
+    out = logits_of(m(x))
+    out.square().mean().backward()
+    fresh = mk()
+    fresh.load_state_dict(new)
+    fresh.train()
+    ref = logits_of(fresh(x))
+    ref.square().mean().backward()
+    assert float((out - ref).abs().max()) <= 1e-5 * float(ref.abs().max()), "folded levels kept stale composed weights"
+    gm, gf = dict(m.named_parameters()), dict(fresh.named_parameters())
+    for k in gm:
+        if k.startswith(("decode5.0", "decode3.0", "up3", "up2", "up3_conv", "up2_conv")) and gm[k].grad is not None:
+            torch.testing.assert_close(gm[k].grad, gf[k].grad, rtol=1e-3, atol=1e-5 * float(gf[k].grad.abs().max()) + 1e-10, msg=lambda s: f"{k}: {s}")
+
+
 def test_adam_state_dict_round_trip_and_torch_checkpoint():
     torch.manual_seed(3)
     x = torch.rand(2, 1, 32, 32).cuda()

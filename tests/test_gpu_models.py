@@ -37,6 +37,12 @@ GOLDEN_GPU = ["unet2d_f4", "unet2d_f4_o2_dil2", "unet3d_f4", "unet3d_f4_interp",
               "mo3d_f4_trainer_convT", "mo3d_f4_trainer_interp"]
 
 
+# Per-tensor exceptions to the 1e-3 gradient bound of the golden fixtures, as multiples of it: (case, parameter) -> factor.  An entry is
+# allowed only where a measured LeakyReLU / max-pool decision flip against the reference's own CPU run moves that tensor;
+# the measured worst ratio of every case is written to gpurun_out/golden_grad_ratios.txt by the test itself.
+GOLDEN_GRAD_EXC = {}
+
+
 @pytest.mark.parametrize("case", GOLDEN_GPU)
 def test_golden_train_step_fp32(case):
     """Same inputs and weights as the reference run that produced the fixture: outputs, loss, every parameter
@@ -63,13 +69,17 @@ def test_golden_train_step_fp32(case):
     assert abs(float(loss) - float(g["loss"])) < REL * max(1.0, abs(float(g["loss"])))
     loss.backward()
     gscale = max(float(v.abs().max()) for v in g["grad"].values())
+    worst = (0.0, "")
     for k, p in m.named_parameters():
         want = g["grad"][k]
         got = p.grad.cpu() if p.grad is not None else torch.zeros_like(want)
         # per-tensor 1e-3 of its own scale, with a floor at 1e-5 of the largest gradient in the net
         # (conv biases in front of a train-mode BN have true gradient 0: the reference value is rounding noise)
-        tol = 2 * REL * float(want.abs().max()) + 1e-5 * gscale
-        assert float((got - want).abs().max()) <= tol, f"grad.{k}: {float((got - want).abs().max())} > {tol}"
+        tol = REL * float(want.abs().max()) + 1e-5 * gscale
+        ratio = float((got - want).abs().max()) / tol
+        worst = max(worst, (ratio, k))
+        assert ratio <= GOLDEN_GRAD_EXC.get((case, k), 1.0), f"grad.{k}: {float((got - want).abs().max())} = {ratio:.2f} x {tol}"
+    _record("golden_grad_ratios.txt", f"{case}: worst gradient error {worst[0]:.3f} x (1e-3 of the tensor's scale + 1e-5 of the net's) at {worst[1]}")
     sd_now = m.state_dict()
     for k, v in g["sd1"].items():
         torch.testing.assert_close(sd_now[k].cpu(), v, rtol=REL, atol=1e-5, msg=lambda s: f"sd1.{k}: {s}")
@@ -170,10 +180,10 @@ def _problem(kind, seed):
     return mk, init(3 + seed), fkind, xs, tg
 
 
-def _oracle_run(fkind, sd, xs, tg, dt, emu=False):
+def _oracle_run(fkind, sd, xs, tg, dt, emu=False, training=True):
     osd = O.clone_state({k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in sd.items()}, requires_grad=True)
     with O.emulate_bf16(emu):
-        outs = _oracle_forward(fkind, osd, [x.to(dt) for x in xs], True)
+        outs = _oracle_forward(fkind, osd, [x.to(dt) for x in xs], training)
         loss = _loss(outs, {k: v.to(dt) for k, v in tg.items()})
         grads = O.grads_of(loss, osd)
     return {k: v.detach() for k, v in outs.items()}, loss.detach(), grads, osd
@@ -271,7 +281,52 @@ def test_midsize_fp32_vs_oracle(kind):
         oe = oe if isinstance(oe, dict) else dict(zip(("prob", "logits"), oe))
         re_ = _oracle_forward(fkind, {k: v.detach() for k, v in osd.items()}, xs, False)
     for k, want in re_.items():
-        assert relerr(oe[k].cpu(), want) < 2e-3, f"eval {k}"
+        assert relerr(oe[k].cpu(), want) < REL, f"eval {k}: {relerr(oe[k].cpu(), want)}"
+
+
+@pytest.mark.parametrize("kind", ["unet2d_f16", "cfg3_siam_max_f32", "cfg4_unet3d_f32", "cfg5_mo3d_f32_interp"])
+def test_eval_mode_backward_fp32_vs_oracle(kind):
+    """``model.eval(); loss.backward()`` -- frozen-BatchNorm fine-tuning, which the reference's plain nn.BatchNorm2d/3d blocks allow
+    (unet/unet.py:54-60, unet3d/unet3d.py:52-58): running statistics are constants, dy = scale * dz, gamma / beta and -- unlike in train
+    mode -- the conv biases receive real gradients.  Every parameter gradient against the fp64 oracle in eval mode on the engine's own
+    LeakyReLU / max-pool branch (as test_midsize_fp32_vs_oracle); covers the folded decoder levels (cfg4: biu_foldt_bwd_weight_bn with
+    dy_sum; cfg5: the folded up-convs) and the weight-shared Siam encoder."""
+    from tests import insitu
+    mk, sd, fkind, xs, tg = _problem(kind, 1)
+    g = torch.Generator().manual_seed(77)
+    sd = dict(sd)
+    for k in sd:                                          # non-trivial running statistics
+        if k.endswith("running_mean"):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+        if k.endswith("running_var"):
+            sd[k] = torch.rand(sd[k].shape, generator=g) + 0.5
+    m = mk().cuda()
+    m.load_state_dict(sd)
+    m.eval()
+    outs = m(*[x.cuda() for x in xs])
+    od = outs if isinstance(outs, dict) else dict(zip(("prob", "logits"), outs))
+    loss = _loss(od, {k: v.cuda() for k, v in tg.items()})
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {k: p.grad.cpu() for k, p in m.named_parameters()}
+    q = insitu.extract_decisions(list(m._engines.values())[-1][-1])
+    with O.forced_decisions(q):
+        t_outs, t_loss, t_grads, _ = _oracle_run(fkind, sd, xs, tg, torch.float64, training=False)
+    for k, want in t_outs.items():
+        assert relerr(od[k].detach().cpu(), want.float()) < REL, f"{k} rel err {relerr(od[k].detach().cpu(), want.float())}"
+    assert abs(float(loss) - float(t_loss)) < REL * max(1.0, abs(float(t_loss)))
+    errs = _grad_errors(grads, t_grads)
+    rows = sorted(((v[0], k) for k, v in errs.items()), reverse=True)
+    _record("parity_fp32_eval_backward.txt", f"{kind}: worst " + "; ".join(f"{k} {e:.2e}" for e, k in rows[:6]))
+    for e, k in rows:
+        assert e <= REL, f"grad {k}: err {e} > 1e-3"
+    # the conv biases are live in eval mode: their gradients must not be the train-mode zeros
+    live = [k for k in t_grads if _dead(k) and float(t_grads[k].abs().max()) > 0]
+    assert live and all(float(grads[k].abs().max()) > 0 for k in live)
+    # buffers untouched by an eval-mode step
+    for k, v in sd.items():
+        if "running_" in k:
+            torch.testing.assert_close(m.state_dict()[k].cpu(), v)
 
 
 @pytest.mark.parametrize("kind", list(KINDS))

@@ -23,6 +23,14 @@ def test_library_exports_every_declared_symbol():
     unbound = [s for s in sorted(declared) if s not in L.SIGNATURES]
     assert not unbound, f"declared in biu.h but not bound in _lib.SIGNATURES: {unbound}"
     assert L.lib.biu_version() >= 100
+    # ... and the other way round: the library exports nothing with C linkage that the header does not declare (INTEGRATION.md section 2:
+    # "exports exactly include/biu.h"; cross-translation-unit helpers carry hidden visibility)
+    import subprocess
+    so = os.path.join(ROOT, "bio_image_unet_amd", "libbiu_hip.so")
+    nm = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if ln.split()}
+    extra = sorted(s for s in exported if s.startswith("biu_") and s not in declared)
+    assert not extra, f"exported with C linkage but not declared in biu.h: {extra}"
 
 
 def test_fp32_product_mode_switch_validates_its_argument():

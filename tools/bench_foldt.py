@@ -70,6 +70,6 @@ for name, n, cl, cup, cs, cout, (d, h, w) in (("decode5", 4, 64, 64, 32, 32, (64
         out.append(f"dgrad {t:.3f} ms {fl / t / 1e9:.0f} TF/s")
     if "wg" in legs:
         t = timed(lambda: check(lib.biu_foldt_bwd_weight_bn(C.byref(axl), C.byref(xfl), C.byref(ask), C.byref(xfs), C.byref(ady), C.byref(ay), P(kv[0]), P(kv[1]), P(kv[2]),
-                                                            P(kv[3]), P(kv[4]), P(kv[5]), P(wc), P(wt), P(bt), cup, P(dwc), P(dwt), P(dbt), P(ws), ws.numel(), code, st)))
+                                                            P(kv[3]), P(kv[4]), P(kv[5]), None, P(wc), P(wt), P(bt), cup, P(dwc), P(dwt), P(dbt), P(ws), ws.numel(), code, st)))
         out.append(f"wgrad_bn {t:.3f} ms {fl / t / 1e9:.0f} TF/s")
     print(f"{name} x_low {cl} ch @{(d, h, w)}, up {cup} | skip {cs} -> {cout} @{(2 * d, 2 * h, 2 * w)}: " + " | ".join(out), flush=True)
