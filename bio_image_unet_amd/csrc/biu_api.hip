@@ -145,7 +145,7 @@ extern "C" int biu_conv_bwd_data_bnred(const biu_act* dy, const float* w, const 
     const bool yok = ((uintptr_t)y_up->p % 16) == 0 && ((size_t)y_up->pitch * es) % 16 == 0;
     if (packed && yok && !disabled("conv_dgrad") && !disabled("dgrad_bnred") && biu_mfma_conv_ok(dy, dx, kd, kh, kw, dilation, dtype) &&
         !will_split(dy->c, dx, nullptr, kd, dtype, ws, ws_bytes)) {
-        const int nb = biu_mfma_conv_stat_rows(dx, kd, dy, dtype);           // one partial row per workgroup column (as the forward)
+        const int nb = biu_mfma_conv_stat_rows(dx, kd, dy, dtype, true);     // one partial row per workgroup column (as the forward)
         if ((size_t)nb * dx->c * 2 <= partial_floats) {
             BnRedFuse red{y_up, scale, shift, slope, mean, invstd};
             int rc = biu_mfma_conv(dy, nullptr, packed, nullptr, kd, kh, kw, dx, 0, partial, dtype, (hipStream_t)stream, &red);

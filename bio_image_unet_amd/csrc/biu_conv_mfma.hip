@@ -1615,7 +1615,8 @@ int biu_mfma_conv_bricks(const biu_act* y, int kd, const biu_act* x, int dtype) 
 }
 // number of workgroup columns of that launch (= BatchNorm statistics partial rows of the forward kernels: one per block);
 // must mirror launch_cfg_r's / launch_conv16's grid computation
-int biu_mfma_conv_stat_rows(const biu_act* y, int kd, const biu_act* x, int dtype) {
+int biu_mfma_conv_stat_rows(const biu_act* y, int kd, const biu_act* x, int dtype, bool red) {
+    if (x && kd == 3 && biu_conv_roll_ok(x, y, dtype, false, 0, red)) return biu_conv_roll_rows(x, y, dtype);
     if (m16_ok(x, y, dtype)) {
         const int g = m16_grid_x(y->c / (16 * m16_mtl(x->c, y->c, dtype)));
         const int nbricks = bricks_of(y, m16_brick(kd));
@@ -1764,6 +1765,11 @@ int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, con
                 return BIU_OK;
             }
         }
+    }
+    // the rolling-window kernel with register-resident weights (biu_conv_roll.hip): narrow 3-D bf16 layers on one input and one output tensor
+    if (kd == 3 && !(cat && (cat->x1 || cat->y1)) && biu_conv_roll_ok(x, y, dtype, false, accumulate, red != nullptr)) {
+        const void* img = biu_conv_roll_mshape(x, y, dtype) == 16 ? (const void*)((const char*)packed + regular_packed_bytes(x->c, y->c, 27, dtype)) : packed;
+        return biu_conv_roll(x, xf, img, bias, y, bn_partial, red, st);
     }
     {   // the 16-row kernel: one input tensor; one output, or the two outputs of a split data gradient when every 32-channel column lies in one of them
         biu_act yall = *y;

@@ -36,13 +36,19 @@ struct ConvCat {              // channel concatenation without a concat buffer: 
 int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, int kh, int kw,
                   const biu_act* y, int accumulate, float* bn_partial, int dtype, hipStream_t st, const BnRedFuse* red = nullptr,
                   const ConvCat* cat = nullptr, void* split_ws = nullptr, size_t split_ws_bytes = 0);
+// biu_conv_roll.hip: rolling-window 3x3x3 bf16 convolution with register-resident weights (narrow full-resolution layers)
+bool biu_conv_roll_ok(const biu_act* x, const biu_act* y, int dtype, bool has_cat, int accumulate, bool red);
+int biu_conv_roll_mshape(const biu_act* x, const biu_act* y, int dtype);       // 32 | 16: which packed fragment image the launch reads
+int biu_conv_roll_rows(const biu_act* x, const biu_act* y, int dtype);         // partial rows of its epilogue sums (= blocks per column)
+int biu_conv_roll(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, const biu_act* y, float* bn_partial, const BnRedFuse* red,
+                  hipStream_t st);
 size_t biu_mfma_conv_split_bytes(int cin, const biu_act* y, const biu_act* y1, int kd, int dtype);   // 0: the launch is not split
 int biu_mfma_convt_dgrad_bricks(const biu_act* dx, int kd);
 int biu_mfma_convt_dgrad_rows(const biu_act* dx, int kd);
 int biu_mfma_pack_batch(const biu_pack_job* jobs_device, int n, int dtype, hipStream_t st);
 int biu_mfma_set_fp32_products(int mode);
 int biu_mfma_conv_ksplit(int cin, const biu_act* y, int kd, int dtype);
-int biu_mfma_conv_stat_rows(const biu_act* y, int kd, const biu_act* x = nullptr, int dtype = -1);
+int biu_mfma_conv_stat_rows(const biu_act* y, int kd, const biu_act* x = nullptr, int dtype = -1, bool red = false);
 int biu_mfma_conv_bricks(const biu_act* y, int kd, const biu_act* x = nullptr, int dtype = -1);
 size_t biu_mfma_wgrad_workspace(int cin, int cout, int kd, int kh, int kw, int dtype);
 bool biu_mfma_wgrad_ok(const biu_act* x, const biu_act* dy, int kd, int kh, int kw, int dilation, int dtype);

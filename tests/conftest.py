@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 # the test networks are small: take it wherever the kernels serve the shapes, so that every parity test exercises it (the library reads the
 # variable once, at its first biu_foldt_ok call; the size rule itself is what bench.py and a default process run)
 os.environ.setdefault("BIU_FOLDT", "always")
+# The rolling-window convolution with register-resident weights (biu_conv_roll.hip) is taken by size too (narrow 3-D bf16 layers whose volume
+# fills the chip): the tests take it wherever it serves the shapes; BIU_DISABLE=croll is the A/B switch (tests/test_gpu_variants.py)
+os.environ.setdefault("BIU_ROLL", "always")
 
 
 def pytest_configure(config):

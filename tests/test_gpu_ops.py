@@ -427,6 +427,93 @@ def test_conv_mfma_fwd_dgrad(case, dtype):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# rolling-window 3x3x3 convolution with register-resident weights (biu_conv_roll.hip): narrow bf16 layers, forward + statistics and data
+# gradient + the upstream block's BatchNorm-backward sums, through the ordinary entry points (tests/conftest.py: BIU_ROLL=always drops the
+# size rule so that these small volumes take the kernel: windows of 8 x 32 in (H, W), depth segments, planes and columns off the window)
+# ---------------------------------------------------------------------------------------------------------------
+ROLL_CASES = [
+    # (N, Cin, Cout, (D, H, W))
+    (2, 16, 32, (7, 13, 37)),          # 32x32x16, two planes per step: odd depth, two windows each way with ragged edges
+    (1, 32, 16, (9, 8, 32)),           # 16x16x32, one plane per step, one exact window
+    (1, 32, 32, (20, 11, 40)),         # 32x32x16, 32-channel input: depth segments (20 planes over few columns)
+    (3, 16, 32, (4, 5, 9)),            # minimum depth, a window mostly outside the volume
+    (1, 32, 16, (24, 20, 70)),         # several depth segments and three windows along W
+]
+
+
+@pytest.mark.parametrize("case", ROLL_CASES)
+def test_conv_roll_fwd_stats_and_dgrad_bnred(case):
+    n, cin, cout, sp = case
+    dtype, code = "bf16", DT["bf16"][1]
+    x = rnd(n, cin, *sp, seed=1)
+    w = rnd(cout, cin, 3, 3, 3, seed=2) * (1.0 / (cin * 27) ** 0.5)
+    b = rnd(cout, seed=3)
+    xf = XF(cin, seed=4)
+    xd = Dev(x, dtype=dtype, pitch=cin + 16, c0=8)
+    yd = Dev(shape=(n, cout, *sp), dtype=dtype, pitch=cout + 8, c0=8)
+    xa = xf.apply(xd.ref()).bfloat16().float().requires_grad_(True)          # T(x) is rounded to bf16 where it is staged
+    wq = w.bfloat16().float()
+    yref = F.conv3d(xa, wq, b, padding=1)
+    wd, bd = w.cuda(), b.cuda()
+    pk = torch.empty(lib.biu_conv_packed_bytes(0, cin, cout, 3, 3, 3, 1, code), dtype=torch.uint8, device="cuda")
+    check(lib.biu_conv_pack(0, ptr(wd), cin, cout, 3, 3, 3, code, ptr(pk), stream()), "conv_pack")
+    nfl = lib.biu_conv_fwd_stats_floats(yd.a(), 3)
+    part = torch.full((nfl,), float("nan"), device="cuda")
+    nblk = C.c_int(0)
+    ws = torch.empty(16, dtype=torch.uint8, device="cuda")
+    check(lib.biu_conv_fwd_stats(xd.a(), xf.x(), ptr(wd), ptr(pk), ptr(bd), 3, 3, 3, 1, yd.a(), ptr(part), nfl, C.byref(nblk), ptr(ws), 0, code, stream()),
+          "conv_fwd_stats(roll)")
+    got = yd.get()
+    torch.testing.assert_close(got, yref.detach(), rtol=1e-2, atol=1e-2 * float(yref.abs().max()))
+    assert torch.isnan(yd.buf[..., :8].float()).all()                        # channels outside the slice untouched
+    sums = part[:nblk.value * cout * 2].view(nblk.value, cout, 2).double().sum(0).cpu()
+    gd = got.double()
+    torch.testing.assert_close(sums[:, 0], gd.sum(dim=(0, 2, 3, 4)), rtol=1e-4, atol=1e-4 * float(gd.abs().sum() / cout))
+    torch.testing.assert_close(sums[:, 1], (gd * gd).sum(dim=(0, 2, 3, 4)), rtol=1e-4, atol=1e-6)
+    # the plain forward (no statistics, identity transform) through biu_conv_fwd
+    yd2 = Dev(shape=(n, cout, *sp), dtype=dtype)
+    check(lib.biu_conv_fwd(xd.a(), None, ptr(wd), ptr(pk), ptr(bd), 3, 3, 3, 1, yd2.a(), ptr(ws), 0, code, stream()), "conv_fwd(roll, identity)")
+    yref2 = F.conv3d(xd.ref(), wq, b, padding=1)
+    torch.testing.assert_close(yd2.get(), yref2, rtol=1e-2, atol=1e-2 * float(yref2.abs().max()))
+    # data gradient + (sum dz, sum dz * yhat) of the upstream block whose raw output is y_up (the data gradient maps dy: cout -> cin channels)
+    dyd = Dev(rnd(n, cout, *sp, seed=5), dtype=dtype)
+    yref.backward(dyd.ref())
+    pk2 = torch.empty(lib.biu_conv_packed_bytes(1, cin, cout, 3, 3, 3, 1, code), dtype=torch.uint8, device="cuda")
+    check(lib.biu_conv_pack(1, ptr(wd), cin, cout, 3, 3, 3, code, ptr(pk2), stream()), "conv_pack(dgrad)")
+    dxd = Dev(shape=(n, cin, *sp), dtype=dtype, pitch=cin + 8, c0=0)
+    yup = Dev(rnd(n, cin, *sp, seed=6), dtype=dtype, pitch=cin + 8, c0=8)
+    uxf = XF(cin, seed=7)
+    mean, invstd = rnd(cin, seed=8) * 0.2, rnd(cin, seed=9).abs() + 0.5
+    md, isd = mean.cuda(), invstd.cuda()
+    nfl2 = lib.biu_bwd_data_bnred_floats(dxd.a(), 3, 0)
+    part2 = torch.full((nfl2,), float("nan"), device="cuda")
+    nb2 = C.c_int(0)
+    check(lib.biu_conv_bwd_data_bnred(dyd.a(), ptr(wd), ptr(pk2), 3, 3, 3, 1, dxd.a(), yup.a(), ptr(uxf.d[0]), ptr(uxf.d[1]), ptr(uxf.d[2]), ptr(md), ptr(isd),
+                                      ptr(part2), nfl2, C.byref(nb2), ptr(ws), 0, code, stream()), "conv_bwd_data_bnred(roll)")
+    gdx = dxd.get()
+    torch.testing.assert_close(gdx, xa.grad, rtol=1e-2, atol=1e-2 * float(xa.grad.abs().max()))
+    # reference sums on the STORED dx (as the separate reduce pass would see it)
+    yu = yup.ref().double()
+    shp = (1, -1, 1, 1, 1)
+    t_ = yu * uxf.scale.double().view(shp) + uxf.shift.double().view(shp)
+    dz = gdx.double() * torch.where(t_ > 0, torch.ones_like(t_), uxf.slope.double().view(shp).expand_as(t_))
+    s1 = dz.sum(dim=(0, 2, 3, 4))
+    s2 = (dz * (yu - mean.double().view(shp)) * invstd.double().view(shp)).sum(dim=(0, 2, 3, 4))
+    got2 = part2[:nb2.value * cin * 2].view(nb2.value, cin, 2).double().sum(0).cpu()
+    sc_ = float(dz.abs().sum() / cin)
+    torch.testing.assert_close(got2[:, 0], s1, rtol=1e-3, atol=1e-4 * sc_)
+    torch.testing.assert_close(got2[:, 1], s2, rtol=1e-3, atol=1e-4 * sc_ * float(invstd.max()) * 4)
+    # plain data gradient, then accumulate (the accumulate form falls back to the brick kernels: both must agree)
+    dxd2 = Dev(shape=(n, cin, *sp), dtype=dtype)
+    check(lib.biu_conv_bwd_data(dyd.a(), ptr(wd), ptr(pk2), 3, 3, 3, 1, dxd2.a(), 0, ptr(ws), 0, code, stream()), "conv_bwd_data(roll)")
+    # (32 -> 32 with the sums runs on the brick kernel -- no room beside 216 weight registers: two kernels, two summation orders)
+    same = not (cin == 32 and cout == 32)
+    torch.testing.assert_close(dxd2.get(), gdx, rtol=0 if same else 1e-2, atol=0 if same else 1e-2 * float(gdx.abs().max()))
+    check(lib.biu_conv_bwd_data(dyd.a(), ptr(wd), ptr(pk2), 3, 3, 3, 1, dxd2.a(), 1, ptr(ws), 0, code, stream()), "conv_bwd_data(acc)")
+    torch.testing.assert_close(dxd2.get(), 2 * xa.grad, rtol=2e-2, atol=2e-2 * float(xa.grad.abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # nearest-neighbour up-sampling folded into the 3x3x3 convolution behind it (forward): 8 parity classes x 2x2x2 taps on the coarse tensor
 # ---------------------------------------------------------------------------------------------------------------
 UPCONV_CASES = [

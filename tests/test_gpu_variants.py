@@ -41,6 +41,9 @@ def _run(which, disable, tmp_path):
     #  -- a wrong tap or tile would move them by tens of percent
     ("unet3d_bf16", "m16,rr16", 2e-2, 6e-2),
     ("unet3d_bf16", "m16x2", 2e-2, 6e-2),                 # only the two-tile form of the 16-row kernel (32-channel tiles of single-chunk layers)
+    # the rolling-window convolution with register-resident weights (biu_conv_roll.hip: the 16 <-> 32 and 32 -> 32 layers of the first level,
+    # forward and data gradient) against the brick kernels it replaces (BIU_DISABLE=croll): same products, another summation order
+    ("unet3d_bf16", "croll", 2e-2, 6e-2),
     # the rolling-window weight gradient (k_wgrad_roll) against the brick kernel it replaces (BIU_DISABLE=wroll): the forward is untouched
     # and the dy both write back over da is the same rounding sequence, so only the order of the fp32 sums inside dW differs
     ("unet3d_bf16", "wroll", 1e-6, 2.5e-4),

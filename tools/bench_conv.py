@@ -79,6 +79,16 @@ def main():
             "wg_bn": lambda: lib.biu_conv_bwd_weight_bn(C.byref(ax), C.byref(xf), C.byref(ady), C.byref(ay), P(kvec[0]), P(kvec[1]), P(kvec[2]),
                                                         P(kvec[3]), P(kvec[4]), P(kvec[5]), kd, 3, 3, 1, P(dw), P(ws), ws.numel(), code, st),
         }
+        # the data gradient with the upstream block's BatchNorm-backward sums in its epilogue (what a train step runs for most layers)
+        yup = torch.randn(n, d, h, w, cin, device="cuda").to(tdt)
+        ayup = biu_act(yup.data_ptr(), n, d, h, w, cin, cin)
+        uvec = [torch.rand(cin, device="cuda") + 0.5, torch.zeros(cin, device="cuda"), torch.full((cin,), 0.1, device="cuda"), torch.zeros(cin, device="cuda"),
+                torch.ones(cin, device="cuda")]
+        part = torch.empty(lib.biu_bwd_data_bnred_floats(C.byref(adx), kd, 0), device="cuda")
+        nb2 = C.c_int(0)
+        keep.extend([yup, uvec, part])
+        calls["dg_red"] = lambda: lib.biu_conv_bwd_data_bnred(C.byref(ady), P(wt), P(pk1), kd, 3, 3, 1, C.byref(adx), C.byref(ayup), P(uvec[0]), P(uvec[1]), P(uvec[2]),
+                                                              P(uvec[3]), P(uvec[4]), P(part), part.numel(), C.byref(nb2), None, 0, code, st)
         # two-source forms (what the decoder's first conv runs): x = concat(x0 | x1) held in two dense tensors, split 2:1 like up(2F) | skip(F)
         c0 = (2 * cin // 3) // 32 * 32
         if cin % 96 == 0 and c0 > 0 and lib.biu_conv_cat_ok is not None:
