@@ -89,6 +89,8 @@ def make_step(wl, device, graph=False):
 
     from bio_image_unet_amd.ddp import GradAverager
     avg = GradAverager(model)
+    avg_ms = []                                    # host milliseconds every average() spent launching leftovers + waiting (per step)
+    avg.wait_log = avg_ms
 
     def step():
         outs = fwd()
@@ -96,6 +98,7 @@ def make_step(wl, device, graph=False):
         opt.zero_grad(set_to_none=True)
         loss.backward()
         avg.average()                              # (a no-op at N = 1) -- BEFORE the clip: buckets that left during backward are not re-read
+        avg_ms.append(avg.average_wait_ms)
         if wl["model"] == "MultiOutputUnet3D":     # multi_output_unet3d/train.py:201, on the global-batch gradient
             opt.clip_grad_norm_(1.0)
         opt.step()
@@ -363,7 +366,15 @@ def main():
         torch.cuda.synchronize()
     watched, lib.watch = lib.watched, None
     ranks_seen = 1
+    per_rank = None
     if world > 1:
+        # every rank's own step time and the host time its average() calls took: a measured scaling curve can then be attributed
+        # (stragglers vs. exposed all-reduce)
+        waits = getattr(avg, "wait_log", [])[-args.steps:]
+        mine = torch.tensor([dt / args.steps * 1e3, median_ms, sum(waits) / max(len(waits), 1), max(waits) if waits else 0.0], device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        per_rank = [[round(float(v), 4) for v in r_.tolist()] for r_ in allr]
         t = torch.tensor([dt, median_ms], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt, median_ms = float(t[0].item()), float(t[1].item())
@@ -460,7 +471,10 @@ def main():
             rccl = None
         out["ddp"] = {"ranks_seen": ranks_seen, "backend": torch.distributed.get_backend(), "rccl_version": rccl,
                       "buckets": len(avg.buckets), "launched_in_backward": avg.launched_in_backward,
-                      "bucket_mbytes": [round(b.flat.numel() * 4 / 2 ** 20, 2) for b in avg.buckets]}
+                      "bucket_mbytes": [round(b.flat.numel() * 4 / 2 ** 20, 2) for b in avg.buckets],
+                      "grad_copies_in_backward": avg.copies_in_backward,
+                      "per_rank": {"columns": ["ms_per_step", "median_ms_per_step", "average_wait_ms_mean", "average_wait_ms_max"], "rows": per_rank},
+                      "step_ms_min_max_over_ranks": [min(r_[0] for r_ in per_rank), max(r_[0] for r_ in per_rank)] if per_rank else None}
     if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores, bounded sample)
         out["cpu_baseline"] = cpu_baseline(args.workload)
     print(json.dumps(out), flush=True)

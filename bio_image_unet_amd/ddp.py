@@ -35,12 +35,13 @@ class _Bucket:
     __slots__ = ("flat", "params", "views", "pending", "work", "late")
 
     def __init__(self, params, device):
-        n = sum(p.numel() for p in params)
+        # every slot starts on a 16-byte boundary: the gradient kernels write straight into the slots (GradAverager._alloc)
+        n = sum((p.numel() + 3) // 4 * 4 for p in params)
         self.flat = torch.zeros(n, dtype=torch.float32, device=device)
         self.params, self.views, o = list(params), [], 0
         for p in params:
             self.views.append(self.flat[o:o + p.numel()].view_as(p))
-            o += p.numel()
+            o += (p.numel() + 3) // 4 * 4
         self.pending, self.work, self.late = set(), None, False
 
 
@@ -49,7 +50,8 @@ class GradAverager:
 
     Parameters are grouped into buckets of ``bucket_mb`` MiB in the order their gradients become final during backward -- the
     REVERSE of registration order, i.e. decoder first, encoder last.  Networks of this package report each finished
-    parameter gradient from inside ``Engine.backward`` (``register_grad_ready_hook``): it is copied into its bucket and, when the
+    parameter gradient from inside ``Engine.backward`` (``register_grad_ready_hook``); the engine has WRITTEN it into its bucket slot
+    already (``register_grad_alloc``: the bucket view is the gradient tensor the kernels fill -- no per-parameter copy) and, when the
     bucket is complete, ``all_reduce(async_op=True)`` is issued at once -- RCCL's stream then runs beside the remaining backward
     kernels (xGMI is point-to-point: a 19 MB UNet3D gradient is ~0.2 ms of ring time against a >= 10 ms step, so three or four
     buckets hide all of it behind the encoder's backward).  ``average()`` after backward launches whatever is still incomplete
@@ -91,14 +93,38 @@ class GradAverager:
         self.hooked = hasattr(module, "register_grad_ready_hook")
         if self.hooked and self.world > 1:
             module.register_grad_ready_hook(self._on_grad_ready)
+            if hasattr(module, "register_grad_alloc"):
+                # the engine writes each parameter gradient STRAIGHT INTO its bucket (no per-parameter device copy: ~70 launches per
+                # UNet3D step otherwise): Engine.new_grad asks here for the destination
+                module.register_grad_alloc(self._alloc)
+        # RCCL averages in the collective itself (ReduceOp.AVG); gloo (the CPU tests) sums and average() scales
+        self._avg_op = self.world > 1 and dist.get_backend() == "nccl"
         self.launched_in_backward = 0                    # buckets whose all-reduce went out before backward returned (last step)
+        self.copies_in_backward = 0                      # gradients that still had to be copied into their bucket (last step)
+        self.average_wait_ms = 0.0                       # host time the last average() spent launching the rest and waiting
+
+    _copies = 0
 
     def _reset(self):
         for b in self.buckets:
             b.pending, b.work, b.late = set(range(len(b.params))), None, False
 
     def _launch(self, b: _Bucket):
-        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, async_op=True)
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if self._avg_op else dist.ReduceOp.SUM, async_op=True)
+
+    def _alloc(self, p: torch.nn.Parameter):
+        """Destination of the gradient the engine is about to compute for ``p``: a FRESH view of its bucket slot (a fresh tensor object, so
+        that autograd's AccumulateGrad takes it as ``p.grad`` instead of cloning it), or None when the gradient cannot live there --
+        ``p.grad`` already holds something (accumulation: autograd will add in place, possibly into this very memory) or the bucket is
+        no longer collecting."""
+        hit = self._where.get(p)
+        if hit is None or p.grad is not None:
+            return None
+        b, i = hit
+        if b.late or i not in b.pending or b.work is not None:
+            return None
+        v = b.views[i]
+        return b.flat[v.storage_offset():v.storage_offset() + v.numel()].view_as(p)
 
     @torch.no_grad()
     def _on_grad_ready(self, p: torch.nn.Parameter, g: torch.Tensor):
@@ -116,7 +142,9 @@ class GradAverager:
                 b.work.wait()
                 b.work = None
             return
-        b.views[i].copy_(g)
+        if g.data_ptr() != b.views[i].data_ptr():        # (a gradient the engine could not write in place: shared weights, the zero conv biases)
+            b.views[i].copy_(g)
+            self._copies += 1
         b.pending.discard(i)
         if not b.pending and b.work is None:
             self._launch(b)
@@ -127,6 +155,8 @@ class GradAverager:
         """Call after backward(): leaves p.grad = mean over ranks (views of the flat fp32 buckets)."""
         if self.world == 1:
             return
+        import time
+        t0 = time.perf_counter()
         early = sum(1 for b in self.buckets if b.work is not None)
         for b in self.buckets:
             if b.work is None:
@@ -139,8 +169,12 @@ class GradAverager:
                 self._launch(b)
         for b in self.buckets:
             b.work.wait()
-            b.flat.mul_(1.0 / self.world)
+            if not self._avg_op:
+                b.flat.mul_(1.0 / self.world)
             for p, v in zip(b.params, b.views):
-                p.grad = v
+                if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                    p.grad = v
         self.launched_in_backward = early
+        self.copies_in_backward, self._copies = self._copies, 0
+        self.average_wait_ms = (time.perf_counter() - t0) * 1e3
         self._reset()

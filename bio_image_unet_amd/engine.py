@@ -453,7 +453,7 @@ class ConvBlockNode(Node):
         else:
             # eval-mode BatchNorm: constants instead of statistics -- dy = scale * dz, and the conv bias gradient sum_v dy = scale * sum dz
             # is a real number again (it is also what the folded decoder's ConvT-bias chain rule needs: biu_foldt_bwd_weight_bn, dy_sum)
-            dy_sum = eng.new_grad(self.bn.bias)
+            dy_sum = torch.empty(cout, dtype=torch.float32, device=eng.device)
             check(lib.biu_bn_bwd_finalize_eval(_ptr(partial), nblk.value, cout, scale, _ptr(dgamma), _ptr(dbeta), _ptr(dy_sum), _ptr(A), _ptr(B),
                                                _ptr(Cc), st), "bn_bwd_finalize_eval")
             db = dy_sum if self.conv.bias is not None else None
@@ -892,6 +892,7 @@ class Engine:
         self._slots: List[dict] = []
         self._job_key, self._job_tab = None, None
         self.grad_hook = None        # callable(param, grad) fired inside backward when a parameter's gradient is final (ddp.py)
+        self.grad_alloc = None       # callable(param) -> fp32 tensor to compute the gradient INTO (a bucket view), or None (ddp.py)
         self.trace = None            # test hook: trace(phase, node, when) around every node ("fwd"/"bwd", node, "pre"/"post")
         self.generation = 0          # bumped by every forward: a backward must see the generation of ITS forward
         self._live = None            # weakref to the token of the autograd node that still needs this engine's buffers
@@ -1043,6 +1044,10 @@ class Engine:
         return a
 
     def new_grad(self, p: nn.Parameter) -> torch.Tensor:
+        if self.grad_alloc is not None and self._pcount.get(p, 1) == 1:      # (shared weights sum several contributions: own tensors)
+            v = self.grad_alloc(p)
+            if v is not None:
+                return v
         return torch.empty(p.shape, dtype=torch.float32, device=self.device)
 
     def zero_like_bias(self, b: torch.Tensor) -> torch.Tensor:

@@ -68,6 +68,14 @@ class _HipNet(nn.Module):
             for e in engs:
                 e.grad_hook = fn
 
+    def register_grad_alloc(self, fn):
+        """``fn(param) -> tensor | None``: where the engine should compute that parameter's gradient (``ddp.GradAverager`` hands out views of
+        its flat all-reduce buckets, so no gradient is copied on its way to the wire)."""
+        self._grad_alloc = fn
+        for engs in self._engines.values():
+            for e in engs:
+                e.grad_alloc = fn
+
     def invalidate_packed(self):
         """Call after writing parameters through ``.data`` (EMA, clipping, manual broadcast): such writes do not bump
         ``Tensor._version``, which is what the cached MFMA weight packings are keyed on.  In-place ops under ``no_grad``,
@@ -107,6 +115,7 @@ class _HipNet(nn.Module):
             self._build(eng, *[tuple(t.shape) for t in xs])
             eng.finalize()
             eng.grad_hook = getattr(self, "_grad_hook", None)
+            eng.grad_alloc = getattr(self, "_grad_alloc", None)
             names = {id(mod): name for name, mod in self.named_modules()}
             for nd_ in eng.nodes:       # labels for profiling: the reference attribute name of the layer
                 mod = getattr(nd_, "conv", None) or getattr(nd_, "up", None)
