@@ -404,7 +404,11 @@ extern "C" int biu_foldt_pack(const float* w_conv, const float* b_conv, const fl
     BIU_REQUIRE(w_conv && w_t && packed && cin_low > 0 && cup > 0 && cskip > 0 && cout > 0, BIU_ERR_SHAPE, "foldt_pack: null pointer or empty shape");
     return biu_mfma_foldt_pack(w_conv, b_conv, w_t, b_t, cin_low, cup, cskip, cout, dtype, packed, (hipStream_t)stream);
 }
-extern "C" size_t biu_foldt_fwd_stats_floats(const biu_act* x_low, const biu_act* y) { return (size_t)biu_mfma_foldt_stat_rows(x_low, y) * y->c * 2; }
+extern "C" size_t biu_foldt_fwd_stats_floats(const biu_act* x_low, const biu_act* y) {
+    // (an upper bound over the forms the launch can take: 8 rows per block of the brick form, at most one row per CU x 4 of the rolling one)
+    const size_t a = (size_t)biu_mfma_foldt_stat_rows(x_low, y) * y->c * 2, b = (size_t)1024 * y->c * 2;
+    return a > b ? a : b;
+}
 extern "C" int biu_foldt_fwd(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const void* packed,
                              const biu_act* y, float* bn_partial, size_t bn_partial_floats, int* bn_nblk, int dtype, biu_stream stream) {
     BIU_REQUIRE(x_low && skip && y && packed, BIU_ERR_SHAPE, "foldt_fwd: null pointer");
@@ -412,7 +416,7 @@ extern "C" int biu_foldt_fwd(const biu_act* x_low, const biu_xform* xf_low, cons
     if (bn_nblk) *bn_nblk = 0;
     if (bn_partial) {
         BIU_REQUIRE(bn_nblk, BIU_ERR_SHAPE, "foldt_fwd: bn_partial without bn_nblk");
-        const int nb = biu_mfma_foldt_stat_rows(x_low, y);
+        const int nb = biu_mfma_foldt_stat_rows(x_low, y, skip, dtype);            // (the rolling-window form: one row per block of the skip half's launch)
         BIU_REQUIRE((size_t)nb * y->c * 2 <= bn_partial_floats, BIU_ERR_WORKSPACE, "foldt_fwd: partial buffer too small");
         int rc = biu_mfma_foldt_fwd(x_low, xf_low, skip, xf_skip, packed, y, bn_partial, dtype, (hipStream_t)stream);
         if (rc == BIU_OK) *bn_nblk = nb;

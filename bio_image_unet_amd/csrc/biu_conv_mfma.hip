@@ -1769,7 +1769,7 @@ int biu_mfma_conv(const biu_act* x, const biu_xform* xf, const void* packed, con
     // the rolling-window kernel with register-resident weights (biu_conv_roll.hip): narrow 3-D bf16 layers on one input and one output tensor
     if (kd == 3 && !(cat && (cat->x1 || cat->y1)) && biu_conv_roll_ok(x, y, dtype, false, accumulate, red != nullptr)) {
         const void* img = biu_conv_roll_mshape(x, y, dtype) == 16 ? (const void*)((const char*)packed + regular_packed_bytes(x->c, y->c, 27, dtype)) : packed;
-        return biu_conv_roll(x, xf, img, bias, y, bn_partial, red, st);
+        return biu_conv_roll(x, xf, img, bias, y, bn_partial, red, st, accumulate);
     }
     {   // the 16-row kernel: one input tensor; one output, or the two outputs of a split data gradient when every 32-channel column lies in one of them
         biu_act yall = *y;
@@ -2486,11 +2486,28 @@ int biu_mfma_foldt_pack(const float* w_conv, const float* b_conv, const float* w
     if (rc == BIU_OK) rc = mfma_pack_strided(1, w_conv + (size_t)cup * 27, ccat, cskip, cout, 3, 3, 3, dtype, base + b.sdg, st);
     return rc;
 }
-int biu_mfma_foldt_stat_rows(const biu_act* x_low, const biu_act* y) { return biu_mfma_upconv_stat_rows(x_low, y); }
+// The rolling-window form (biu_conv_roll.hip): the up half FIRST (k_fold_roll: composed weights of a wave's two parity classes in registers, the
+// coarse tile staged once for all eight classes, the ConvT-bias border correction as the accumulators' initial value), then the skip half
+// accumulating onto it with the BatchNorm statistics from its epilogue -- y is written twice and read once, rounded to the storage type twice
+// (three times and with a border pass in the brick form below).  BIU_DISABLE=froll keeps the brick form.
+static bool foldt_roll_ok(const biu_act* x_low, const biu_act* skip, const biu_act* y, int dtype) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("BIU_DISABLE"); off = (e && strstr(e, "froll")) ? 1 : 0; }
+    return !off && skip && biu_fold_roll_ok(x_low, y, dtype) && biu_conv_roll_ok(skip, y, dtype, false, 1, false);
+}
+int biu_mfma_foldt_stat_rows(const biu_act* x_low, const biu_act* y, const biu_act* skip, int dtype) {
+    if (skip && foldt_roll_ok(x_low, skip, y, dtype)) return biu_conv_roll_rows(skip, y, dtype);
+    return biu_mfma_upconv_stat_rows(x_low, y);
+}
 int biu_mfma_foldt_fwd(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const void* packed, const biu_act* y,
                        float* bn_partial, int dtype, hipStream_t st) {
     const FoldtBlob b = foldt_blob(x_low->c, skip->c, y->c, dtype);
     const char* base = (const char*)packed;
+    if (foldt_roll_ok(x_low, skip, y, dtype)) {
+        int rc = biu_fold_roll(x_low, xf_low, base + b.fwd, (const float*)(base + b.bias), (const float*)(base + b.fix), y, st);
+        if (rc != BIU_OK) return rc;
+        return biu_mfma_conv(skip, xf_skip, base + b.sfwd, nullptr, 3, 3, 3, y, 1, bn_partial, dtype, st, nullptr, nullptr, nullptr, 0);
+    }
     // 1. skip half + both biases (the full 27-tap ConvT-bias sum; the border shell is corrected next)
     int rc = biu_mfma_conv(skip, xf_skip, base + b.sfwd, (const float*)(base + b.bias), 3, 3, 3, y, 0, nullptr, dtype, st, nullptr, nullptr, nullptr, 0);
     if (rc != BIU_OK) return rc;

@@ -161,9 +161,10 @@ __device__ __forceinline__ void rl_mfma16(floatx4m& acc, const uint4& w, const u
 // XF: the input carries a lazy producer transform.  PS: output planes per step.  LA: fetch lookahead in steps (>= 2).  ST: epilogue sums -- 0 none, 1 BatchNorm statistics (sum y, sum y^2) of the
 // stored output, 2 ("RED") the output is d loss / d a of an upstream conv block whose raw output is red_y: (sum dz, sum dz * yhat)
 // (k_conv_pipe's red_mode 1).
-template <int CIN, int M, int PS, int LA, int ST, bool XF>
+template <int CIN, int M, int PS, int LA, int ST, bool XF, bool ACC = false>
 __global__ __launch_bounds__(256, 1) void k_conv_roll(RollArgs a) {
     constexpr bool RED = ST == 2;
+    static_assert(!(RED && ACC) && (!ACC || M == 32), "the accumulate form exists for 32-row tiles without the BatchNorm-backward sums");
     static_assert(CIN == 16 || CIN == 32, "input channels");
     static_assert(M == 32 || (M == 16 && CIN == 32), "MFMA shape");
     static_assert(LA >= 2 && LA <= 4 && (PS == 1 || PS == 2), "pipeline depth");
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_roll(RollArgs a) {
     constexpr int NPL = PS * (LA + 1) + 2;             // ring slots (planes)
     constexpr int NKS = CIN / 16;                      // k-steps of the 32x32x16 shape
     constexpr bool G32 = M == 32;
-    constexpr int NRL = RED ? 4 * PS : 0;              // vector-memory instructions a wave issues per step besides the fetch: y loads ...
+    constexpr int NRL = (RED || ACC) ? 4 * PS : 0;     // vector-memory instructions a wave issues per step besides the fetch: y loads ...
     constexpr int NST = 4 * PS;                        // ... and output stores
 
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
@@ -388,10 +389,23 @@ __global__ __launch_bounds__(256, 1) void k_conv_roll(RollArgs a) {
         else fr[j] = *(const uint4*)(pbase + fa[((j % 4) * 2 + j / 4) * 3 + kw]);
     };
     // RED: upstream raw output at this lane's output voxels of the step whose first plane is d (always NRL load instructions)
-    struct YQ { uint4 v4[(RED && G32) ? 4 * PS : 1]; v2u_t v2[(RED && !G32) ? 4 * PS : 1]; };
+    struct YQ { uint4 v4[((RED || ACC) && G32) ? 4 * PS : 1]; v2u_t v2[(RED && !G32) ? 4 * PS : 1]; };
     struct Acc { floatx16 a32[G32 ? PS : 1][2]; floatx4m a16[G32 ? 1 : PS][2][2]; };
     struct Park { uint4 p4[G32 ? 4 * PS : 1]; uint2 p2[G32 ? 1 : 4 * PS]; };     // a step's output pieces in the storage type, as they will be stored
     auto load_y = [&](int d, uint4* o4, v2u_t* o2) __attribute__((always_inline)) {
+        if constexpr (ACC) {                            // the output's present content at the step's voxels (the sum starts from it)
+#pragma unroll
+            for (int pl = 0; pl < PS; ++pl)
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    const unsigned ro = row_off(d + pl, r2, rowY);
+#pragma unroll
+                    for (int x2 = 0; x2 < 2; ++x2) {
+                        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)(vY[0] + ro + 32u * x2), 0, 0);
+                        o4[(pl * 2 + r2) * 2 + x2] = make_uint4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+        }
         if constexpr (RED) {
 #pragma unroll
             for (int pl = 0; pl < PS; ++pl)
@@ -421,7 +435,10 @@ __global__ __launch_bounds__(256, 1) void k_conv_roll(RollArgs a) {
         // ---- prologue: planes -1 .. LA * PS in flight, the first PS + 2 of them landed and transformed ---------------------------
         constexpr int NU0 = (LA * PS + 2) / PS;         // units of the prologue: q0 = -1, -1 + PS, ...
         constexpr int NW0 = (PS + 2 + PS - 1) / PS;     // ... of which step 0 needs the first NW0 (PS = 1: 3, PS = 2: 2)
-        // (the y loads of step 0 go out with step 0 itself: its epilogue runs during step 1)
+        // (RED: the y loads of step 0 go out with step 0 itself: its epilogue runs during step 1.  ACC: the output's content at step 0's voxels is
+        //  requested here, in front of every fetch, so that the prologue's wait lands it)
+        YQ yq_cur, yq_prev;
+        if constexpr (ACC) load_y(d0, yq_cur.v4, yq_cur.v2);
 #pragma unroll
         for (int u = 0; u < NU0; ++u)
 #pragma unroll
@@ -486,7 +503,6 @@ __global__ __launch_bounds__(256, 1) void k_conv_roll(RollArgs a) {
         float x_f[8], x_t[8], x_u[8], x_sc[8], x_sh[8], x_sl[8];
         if constexpr (XF && ST != 2) load_xf(x_sc, x_sh, x_sl);          // (registers to spare: the vectors stay resident; ST = 2 reads them per piece)
         Park park;
-        YQ yq_cur, yq_prev;
         if constexpr (RED) {                            // (step 0 runs a fully masked epilogue on these: 0 x garbage could be a NaN)
 #pragma unroll
             for (int i = 0; i < ((RED && G32) ? 4 * PS : 1); ++i) yq_cur.v4[i] = make_uint4(0, 0, 0, 0);
@@ -634,8 +650,33 @@ __global__ __launch_bounds__(256, 1) void k_conv_roll(RollArgs a) {
                 yq_prev = yq_cur;
                 load_y(dcur, yq_cur.v4, yq_cur.v2);
             }
+            if constexpr (ACC) {                        // (yq_cur: this step's initial values, requested a step ago; yq_prev is reused for the next step's)
+                yq_prev = yq_cur;
+                load_y(dcur + PS, yq_cur.v4, yq_cur.v2);
+            }
             // -- accumulators start at the bias
-            if constexpr (G32) {
+            if constexpr (ACC) {
+                // the accumulators start at the stored output (+ bias): a stored piece is channels 16 x2 + 8 hf .. + 7 of the lane's voxel; the
+                // epilogue's permlane32 swap is its own inverse and hands back the lane's MFMA rows 8 g + 4 hf + i
+#pragma unroll
+                for (int pl = 0; pl < PS; ++pl)
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                        for (int x2 = 0; x2 < 2; ++x2) {
+                            const uint4 P = yq_prev.v4[(pl * 2 + r2) * 2 + x2];
+                            const auto sx = __builtin_amdgcn_permlane32_swap(P.x, P.z, false, false);
+                            const auto sy = __builtin_amdgcn_permlane32_swap(P.y, P.w, false, false);
+                            const unsigned u[4] = {sx[0], sy[0], sx[1], sy[1]};
+                            const float4 b0 = *(const float4*)(lbias + 16 * x2 + 4 * (lane >> 5)), b1 = *(const float4*)(lbias + 16 * x2 + 8 + 4 * (lane >> 5));
+                            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                cur.a32[pl][r2][8 * x2 + 2 * e] = __uint_as_float(u[e] << 16) + bb[2 * e];
+                                cur.a32[pl][r2][8 * x2 + 2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u) + bb[2 * e + 1];
+                            }
+                        }
+            } else if constexpr (G32) {
                 // (lane holds channels 8 g + 4 hf + i of its voxel: four float4 reads of the bias row)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
@@ -789,6 +830,355 @@ __global__ __launch_bounds__(256, 1) void k_conv_roll(RollArgs a) {
 #endif
 }
 
+// =====================================================================================================================================
+// The UP HALF of a folded decoder level (ConvTranspose(k2, s2) + concat + 3x3x3 conv as one op) on the same machinery:
+//   y[2v + p] = bias_eff[border state] + sum_{t in {0,1}^3} W'[p][t] . T(x_low)[v + t - 1 + p]        8 parity classes p x 8 coarse taps t
+// as the FIRST writer of y (the skip half then accumulates onto it in k_conv_roll's ACC form and rounds the sum once).
+// k_conv_pipe<.., 2, 2, 1, ..> ran this as one block per parity class with the coarse tile re-staged eight times, a weight fragment from LDS
+// for every two MFMAs and a read-modify-write epilogue: an item spent 8.8 k cycles for 1 k cycles of MFMA (profiles/r03_mfma_shape_ab.md
+// section 5).  Here a block is 4 waves = the 4 (pd, ph) class pairs; a wave keeps the composed weights of ITS two classes (pw = 0, 1) in
+// registers (2 x 8 taps x 4 k-steps = 256 registers for 64 -> 32 channels) and the block walks a coarse column: a 4 x 32 window in (H, W),
+// one coarse plane per step, the 64-channel coarse planes in an LDS ring filled by LDS-DMA and transformed in place.  Every wave reads the
+// same ring: the coarse tile is staged ONCE for all eight classes.  A step is two half-steps (pw = 0, then 1) of 128 MFMAs each; the
+// half-step's 8 output pieces are parked in the storage type and stored between the MFMAs of the next half-step.
+// The ConvTranspose bias reaches the output through the conv's taps: bias_eff[state][co] = b_conv + sum_k Wb[k] - (the Wb[k] of the taps
+// that fall outside the fine tensor in that border state) -- the table biu_foldt_pack already builds (fix, bias) -- is the accumulators'
+// initial value, looked up per output row (d, h states) and lane (w state): no border pass over y.
+// =====================================================================================================================================
+struct FoldArgs {
+    const char* x; char* y;            // coarse input (ID, IH, IW), fine output (2 ID, 2 IH, 2 IW)
+    const uint4* wpk;                  // k_pack_upconv image: [class][n-tile][k-step][tap][lane]
+    const float* bias; const float* fix;          // [Cout], [27][Cout]
+    const float* xs; const float* xb; const float* xl;
+    int xpitch, ypitch;
+    int N, D, H, W;                    // coarse extents
+    int Cout;
+    int nbh, nbw, nseg, seg;
+    unsigned long long* diag;
+};
+constexpr int FR_TH = 4, FR_TW = 32, FR_HH = FR_TH + 2, FR_HW = FR_TW + 2, FR_PLV = FR_HH * FR_HW;      // 204 halo voxels per coarse plane
+constexpr int FR_NBLK = (FR_PLV + 15) / 16;                                                           // 13 blocks of 16 voxels
+
+template <int LA, bool XF>
+__global__ __launch_bounds__(256, 1) void k_fold_roll(FoldArgs a) {
+    constexpr int CIN = 64, M = 32, NKS = CIN / 16, PCS = CIN / 8;
+    constexpr int TH = FR_TH, TW = FR_TW, HW = FR_HW, PLV = FR_PLV;
+    constexpr int BLKB = 256 * PCS, PB = FR_NBLK * BLKB, NPI = PB / 1024, KPP = (NPI + 3) / 4, NK = KPP;      // 26 instructions per plane, 7 per wave
+    constexpr int NPL = LA + 3;                                  // ring slots: 3 planes being read, LA - 1 in flight, 1 being transformed
+    constexpr int NST = 8;                                       // output pieces (stores) of a HALF-step and wave: 4 rows x 2 pieces
+    static_assert(LA == 2, "the 64-channel ring holds five planes");
+
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+    char* ring = (char*)lds;
+    char* dump = ring + NPL * PB;
+    float* lxf = (float*)(dump + 1024);                         // [3][CIN]
+    float* lbe = lxf + 3 * CIN;                                 // [27][M] bias_eff
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pd = wave >> 1, ph = wave & 1;
+    const int co0 = (int)blockIdx.y * M;
+    if (tid < CIN) {
+        lxf[tid] = XF ? a.xs[tid] : 1.f;
+        lxf[CIN + tid] = XF ? a.xb[tid] : 0.f;
+        lxf[2 * CIN + tid] = XF ? a.xl[tid] : 1.f;
+    }
+    for (int i = tid; i < 27 * M; i += 256) {
+        const int st = i / M, co = co0 + i % M;
+        lbe[i] = co < a.Cout ? (a.bias ? a.bias[co] : 0.f) - (a.fix ? a.fix[st * a.Cout + co] : 0.f) : 0.f;
+    }
+    // weights of this wave's two classes: [pw][tap][k-step]
+    uint4 wr[2][8][NKS];
+    {
+        const size_t slice = (size_t)((a.Cout + 31) / 32) * NKS * 8 * 64;
+#pragma unroll
+        for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks)
+                    wr[pw][t][ks] = a.wpk[(size_t)((pd << 2) | (ph << 1) | pw) * slice + (((size_t)blockIdx.y * NKS + ks) * 8 + t) * 64 + lane];
+    }
+    const int l_piece = (wave & 1) * 4 + (lane >> 4);           // instruction wave + 4 kk covers half-block (wave + 4 kk) & 1 = wave & 1
+    const unsigned rowB = (unsigned)a.xpitch * 2u;
+    const unsigned planeB = (unsigned)(a.H * a.W) * rowB;
+    const size_t sampX = (size_t)a.D * planeB;
+    const unsigned rowY = (unsigned)a.ypitch * 2u;
+    const int OD = 2 * a.D, OH = 2 * a.H, OW = 2 * a.W;
+    const size_t sampY = (size_t)OD * OH * OW * rowY;
+    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)ring);
+    constexpr unsigned BAD = 0x40000000u, BAD2 = 0x80000000u;
+
+    // fragment addresses: halo rows ph + j (j = 0..4), column offset kwv = pw + tw (0..2); piece 2 ks + hf -> + ks * 512
+    unsigned fa[5 * 3];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int kwv = 0; kwv < 3; ++kwv) {
+            const int hv = (ph + j) * HW + kwv + (lane & 31);
+            fa[j * 3 + kwv] = (unsigned)((hv >> 4) * BLKB + (hv & 15) * 16 + (lane >> 5) * 256);
+        }
+
+    const int G = gridDim.x;
+    const int ncols = a.N * a.nbh * a.nbw, nitems = ncols * a.nseg;
+    auto item_of = [&](int k) -> int {
+        if ((G & 7) == 0) return k * G + (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);
+        return k * G + (int)blockIdx.x;
+    };
+    int cn = 0, h0 = 0, w0 = 0, d0 = 0, dend = 0;
+    v4u_t rsX;
+    __amdgpu_buffer_rsrc_t rsY;
+    unsigned bbase[NK];
+    unsigned vY[2];                                             // per-lane output base of the two classes (pw = 0, 1), BAD outside the volume
+    int lsw[2];                                                 // the lane's w border state for pw = 0, 1 (0 first, 1 interior, 2 last)
+    auto set_item = [&](int item) __attribute__((always_inline)) {
+        int c = item;
+        const int sg = c % a.nseg; c /= a.nseg;
+        const int wb = c % a.nbw; c /= a.nbw;
+        const int hb = c % a.nbh;
+        cn = c / a.nbh;
+        h0 = hb * TH; w0 = wb * TW;
+        d0 = sg * a.seg;
+        dend = min(a.D, d0 + a.seg);
+        rsX = rl_rsrc(a.x + (size_t)cn * sampX, (unsigned)sampX);
+        rsY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (size_t)cn * sampY), 0, (int)(unsigned)sampY, 0x00020000);
+#pragma unroll
+        for (int kk = 0; kk < KPP; ++kk) {
+            const int ji = wave + 4 * kk;
+            const int hv = (ji >> 1) * 16 + (lane & 15);
+            const int hh = hv / HW, hw = hv - hh * HW;
+            const int gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+            const bool ok = ji < NPI && hv < PLV && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
+            bbase[kk] = ok ? (unsigned)(gh * a.W + gw) * rowB + (unsigned)l_piece * 16u : BAD;
+        }
+        const int gw = w0 + (lane & 31);
+#pragma unroll
+        for (int pw = 0; pw < 2; ++pw) {
+            const int ow = 2 * gw + pw;
+            vY[pw] = gw < a.W ? (unsigned)ow * rowY + (unsigned)(co0 + 8 * (lane >> 5)) * 2u : BAD;
+            lsw[pw] = ow == 0 ? 0 : (ow == OW - 1 ? 2 : 1);
+        }
+    };
+    auto slot_of = [&](int q) -> int { return (q + 1) % NPL; };
+    auto piece_voff = [&](int q, int k) __attribute__((always_inline)) -> unsigned {
+        const int dg = d0 + q;
+        const unsigned dof = rl_opaque((unsigned)dg < (unsigned)a.D ? (unsigned)dg * planeB : BAD2);
+        return bbase[k] + dof;
+    };
+    auto piece_lds = [&](int q, int k) __attribute__((always_inline)) -> unsigned {
+        const int ji = wave + 4 * k;
+        const unsigned in_ring = (unsigned)(slot_of(q) * PB) + (unsigned)ji * 1024u;
+        if (4 * k + 3 < NPI) return rl_opaque(in_ring);
+        return rl_opaque(ji < NPI ? in_ring : (unsigned)(NPL * PB));
+    };
+    auto fetch_piece = [&](int q, int k) __attribute__((always_inline)) { rl_bload_lds16(piece_voff(q, k), rsX, lds0 + piece_lds(q, k)); };
+    auto load_xf = [&](float* sc, float* sh, float* sl) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = lxf[l_piece * 8 + e]; sh[e] = lxf[CIN + l_piece * 8 + e]; sl[e] = lxf[2 * CIN + l_piece * 8 + e]; }
+    };
+    auto finish_piece = [&](int q, int k) __attribute__((always_inline)) {       // (prologue only: the steps run the staged form)
+        float f[8], sc[8], sh[8], sl[8];
+        load_xf(sc, sh, sl);
+        uint4* p_ = (uint4*)(ring + piece_lds(q, k) + lane * 16);
+        const uint4 v = *p_;
+        rl_unpack8(v, f);
+        rl_lrelu_affine8(f, sc, sh, sl);
+        const uint4 t = rl_pack8(f);
+        const bool ok = piece_voff(q, k) < (unsigned)sampX;
+        *p_ = make_uint4(ok ? t.x : v.x, ok ? t.y : v.y, ok ? t.z : v.z, ok ? t.w : v.w);
+    };
+#ifdef BIU_DIAG
+    unsigned long long tprev_ = __builtin_readcyclecounter();
+    unsigned long long dsum_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t0c_ = tprev_, t0r_ = __builtin_amdgcn_s_memrealtime();
+#endif
+    // a half-step's MFMA groups: (td, tw, ks) -> 16 groups of 8 MFMAs; fragments of a group: the 5 halo rows at (plane td, kwv = pw + tw, ks)
+    constexpr int NGRP = 16, NF = 5, NMT = 128;
+    uint4 frb[2][NF];
+    auto load_frag1 = [&](uint4 (&fr)[NF], int s, int pw, int g, int j) __attribute__((always_inline)) {
+        const int td = g >> 3, tw = (g >> 2) & 1, ks = g & 3;
+        const char* pbase = ring + rl_opaque((unsigned)(slot_of(s + pd - 1 + td) * PB));
+        fr[j] = *(const uint4*)(pbase + fa[j * 3 + pw + tw] + ks * 512);
+    };
+    __syncthreads();
+    for (int kc = 0;; ++kc) {
+        const int item = item_of(kc);
+        if (item >= nitems) break;
+        set_item(item);
+        const int nsteps = dend - d0;
+        // prologue: planes -1, 0, 1 landed and transformed, plane 2 in flight (LA = 2)
+#pragma unroll
+        for (int u = 0; u < LA + 2; ++u)
+#pragma unroll
+            for (int k = 0; k < NK; ++k) fetch_piece(-1 + u, k);
+        rl_wait_vmcnt<(LA - 1) * NK>();
+        if constexpr (XF) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int k = 0; k < NK; ++k) finish_piece(-1 + u, k);
+        }
+        __syncthreads();
+        // ---- stage streams of a half-step (see k_conv_roll): O(i) i < 8: store piece i of the PREVIOUS half-step (2 stages); D(k): fetch piece k
+        // of plane s + LA + 1; X(k): transform piece k of plane s + 2.  Half 0 carries k = 0..3, half 1 k = 4..6.
+        constexpr int SO = 2, SX = XF ? 7 : 0;
+        uint4 park[NST];
+        uint4 o_piece = make_uint4(0, 0, 0, 0);
+        unsigned o_off = 0;
+        uint4 x_v = make_uint4(0, 0, 0, 0);
+        float x_f[8], x_t[8], x_u[8], x_sc[8], x_sh[8], x_sl[8];
+        floatx16 acc[TH];
+        auto row_off = [&](int dcv, int r, int hpw) __attribute__((always_inline)) -> unsigned {      // fine row (2 dcv + pd, 2 (h0 + r) + ph)
+            const int gh = h0 + r;
+            return rl_opaque((dcv < dend && dcv >= d0 && gh < a.H) ? (unsigned)(((2 * dcv + pd) * OH + 2 * gh + ph) * OW) * rowY : BAD2);
+        };
+        auto o_stage = [&](auto I_, auto ST_, int dcv, int hpw) __attribute__((always_inline)) {
+            constexpr int i = decltype(I_)::value, st = decltype(ST_)::value;
+            constexpr int r = i / 2, x2 = i % 2;
+            if constexpr (st == 0) {
+                o_off = vY[hpw] + row_off(dcv, r, hpw) + 32u * x2;
+                o_piece = park[i];
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(v4u_t{o_piece.x, o_piece.y, o_piece.z, o_piece.w}, rsY, (int)o_off, 0, 0);
+            }
+        };
+        auto x_stage = [&](int k, auto ST_, int q_fin) __attribute__((always_inline)) {
+            constexpr int st = decltype(ST_)::value;
+            if constexpr (st == 0) {
+                x_v = *(const uint4*)(ring + piece_lds(q_fin, k) + lane * 16);
+                load_xf(x_sc, x_sh, x_sl);
+            } else if constexpr (st == 1) {
+                rl_unpack8(x_v, x_f);
+            } else if constexpr (st == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const floatx2 v = {x_f[e], x_f[e + 1]}, sc2 = {x_sc[e], x_sc[e + 1]}, b = {x_sh[e], x_sh[e + 1]};
+                    const floatx2 t = __builtin_elementwise_fma(sc2, v, b);
+                    x_t[e] = t[0]; x_t[e + 1] = t[1];
+                }
+            } else if constexpr (st == 3) {
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const floatx2 t = {x_t[e], x_t[e + 1]}, l = {x_sl[e], x_sl[e + 1]};
+                    const floatx2 u = l * t;
+                    x_u[e] = u[0]; x_u[e + 1] = u[1];
+                }
+            } else if constexpr (st == 4) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x_f[e] = fmaxf(x_t[e], x_u[e]);
+            } else if constexpr (st == 5) {
+                const uint4 t = rl_pack8(x_f);
+                x_f[0] = __uint_as_float(t.x); x_f[1] = __uint_as_float(t.y); x_f[2] = __uint_as_float(t.z); x_f[3] = __uint_as_float(t.w);
+            } else {
+                const bool ok = piece_voff(q_fin, k) < (unsigned)sampX;
+                *(uint4*)(ring + piece_lds(q_fin, k) + lane * 16) =
+                    make_uint4(ok ? __float_as_uint(x_f[0]) : x_v.x, ok ? __float_as_uint(x_f[1]) : x_v.y, ok ? __float_as_uint(x_f[2]) : x_v.z,
+                               ok ? __float_as_uint(x_f[3]) : x_v.w);
+            }
+        };
+        // work list of half `HP` (compile time): items i = 0..7: O(i) [2 stages], then for i < NKH: D(KB + i) [1], X(KB + i) [SX]
+        auto half_step = [&](auto HP_, int s, int dprev, int hprev) __attribute__((always_inline)) {
+            constexpr int hp = decltype(HP_)::value;                      // = pw of this half
+            constexpr int KB = hp == 0 ? 0 : 4, NKH = hp == 0 ? 4 : NK - 4;
+            constexpr int WT = NST * SO + NKH * (1 + SX);
+            constexpr int MAXW = (WT + NMT - 1) / NMT + 1;
+            const int q_issue = s + LA + 1, q_fin = s + 2;
+            // accumulators start at bias_eff[state]: d / h states are wave-uniform per row, the w state is the lane's
+            {
+                const int od = 2 * (d0 + s) + pd;
+                const int sd = od == 0 ? 0 : (od == OD - 1 ? 2 : 1);
+#pragma unroll
+                for (int r = 0; r < TH; ++r) {
+                    const int oh = 2 * (h0 + r) + ph;
+                    const int sh = oh == 0 ? 0 : (oh >= OH - 1 ? 2 : 1);
+                    const float* row = lbe + ((sd * 3 + sh) * 3 + lsw[hp]) * M + 4 * (lane >> 5);
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const float4 b4 = *(const float4*)(row + 8 * g4);
+                        acc[r][4 * g4] = b4.x; acc[r][4 * g4 + 1] = b4.y; acc[r][4 * g4 + 2] = b4.z; acc[r][4 * g4 + 3] = b4.w;
+                    }
+                }
+            }
+            auto run_stage = [&](auto W_) __attribute__((always_inline)) {
+                constexpr int w = decltype(W_)::value;
+                rl_static_for<NST>([&](auto I_) {
+                    constexpr int i = decltype(I_)::value;
+                    constexpr int base = [] { int b = 0; for (int i2 = 0; i2 < i; ++i2) b += SO + (i2 < NKH ? 1 + SX : 0); return b; }();
+                    constexpr int sd_ = i < NKH ? 1 : 0, sx_ = i < NKH ? SX : 0;
+                    if constexpr (w >= base && w < base + SO) {
+                        o_stage(I_, std::integral_constant<int, w - base>{}, dprev, hprev);
+                    } else if constexpr (w >= base + SO && w < base + SO + sd_) {
+                        fetch_piece(q_issue, KB + i);
+                    } else if constexpr (w >= base + SO + sd_ && w < base + SO + sd_ + sx_) {
+                        x_stage(KB + i, std::integral_constant<int, w - base - SO - sd_>{}, q_fin);
+                    }
+                });
+            };
+            rl_static_for<NGRP>([&](auto G_) {
+                constexpr int g = decltype(G_)::value;
+                constexpr int td = g >> 3, tw = (g >> 2) & 1, ks = g & 3;
+                const uint4 (&fr)[NF] = frb[g & 1];
+                rl_static_for<8>([&](auto E_) {
+                    constexpr int th = decltype(E_)::value / 4, r = decltype(E_)::value % 4, j = decltype(E_)::value;
+                    constexpr int t = g * 8 + j;                                       // slot of the half-step
+                    if constexpr (g + 1 < NGRP && j < NF) load_frag1(frb[(g + 1) & 1], s, hp, g + 1, j);
+                    constexpr int lo = (t * WT) / NMT, hi = ((t + 1) * WT) / NMT;
+                    rl_static_for<MAXW>([&](auto DW_) {
+                        constexpr int w = lo + decltype(DW_)::value;
+                        if constexpr (w < hi) run_stage(std::integral_constant<int, w>{});
+                    });
+                    rl_mfma32(acc[r], wr[hp][td * 4 + th * 2 + tw][ks], fr[r + th]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+            // park the half-step's outputs in the storage type (bf16; the half-waves exchange channel groups so that a lane holds 16 bytes)
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+                const int r = i / 2, x2 = i % 2;
+                bf16x4 g0, g1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { g0[e] = (__bf16)acc[r][8 * x2 + e]; g1[e] = (__bf16)acc[r][8 * x2 + 4 + e]; }
+                const uint2 ua = __builtin_bit_cast(uint2, g0), ub = __builtin_bit_cast(uint2, g1);
+                const auto sx = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+                park[i] = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            }
+        };
+        // Vector-memory instructions of a wave per step, in issue order: half 0: O0 D0 O1 D1 O2 D2 O3 D3 O4 .. O7; half 1: O0 D4 O1 D5 O2 D6 O3 .. O7
+        for (int s = 0; s < nsteps; ++s) {
+            RL_STAMP(0);
+            // wait for this wave's pieces of plane s + 2 (issued by step s - 1, or by the prologue): behind its last piece D6 that step's O3 .. O7
+            if (s >= 1) rl_wait_vmcnt<5>(); else rl_wait_vmcnt<0>();
+            RL_STAMP(1);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) load_frag1(frb[0], s, 0, 0, j);
+            half_step(std::integral_constant<int, 0>{}, s, s > 0 ? d0 + s - 1 : -0x40000000, 1);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) load_frag1(frb[0], s, 1, 0, j);
+            half_step(std::integral_constant<int, 1>{}, s, d0 + s, 0);
+            RL_STAMP(2);
+            RL_STAMP(3);
+            __syncthreads();
+            RL_STAMP(4);
+#ifdef BIU_DIAG
+            dsum_[7] += 1;
+#endif
+        }
+        // the last half-step's stores
+        rl_static_for<NST>([&](auto I_) { rl_static_for<SO>([&](auto S_) { o_stage(I_, S_, d0 + nsteps - 1, 1); }); });
+        rl_wait_vmcnt<0>();
+        __syncthreads();
+    }
+#ifdef BIU_DIAG
+    if (a.diag && tid == 0) {
+        for (int q_ = 0; q_ < 8; ++q_) atomicAdd(a.diag + q_, dsum_[q_]);
+        atomicAdd(a.diag + 8, __builtin_readcyclecounter() - t0c_);
+        atomicAdd(a.diag + 9, __builtin_amdgcn_s_memrealtime() - t0r_);
+    }
+#endif
+}
+
+
 int roll_num_cus() {
     static int n = 0;
     if (!n) {
@@ -815,7 +1205,8 @@ struct RollPlan { int ok, m, ps, la, nbh, nbw, nseg, seg, grid, cols; size_t lds
 
 RollPlan roll_plan(const biu_act* x, const biu_act* y, int dtype, bool has_cat, int accumulate, bool red = false) {
     RollPlan p{};
-    if (roll_mode() == 0 || dtype != BIU_BF16 || has_cat || accumulate) return p;
+    if (roll_mode() == 0 || dtype != BIU_BF16 || has_cat) return p;
+    if (accumulate && (red || !(x->c == 32 && y->c == 32))) return p;      // the accumulate form: 32 -> 32 only (the skip half of a folded decoder level)
     const int cin = x->c, cout = y->c;
     if (!(cin == 16 || cin == 32)) return p;
     if (cout == 16 && cin == 32) p.m = 16;
@@ -863,9 +1254,9 @@ RollPlan roll_plan(const biu_act* x, const biu_act* y, int dtype, bool has_cat, 
     return p;
 }
 
-// REDF: 0 = only the forms without the BatchNorm-backward sums, 1 = only that form, 2 = all
-template <int CIN, int M, int PS, int LA, int REDF>
-int roll_launch(const RollArgs& a, const RollPlan& p, bool red, hipStream_t st) {
+// REDF: 0 = only the forms without the BatchNorm-backward sums, 1 = only that form, 2 = all; ACCF: the accumulate forms are built too
+template <int CIN, int M, int PS, int LA, int REDF, bool ACCF = false>
+int roll_launch(const RollArgs& a, const RollPlan& p, bool red, hipStream_t st, bool acc = false) {
     auto go = [&](auto kern) -> int {
         static size_t attr_set = 0;
         if (attr_set < p.lds) {
@@ -878,6 +1269,13 @@ int roll_launch(const RollArgs& a, const RollPlan& p, bool red, hipStream_t st) 
         return BIU_OK;
     };
     const bool xf = a.xs != nullptr;
+    if constexpr (ACCF) {
+        if (acc && !red) {
+            if (a.bn_partial) return xf ? go(k_conv_roll<CIN, M, PS, LA, 1, true, true>) : go(k_conv_roll<CIN, M, PS, LA, 1, false, true>);
+            return xf ? go(k_conv_roll<CIN, M, PS, LA, 0, true, true>) : go(k_conv_roll<CIN, M, PS, LA, 0, false, true>);
+        }
+    }
+    if (acc) return biu_fail(BIU_ERR_UNSUPPORTED, "conv_roll: no accumulate form for %d input channels on the %d-row shape", CIN, M);
     if constexpr (REDF >= 1) {
         if (red) return xf ? go(k_conv_roll<CIN, M, PS, LA, 2, true>) : go(k_conv_roll<CIN, M, PS, LA, 2, false>);
     }
@@ -888,7 +1286,68 @@ int roll_launch(const RollArgs& a, const RollPlan& p, bool red, hipStream_t st) 
     return biu_fail(BIU_ERR_UNSUPPORTED, "conv_roll: this epilogue form is not built for %d input channels on the %d-row shape", CIN, M);
 }
 
+struct FoldPlan { int ok, nbh, nbw, nseg, seg, grid; size_t lds; };
+FoldPlan fold_plan(const biu_act* x_low, const biu_act* y, int dtype) {
+    FoldPlan p{};
+    if (roll_mode() == 0 || dtype != BIU_BF16 || x_low->c != 64 || y->c != 32) return p;
+    if (y->n != x_low->n || y->d != 2 * x_low->d || y->h != 2 * x_low->h || y->w != 2 * x_low->w || x_low->d < 2) return p;
+    const long long lim = 1LL << 30;
+    if ((long long)x_low->d * x_low->h * x_low->w * x_low->pitch * 2 >= lim || (long long)y->d * y->h * y->w * y->pitch * 2 >= lim) return p;
+    if ((uintptr_t)x_low->p % 16 || (uintptr_t)y->p % 16 || (x_low->pitch * 2) % 16 || (y->pitch * 2) % 16) return p;
+    p.lds = (size_t)5 * FR_NBLK * 2048 + 1024 + (size_t)(3 * 64 + 27 * 32) * sizeof(float);
+    p.nbh = (x_low->h + FR_TH - 1) / FR_TH;
+    p.nbw = (x_low->w + FR_TW - 1) / FR_TW;
+    const int ncols = x_low->n * p.nbh * p.nbw, budget = roll_num_cus();
+    int nseg = 1;
+    while (ncols * nseg < budget && (x_low->d / (nseg * 2)) >= 8) nseg *= 2;
+    int seg = (x_low->d + nseg - 1) / nseg;
+    nseg = (x_low->d + seg - 1) / seg;
+    p.nseg = nseg; p.seg = seg;
+    const int items = ncols * nseg;
+    p.grid = items < budget ? items : budget;
+    if ((p.grid & 7) != 0 && p.grid > 8) p.grid &= ~7;
+    if (roll_mode() != 2) {
+        const double cover = (double)x_low->h * x_low->w / ((double)p.nbh * FR_TH * p.nbw * FR_TW);
+        if (cover < 0.75 || items * 2 < roll_num_cus() || x_low->d < 16) return FoldPlan{};
+    }
+    p.ok = 1;
+    return p;
+}
+
 }  // namespace
+
+// The up half of a folded decoder level as the first writer of y (k_fold_roll): 64 -> 32 channels, bf16.
+bool biu_fold_roll_ok(const biu_act* x_low, const biu_act* y, int dtype) { return fold_plan(x_low, y, dtype).ok != 0; }
+int biu_fold_roll(const biu_act* x_low, const biu_xform* xf, const void* packed_fwd, const float* bias_sum, const float* fix, const biu_act* y, hipStream_t st) {
+    const FoldPlan p = fold_plan(x_low, y, BIU_BF16);
+    BIU_REQUIRE(p.ok, BIU_ERR_UNSUPPORTED, "fold_roll: shape not served");
+    FoldArgs a;
+    a.x = (const char*)x_low->p; a.y = (char*)y->p; a.wpk = (const uint4*)packed_fwd; a.bias = bias_sum; a.fix = fix;
+    const bool has = xf && (xf->scale || xf->shift || xf->slope);
+    if (has) BIU_REQUIRE(xf->scale && xf->shift && xf->slope, BIU_ERR_UNSUPPORTED, "fold_roll: partial biu_xform (need all three vectors)");
+    a.xs = has ? xf->scale : nullptr; a.xb = has ? xf->shift : nullptr; a.xl = has ? xf->slope : nullptr;
+    a.xpitch = x_low->pitch; a.ypitch = y->pitch;
+    a.N = x_low->n; a.D = x_low->d; a.H = x_low->h; a.W = x_low->w;
+    a.Cout = y->c;
+    a.nbh = p.nbh; a.nbw = p.nbw; a.nseg = p.nseg; a.seg = p.seg;
+#ifdef BIU_DIAG
+    a.diag = biu_diag_buffer;
+#else
+    a.diag = nullptr;
+#endif
+    auto go = [&](auto kern) -> int {
+        static size_t attr_set = 0;
+        if (attr_set < p.lds) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) != hipSuccess)
+                return biu_fail(BIU_ERR_LAUNCH, "fold_roll: cannot reserve %zu bytes of LDS", p.lds);
+            attr_set = p.lds;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)p.grid, 1), dim3(256), p.lds, st, a);
+        BIU_CHECK_LAUNCH("fold_roll");
+        return BIU_OK;
+    };
+    return has ? go(k_fold_roll<2, true>) : go(k_fold_roll<2, false>);
+}
 
 bool biu_conv_roll_ok(const biu_act* x, const biu_act* y, int dtype, bool has_cat, int accumulate, bool red) { return roll_plan(x, y, dtype, has_cat, accumulate, red).ok != 0; }
 int biu_conv_roll_mshape(const biu_act* x, const biu_act* y, int dtype) { return roll_plan(x, y, dtype, false, 0).m; }
@@ -897,8 +1356,8 @@ int biu_conv_roll_rows(const biu_act* x, const biu_act* y, int dtype) { return r
 
 // `packed`: the fragment image of the MFMA shape the plan picked (biu_conv_roll_mshape: 32 = k_pack_weights' image, 16 = k_pack_weights16's)
 int biu_conv_roll(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, const biu_act* y, float* bn_partial, const BnRedFuse* red,
-                  hipStream_t st) {
-    const RollPlan p = roll_plan(x, y, BIU_BF16, false, 0, red != nullptr);
+                  hipStream_t st, int accumulate) {
+    const RollPlan p = roll_plan(x, y, BIU_BF16, false, accumulate, red != nullptr);
     BIU_REQUIRE(p.ok, BIU_ERR_UNSUPPORTED, "conv_roll: shape not served");
     RollArgs a;
     a.x = (const char*)x->p; a.y = (char*)y->p; a.wpk = (const uint4*)packed; a.bias = bias;
@@ -927,7 +1386,7 @@ int biu_conv_roll(const biu_act* x, const biu_xform* xf, const void* packed, con
         BIU_REQUIRE(rb < (1LL << 30) && (uintptr_t)red->y->p % 16 == 0 && (red->y->pitch * 2) % 16 == 0, BIU_ERR_UNSUPPORTED,
                     "conv_roll: the upstream output must be 16-byte aligned with samples under 2^30 bytes");
     }
-    if (x->c == 32 && p.m == 32) return roll_launch<32, 32, 1, 3, 0>(a, p, r, st);
+    if (x->c == 32 && p.m == 32) return roll_launch<32, 32, 1, 3, 0, true>(a, p, r, st, accumulate != 0);
     if (x->c == 32 && p.m == 16) return roll_launch<32, 16, 1, 4, 2>(a, p, r, st);
     if (x->c == 16 && p.m == 32) return r ? roll_launch<16, 32, 1, 4, 1>(a, p, r, st) : roll_launch<16, 32, 2, 3, 0>(a, p, r, st);
     return biu_fail(BIU_ERR_UNSUPPORTED, "conv_roll: no instantiation for %d -> %d channels", x->c, y->c);

@@ -41,7 +41,10 @@ bool biu_conv_roll_ok(const biu_act* x, const biu_act* y, int dtype, bool has_ca
 int biu_conv_roll_mshape(const biu_act* x, const biu_act* y, int dtype);       // 32 | 16: which packed fragment image the launch reads
 int biu_conv_roll_rows(const biu_act* x, const biu_act* y, int dtype);         // partial rows of its epilogue sums (= blocks per column)
 int biu_conv_roll(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, const biu_act* y, float* bn_partial, const BnRedFuse* red,
-                  hipStream_t st);
+                  hipStream_t st, int accumulate = 0);
+// the up half of a folded decoder level (64 -> 32 channels) as the first writer of y: composed 8-class weights in registers, border-state bias table
+bool biu_fold_roll_ok(const biu_act* x_low, const biu_act* y, int dtype);
+int biu_fold_roll(const biu_act* x_low, const biu_xform* xf, const void* packed_fwd, const float* bias_sum, const float* fix, const biu_act* y, hipStream_t st);
 size_t biu_mfma_conv_split_bytes(int cin, const biu_act* y, const biu_act* y1, int kd, int dtype);   // 0: the launch is not split
 int biu_mfma_convt_dgrad_bricks(const biu_act* dx, int kd);
 int biu_mfma_convt_dgrad_rows(const biu_act* dx, int kd);
@@ -82,7 +85,7 @@ bool biu_mfma_foldt_worth(const biu_act* x_low, const biu_act* y);
 size_t biu_mfma_foldt_packed_bytes(int cin_low, int cskip, int cout, int dtype);
 int biu_mfma_foldt_pack(const float* w_conv, const float* b_conv, const float* w_t, const float* b_t, int cin_low, int cup, int cskip, int cout, int dtype,
                         void* packed, hipStream_t st);
-int biu_mfma_foldt_stat_rows(const biu_act* x_low, const biu_act* y);
+int biu_mfma_foldt_stat_rows(const biu_act* x_low, const biu_act* y, const biu_act* skip = nullptr, int dtype = -1);
 int biu_mfma_foldt_fwd(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const void* packed, const biu_act* y,
                        float* bn_partial, int dtype, hipStream_t st);
 int biu_mfma_foldt_dgrad(const biu_act* dy, const void* packed, const biu_act* dx_low, int acc_low, const biu_act* dskip, int acc_skip, int dtype,

@@ -63,7 +63,8 @@ class GradAverager:
     torch DDP users get too).  Gradient ACCUMULATION is supported: when a hook fires for a parameter whose ``p.grad`` already
     holds something (second ``backward()`` before ``average()``, or ``zero_grad(set_to_none=False)`` / last step's bucket views
     still installed), autograd is about to add into ``p.grad`` in place, so that bucket is not launched early (an in-flight
-    all-reduce of it is waited for and dropped) and ``average()`` takes the whole bucket from ``p.grad``."""
+    all-reduce of it is waited for: the bucket -- which IS ``p.grad``'s memory -- then holds the mean of the first gradients, the new local
+    gradient is added on top, and the second all-reduce of ``average()`` turns the sum into mean + mean)."""
 
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 8.0):
         self.params: List[torch.nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
@@ -112,6 +113,15 @@ class GradAverager:
     def _launch(self, b: _Bucket):
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if self._avg_op else dist.ReduceOp.SUM, async_op=True)
 
+    def _wait(self, b: _Bucket):
+        """Completes the bucket's all-reduce: the bucket then holds the MEAN over the ranks (RCCL averages in the collective, gloo sums and is
+        scaled here).  p.grad aliases the bucket, so a gradient accumulated on top of an already reduced bucket (second backward before
+        average()) stays right: mean(g1) + g2_local is reduced again to mean(g1) + mean(g2)."""
+        b.work.wait()
+        b.work = None
+        if not self._avg_op:
+            b.flat.mul_(1.0 / self.world)
+
     def _alloc(self, p: torch.nn.Parameter):
         """Destination of the gradient the engine is about to compute for ``p``: a FRESH view of its bucket slot (a fresh tensor object, so
         that autograd's AccumulateGrad takes it as ``p.grad`` instead of cloning it), or None when the gradient cannot live there --
@@ -139,8 +149,7 @@ class GradAverager:
             # b.flat): wait out an early launch, and let average() read the whole bucket from p.grad.
             b.late = True
             if b.work is not None:
-                b.work.wait()
-                b.work = None
+                self._wait(b)
             return
         if g.data_ptr() != b.views[i].data_ptr():        # (a gradient the engine could not write in place: shared weights, the zero conv biases)
             b.views[i].copy_(g)
@@ -168,9 +177,7 @@ class GradAverager:
                         b.views[i].copy_(g)
                 self._launch(b)
         for b in self.buckets:
-            b.work.wait()
-            if not self._avg_op:
-                b.flat.mul_(1.0 / self.world)
+            self._wait(b)
             for p, v in zip(b.params, b.views):
                 if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                     p.grad = v

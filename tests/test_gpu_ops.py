@@ -631,6 +631,8 @@ def test_upconv_bwd_weight_matches_the_unfolded_weight_gradient(case, dtype):
 FOLDT_CASES = [
     # (N, Cin_low, Cup, Cskip, Cout, coarse extent)
     (1, 64, 64, 32, 32, (4, 8, 16)),          # decode5 of UNet3D(n_filter = 32)
+    (2, 64, 64, 32, 32, (5, 6, 19)),          # the same widths off the window: bf16 takes the rolling-window form (k_fold_roll + accumulating skip half)
+    (1, 64, 64, 32, 32, (18, 9, 40)),         # ... with depth segments and two windows along W
     (2, 32, 32, 16, 32, (3, 5, 9)),
     (1, 128, 128, 64, 64, (2, 4, 8)),         # decode3
     (1, 48, 32, 32, 64, (5, 3, 7)),
