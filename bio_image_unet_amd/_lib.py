@@ -109,6 +109,7 @@ SIGNATURES = {
     "biu_foldt_packed_bytes": (_Z, [_I, _I, _I, _I]),
     "biu_foldt_pack": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "biu_foldt_fwd_stats_floats": (_Z, [_A, _A]),
+    "biu_foldt_fwd_form": (_I, [_A, _A, _A, _I]),
     "biu_foldt_fwd": (_I, [_A, _X, _A, _X, _P, _A, _P, _Z, C.POINTER(C.c_int), _I, _P]),
     "biu_foldt_bwd_data_bnred_floats": (_Z, [_A]),
     "biu_foldt_bwd_data": (_I, [_A, _P, _A, _I, _A, _I, _A, _P, _P, _P, _P, _P, _P, _Z, C.POINTER(C.c_int), _P, _Z, _I, _P]),

@@ -404,6 +404,13 @@ extern "C" int biu_foldt_pack(const float* w_conv, const float* b_conv, const fl
     BIU_REQUIRE(w_conv && w_t && packed && cin_low > 0 && cup > 0 && cskip > 0 && cout > 0, BIU_ERR_SHAPE, "foldt_pack: null pointer or empty shape");
     return biu_mfma_foldt_pack(w_conv, b_conv, w_t, b_t, cin_low, cup, cskip, cout, dtype, packed, (hipStream_t)stream);
 }
+// which form biu_foldt_fwd takes for these tensors: 0 = brick kernels (skip half + biases stored, border shell corrected, fold accumulated on top),
+// 1 = rolling-window kernels (fold + border-state bias stored first, the skip half accumulated onto it): the two round intermediate results at
+// different places, which a checker that models the storage roundings must know (tests/insitu.py)
+extern "C" int biu_foldt_fwd_form(const biu_act* x_low, const biu_act* skip, const biu_act* y, int dtype) {
+    if (!x_low || !skip || !y) return 0;
+    return biu_mfma_foldt_form(x_low, skip, y, dtype);
+}
 extern "C" size_t biu_foldt_fwd_stats_floats(const biu_act* x_low, const biu_act* y) {
     // (an upper bound over the forms the launch can take: 8 rows per block of the brick form, at most one row per CU x 4 of the rolling one)
     const size_t a = (size_t)biu_mfma_foldt_stat_rows(x_low, y) * y->c * 2, b = (size_t)1024 * y->c * 2;

@@ -2495,6 +2495,7 @@ static bool foldt_roll_ok(const biu_act* x_low, const biu_act* skip, const biu_a
     if (off < 0) { const char* e = getenv("BIU_DISABLE"); off = (e && strstr(e, "froll")) ? 1 : 0; }
     return !off && skip && biu_fold_roll_ok(x_low, y, dtype) && biu_conv_roll_ok(skip, y, dtype, false, 1, false);
 }
+int biu_mfma_foldt_form(const biu_act* x_low, const biu_act* skip, const biu_act* y, int dtype) { return foldt_roll_ok(x_low, skip, y, dtype) ? 1 : 0; }
 int biu_mfma_foldt_stat_rows(const biu_act* x_low, const biu_act* y, const biu_act* skip, int dtype) {
     if (skip && foldt_roll_ok(x_low, skip, y, dtype)) return biu_conv_roll_rows(skip, y, dtype);
     return biu_mfma_upconv_stat_rows(x_low, y);

@@ -86,6 +86,7 @@ size_t biu_mfma_foldt_packed_bytes(int cin_low, int cskip, int cout, int dtype);
 int biu_mfma_foldt_pack(const float* w_conv, const float* b_conv, const float* w_t, const float* b_t, int cin_low, int cup, int cskip, int cout, int dtype,
                         void* packed, hipStream_t st);
 int biu_mfma_foldt_stat_rows(const biu_act* x_low, const biu_act* y, const biu_act* skip = nullptr, int dtype = -1);
+int biu_mfma_foldt_form(const biu_act* x_low, const biu_act* skip, const biu_act* y, int dtype);
 int biu_mfma_foldt_fwd(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const void* packed, const biu_act* y,
                        float* bn_partial, int dtype, hipStream_t st);
 int biu_mfma_foldt_dgrad(const biu_act* dy, const void* packed, const biu_act* dx_low, int acc_low, const biu_act* dskip, int acc_skip, int dtype,

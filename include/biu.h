@@ -355,6 +355,10 @@ size_t biu_foldt_packed_bytes(int cin_low, int cskip, int cout, int dtype);
 int    biu_foldt_pack(const float* w_conv, const float* b_conv, const float* w_t, const float* b_t, int cin_low, int cup, int cskip, int cout,
                       int dtype, void* packed, biu_stream stream);
 size_t biu_foldt_fwd_stats_floats(const biu_act* x_low, const biu_act* y);
+/* which form biu_foldt_fwd takes: 0 = brick kernels (the skip half + biases stored, the border shell corrected, the fold accumulated on top);
+ * 1 = rolling-window kernels for 64 -> 32 | 32-channel levels (the fold + border-state bias stored first, the skip half accumulated onto it and
+ * rounded once).  Same function; the storage roundings of the intermediate differ (a bit-level checker needs to know: tests/insitu.py). */
+int    biu_foldt_fwd_form(const biu_act* x_low, const biu_act* skip, const biu_act* y, int dtype);
 int    biu_foldt_fwd(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const void* packed,
                      const biu_act* y, float* bn_partial, size_t bn_partial_floats, int* bn_nblk, int dtype, biu_stream stream);
 /* backward of the same op.  biu_foldt_bwd_data: d skip (the conv's data gradient restricted to the skip channels) and d x_low (the composed fold

@@ -20,6 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from bio_image_unet_amd import engine as E
+from bio_image_unet_amd._lib import lib
 
 LRELU = E.LRELU_SLOPE
 
@@ -190,14 +191,17 @@ class InSitu:
         xs = _r(act_T(skip).float(), self.bf16).double()
         cout, cl = wc.shape[0], wt.shape[0]
         wb = torch.einsum("ocdhw,c->odhw", wc[:, :cup].double(), bt)                       # Wb[co][k]
-        y1 = F.conv3d(xs, _r(wc[:, cup:], self.bf16).double(), (bc + wb.sum(dim=(1, 2, 3))).float().double(), padding=1)
-        y1 = _r(y1.float(), self.bf16).double()
+        form = lib.biu_foldt_fwd_form(lo.a(), skip.a(), nd.y.a(), nd.y.buf.eng.dtype)     # 1: rolling-window kernels (the fold is stored first)
+        y1 = F.conv3d(xs, _r(wc[:, cup:], self.bf16).double(), None if form == 1 else (bc + wb.sum(dim=(1, 2, 3))).float().double(), padding=1)
+        if form != 1:
+            y1 = _r(y1.float(), self.bf16).double()
         # taps outside the tensor carry no ConvT bias: subtract them on the border shell
         n, _, d2, h2, w2 = y1.shape
         ones = torch.ones(1, 1, d2, h2, w2, dtype=torch.float64)
         inside = torch.stack([F.conv3d(ones, torch.eye(27, dtype=torch.float64)[k].view(1, 1, 3, 3, 3), padding=1)[0, 0] for k in range(27)])   # [27][d][h][w]
         fix = torch.einsum("ok,kdhw->odhw", wb.reshape(cout, 27), 1.0 - inside)
-        y1 = _r((y1 - fix.unsqueeze(0)).float(), self.bf16).double()
+        if form != 1:
+            y1 = _r((y1 - fix.unsqueeze(0)).float(), self.bf16).double()
         cls = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}
         xp = F.pad(xl, (1, 1, 1, 1, 1, 1))
         d, h, w_ = xl.shape[2:]
@@ -218,6 +222,11 @@ class InSitu:
                                             acc = acc + wc[:, :cup, kd, kh, kw] @ wtv[:, :, q].t()
                                 k8[:, :, td, th, tw] = acc
                     fold[:, :, pd::2, ph::2, pw::2] = F.conv3d(xp[:, :, pd:pd + d + 1, ph:ph + h + 1, pw:pw + w_ + 1], _r(k8, self.bf16).double())
+        if form == 1:
+            # the fold with the border-state bias (an fp32 table: b_conv + sum_k Wb[k] - the Wb[k] of the taps outside) is the stored
+            # intermediate; the skip half is added in fp32 and the sum rounded once
+            base = (bc + wb.sum(dim=(1, 2, 3))).float().double().view(1, -1, 1, 1, 1) - fix.float().double().unsqueeze(0)
+            return _r((fold + base).float(), self.bf16).double() + y1
         return y1 + fold
 
     def _foldt_cat(self, nd, round_inputs):
