@@ -30,7 +30,7 @@ import torch  # noqa: E402
 
 HBM_PEAK = 8.0e12            # B/s   (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
 MFMA_PEAK = {"bf16": 2.5e15, "f32": 157.3e12}
-# --fp32-products (fp32 workloads only): how the 2-D 3x3 kernels multiply fp32 tensors.  bf16x6 (the library's default): six
+# --fp32-products (fp32 workloads only; profiles/HISTORY.md 3.4): how the 2-D 3x3 kernels multiply fp32 tensors.  bf16x6 (the library's default): six
 # bf16 MFMA terms per product, fp32-grade; exact: the fp32 MFMA; bf16x3 (opt-in): three terms, <= 2^-15 per product.  The ceiling of
 # the split launches is the bf16 dense peak over their number of terms.
 
@@ -123,7 +123,7 @@ def make_step(wl, device, graph=False):
 
 def call_cost(eng, api, label, executed=False):
     """Algorithmic FLOPs and bytes (SURVEY.md 8d convention: the work of the reference ops the call stands for) of one C-ABI call, from the
-    node's shapes.  ``executed=True``: the FLOPs the kernels actually issue -- fewer for the folded decoder ops (DESIGN.md 3.5), which compute
+    node's shapes.  ``executed=True``: the FLOPs the kernels actually issue -- fewer for the folded decoder ops (DESIGN.md 3.4), which compute
     the same function with 8 parity classes x 8 coarse taps instead of 27 fine taps on the up-sampled channels."""
     from bio_image_unet_amd import engine as E
     esz = 2 if eng.tdtype == torch.bfloat16 else 4
@@ -314,7 +314,7 @@ def main():
         with open(args.breakdown, "w") as f:
             f.write(f"# per-launch HIP-event times of one profiled step, workload {args.workload}; sum = {total_kernel_ms:.3f} ms\n")
             f.write("# TFLOP/s (executed) and GB/s: the FLOPs the kernels of the call ISSUE and its algorithmic bytes (SURVEY 8d) -- hardware utilisation; "
-                    "'alg': the FLOPs of the reference ops the call stands for (larger for the folded decoder calls biu_foldt_*, biu_upconv_*: DESIGN.md 3.5); "
+                    "'alg': the FLOPs of the reference ops the call stands for (larger for the folded decoder calls biu_foldt_*, biu_upconv_*: DESIGN.md 3.4); "
                     "'roof': max(executed FLOP / MFMA peak, bytes / 8 TB/s) / time\n")
             for ms, (api, label) in rows:
                 fl, by = call_cost(eng, api, label)
@@ -416,7 +416,7 @@ def main():
     roof["frac"] = roof["achieved"] / roof["peak"]
     if fl_alg != fl and fl > 0:
         roof["algorithmic_equivalent"] = {"TFLOP_per_call": fl_alg / 1e12, "TFLOPps": fl_alg / (dom_launch_ms * 1e-3) / 1e12,
-                                          "note": "folded op (DESIGN.md 3.5): the kernels issue 8 parity classes x 2x2x2 coarse taps instead of 27 fine taps on the "
+                                          "note": "folded op (DESIGN.md 3.4): the kernels issue 8 parity classes x 2x2x2 coarse taps instead of 27 fine taps on the "
                                                   "up-sampled channels; `achieved` / `frac` count the issued FLOPs, this entry the FLOPs of the reference ops "
                                                   "(Conv3d on all concat channels + ConvTranspose3d) the call replaces -- not a utilisation figure"}
     roof["traffic"] = None          # HBM bytes per launch from PMC counters (tools/pmc_traffic.py), when measured for this call

@@ -3390,8 +3390,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // MFMA's result belong to plane 0 and rows 16-31 to plane 1: against halo plane j of the tapped operand that is depth tap kd = j for the upper
 // half and kd = j - 1 for the lower one.  Four halo planes x 9 (kh, kw) = 36 accumulators cover all 27 taps of both planes with 288 MFMAs per
 // step instead of 432; unit (j, kw): waves 0-3 own (w, 0) and (w, 2), waves 4-7 own (w - 4, 1) -- 72 MFMAs per SIMD and step.
-template <bool BNF, bool K2D, bool A16 = false>
-__global__ __launch_bounds__(512, 2) void k_wgrad_roll(WgradArgs a) {
+// PC (round 4): producer / consumer waves.  The block has 16 waves: waves 0-7 only multiply (fragment reads + MFMAs, no vector-memory
+// instruction in their stream), waves 8-15 own the fetch pipeline of wave - 8 (LDS-DMA issue, counted wait, in-place producer transform,
+// fused BatchNorm backward + dy write-back).  A vector-memory instruction holds the ISSUING wave for ~50 cycles while the CU's single
+// address path drains the other waves' requests (profiles/r04_roll_ablation.txt); in the 8-wave form those cycles came out of the MFMA
+// rows of both waves of a SIMD.  Same registers per wave (128: 4 waves per SIMD), same LDS, same arithmetic and rounding.
+template <bool BNF, bool K2D, bool A16 = false, bool PC = false>
+__global__ __launch_bounds__(PC ? 1024 : 512, PC ? 1 : 2) void k_wgrad_roll(WgradArgs a) {
     static_assert(!(K2D && A16), "the 16-channel plain operand form exists for volumes only");
     using T = bf16_t;
     using F = Frag<T>;
@@ -3407,7 +3412,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_roll(WgradArgs a) {
     constexpr int LB = 0, LBN = 3 * CT;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_prod = PC && wave_all >= 8;            // (wave-uniform)
+    const int wave = wave_all & 7;                       // consumer: owner of taps; producer: owner of the DMA pieces of wave & 7
     const int it = blockIdx.y / a.jt_count, jt = a.jt_begin + blockIdx.y % a.jt_count;
     const int piece = lane & 3;
     const int apc = A16 ? (piece & 1) : piece;           // channel piece of the plain operand this lane stages (A16: pieces 2, 3 are plane 1)
@@ -3754,6 +3761,20 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_roll(WgradArgs a) {
         RSTAMP(0);
         const FetchCtx fc = fetch_ctx((s + 3) & 3, 2 * s + 5, (s + 2) % 3, 2 * s + 4);
         RSTAMP(1);
+        if constexpr (PC) {
+            if (is_prod) {
+                if (f2) fetch_all(mine, fc, true);
+                if (f1) {
+                    wait_older(f2);
+                    finish(other, (s + 2) & 3, (s + 1) % 3, 2 * s + 2, true);
+                }
+            } else {
+                auto issue = [&](int) __attribute__((always_inline)) {};
+                if (has_x) mfma_step(std::true_type{}, s & 3, s % 3, issue); else mfma_step(std::false_type{}, s & 3, s % 3, issue);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            RSTAMP(2);
+        } else {
         auto issue = [&](int i) __attribute__((always_inline)) { if (f2) fetch_piece(mine, fc, i); };           // block-uniform f2
         if (has_x) mfma_step(std::true_type{}, s & 3, s % 3, issue); else mfma_step(std::false_type{}, s & 3, s % 3, issue);
         __builtin_amdgcn_sched_barrier(0);
@@ -3762,6 +3783,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_roll(WgradArgs a) {
             wait_older(f2);
             RSTAMP(3);
             finish(other, (s + 2) & 3, (s + 1) % 3, 2 * s + 2, true);
+        }
         }
         RSTAMP(4);
         __syncthreads();
@@ -3777,13 +3799,15 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_roll(WgradArgs a) {
         set_column(col);
         // prologue: planes -1, 0 -> pair 0 (finished at once); step 0: planes 1, 2 -> pair 1 + A buffer 0 (slot 0); step 1: planes 3, 4 ->
         // pair 2 + A buffer 1 (slot 1)
-        fetch_all(sl0, fetch_ctx(0, -1, 0, 0), false);
-        wait_vmcnt<0>();
-        finish(sl0, 0, 0, 0, false);
-        fetch_all(sl0, fetch_ctx(1, 1, 0, 0), true);
-        if (nsteps > 1) fetch_all(sl1, fetch_ctx(2, 3, 1, 2), true);
-        wait_vmcnt<0>();
-        finish(sl0, 1, 0, 0, true);                      // (step 1's fetch, slot 1, is finished by step 0 like every later one)
+        if (!PC || is_prod) {
+            fetch_all(sl0, fetch_ctx(0, -1, 0, 0), false);
+            wait_vmcnt<0>();
+            finish(sl0, 0, 0, 0, false);
+            fetch_all(sl0, fetch_ctx(1, 1, 0, 0), true);
+            if (nsteps > 1) fetch_all(sl1, fetch_ctx(2, 3, 1, 2), true);
+            wait_vmcnt<0>();
+            finish(sl0, 1, 0, 0, true);                  // (step 1's fetch, slot 1, is finished by step 0 like every later one)
+        }
         __syncthreads();
         for (int s = 0; s < nsteps; s += 2) {
             step(sl0, sl1, s);
@@ -3799,6 +3823,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_roll(WgradArgs a) {
     }
 #endif
     // ---- flush once per block (k_wgrad_pipe's layout: ws[tap][i][j], two 128-B segments per wave-instruction) ----------------------
+    if (is_prod) return;
     const int hf = lane >> 5;
     const int jj = jt * CT + (lane & 31);
     if constexpr (A16) {
@@ -3878,15 +3903,19 @@ static int launch_wgrad_roll(WgradArgs a, hipStream_t st, bool k2d = false) {
 #else
     a.diag = nullptr;
 #endif
+    static int pc_on = -1;               // producer / consumer waves (16-wave blocks) unless BIU_DISABLE=wpc
+    if (pc_on < 0) { const char* e = getenv("BIU_DISABLE"); pc_on = (e && strstr(e, "wpc")) ? 0 : 1; }
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_wgrad_roll<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_wgrad_roll<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_wgrad_roll<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_wgrad_roll<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_wgrad_roll<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_wgrad_roll<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess)
-            return biu_fail(BIU_ERR_LAUNCH, "wgrad_roll: cannot reserve %zu bytes of LDS", WR_LDS);
+        bool ok = true;
+        auto reserve = [&](const void* f) { ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) == hipSuccess; };
+        reserve((const void*)k_wgrad_roll<false, false>); reserve((const void*)k_wgrad_roll<true, false>);
+        reserve((const void*)k_wgrad_roll<false, true>); reserve((const void*)k_wgrad_roll<true, true>);
+        reserve((const void*)k_wgrad_roll<false, false, true>); reserve((const void*)k_wgrad_roll<true, false, true>);
+        reserve((const void*)k_wgrad_roll<false, false, false, true>); reserve((const void*)k_wgrad_roll<true, false, false, true>);
+        reserve((const void*)k_wgrad_roll<false, true, false, true>); reserve((const void*)k_wgrad_roll<true, true, false, true>);
+        reserve((const void*)k_wgrad_roll<false, false, true, true>); reserve((const void*)k_wgrad_roll<true, false, true, true>);
+        if (!ok) return biu_fail(BIU_ERR_LAUNCH, "wgrad_roll: cannot reserve %zu bytes of LDS", WR_LDS);
         attr_set = true;
     }
     auto launch = [&](int jt_begin, int jt_count, int write_back, bool with_bn) {
@@ -3898,15 +3927,27 @@ static int launch_wgrad_roll(WgradArgs a, hipStream_t st, bool k2d = false) {
         if (g >= 16) g = grid_per_column(num_cus(), pairs);
         if (g < 1) g = 1;
         if (g > ncols) g = ncols;
-        if (k2d) {
-            if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, true>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
-            else hipLaunchKernelGGL((k_wgrad_roll<false, true>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
+        const dim3 gr(g, pairs);
+        if (pc_on) {
+            if (k2d) {
+                if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, true, false, true>), gr, dim3(1024), WR_LDS, st, b);
+                else hipLaunchKernelGGL((k_wgrad_roll<false, true, false, true>), gr, dim3(1024), WR_LDS, st, b);
+            } else if (a16) {
+                if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, false, true, true>), gr, dim3(1024), WR_LDS, st, b);
+                else hipLaunchKernelGGL((k_wgrad_roll<false, false, true, true>), gr, dim3(1024), WR_LDS, st, b);
+            } else {
+                if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, false, false, true>), gr, dim3(1024), WR_LDS, st, b);
+                else hipLaunchKernelGGL((k_wgrad_roll<false, false, false, true>), gr, dim3(1024), WR_LDS, st, b);
+            }
+        } else if (k2d) {
+            if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, true>), gr, dim3(512), WR_LDS, st, b);
+            else hipLaunchKernelGGL((k_wgrad_roll<false, true>), gr, dim3(512), WR_LDS, st, b);
         } else if (a16) {
-            if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, false, true>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
-            else hipLaunchKernelGGL((k_wgrad_roll<false, false, true>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
+            if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, false, true>), gr, dim3(512), WR_LDS, st, b);
+            else hipLaunchKernelGGL((k_wgrad_roll<false, false, true>), gr, dim3(512), WR_LDS, st, b);
         } else {
-            if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, false>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
-            else hipLaunchKernelGGL((k_wgrad_roll<false, false>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
+            if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, false>), gr, dim3(512), WR_LDS, st, b);
+            else hipLaunchKernelGGL((k_wgrad_roll<false, false>), gr, dim3(512), WR_LDS, st, b);
         }
     };
     if (a.py && a.njt > 1) {             // as launch_wgrad: the first input-channel tile turns da into dy in place, the others read the finished dy

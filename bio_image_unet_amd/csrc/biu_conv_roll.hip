@@ -831,7 +831,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_roll(RollArgs a) {
 }
 
 // =====================================================================================================================================
-// The UP HALF of a folded decoder level (ConvTranspose(k2, s2) + concat + 3x3x3 conv as one op, DESIGN.md 3.5) on the same machinery:
+// The UP HALF of a folded decoder level (ConvTranspose(k2, s2) + concat + 3x3x3 conv as one op, DESIGN.md 3.4) on the same machinery:
 //   y[2v + p] = bias_eff[border state] + sum_{t in {0,1}^3} W'[p][t] . T(x_low)[v + t - 1 + p]        8 parity classes p x 8 coarse taps t
 // as the FIRST writer of y (the skip half then accumulates onto it in k_conv_roll's ACC form and rounds the sum once).
 // k_conv_pipe<.., 2, 2, 1, ..> ran this as one block per parity class with the coarse tile re-staged eight times, a weight fragment from LDS
