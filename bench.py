@@ -136,7 +136,10 @@ def call_cost(eng, api, label, executed=False):
         taps = node.kd * node.kh * node.kw
         v = node.y.nvox
         return 2.0 * v * taps * node.xin.c * node.y.c, float(v) * (node.xin.c + node.y.c) * esz
-    if isinstance(node, E.ConvBlockNode) and api in ("biu_foldt_fwd", "biu_foldt_bwd_data", "biu_foldt_bwd_weight_bn") and node.foldt is not None:
+    if label.endswith("/chain"):               # the chain rule of a folded level on its tables (side stream): weight-space work only
+        return 0.0, 0.0
+    if isinstance(node, E.ConvBlockNode) and api in ("biu_foldt_fwd", "biu_foldt_bwd_data", "biu_foldt_bwd_weight_bn", "biu_foldt_bwd_weight_bn_phase") \
+            and node.foldt is not None:
         # ConvTranspose + concat + conv as one op: 27 taps on the skip channels, 8 parity classes x 8 coarse taps on the ConvT's input channels
         # (the work the kernels do; the unfolded op would be 27 taps on all concat channels plus the ConvT); bytes: coarse input, skip, output
         v = node.y.nvox

@@ -115,6 +115,7 @@ SIGNATURES = {
     "biu_foldt_bwd_data": (_I, [_A, _P, _A, _I, _A, _I, _A, _P, _P, _P, _P, _P, _P, _Z, C.POINTER(C.c_int), _P, _Z, _I, _P]),
     "biu_foldt_bwd_weight_workspace": (_Z, [_I, _I, _I, _I]),
     "biu_foldt_bwd_weight_bn": (_I, [_A, _X, _A, _X, _A, _A, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _I, _P]),
+    "biu_foldt_bwd_weight_bn_phase": (_I, [_A, _X, _A, _X, _A, _A, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _I, _I, _P]),
     "biu_convt_fwd": (_I, [_A, _X, _P, _P, _P, _I, _A, _I, _P]),
     "biu_convt_bwd_data": (_I, [_A, _P, _P, _I, _A, _I, _I, _P]),
     "biu_convt_bwd_weight_workspace": (_Z, [_I, _I, _I, _I]),

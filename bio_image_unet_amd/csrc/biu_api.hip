@@ -453,10 +453,11 @@ extern "C" int biu_foldt_bwd_data(const biu_act* dy, const void* packed, const b
     return biu_mfma_foldt_dgrad(dy, packed, dx_low, acc_low, dskip, acc_skip, dtype, (hipStream_t)stream, nullptr, nullptr, ws, ws_bytes);
 }
 extern "C" size_t biu_foldt_bwd_weight_workspace(int cin_low, int cskip, int cout, int dtype) { return biu_mfma_foldt_wgrad_workspace(cin_low, cskip, cout, dtype); }
-extern "C" int biu_foldt_bwd_weight_bn(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const biu_act* da,
-                                       const biu_act* y, const float* scale, const float* shift, const float* slope, const float* coefA,
-                                       const float* coefB, const float* coefC, const float* dy_sum, const float* w_conv, const float* w_t, const float* b_t,
-                                       int cup, float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes, int dtype, biu_stream stream) {
+extern "C" int biu_foldt_bwd_weight_bn_phase(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const biu_act* da,
+                                             const biu_act* y, const float* scale, const float* shift, const float* slope, const float* coefA,
+                                             const float* coefB, const float* coefC, const float* dy_sum, const float* w_conv, const float* w_t, const float* b_t,
+                                             int cup, float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes, int dtype, int phases, biu_stream stream) {
+    BIU_REQUIRE(phases >= 1 && phases <= 3, BIU_ERR_SHAPE, "foldt_bwd_weight_bn: phases must be 1 (tensor passes), 2 (chain rule) or 3 (both)");
     BIU_REQUIRE(x_low && skip && da && w_conv && w_t && dw_conv && dw_t && ws && cup > 0, BIU_ERR_SHAPE, "foldt_bwd_weight_bn: null pointer");
     BIU_REQUIRE(biu_mfma_foldt_ok(x_low, skip, da, dtype) && biu_mfma_wgrad_ok(skip, da, 3, 3, 3, 1, dtype), BIU_ERR_UNSUPPORTED,
                 "foldt_bwd_weight_bn: shapes are not served by the folded kernels");
@@ -471,15 +472,23 @@ extern "C" int biu_foldt_bwd_weight_bn(const biu_act* x_low, const biu_xform* xf
         const bool yok = ((uintptr_t)y->p % 16) == 0 && ((size_t)y->pitch * es) % 16 == 0 &&
                          (i64)y->d * y->h * y->w * y->pitch * (i64)es < (1LL << 32) - 65536;
         if (!yok) {                                      // the BatchNorm-fused loader reads y in 16-byte pieces through a 32-bit descriptor: apply first
-            int rc = biu_bn_bwd_apply(da, y, scale, shift, slope, coefA, coefB, coefC, da, dtype, stream);
+            int rc = (phases & 1) ? biu_bn_bwd_apply(da, y, scale, shift, slope, coefA, coefB, coefC, da, dtype, stream) : BIU_OK;
             if (rc != BIU_OK) return rc;
             return biu_mfma_foldt_wgrad(x_low, xf_low, skip, xf_skip, da, nullptr, dy_sum, w_conv, w_t, b_t, cup, dw_conv, dw_t, db_t, ws, ws_bytes, dtype,
-                                        (hipStream_t)stream);
+                                        (hipStream_t)stream, phases);
         }
         BnBwdFuse bn{y, scale, shift, slope, coefA, coefB, coefC};
-        return biu_mfma_foldt_wgrad(x_low, xf_low, skip, xf_skip, da, &bn, dy_sum, w_conv, w_t, b_t, cup, dw_conv, dw_t, db_t, ws, ws_bytes, dtype, (hipStream_t)stream);
+        return biu_mfma_foldt_wgrad(x_low, xf_low, skip, xf_skip, da, &bn, dy_sum, w_conv, w_t, b_t, cup, dw_conv, dw_t, db_t, ws, ws_bytes, dtype, (hipStream_t)stream, phases);
     }
-    return biu_mfma_foldt_wgrad(x_low, xf_low, skip, xf_skip, da, nullptr, dy_sum, w_conv, w_t, b_t, cup, dw_conv, dw_t, db_t, ws, ws_bytes, dtype, (hipStream_t)stream);
+    return biu_mfma_foldt_wgrad(x_low, xf_low, skip, xf_skip, da, nullptr, dy_sum, w_conv, w_t, b_t, cup, dw_conv, dw_t, db_t, ws, ws_bytes, dtype, (hipStream_t)stream, phases);
+}
+
+extern "C" int biu_foldt_bwd_weight_bn(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const biu_act* da,
+                                       const biu_act* y, const float* scale, const float* shift, const float* slope, const float* coefA,
+                                       const float* coefB, const float* coefC, const float* dy_sum, const float* w_conv, const float* w_t, const float* b_t,
+                                       int cup, float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes, int dtype, biu_stream stream) {
+    return biu_foldt_bwd_weight_bn_phase(x_low, xf_low, skip, xf_skip, da, y, scale, shift, slope, coefA, coefB, coefC, dy_sum, w_conv, w_t, b_t, cup, dw_conv, dw_t,
+                                         db_t, ws, ws_bytes, dtype, 3, stream);
 }
 
 extern "C" int biu_convt_fwd(const biu_act* x, const biu_xform* xf, const float* w, const void* packed, const float* bias,

@@ -3390,13 +3390,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // MFMA's result belong to plane 0 and rows 16-31 to plane 1: against halo plane j of the tapped operand that is depth tap kd = j for the upper
 // half and kd = j - 1 for the lower one.  Four halo planes x 9 (kh, kw) = 36 accumulators cover all 27 taps of both planes with 288 MFMAs per
 // step instead of 432; unit (j, kw): waves 0-3 own (w, 0) and (w, 2), waves 4-7 own (w - 4, 1) -- 72 MFMAs per SIMD and step.
-// PC (round 4): producer / consumer waves.  The block has 16 waves: waves 0-7 only multiply (fragment reads + MFMAs, no vector-memory
-// instruction in their stream), waves 8-15 own the fetch pipeline of wave - 8 (LDS-DMA issue, counted wait, in-place producer transform,
-// fused BatchNorm backward + dy write-back).  A vector-memory instruction holds the ISSUING wave for ~50 cycles while the CU's single
-// address path drains the other waves' requests (profiles/r04_roll_ablation.txt); in the 8-wave form those cycles came out of the MFMA
-// rows of both waves of a SIMD.  Same registers per wave (128: 4 waves per SIMD), same LDS, same arithmetic and rounding.
-template <bool BNF, bool K2D, bool A16 = false, bool PC = false>
-__global__ __launch_bounds__(PC ? 1024 : 512, PC ? 1 : 2) void k_wgrad_roll(WgradArgs a) {
+template <bool BNF, bool K2D, bool A16 = false>
+__global__ __launch_bounds__(512, 2) void k_wgrad_roll(WgradArgs a) {
     static_assert(!(K2D && A16), "the 16-channel plain operand form exists for volumes only");
     using T = bf16_t;
     using F = Frag<T>;
@@ -3412,9 +3407,7 @@ __global__ __launch_bounds__(PC ? 1024 : 512, PC ? 1 : 2) void k_wgrad_roll(Wgra
     constexpr int LB = 0, LBN = 3 * CT;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool is_prod = PC && wave_all >= 8;            // (wave-uniform)
-    const int wave = wave_all & 7;                       // consumer: owner of taps; producer: owner of the DMA pieces of wave & 7
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int it = blockIdx.y / a.jt_count, jt = a.jt_begin + blockIdx.y % a.jt_count;
     const int piece = lane & 3;
     const int apc = A16 ? (piece & 1) : piece;           // channel piece of the plain operand this lane stages (A16: pieces 2, 3 are plane 1)
@@ -3761,20 +3754,6 @@ __global__ __launch_bounds__(PC ? 1024 : 512, PC ? 1 : 2) void k_wgrad_roll(Wgra
         RSTAMP(0);
         const FetchCtx fc = fetch_ctx((s + 3) & 3, 2 * s + 5, (s + 2) % 3, 2 * s + 4);
         RSTAMP(1);
-        if constexpr (PC) {
-            if (is_prod) {
-                if (f2) fetch_all(mine, fc, true);
-                if (f1) {
-                    wait_older(f2);
-                    finish(other, (s + 2) & 3, (s + 1) % 3, 2 * s + 2, true);
-                }
-            } else {
-                auto issue = [&](int) __attribute__((always_inline)) {};
-                if (has_x) mfma_step(std::true_type{}, s & 3, s % 3, issue); else mfma_step(std::false_type{}, s & 3, s % 3, issue);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            RSTAMP(2);
-        } else {
         auto issue = [&](int i) __attribute__((always_inline)) { if (f2) fetch_piece(mine, fc, i); };           // block-uniform f2
         if (has_x) mfma_step(std::true_type{}, s & 3, s % 3, issue); else mfma_step(std::false_type{}, s & 3, s % 3, issue);
         __builtin_amdgcn_sched_barrier(0);
@@ -3783,7 +3762,6 @@ __global__ __launch_bounds__(PC ? 1024 : 512, PC ? 1 : 2) void k_wgrad_roll(Wgra
             wait_older(f2);
             RSTAMP(3);
             finish(other, (s + 2) & 3, (s + 1) % 3, 2 * s + 2, true);
-        }
         }
         RSTAMP(4);
         __syncthreads();
@@ -3799,15 +3777,13 @@ __global__ __launch_bounds__(PC ? 1024 : 512, PC ? 1 : 2) void k_wgrad_roll(Wgra
         set_column(col);
         // prologue: planes -1, 0 -> pair 0 (finished at once); step 0: planes 1, 2 -> pair 1 + A buffer 0 (slot 0); step 1: planes 3, 4 ->
         // pair 2 + A buffer 1 (slot 1)
-        if (!PC || is_prod) {
-            fetch_all(sl0, fetch_ctx(0, -1, 0, 0), false);
-            wait_vmcnt<0>();
-            finish(sl0, 0, 0, 0, false);
-            fetch_all(sl0, fetch_ctx(1, 1, 0, 0), true);
-            if (nsteps > 1) fetch_all(sl1, fetch_ctx(2, 3, 1, 2), true);
-            wait_vmcnt<0>();
-            finish(sl0, 1, 0, 0, true);                  // (step 1's fetch, slot 1, is finished by step 0 like every later one)
-        }
+        fetch_all(sl0, fetch_ctx(0, -1, 0, 0), false);
+        wait_vmcnt<0>();
+        finish(sl0, 0, 0, 0, false);
+        fetch_all(sl0, fetch_ctx(1, 1, 0, 0), true);
+        if (nsteps > 1) fetch_all(sl1, fetch_ctx(2, 3, 1, 2), true);
+        wait_vmcnt<0>();
+        finish(sl0, 1, 0, 0, true);                      // (step 1's fetch, slot 1, is finished by step 0 like every later one)
         __syncthreads();
         for (int s = 0; s < nsteps; s += 2) {
             step(sl0, sl1, s);
@@ -3823,7 +3799,6 @@ __global__ __launch_bounds__(PC ? 1024 : 512, PC ? 1 : 2) void k_wgrad_roll(Wgra
     }
 #endif
     // ---- flush once per block (k_wgrad_pipe's layout: ws[tap][i][j], two 128-B segments per wave-instruction) ----------------------
-    if (is_prod) return;
     const int hf = lane >> 5;
     const int jj = jt * CT + (lane & 31);
     if constexpr (A16) {
@@ -3903,19 +3878,15 @@ static int launch_wgrad_roll(WgradArgs a, hipStream_t st, bool k2d = false) {
 #else
     a.diag = nullptr;
 #endif
-    static int pc_on = -1;               // producer / consumer waves (16-wave blocks) unless BIU_DISABLE=wpc
-    if (pc_on < 0) { const char* e = getenv("BIU_DISABLE"); pc_on = (e && strstr(e, "wpc")) ? 0 : 1; }
     static bool attr_set = false;
     if (!attr_set) {
-        bool ok = true;
-        auto reserve = [&](const void* f) { ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) == hipSuccess; };
-        reserve((const void*)k_wgrad_roll<false, false>); reserve((const void*)k_wgrad_roll<true, false>);
-        reserve((const void*)k_wgrad_roll<false, true>); reserve((const void*)k_wgrad_roll<true, true>);
-        reserve((const void*)k_wgrad_roll<false, false, true>); reserve((const void*)k_wgrad_roll<true, false, true>);
-        reserve((const void*)k_wgrad_roll<false, false, false, true>); reserve((const void*)k_wgrad_roll<true, false, false, true>);
-        reserve((const void*)k_wgrad_roll<false, true, false, true>); reserve((const void*)k_wgrad_roll<true, true, false, true>);
-        reserve((const void*)k_wgrad_roll<false, false, true, true>); reserve((const void*)k_wgrad_roll<true, false, true, true>);
-        if (!ok) return biu_fail(BIU_ERR_LAUNCH, "wgrad_roll: cannot reserve %zu bytes of LDS", WR_LDS);
+        if (hipFuncSetAttribute((const void*)k_wgrad_roll<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_wgrad_roll<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_wgrad_roll<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_wgrad_roll<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_wgrad_roll<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_wgrad_roll<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess)
+            return biu_fail(BIU_ERR_LAUNCH, "wgrad_roll: cannot reserve %zu bytes of LDS", WR_LDS);
         attr_set = true;
     }
     auto launch = [&](int jt_begin, int jt_count, int write_back, bool with_bn) {
@@ -3927,27 +3898,15 @@ static int launch_wgrad_roll(WgradArgs a, hipStream_t st, bool k2d = false) {
         if (g >= 16) g = grid_per_column(num_cus(), pairs);
         if (g < 1) g = 1;
         if (g > ncols) g = ncols;
-        const dim3 gr(g, pairs);
-        if (pc_on) {
-            if (k2d) {
-                if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, true, false, true>), gr, dim3(1024), WR_LDS, st, b);
-                else hipLaunchKernelGGL((k_wgrad_roll<false, true, false, true>), gr, dim3(1024), WR_LDS, st, b);
-            } else if (a16) {
-                if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, false, true, true>), gr, dim3(1024), WR_LDS, st, b);
-                else hipLaunchKernelGGL((k_wgrad_roll<false, false, true, true>), gr, dim3(1024), WR_LDS, st, b);
-            } else {
-                if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, false, false, true>), gr, dim3(1024), WR_LDS, st, b);
-                else hipLaunchKernelGGL((k_wgrad_roll<false, false, false, true>), gr, dim3(1024), WR_LDS, st, b);
-            }
-        } else if (k2d) {
-            if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, true>), gr, dim3(512), WR_LDS, st, b);
-            else hipLaunchKernelGGL((k_wgrad_roll<false, true>), gr, dim3(512), WR_LDS, st, b);
+        if (k2d) {
+            if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, true>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
+            else hipLaunchKernelGGL((k_wgrad_roll<false, true>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
         } else if (a16) {
-            if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, false, true>), gr, dim3(512), WR_LDS, st, b);
-            else hipLaunchKernelGGL((k_wgrad_roll<false, false, true>), gr, dim3(512), WR_LDS, st, b);
+            if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, false, true>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
+            else hipLaunchKernelGGL((k_wgrad_roll<false, false, true>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
         } else {
-            if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, false>), gr, dim3(512), WR_LDS, st, b);
-            else hipLaunchKernelGGL((k_wgrad_roll<false, false>), gr, dim3(512), WR_LDS, st, b);
+            if (with_bn) hipLaunchKernelGGL((k_wgrad_roll<true, false>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
+            else hipLaunchKernelGGL((k_wgrad_roll<false, false>), dim3(g, pairs), dim3(512), WR_LDS, st, b);
         }
     };
     if (a.py && a.njt > 1) {             // as launch_wgrad: the first input-channel tile turns da into dy in place, the others read the finished dy
@@ -4408,7 +4367,9 @@ size_t biu_mfma_foldt_wgrad_workspace(int cin_low, int cskip, int cout, int dtyp
 // da -> dy in place (BatchNorm + LeakyReLU backward in the loader of the skip half's weight gradient, which runs first); then G on the finished dy
 int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const biu_act* da, const BnBwdFuse* bn,
                          const float* dy_sum, const float* w_conv, const float* w_t, const float* b_t, int cup, float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes,
-                         int dtype, hipStream_t st) {
+                         int dtype, hipStream_t st, int phases) {
+    // phases: bit 0 = the passes over the tensors (skip half, G, border sums of dy -> tables in ws); bit 1 = the chain rule on those tables
+    // (reads ws and the parameters only: may run on another stream once phase 1 is complete, ws untouched in between)
     const int cin_low = x_low->c, cskip = skip->c, cout = da->c, ccat = cup + cskip;
     const size_t need = biu_mfma_foldt_wgrad_workspace(cin_low, cskip, cout, dtype);
     BIU_REQUIRE(need > 0 && ws_bytes >= need, BIU_ERR_WORKSPACE, "foldt_wgrad: workspace %zu too small (need %zu)", ws_bytes, need);
@@ -4416,22 +4377,29 @@ int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const bi
     const size_t main_bytes = need - pbytes - sbytes;
     float* R = (float*)((char*)ws + main_bytes);                    // per-block border tables
     float* Sk = (float*)((char*)ws + main_bytes + pbytes);
-    // 1. skip half of dW_conv (its slice of the channel axis), BatchNorm backward in the loader: da becomes dy
-    int rc = biu_mfma_wgrad(skip, xf_skip, da, 3, 3, 3, dw_conv, nullptr, ws, main_bytes, dtype, st, bn, nullptr, nullptr, ccat, cup);
-    if (rc != BIU_OK) return rc;
-    // 2. G[p][t] on the finished dy
-    rc = biu_mfma_upconv_wgrad(x_low, xf_low, da, nullptr, ws, main_bytes, dtype, st, nullptr);
-    if (rc != BIU_OK) return rc;
-    // 3. the ConvT bias: border sums of dy -> S_k (taps inside), needed by dW_conv (b_T is part of `up`) and by db_T
     const bool has_bias = b_t != nullptr || db_t != nullptr;
+    if (phases & 1) {
+        // 1. skip half of dW_conv (its slice of the channel axis), BatchNorm backward in the loader: da becomes dy
+        int rc = biu_mfma_wgrad(skip, xf_skip, da, 3, 3, 3, dw_conv, nullptr, ws, main_bytes, dtype, st, bn, nullptr, nullptr, ccat, cup);
+        if (rc != BIU_OK) return rc;
+        // 2. G[p][t] on the finished dy
+        rc = biu_mfma_upconv_wgrad(x_low, xf_low, da, nullptr, ws, main_bytes, dtype, st, nullptr);
+        if (rc != BIU_OK) return rc;
+        // 3. the ConvT bias: border sums of dy, one table per block
+        if (has_bias) {
+            const ShellDims sh = shell_dims(da->n, da->d, da->h, da->w);
+            BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_foldt_border_sums<T>, dim3(FOLDT_SUM_BLOCKS), dim3(256), foldt_sum_lds(cout), st,
+                                                         (const char*)da->p, sh, da->c, da->pitch, R));
+            BIU_CHECK_LAUNCH("foldt_border_sums");
+        }
+    }
+    if (!(phases & 2)) return BIU_OK;
+    // ... -> S_k (taps inside), needed by dW_conv (b_T is part of `up`) and by db_T
     if (has_bias) {
-        const ShellDims sh = shell_dims(da->n, da->d, da->h, da->w);
-        BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_foldt_border_sums<T>, dim3(FOLDT_SUM_BLOCKS), dim3(256), foldt_sum_lds(cout), st,
-                                                     (const char*)da->p, sh, da->c, da->pitch, R));
         float* Rsum = Sk + 27 * cout;                                   // (rest of the Sk region: FOLDT_RED_SPLIT tables)
         hipLaunchKernelGGL(k_foldt_reduce_tables, dim3(27, FOLDT_RED_SPLIT), dim3(256), 0, st, (const float*)R, FOLDT_SUM_BLOCKS, cout, Rsum);
         hipLaunchKernelGGL(k_foldt_inside_sums, dim3(27, (cout + 31) / 32), dim3(256), 0, st, (const float*)Rsum, FOLDT_RED_SPLIT, cout, Sk, dy_sum);
-        BIU_CHECK_LAUNCH("foldt_border_sums");
+        BIU_CHECK_LAUNCH("foldt_inside_sums");
     }
     // 4. chain rule to the up half of dW_conv, to dW_T and to db_T
     const size_t slice_f = wgrad_acc_bytes(cout, cin_low, 8) / sizeof(float);

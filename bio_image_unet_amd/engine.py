@@ -239,6 +239,7 @@ class ConvBlockNode(Node):
         # half folded onto convt's coarse input (include/biu.h: biu_foldt_*), forward and backward; the ConvT node is skipped altogether and
         # this node delivers the gradients of its parameters too.
         self.foldt, self.foldt_blob, self.foldt_ver = None, None, None
+        self.fold_ws, self.fold_ev = None, None      # own workspace + events of the folded weight gradient's side-stream chain rule
         # the block's activation as a leaky slope: LeakyReLU(s) -> s, ReLU -> 0 (Unet_v0 / BabyUnet), none or a later
         # non-piecewise-linear one (the attention gate's Sigmoid, applied by GateNode) -> 1
         act = seq[2] if len(seq) > 2 else None
@@ -408,11 +409,36 @@ class ConvBlockNode(Node):
         ct, skip, y = self.foldt, self.xin.parts[1], self.y
         lo = ct.xin
         dwt, dbt = eng.new_grad(ct.up.weight), eng.new_grad(ct.up.bias)
-        check(lib.biu_foldt_bwd_weight_bn(lo.a(), lo.xf(), skip.a(), skip.xf(), y.g(), y.a(), scale, shift, slope, _ptr(A), _ptr(B), _ptr(Cc), _ptr(dy_sum),
-                                          _ptr(self.conv.weight.data), _ptr(ct.up.weight.data), _ptr(ct.up.bias.data), ct.y.c, _ptr(dw), _ptr(dwt),
-                                          _ptr(dbt), _ptr(eng.ws), eng.ws_bytes, eng.dtype, st), "foldt_bwd_weight_bn")
-        eng.add_grad(ct.up.weight, dwt)
-        eng.add_grad(ct.up.bias, dbt)
+        side = eng.chain_stream()
+        if side is None:
+            check(lib.biu_foldt_bwd_weight_bn(lo.a(), lo.xf(), skip.a(), skip.xf(), y.g(), y.a(), scale, shift, slope, _ptr(A), _ptr(B), _ptr(Cc), _ptr(dy_sum),
+                                              _ptr(self.conv.weight.data), _ptr(ct.up.weight.data), _ptr(ct.up.bias.data), ct.y.c, _ptr(dw), _ptr(dwt),
+                                              _ptr(dbt), _ptr(eng.ws), eng.ws_bytes, eng.dtype, st), "foldt_bwd_weight_bn")
+            eng.add_grad(ct.up.weight, dwt)
+            eng.add_grad(ct.up.bias, dbt)
+            deferred = False
+        else:
+            # the passes over the tensors here; the chain rule on their tables (seven small launches, 0.12-0.16 ms per level at cfg4, needed by
+            # the optimizer only) on the side stream, beside the data gradient and the next layers: its gradients are handed over one node later
+            if self.fold_ws is None:
+                self.fold_ws = torch.empty(lib.biu_foldt_bwd_weight_workspace(lo.c, skip.c, y.c, eng.dtype), dtype=torch.uint8, device=eng.device)
+                self.fold_ev = (torch.cuda.Event(), torch.cuda.Event())
+            args = (lo.a(), lo.xf(), skip.a(), skip.xf(), y.g(), y.a(), scale, shift, slope, _ptr(A), _ptr(B), _ptr(Cc), _ptr(dy_sum),
+                    _ptr(self.conv.weight.data), _ptr(ct.up.weight.data), _ptr(ct.up.bias.data), ct.y.c, _ptr(dw), _ptr(dwt), _ptr(dbt),
+                    _ptr(self.fold_ws), self.fold_ws.numel(), eng.dtype)
+            check(lib.biu_foldt_bwd_weight_bn_phase(*args, 1, st), "foldt_bwd_weight_bn_phase(1)")
+            cur = torch.cuda.current_stream()
+            ready, done = self.fold_ev
+            ready.record(cur)
+            side.wait_event(ready)
+            label = lib.label
+            with torch.cuda.stream(side):
+                lib.label = label + "/chain"
+                check(lib.biu_foldt_bwd_weight_bn_phase(*args, 2, _stream()), "foldt_bwd_weight_bn_phase(2)")
+                done.record(side)
+            lib.label = label
+            eng.defer_grads(done, [(ct.up.weight, dwt), (ct.up.bias, dbt), (self.conv.weight, dw)], keep=(A, B, Cc, dy_sum))
+            deferred = True
         blob = self._foldt_packed(st)
         want_lo = eng.wants_grad(lo)
         up = _fusable_producer(lo) if want_lo else None
@@ -431,6 +457,7 @@ class ConvBlockNode(Node):
                                          None, 0, None, _ptr(eng.ws), eng.ws_bytes, eng.dtype, st), "foldt_bwd_data")
         lo.mark_g()
         skip.mark_g()
+        return deferred
 
     def bwd(self, eng):
         if not self.y.g_written():
@@ -468,8 +495,8 @@ class ConvBlockNode(Node):
         # BatchNorm+LeakyReLU backward (da -> dy, in place) rides inside the weight-gradient kernel's tile loader
         cat = self.xin.parts if isinstance(self.xin, CatAct) else None
         if self.foldt is not None:
-            self._bwd_foldt(eng, st, scale, shift, slope, A, B, Cc, dw, dy_sum)
-            eng.add_grad(self.conv.weight, dw)
+            if not self._bwd_foldt(eng, st, scale, shift, slope, A, B, Cc, dw, dy_sum):
+                eng.add_grad(self.conv.weight, dw)
             if db is not None:
                 eng.add_grad(self.conv.bias, db)
             eng.add_grad(self.bn.weight, dgamma)
@@ -904,7 +931,9 @@ class Engine:
         self.trace = None            # test hook: trace(phase, node, when) around every node ("fwd"/"bwd", node, "pre"/"post")
         self.generation = 0          # bumped by every forward: a backward must see the generation of ITS forward
         self._live = None            # weakref to the token of the autograd node that still needs this engine's buffers
-        self._side = None            # side stream of the composed-weight packing of the folded decoder levels (_prepack_folds)
+        self._side = None            # side stream of the composed-weight packing of the folded decoder levels (_prepack_folds) and of their chain rule
+        self._deferred = []
+        self._no_side_chain = os.environ.get("BIU_DISABLE", "").find("sidechain") >= 0
         self._fold_ev = None
 
     def busy(self) -> bool:
@@ -1143,9 +1172,30 @@ class Engine:
             for k, ts in by_k.items():
                 torch._foreach_add_(ts, k)
 
+    def chain_stream(self):
+        """Side stream for work only the optimizer waits for (the chain rule of the folded decoder levels), or None: under stream capture, while a
+        trace hook compares intermediate results, or with BIU_DISABLE=sidechain."""
+        if self.trace or self._no_side_chain or torch.cuda.is_current_stream_capturing():
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
+    def defer_grads(self, done: "torch.cuda.Event", grads, keep=()):
+        self._deferred.append((done, grads, keep))
+
+    def _flush_deferred(self, keep_last: int):
+        """Hand over the gradients whose side-stream work was enqueued at least `keep_last` nodes ago: the current stream waits for their event."""
+        while len(self._deferred) > keep_last:
+            done, grads, _ = self._deferred.pop(0)
+            torch.cuda.current_stream().wait_event(done)
+            for p, g in grads:
+                self.add_grad(p, g)
+
     def backward(self, head_grads: Sequence[Optional[torch.Tensor]]):
         """head_grads[i] = None or (d loss / d logits, d loss / d activated output, activated output) of head i."""
         self.grads = {}
+        self._deferred = []
         self._pseen: Dict[nn.Parameter, int] = {}
         self._zero_flat, self._zero_used = None, 0
         for b in self.bufs:
@@ -1164,9 +1214,12 @@ class Engine:
             lib.label = nd_.label + ":bwd"
             if self.trace:
                 self.trace("bwd", nd_, "pre")
+            self._flush_deferred(1)                      # (a level's chain rule is handed over when the next folded level defers its own, or at the end:
+                                                         #  beside the persistent kernels of the main stream its small grids only get the CUs' spare slots)
             nd_.bwd(self)
             if self.trace:
                 self.trace("bwd", nd_, "post")
+        self._flush_deferred(0)
         return self.grads
 
     def _backward_heads(self, head_grads):

@@ -169,7 +169,9 @@ def test_adam_state_dict_round_trip_and_torch_checkpoint():
         again = run(1, True, first)
         for k, v in straight.items():
             if v.is_floating_point() and not (k.endswith(".0.bias") and not k.startswith("final")):
-                torch.testing.assert_close(again[k], v, rtol=1e-4, atol=2e-5, msg=lambda s: f"{first.__name__} {k}: {s}")
+                # (fp32 atomics order the weight-gradient sums differently from run to run; Adam's m / sqrt(v) turns that into up to a few
+                # percent of one lr = 1e-3 step on an element whose gradient is near zero)
+                torch.testing.assert_close(again[k], v, rtol=1e-4, atol=1e-4, msg=lambda s: f"{first.__name__} {k}: {s}")
 
 
 def test_dtype_cast_is_refused_and_copies_drop_engines():
