@@ -2436,7 +2436,7 @@ __global__ void k_foldt_border_fix(char* __restrict__ y, ShellDims sd, int c, in
         }
 }
 
-struct FoldtBlob { size_t fwd, dg, sfwd, sdg, wfold, wb, fix, bias, total; };
+struct FoldtBlob { size_t fwd, dg, sfwd, sdg, wfold, wb, fix, bias, lay, total; };
 static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 static FoldtBlob foldt_blob(int cin_low, int cskip, int cout, int dtype) {
     FoldtBlob b;
@@ -2449,6 +2449,8 @@ static FoldtBlob foldt_blob(int cin_low, int cskip, int cout, int dtype) {
     b.wb = o;    o += al256((size_t)27 * cout * sizeof(float));
     b.fix = o;   o += al256((size_t)27 * cout * sizeof(float));
     b.bias = o;  o += al256((size_t)cout * sizeof(float));
+    // GEMM layouts of W_conv's up channels and of W_T (biu_fold_gemm.hip); the ConvT's output channels are not known here: sized for cup <= cin_low
+    b.lay = o;   o += al256(biu_fold_gemm_layout_floats(cin_low, cin_low, cout) * sizeof(float));
     b.total = o;
     return b;
 }
@@ -2461,11 +2463,13 @@ bool biu_mfma_foldt_ok(const biu_act* x_low, const biu_act* skip, const biu_act*
     if (y->c > 512) return false;                          // (k_foldt_border_sums: 27 x Cout floats of LDS per block)
     return biu_mfma_upconv_packed_bytes(1, x_low->c, y->c, dtype) > 0 && biu_mfma_packed_bytes(1, skip->c, y->c, 3, 3, 3, 1, dtype) > 0;
 }
-// The composed weights and the chain rule cost 3 x 216 small fp32 GEMMs of Cout x Cup x Cin_low per step, whatever the volume: the fold pays only
-// where the voxel-space work it saves ((27 - 8) Cup Cout per fine voxel) dwarfs them (UNet3D(32) at 4 x 128^3: decode5 and decode3, not the 32^3 level)
+// The composed weights and the chain rule cost 3 x 216 small fp32 GEMMs of Cout x Cup x Cin_low per step, whatever the volume: the fold pays
+// where the voxel-space work it saves ((27 - 8) Cup Cout per fine voxel) outweighs them.  Since round 4 those GEMMs run on the fp32 matrix
+// pipe (biu_fold_gemm.hip) and the engine keeps them off the critical path (side stream), which moved the break-even down by a factor of
+// five: UNet3D(32) at 4 x 128^3 folds all three decoder levels (the 32^3 level: step 11.90 -> 11.64 ms, same box).
 bool biu_mfma_foldt_worth(const biu_act* x_low, const biu_act* y) {
     const double vox = (double)y->n * y->d * y->h * y->w;
-    return vox * 19.0 >= 64.0 * 648.0 * x_low->c;
+    return vox * 19.0 >= 12.0 * 648.0 * x_low->c;
 }
 size_t biu_mfma_foldt_packed_bytes(int cin_low, int cskip, int cout, int dtype) { return foldt_blob(cin_low, cskip, cout, dtype).total; }
 // w_conv: (Cout, cup + cskip, 3, 3, 3), concat order (up | skip) [unet3d/unet3d.py:86: torch.cat([up, skip])]; w_t: (Cin_low, cup, 2, 2, 2)
@@ -2475,8 +2479,15 @@ int biu_mfma_foldt_pack(const float* w_conv, const float* b_conv, const float* w
     char* base = (char*)packed;
     float* wfold = (float*)(base + b.wfold);
     const int ccat = cup + cskip;
-    hipLaunchKernelGGL(k_foldt_compose, dim3((cin_low + 31) / 32, (cout + 31) / 32, 64), dim3(256), 0, st, w_conv, ccat, 0, cup, cout, w_t, cin_low, wfold);
-    hipLaunchKernelGGL(k_foldt_wb, dim3((27 * cout + 127) / 128), dim3(128), 0, st, w_conv, ccat, 0, cup, cout, b_t, (float*)(base + b.wb));
+    if (cup <= cin_low && biu_fold_gemm_ok(cin_low, cup, cout)) {
+        float* lay = (float*)(base + b.lay);
+        int rc = biu_fold_gemm_layouts(w_conv, ccat, cup, cout, w_t, cin_low, lay, st);
+        if (rc == BIU_OK) rc = biu_fold_gemm_compose(lay, cin_low, cup, cout, b_t, wfold, (float*)(base + b.wb), st);
+        if (rc != BIU_OK) return rc;
+    } else {
+        hipLaunchKernelGGL(k_foldt_compose, dim3((cin_low + 31) / 32, (cout + 31) / 32, 64), dim3(256), 0, st, w_conv, ccat, 0, cup, cout, w_t, cin_low, wfold);
+        hipLaunchKernelGGL(k_foldt_wb, dim3((27 * cout + 127) / 128), dim3(128), 0, st, w_conv, ccat, 0, cup, cout, b_t, (float*)(base + b.wb));
+    }
     hipLaunchKernelGGL(k_foldt_fix, dim3((27 * cout + 127) / 128), dim3(128), 0, st, (const float*)(base + b.wb), cout, b_conv, (float*)(base + b.fix),
                        (float*)(base + b.bias));
     BIU_CHECK_LAUNCH("foldt_compose");
@@ -4362,7 +4373,8 @@ __global__ __launch_bounds__(256) void k_foldt_chain_bt(const float* __restrict_
 size_t biu_mfma_foldt_wgrad_workspace(int cin_low, int cskip, int cout, int dtype) {
     if (!wgrad_chan_ok(cin_low, cout) || !wgrad_chan_ok(cskip, cout)) return 0;
     const size_t g = 8 * wgrad_acc_bytes(cout, cin_low, 8), sk = biu_mfma_wgrad_workspace(cskip, cout, 3, 3, 3, dtype);
-    return (g > sk ? g : sk) + al256((size_t)FOLDT_SUM_BLOCKS * 27 * cout * sizeof(float)) + al256((size_t)(1 + FOLDT_RED_SPLIT) * 27 * cout * sizeof(float));
+    return (g > sk ? g : sk) + al256((size_t)FOLDT_SUM_BLOCKS * 27 * cout * sizeof(float)) + al256((size_t)(1 + FOLDT_RED_SPLIT) * 27 * cout * sizeof(float)) +
+           al256(biu_fold_gemm_layout_floats(cin_low, cin_low, cout) * sizeof(float));          // (GEMM layouts of the chain rule, cup <= cin_low)
 }
 // da -> dy in place (BatchNorm + LeakyReLU backward in the loader of the skip half's weight gradient, which runs first); then G on the finished dy
 int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const biu_act* da, const BnBwdFuse* bn,
@@ -4374,9 +4386,11 @@ int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const bi
     const size_t need = biu_mfma_foldt_wgrad_workspace(cin_low, cskip, cout, dtype);
     BIU_REQUIRE(need > 0 && ws_bytes >= need, BIU_ERR_WORKSPACE, "foldt_wgrad: workspace %zu too small (need %zu)", ws_bytes, need);
     const size_t pbytes = al256((size_t)FOLDT_SUM_BLOCKS * 27 * cout * sizeof(float)), sbytes = al256((size_t)(1 + FOLDT_RED_SPLIT) * 27 * cout * sizeof(float));
-    const size_t main_bytes = need - pbytes - sbytes;
+    const size_t lbytes = al256(biu_fold_gemm_layout_floats(cin_low, cin_low, cout) * sizeof(float));
+    const size_t main_bytes = need - pbytes - sbytes - lbytes;
     float* R = (float*)((char*)ws + main_bytes);                    // per-block border tables
     float* Sk = (float*)((char*)ws + main_bytes + pbytes);
+    float* lay = (float*)((char*)ws + main_bytes + pbytes + sbytes);
     const bool has_bias = b_t != nullptr || db_t != nullptr;
     if (phases & 1) {
         // 1. skip half of dW_conv (its slice of the channel axis), BatchNorm backward in the loader: da becomes dy
@@ -4403,6 +4417,14 @@ int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const bi
     }
     // 4. chain rule to the up half of dW_conv, to dW_T and to db_T
     const size_t slice_f = wgrad_acc_bytes(cout, cin_low, 8) / sizeof(float);
+    if (cup <= cin_low && biu_fold_gemm_ok(cin_low, cup, cout)) {
+        int rc = biu_fold_gemm_layouts(w_conv, ccat, cup, cout, w_t, cin_low, lay, st);
+        if (rc == BIU_OK) rc = biu_fold_gemm_chain((const float*)ws, slice_f, lay, cin_low, cup, cout, ccat, dw_conv, dw_t, b_t, (const float*)Sk, st);
+        if (rc != BIU_OK) return rc;
+        if (db_t) hipLaunchKernelGGL(k_foldt_chain_bt, dim3(cup), dim3(256), 0, st, (const float*)Sk, w_conv, cup, cout, ccat, db_t);
+        BIU_CHECK_LAUNCH("foldt_chain_bt");
+        return BIU_OK;
+    }
     hipLaunchKernelGGL(k_foldt_chain_wconv, dim3((cup + 31) / 32, (cout + 31) / 32, 27), dim3(256), 0, st, (const float*)ws, slice_f, w_t, cin_low, cup, cout, ccat,
                        dw_conv, b_t, (const float*)Sk);
     hipLaunchKernelGGL(k_foldt_chain_wt, dim3((cup + 31) / 32, (cin_low + 31) / 32, 8), dim3(256), 0, st, (const float*)ws, slice_f, w_conv, cin_low, cup, cout, ccat,

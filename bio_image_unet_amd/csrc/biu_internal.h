@@ -45,6 +45,13 @@ int biu_conv_roll(const biu_act* x, const biu_xform* xf, const void* packed, con
 // the up half of a folded decoder level (64 -> 32 channels) as the first writer of y: composed 8-class weights in registers, border-state bias table
 bool biu_fold_roll_ok(const biu_act* x_low, const biu_act* y, int dtype);
 int biu_fold_roll(const biu_act* x_low, const biu_xform* xf, const void* packed_fwd, const float* bias_sum, const float* fix, const biu_act* y, hipStream_t st);
+// biu_fold_gemm.hip: the weight-space products of a folded level (composed weights; chain rule back to W_conv / W_T) on the fp32 matrix pipe
+size_t biu_fold_gemm_layout_floats(int cin_low, int cup, int cout);
+bool biu_fold_gemm_ok(int cin_low, int cup, int cout);
+int biu_fold_gemm_layouts(const float* w_conv, int ccat, int cup, int cout, const float* w_t, int cin_low, float* layouts, hipStream_t st);
+int biu_fold_gemm_compose(const float* layouts, int cin_low, int cup, int cout, const float* b_t, float* wfold, float* wb, hipStream_t st);
+int biu_fold_gemm_chain(const float* G, size_t slice_f, const float* layouts, int cin_low, int cup, int cout, int ccat, float* dw_conv, float* dw_t,
+                        const float* b_t, const float* Sk, hipStream_t st);
 size_t biu_mfma_conv_split_bytes(int cin, const biu_act* y, const biu_act* y1, int kd, int dtype);   // 0: the launch is not split
 int biu_mfma_convt_dgrad_bricks(const biu_act* dx, int kd);
 int biu_mfma_convt_dgrad_rows(const biu_act* dx, int kd);

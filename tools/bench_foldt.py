@@ -1,5 +1,5 @@
 """ConvTranspose + concat + conv of a decoder level as one folded op (biu_foldt_*) at cfg4's decode5 / decode3 shapes, per call, against the
-three separate ops it replaces.      python tools/bench_foldt.py [bf16|f32] [decode5|decode3]        (BENCH_LEGS=fwd,dg,wg; BENCH_REPS=n)"""
+three separate ops it replaces.      python tools/bench_foldt.py [bf16|f32] [decode5|decode3|decode1]        (BENCH_LEGS=fwd,dg,wg,wg1; BENCH_REPS=n)"""
 import ctypes as C
 import os
 import sys
@@ -31,7 +31,8 @@ def timed(f):
     return e0.elapsed_time(e1) / reps
 
 
-for name, n, cl, cup, cs, cout, (d, h, w) in (("decode5", 4, 64, 64, 32, 32, (64, 64, 64)), ("decode3", 4, 128, 128, 64, 64, (32, 32, 32))):
+for name, n, cl, cup, cs, cout, (d, h, w) in (("decode5", 4, 64, 64, 32, 32, (64, 64, 64)), ("decode3", 4, 128, 128, 64, 64, (32, 32, 32)),
+                                               ("decode1", 4, 256, 256, 128, 128, (16, 16, 16))):
     if only and only != name:
         continue
     xl = torch.randn(n, d, h, w, cl, device="cuda").to(tdt)
@@ -72,4 +73,9 @@ for name, n, cl, cup, cs, cout, (d, h, w) in (("decode5", 4, 64, 64, 32, 32, (64
         t = timed(lambda: check(lib.biu_foldt_bwd_weight_bn(C.byref(axl), C.byref(xfl), C.byref(ask), C.byref(xfs), C.byref(ady), C.byref(ay), P(kv[0]), P(kv[1]), P(kv[2]),
                                                             P(kv[3]), P(kv[4]), P(kv[5]), None, P(wc), P(wt), P(bt), cup, P(dwc), P(dwt), P(dbt), P(ws), ws.numel(), code, st)))
         out.append(f"wgrad_bn {t:.3f} ms {fl / t / 1e9:.0f} TF/s")
+    if "wg1" in legs:                                    # the tensor passes alone (phase 1): wgrad_bn minus this = the chain rule on the tables
+        t = timed(lambda: check(lib.biu_foldt_bwd_weight_bn_phase(C.byref(axl), C.byref(xfl), C.byref(ask), C.byref(xfs), C.byref(ady), C.byref(ay), P(kv[0]), P(kv[1]),
+                                                                  P(kv[2]), P(kv[3]), P(kv[4]), P(kv[5]), None, P(wc), P(wt), P(bt), cup, P(dwc), P(dwt), P(dbt), P(ws),
+                                                                  ws.numel(), code, 1, st)))
+        out.append(f"wgrad_bn(phase 1) {t:.3f} ms")
     print(f"{name} x_low {cl} ch @{(d, h, w)}, up {cup} | skip {cs} -> {cout} @{(2 * d, 2 * h, 2 * w)}: " + " | ".join(out), flush=True)
