@@ -36,6 +36,11 @@ def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+# Under stream capture the side stream forks off the capturing stream (wait_event on an event recorded there) and is joined again by the waits
+# the eager path makes anyway (the decoder's first use of the composed weights; the hand-over of the deferred gradients), so the captured graph
+# holds the same two branches.  BIU_DISABLE=capturefork keeps a captured step single-stream.
+_NO_CAPTURE_FORK = os.environ.get("BIU_DISABLE", "").find("capturefork") >= 0
+
 class Buf:
     """One HBM buffer [N,D,H,W,C] + gradient twin + the consumer-side transform vectors of its channels."""
 
@@ -1131,7 +1136,7 @@ class Engine:
         parameters only: packed at the START of the forward on a side stream, they run beside the encoder instead of in front of the decoder
         (the decoder's first use waits on the event).  Not under stream capture (a captured step packs in line)."""
         self._fold_ev = None
-        if os.environ.get("BIU_DISABLE", "").find("prepack") >= 0 or torch.cuda.is_current_stream_capturing():
+        if os.environ.get("BIU_DISABLE", "").find("prepack") >= 0 or (torch.cuda.is_current_stream_capturing() and _NO_CAPTURE_FORK):
             return
         stale = [n for n in self.nodes if isinstance(n, ConvBlockNode) and n.foldt is not None and n.foldt_ver != n._foldt_version()]
         if not stale:
@@ -1175,7 +1180,7 @@ class Engine:
     def chain_stream(self):
         """Side stream for work only the optimizer waits for (the chain rule of the folded decoder levels), or None: under stream capture, while a
         trace hook compares intermediate results, or with BIU_DISABLE=sidechain."""
-        if self.trace or self._no_side_chain or torch.cuda.is_current_stream_capturing():
+        if self.trace or self._no_side_chain or (torch.cuda.is_current_stream_capturing() and _NO_CAPTURE_FORK):
             return None
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
