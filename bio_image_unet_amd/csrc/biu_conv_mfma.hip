@@ -4058,6 +4058,16 @@ int biu_mfma_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* dy, int
                    int dw_ld_cols, int dw_c_off) {
     WgradArgs a;
     int rc_ = BIU_OK;
+    // Small volumes with several input-channel tiles: the fused form runs as TWO launches (the first tile's blocks turn da into dy, the others
+    // read the finished dy), each a fraction of the chip at these sizes (4 x 16^3: 32 + 96 blocks).  A separate BatchNorm-backward pass over a
+    // tensor that lives in L2 costs less than the second launch's latency: 128 -> 256 @ 4 x 16^3 102 -> ~70 us.  (BIU_DISABLE=wsplitbn: fused)
+    static int split_off = -1;
+    if (split_off < 0) { const char* e = getenv("BIU_DISABLE"); split_off = (e && strstr(e, "wsplitbn")) ? 1 : 0; }
+    if (bn && !split_off && dtype == BIU_BF16 && kd == 3 && x->c + (x1 ? x1->c : 0) > 32 && nvox(dy) <= 4 * 32 * 32 * 32) {
+        rc_ = biu_bn_bwd_apply(dy, bn->y, bn->scale, bn->shift, bn->slope, bn->cA, bn->cB, bn->cC, dy, dtype, (biu_stream)st);
+        if (rc_ != BIU_OK) return rc_;
+        bn = nullptr;
+    }
     if (bn) {
         a.py = (const char*)bn->y->p; a.ypitch = bn->y->pitch;
         a.bn_scale = bn->scale; a.bn_shift = bn->shift; a.bn_slope = bn->slope;
@@ -4161,12 +4171,12 @@ int biu_mfma_upconv_wgrad(const biu_act* x, const biu_xform* xf, const biu_act* 
     static int fall_off = -1;
     if (fall_off < 0) { const char* e = getenv("BIU_DISABLE"); fall_off = (e && strstr(e, "foldall")) ? 1 : 0; }
     static int fall_ca = -1;                               // (BIU_FALL_MAXCA moves the rule below for A/B runs)
-    if (fall_ca < 0) { const char* e = getenv("BIU_FALL_MAXCA"); fall_ca = e ? atoi(e) : 64; }
+    if (fall_ca < 0) { const char* e = getenv("BIU_FALL_MAXCA"); fall_ca = e ? atoi(e) : 128; }
     if (dtype == BIU_BF16 && a.CA <= fall_ca && bn == nullptr && !fall_off) {
         // all eight parity classes in one launch: wave = class, the coarse operand staged once per 2 x 4 x 16 brick (k_wgrad_pipe<..., FALL>);
         // plain dy only (no registers left for the y pieces of a fused BatchNorm backward).  Same-box: decode5 (dy 32 ch) 608 -> 410 us,
-        // cfg4 step 12.69 -> 12.46 ms; with decode3 (dy 64 ch: two tiles, operands staged per tile) 12.30 ms.  Wider dy stays on the
-        // per-class launches below, which stage two dy tiles per block.
+        // cfg4 step 12.69 -> 12.46 ms; with decode3 (dy 64 ch: two tiles, operands staged per tile) 12.30 ms; round 4, with the 32^3 level
+        // folded: dy 128 ch (four tiles) 449 -> 352 us.  Wider dy stays on the per-class launches below, which stage two dy tiles per block.
         a.ws = (float*)ws;
         a.fold_par = 8;
         rc = launch_wgrad<bf16_t, 2, 2, 1, 2, 4, 16, 8, 1, false, true>(a, st);

@@ -636,6 +636,7 @@ FOLDT_CASES = [
     (2, 32, 32, 16, 32, (3, 5, 9)),
     (1, 128, 128, 64, 64, (2, 4, 8)),         # decode3
     (1, 48, 32, 32, 64, (5, 3, 7)),
+    (1, 256, 256, 128, 128, (2, 3, 5)),       # decode1: 128-channel dy (four tiles in the one-launch folded weight gradient)
 ]
 
 
