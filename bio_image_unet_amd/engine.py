@@ -40,6 +40,8 @@ def _ptr(t: Optional[torch.Tensor]):
 # the eager path makes anyway (the decoder's first use of the composed weights; the hand-over of the deferred gradients), so the captured graph
 # holds the same two branches.  BIU_DISABLE=capturefork keeps a captured step single-stream.
 _NO_CAPTURE_FORK = os.environ.get("BIU_DISABLE", "").find("capturefork") >= 0
+# voxels up to which a 3-D block's weight gradient runs on the side stream beside its data gradient (BIU_SIDE_WGRAD_VOX=0: never)
+_SIDE_WGRAD_VOX = int(os.environ.get("BIU_SIDE_WGRAD_VOX", str(4 * 32 ** 3)))
 
 class Buf:
     """One HBM buffer [N,D,H,W,C] + gradient twin + the consumer-side transform vectors of its channels."""
@@ -245,6 +247,7 @@ class ConvBlockNode(Node):
         # this node delivers the gradients of its parameters too.
         self.foldt, self.foldt_blob, self.foldt_ver = None, None, None
         self.fold_ws, self.fold_ev = None, None      # own workspace + events of the folded weight gradient's side-stream chain rule
+        self.wg_ws, self.wg_ev = None, None          # ... of a small layer's side-stream weight gradient
         # the block's activation as a leaky slope: LeakyReLU(s) -> s, ReLU -> 0 (Unet_v0 / BabyUnet), none or a later
         # non-piecewise-linear one (the attention gate's Sigmoid, applied by GateNode) -> 1
         act = seq[2] if len(seq) > 2 else None
@@ -514,11 +517,34 @@ class ConvBlockNode(Node):
         elif self.fold_wg:
             check(lib.biu_upconv_bwd_weight_bn(self.fold_src.a(), self.fold_src.xf(), y.g(), y.a(), scale, shift, slope, _ptr(A), _ptr(B),
                                                _ptr(Cc), _ptr(dw), _ptr(eng.ws), eng.ws_bytes, eng.dtype, st), "upconv_bwd_weight_bn")
+        elif self.kd == 3 and eng.tdtype == torch.bfloat16 and y.nvox <= _SIDE_WGRAD_VOX and eng.chain_stream() is not None:
+            # small volumes (the 32^3 / 16^3 levels of a 128^3 U-Net): weight and data gradient of a block each fill a fraction of the chip.
+            # da -> dy here, then the weight gradient (needed by the optimizer only) on the side stream BESIDE the data gradient; its own
+            # accumulator workspace, the parameter gradient handed over a node or two later (Engine._flush_deferred)
+            side = eng.chain_stream()
+            check(lib.biu_bn_bwd_apply(y.g(), y.a(), scale, shift, slope, _ptr(A), _ptr(B), _ptr(Cc), y.g(), eng.dtype, st), "bn_bwd_apply")
+            if self.wg_ws is None:
+                self.wg_ws = torch.empty(max(lib.biu_conv_bwd_weight_workspace(self.xin.c, cout, self.kd, self.kh, self.kw, eng.dtype), 16), dtype=torch.uint8,
+                                         device=eng.device)
+                self.wg_ev = (torch.cuda.Event(), torch.cuda.Event())
+            ready, done = self.wg_ev
+            ready.record(torch.cuda.current_stream())
+            side.wait_event(ready)
+            label = lib.label
+            with torch.cuda.stream(side):
+                lib.label = label + "/wgrad"
+                check(lib.biu_conv_bwd_weight(self.xin.a(), self.xin.xf(), y.g(), self.kd, self.kh, self.kw, self.dil, _ptr(dw), None, _ptr(self.wg_ws),
+                                              self.wg_ws.numel(), eng.dtype, _stream()), "conv_bwd_weight")
+                done.record(side)
+            lib.label = label
+            eng.defer_grads(done, [(self.conv.weight, dw)])
+            dw = None
         else:
             check(lib.biu_conv_bwd_weight_bn(self.xin.a(), self.xin.xf(), y.g(), y.a(), scale, shift, slope, _ptr(A), _ptr(B),
                                              _ptr(Cc), self.kd, self.kh, self.kw, self.dil, _ptr(dw), _ptr(eng.ws), eng.ws_bytes,
                                              eng.dtype, st), "conv_bwd_weight_bn")
-        eng.add_grad(self.conv.weight, dw)
+        if dw is not None:
+            eng.add_grad(self.conv.weight, dw)
         if db is not None:
             eng.add_grad(self.conv.bias, db)
         eng.add_grad(self.bn.weight, dgamma)
@@ -1219,7 +1245,7 @@ class Engine:
             lib.label = nd_.label + ":bwd"
             if self.trace:
                 self.trace("bwd", nd_, "pre")
-            self._flush_deferred(1)                      # (a level's chain rule is handed over when the next folded level defers its own, or at the end:
+            self._flush_deferred(2)                      # (side-stream work is handed over two deferrals later, or at the end:
                                                          #  beside the persistent kernels of the main stream its small grids only get the CUs' spare slots)
             nd_.bwd(self)
             if self.trace:
