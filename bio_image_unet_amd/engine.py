@@ -59,6 +59,7 @@ class Buf:
         self.ncons: Dict[Tuple[int, int], int] = {}         # (c0, c) -> number of nodes that read this slice
         self.nwr: Dict[Tuple[int, int], int] = {}           # (c0, c) -> gradient contributions received this backward
         self.producer: Dict[Tuple[int, int], "Node"] = {}   # (c0, c) -> ConvBlockNode that wrote it (if any)
+        self.acts = []                                      # every Act handed out (release() clears their pointers)
 
     def slice(self, c0: int, c: int, lazy: bool) -> "Act":
         self.leaves[(c0, c)] = False
@@ -75,9 +76,18 @@ class Buf:
         return Act(self, 0, cov, keys)
 
     def grad(self) -> torch.Tensor:
+        assert self.t is not None, "a released buffer has no gradient either"
         if self.g is None:
             self.g = torch.empty(self.shape, dtype=self.eng.tdtype, device=self.eng.device)
         return self.g
+
+    def release(self):
+        """The tensor is never materialised (the op that would write it runs folded into its consumer): free it.  Its Acts keep their
+        channel counts and extents for the bookkeeping of the graph; their pointers become NULL, which every entry point refuses."""
+        self.t = None
+        self.g = None
+        for a in self.acts:
+            a._a.p = None
 
 
 class Act:
@@ -92,6 +102,7 @@ class Act:
         self._g = None
         self._x = None
         self.is_input = False
+        buf.acts.append(self)
 
     @property
     def nvox(self):

@@ -374,6 +374,8 @@ class _Body3D(_HipNet):
                 blk = E.ConvBlockNode(eng, getattr(self, f"up{lvl}_conv"), r, u, fold_src=t)      # forward folded onto the coarse tensor
                 rs.only_for_backward = blk.fold_src is not None
                 rs.skip = blk.fold_all                                                            # (forward, data and weight gradient folded)
+                if rs.skip:
+                    r.buf.release()                                                               # ... so the up-sampled tensor is never materialised
                 eng.add(blk)
             elif up == "trilinear":                       # F.interpolate(scale_factor=2, mode='trilinear') [unet3d/unet3d.py:82]
                 u = buf.slice(0, up_c[i], lazy=False)
@@ -387,6 +389,8 @@ class _Body3D(_HipNet):
             blk1 = E.ConvBlockNode(eng, b1, cat, a, convt=ctn)       # ConvT + concat + conv as one op when the folded kernels serve the level
             if ctn is not None and blk1.foldt is not None:
                 ctn.folded_into = blk1
+                if isinstance(buf, E.CatBuf):
+                    u.buf.release()                              # the up-sampled tensor (and its gradient) is never materialised: no memory for it
             eng.add(blk1)
             t = eng.new_act(sp, b2[0].out_channels, lazy=True)
             eng.add(E.ConvBlockNode(eng, b2, a, t))
