@@ -2,11 +2,14 @@
 several forwards before a backward, a logging forward between forward and backward, raw ``.data`` writes next to the
 packed-weight cache, optimizer state round trips, dtype casts and copies of a model that already ran."""
 import copy
+import os
+import sys
 
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 import bio_image_unet_amd as B  # noqa: E402
 from bio_image_unet_amd.optim import Adam  # noqa: E402
@@ -188,3 +191,45 @@ def test_dtype_cast_is_refused_and_copies_drop_engines():
     mh = copy.deepcopy(m).half()
     with pytest.raises(RuntimeError, match="set_compute_dtype"):
         mh(x)
+
+
+_SIDE_CODE = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+import bio_image_unet_amd as B
+torch.manual_seed(5)
+m = B.UNet3D(1, 1, 32).cuda(); m.set_compute_dtype(torch.bfloat16); m.train()
+g = torch.Generator(device="cuda").manual_seed(7)
+x = torch.rand(2, 1, 32, 64, 64, device="cuda", generator=g)
+outs = []
+for _ in range(2):                       # the second step reuses every event / workspace / deferred slot of the first
+    m.zero_grad()
+    p, l = m(x)
+    (l.float().square().mean() + p.float().mean()).backward()
+    torch.cuda.synchronize()
+eng = list(m._engines.values())[-1][-1]
+print("SIDE", eng._side is not None)
+torch.save({k: v.grad.detach().float().cpu() for k, v in m.named_parameters()}, sys.argv[2])
+"""
+
+
+@pytest.mark.timeout(600)
+def test_side_stream_gradients_match_the_single_stream_step(tmp_path):
+    """Composed-weight packing, the chain rule of the folded weight gradients and the weight gradients of the small levels run on the
+    engine's side stream: every parameter gradient must equal the single-stream step's up to the summation order of the
+    fp32 atomics (and the one extra storage rounding where a small layer's BatchNorm backward becomes a pass of its own)."""
+    import subprocess
+    res = {}
+    for tag, env in (("side", {}), ("single", {"BIU_SIDE_WGRAD_VOX": "0", "BIU_DISABLE": "sidechain,prepack"})):
+        f = tmp_path / f"{tag}.pt"
+        e = dict(os.environ)
+        e.pop("BIU_DISABLE", None)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", _SIDE_CODE, ROOT, str(f)], env=e, capture_output=True, text=True, timeout=500)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert ("SIDE True" in r.stdout) == (tag == "side"), r.stdout[-500:]
+        res[tag] = torch.load(f)
+    for k, gs in res["side"].items():
+        g1 = res["single"][k]
+        scale = float(g1.abs().max()) + 1e-20
+        assert float((gs - g1).abs().max()) <= 2e-2 * scale, (k, float((gs - g1).abs().max()) / scale)

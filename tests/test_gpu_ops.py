@@ -731,6 +731,24 @@ def test_foldt_fwd_matches_convT_concat_conv(case, dtype):
     for g_, r_ in zip(got3, ref3):
         sc = float(r_.abs().max())
         torch.testing.assert_close(g_.cpu(), r_.cpu(), rtol=1e-3 if dtype == "f32" else 3e-2, atol=(2e-4 if dtype == "f32" else 3e-2) * sc)
+    # the same call in two parts (biu_foldt_bwd_weight_bn_phase): the tensor passes on this stream, the chain rule on ANOTHER one behind an event
+    da2 = Dev(da0, dtype=dtype)
+    two = [torch.full(t_.shape, float("nan"), device="cuda") for t_ in (wc, wt, bt)]
+    args = (xl.a(), xfl.x(), sk.a(), xfs.x(), da2.a(), yv.a(), ptr(yxf.d[0]), ptr(yxf.d[1]), ptr(yxf.d[2]), ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(da_sum),
+            ptr(dev[0]), ptr(dev[2]), ptr(dev[3]), cup, ptr(two[0]), ptr(two[1]), ptr(two[2]), ptr(ws), ws.numel(), code)
+    check(lib.biu_foldt_bwd_weight_bn_phase(*args, 1, stream()), "foldt_bwd_weight_bn_phase(1)")
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    side = torch.cuda.Stream()
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        check(lib.biu_foldt_bwd_weight_bn_phase(*args, 2, C.c_void_p(side.cuda_stream)), "foldt_bwd_weight_bn_phase(2)")
+    torch.cuda.current_stream().wait_stream(side)
+    assert lib.biu_foldt_bwd_weight_bn_phase(*args, 4, stream()) != 0                     # phases: 1, 2 or 3
+    assert torch.equal(da2.get(), da.get())
+    for t2, g_ in zip(two, got3):
+        # (the skip slice of dW_conv and G go through fp32 atomics: equal up to their summation order)
+        torch.testing.assert_close(t2.cpu(), g_.cpu(), rtol=1e-4, atol=1e-5 * float(g_.abs().max()))
 
 
 CONVT_MFMA_CASES = [
