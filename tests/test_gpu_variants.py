@@ -57,6 +57,15 @@ def _run(which, disable, tmp_path):
     # the folded weight gradient's G for all eight parity classes in one launch (k_wgrad_pipe<..., FALL>) against one launch per class
     # (BIU_DISABLE=foldall): the same operands, only the order of the fp32 sums over voxels differs
     ("unet3d_bf16", "foldall", 1e-6, 2.5e-4),
+    # the weight-space products of the fold (composed weights, chain rule) on the fp32 matrix pipe (biu_fold_gemm.hip) against the scalar
+    # kernels they replace (BIU_DISABLE=foldgemm): the same fp32 products in another summation order; the composed weights are then
+    # rounded to bf16 operands, so an output can fall to the other side of a rounding boundary
+    ("unet3d_f32", "foldgemm", 1e-5, 2e-2),
+    ("unet3d_bf16", "foldgemm", 2e-2, 6e-2),
+    # the engine's side stream (packing, chain rule, small weight gradients) against the single-stream step: the forward is the same
+    # kernels; in the backward the small levels take a separate BatchNorm-backward pass + the plain weight gradient instead of the fused
+    # loader (dy rounded by another kernel: the bf16 class of differences)
+    ("unet3d_bf16", "sidechain,prepack,capturefork", 1e-6, 6e-2),
     # 64-channel chunks of the folded forward where the output is one 32-channel tile (decode5) against 32-channel chunks (BIU_DISABLE=foldck8):
     # the same products summed in the same order (chunk by chunk, tap by tap inside a chunk differs) -- outputs may round differently
     ("unet3d_bf16", "foldck8", 2e-2, 6e-2),
