@@ -4390,8 +4390,9 @@ size_t biu_mfma_foldt_wgrad_workspace(int cin_low, int cskip, int cout, int dtyp
 int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const biu_act* da, const BnBwdFuse* bn,
                          const float* dy_sum, const float* w_conv, const float* w_t, const float* b_t, int cup, float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes,
                          int dtype, hipStream_t st, int phases) {
-    // phases: bit 0 = the passes over the tensors (skip half, G, border sums of dy -> tables in ws); bit 1 = the chain rule on those tables
-    // (reads ws and the parameters only: may run on another stream once phase 1 is complete, ws untouched in between)
+    // phases: bit 0 = the passes over the tensors (skip half with da -> dy, G into ws); bit 1 = border sums of the finished dy + the chain
+    // rule on the tables (reads dy's border shell, ws and the parameters: may run on another stream once phase 1 is complete, dy and ws
+    // untouched in between)
     const int cin_low = x_low->c, cskip = skip->c, cout = da->c, ccat = cup + cskip;
     const size_t need = biu_mfma_foldt_wgrad_workspace(cin_low, cskip, cout, dtype);
     BIU_REQUIRE(need > 0 && ws_bytes >= need, BIU_ERR_WORKSPACE, "foldt_wgrad: workspace %zu too small (need %zu)", ws_bytes, need);
@@ -4409,17 +4410,15 @@ int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const bi
         // 2. G[p][t] on the finished dy
         rc = biu_mfma_upconv_wgrad(x_low, xf_low, da, nullptr, ws, main_bytes, dtype, st, nullptr);
         if (rc != BIU_OK) return rc;
-        // 3. the ConvT bias: border sums of dy, one table per block
-        if (has_bias) {
-            const ShellDims sh = shell_dims(da->n, da->d, da->h, da->w);
-            BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_foldt_border_sums<T>, dim3(FOLDT_SUM_BLOCKS), dim3(256), foldt_sum_lds(cout), st,
-                                                         (const char*)da->p, sh, da->c, da->pitch, R));
-            BIU_CHECK_LAUNCH("foldt_border_sums");
-        }
     }
     if (!(phases & 2)) return BIU_OK;
-    // ... -> S_k (taps inside), needed by dW_conv (b_T is part of `up`) and by db_T
+    // 3. the ConvT bias: border sums of the finished dy (its shell only: 25 MB at 4 x 128^3), one table per block -> S_k (taps inside), needed
+    //    by dW_conv (b_T is part of `up`) and by db_T.  Part of phase 2: nothing on the caller's critical path waits for it.
     if (has_bias) {
+        const ShellDims sh = shell_dims(da->n, da->d, da->h, da->w);
+        BIU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_foldt_border_sums<T>, dim3(FOLDT_SUM_BLOCKS), dim3(256), foldt_sum_lds(cout), st,
+                                                     (const char*)da->p, sh, da->c, da->pitch, R));
+        BIU_CHECK_LAUNCH("foldt_border_sums");
         float* Rsum = Sk + 27 * cout;                                   // (rest of the Sk region: FOLDT_RED_SPLIT tables)
         hipLaunchKernelGGL(k_foldt_reduce_tables, dim3(27, FOLDT_RED_SPLIT), dim3(256), 0, st, (const float*)R, FOLDT_SUM_BLOCKS, cout, Rsum);
         hipLaunchKernelGGL(k_foldt_inside_sums, dim3(27, (cout + 31) / 32), dim3(256), 0, st, (const float*)Rsum, FOLDT_RED_SPLIT, cout, Sk, dy_sum);
