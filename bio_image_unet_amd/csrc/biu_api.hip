@@ -457,7 +457,7 @@ extern "C" int biu_foldt_bwd_weight_bn_phase(const biu_act* x_low, const biu_xfo
                                              const biu_act* y, const float* scale, const float* shift, const float* slope, const float* coefA,
                                              const float* coefB, const float* coefC, const float* dy_sum, const float* w_conv, const float* w_t, const float* b_t,
                                              int cup, float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes, int dtype, int phases, biu_stream stream) {
-    BIU_REQUIRE(phases >= 1 && phases <= 3, BIU_ERR_SHAPE, "foldt_bwd_weight_bn: phases must be 1 (tensor passes), 2 (chain rule) or 3 (both)");
+    BIU_REQUIRE(phases >= 1 && phases <= 7, BIU_ERR_SHAPE, "foldt_bwd_weight_bn: phases is a mask of 1 (skip half, da -> dy), 4 (G), 2 (border sums + chain rule)");
     BIU_REQUIRE(x_low && skip && da && w_conv && w_t && dw_conv && dw_t && ws && cup > 0, BIU_ERR_SHAPE, "foldt_bwd_weight_bn: null pointer");
     BIU_REQUIRE(biu_mfma_foldt_ok(x_low, skip, da, dtype) && biu_mfma_wgrad_ok(skip, da, 3, 3, 3, 1, dtype), BIU_ERR_UNSUPPORTED,
                 "foldt_bwd_weight_bn: shapes are not served by the folded kernels");
@@ -488,7 +488,7 @@ extern "C" int biu_foldt_bwd_weight_bn(const biu_act* x_low, const biu_xform* xf
                                        const float* coefB, const float* coefC, const float* dy_sum, const float* w_conv, const float* w_t, const float* b_t,
                                        int cup, float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes, int dtype, biu_stream stream) {
     return biu_foldt_bwd_weight_bn_phase(x_low, xf_low, skip, xf_skip, da, y, scale, shift, slope, coefA, coefB, coefC, dy_sum, w_conv, w_t, b_t, cup, dw_conv, dw_t,
-                                         db_t, ws, ws_bytes, dtype, 3, stream);
+                                         db_t, ws, ws_bytes, dtype, 7, stream);
 }
 
 extern "C" int biu_convt_fwd(const biu_act* x, const biu_xform* xf, const float* w, const void* packed, const float* bias,

@@ -4390,9 +4390,8 @@ size_t biu_mfma_foldt_wgrad_workspace(int cin_low, int cskip, int cout, int dtyp
 int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const biu_act* da, const BnBwdFuse* bn,
                          const float* dy_sum, const float* w_conv, const float* w_t, const float* b_t, int cup, float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes,
                          int dtype, hipStream_t st, int phases) {
-    // phases: bit 0 = the passes over the tensors (skip half with da -> dy, G into ws); bit 1 = border sums of the finished dy + the chain
-    // rule on the tables (reads dy's border shell, ws and the parameters: may run on another stream once phase 1 is complete, dy and ws
-    // untouched in between)
+    // phases: 1 = the skip half (da -> dy in place, its slice of dw_conv); 4 = G on the finished dy into ws; 2 = border sums of dy + the chain
+    // rule on the tables.  Parts 4 and 2 read dy, x_low, ws and the parameters: they may run on another stream once part 1 is complete
     const int cin_low = x_low->c, cskip = skip->c, cout = da->c, ccat = cup + cskip;
     const size_t need = biu_mfma_foldt_wgrad_workspace(cin_low, cskip, cout, dtype);
     BIU_REQUIRE(need > 0 && ws_bytes >= need, BIU_ERR_WORKSPACE, "foldt_wgrad: workspace %zu too small (need %zu)", ws_bytes, need);
@@ -4407,8 +4406,11 @@ int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const bi
         // 1. skip half of dW_conv (its slice of the channel axis), BatchNorm backward in the loader: da becomes dy
         int rc = biu_mfma_wgrad(skip, xf_skip, da, 3, 3, 3, dw_conv, nullptr, ws, main_bytes, dtype, st, bn, nullptr, nullptr, ccat, cup);
         if (rc != BIU_OK) return rc;
-        // 2. G[p][t] on the finished dy
-        rc = biu_mfma_upconv_wgrad(x_low, xf_low, da, nullptr, ws, main_bytes, dtype, st, nullptr);
+    }
+    if (phases & 4) {
+        // 2. G[p][t] on the finished dy (ws: the skip half's accumulators were flushed into dw_conv by its finalize on the same stream --
+        //    a caller that runs this part on another stream orders it behind part 1 with an event)
+        int rc = biu_mfma_upconv_wgrad(x_low, xf_low, da, nullptr, ws, main_bytes, dtype, st, nullptr);
         if (rc != BIU_OK) return rc;
     }
     if (!(phases & 2)) return BIU_OK;

@@ -101,7 +101,7 @@ int biu_mfma_foldt_dgrad(const biu_act* dy, const void* packed, const biu_act* d
 size_t biu_mfma_foldt_wgrad_workspace(int cin_low, int cskip, int cout, int dtype);
 int biu_mfma_foldt_wgrad(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const biu_act* da, const BnBwdFuse* bn,
                          const float* dy_sum, const float* w_conv, const float* w_t, const float* b_t, int cup, float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes,
-                         int dtype, hipStream_t st, int phases = 3);
+                         int dtype, hipStream_t st, int phases = 7);
 bool biu_mfma_convt_ok(int kind, const biu_act* lo, const biu_act* hi, int kd, int dtype);
 int biu_mfma_convt_fwd(const biu_act* x, const biu_xform* xf, const void* packed, const float* bias, int kd, const biu_act* y,
                        int dtype, hipStream_t st);

@@ -381,11 +381,11 @@ int    biu_foldt_bwd_weight_bn(const biu_act* x_low, const biu_xform* xf_low, co
                                const biu_act* y, const float* scale, const float* shift, const float* slope, const float* coefA,
                                const float* coefB, const float* coefC, const float* dy_sum, const float* w_conv, const float* w_t, const float* b_t,
                                int cup, float* dw_conv, float* dw_t, float* db_t, void* ws, size_t ws_bytes, int dtype, biu_stream stream);
-/* the same call in two parts, for a caller that overlaps the chain rule with the rest of its backward.  phases = 1: the passes over the
- * tensors (da -> dy in place, the skip slice of dw_conv, G into ws); phases = 2: the border sums of the finished dy and the chain rule on
- * the tables (the up slice of dw_conv, dw_t, db_t) -- reads the border shell of dy (= da after phase 1), ws, dy_sum and the parameters, so it
- * may be enqueued on ANOTHER stream once phase 1 is complete there (the caller orders the two with an event and leaves dy and ws alone in
- * between; reading dy meanwhile is fine); phases = 3 = biu_foldt_bwd_weight_bn. */
+/* the same call in parts, for a caller that overlaps everything only the optimizer waits for with the rest of its backward.  `phases` is a
+ * mask: 1 = the skip half (da -> dy in place by the fused BatchNorm backward, the skip slice of dw_conv); 4 = G on the finished dy into ws;
+ * 2 = the border sums of dy and the chain rule on the tables (the up slice of dw_conv, dw_t, db_t).  Parts 4 and 2 read dy (= da after part
+ * 1), x_low, ws, dy_sum and the parameters: they may be enqueued on ANOTHER stream once part 1 is complete there (the caller orders them
+ * with an event, part 4 before part 2, and leaves dy and ws alone in between; reading dy meanwhile is fine); 7 = biu_foldt_bwd_weight_bn. */
 int    biu_foldt_bwd_weight_bn_phase(const biu_act* x_low, const biu_xform* xf_low, const biu_act* skip, const biu_xform* xf_skip, const biu_act* da,
                                      const biu_act* y, const float* scale, const float* shift, const float* slope, const float* coefA,
                                      const float* coefB, const float* coefC, const float* dy_sum, const float* w_conv, const float* w_t,

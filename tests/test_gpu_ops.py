@@ -736,15 +736,16 @@ def test_foldt_fwd_matches_convT_concat_conv(case, dtype):
     two = [torch.full(t_.shape, float("nan"), device="cuda") for t_ in (wc, wt, bt)]
     args = (xl.a(), xfl.x(), sk.a(), xfs.x(), da2.a(), yv.a(), ptr(yxf.d[0]), ptr(yxf.d[1]), ptr(yxf.d[2]), ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(da_sum),
             ptr(dev[0]), ptr(dev[2]), ptr(dev[3]), cup, ptr(two[0]), ptr(two[1]), ptr(two[2]), ptr(ws), ws.numel(), code)
-    check(lib.biu_foldt_bwd_weight_bn_phase(*args, 1, stream()), "foldt_bwd_weight_bn_phase(1)")
+    check(lib.biu_foldt_bwd_weight_bn_phase(*args, 1, stream()), "foldt_bwd_weight_bn_phase(1)")          # skip half: da -> dy
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream())
     side = torch.cuda.Stream()
     side.wait_event(ev)
     with torch.cuda.stream(side):
-        check(lib.biu_foldt_bwd_weight_bn_phase(*args, 2, C.c_void_p(side.cuda_stream)), "foldt_bwd_weight_bn_phase(2)")
+        check(lib.biu_foldt_bwd_weight_bn_phase(*args, 4, C.c_void_p(side.cuda_stream)), "foldt_bwd_weight_bn_phase(4)")      # G
+        check(lib.biu_foldt_bwd_weight_bn_phase(*args, 2, C.c_void_p(side.cuda_stream)), "foldt_bwd_weight_bn_phase(2)")      # border sums + chain rule
     torch.cuda.current_stream().wait_stream(side)
-    assert lib.biu_foldt_bwd_weight_bn_phase(*args, 4, stream()) != 0                     # phases: 1, 2 or 3
+    assert lib.biu_foldt_bwd_weight_bn_phase(*args, 8, stream()) != 0                     # phases: a mask of 1 | 4 | 2
     assert torch.equal(da2.get(), da.get())
     for t2, g_ in zip(two, got3):
         # (the skip slice of dW_conv and G go through fp32 atomics: equal up to their summation order)
