@@ -73,9 +73,9 @@ for name, n, cl, cup, cs, cout, (d, h, w) in (("decode5", 4, 64, 64, 32, 32, (64
         t = timed(lambda: check(lib.biu_foldt_bwd_weight_bn(C.byref(axl), C.byref(xfl), C.byref(ask), C.byref(xfs), C.byref(ady), C.byref(ay), P(kv[0]), P(kv[1]), P(kv[2]),
                                                             P(kv[3]), P(kv[4]), P(kv[5]), None, P(wc), P(wt), P(bt), cup, P(dwc), P(dwt), P(dbt), P(ws), ws.numel(), code, st)))
         out.append(f"wgrad_bn {t:.3f} ms {fl / t / 1e9:.0f} TF/s")
-    if "wg1" in legs:                                    # the tensor passes alone (phase 1): wgrad_bn minus this = the chain rule on the tables
+    if "wg1" in legs:                                    # the main-stream part (skip half with da -> dy, G): wgrad_bn minus this = border sums + chain rule
         t = timed(lambda: check(lib.biu_foldt_bwd_weight_bn_phase(C.byref(axl), C.byref(xfl), C.byref(ask), C.byref(xfs), C.byref(ady), C.byref(ay), P(kv[0]), P(kv[1]),
                                                                   P(kv[2]), P(kv[3]), P(kv[4]), P(kv[5]), None, P(wc), P(wt), P(bt), cup, P(dwc), P(dwt), P(dbt), P(ws),
-                                                                  ws.numel(), code, 1, st)))
-        out.append(f"wgrad_bn(phase 1) {t:.3f} ms")
+                                                                  ws.numel(), code, 1 | 4, st)))
+        out.append(f"wgrad_bn(phases 1 | 4) {t:.3f} ms")
     print(f"{name} x_low {cl} ch @{(d, h, w)}, up {cup} | skip {cs} -> {cout} @{(2 * d, 2 * h, 2 * w)}: " + " | ".join(out), flush=True)

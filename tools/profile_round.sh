@@ -13,7 +13,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O -o cfg4 --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_profiler.json 2> $O/bench_under_profiler.err
 echo "trace done" >> $O/progress.txt
-# one pair of counter passes per leg of the folded decode5 op (tools/bench_foldt.py: wg1 = biu_foldt_bwd_weight_bn_phase(1), the tensor passes of the weight gradient; fwd; dg): bench.py's dominant
+# one pair of counter passes per leg of the folded decode5 op (tools/bench_foldt.py: wg1 = biu_foldt_bwd_weight_bn_phase(1 | 4), the main-stream part of the weight gradient; fwd; dg): bench.py's dominant
 # call is one of them (before the fold: tools/bench_conv.py cfg4 bf16 decode5 with BENCH_LEGS=dg_cat | wg_cat | fwd_cat)
 export BENCH_REPS=20
 for L in ${LEG//,/ }; do
