@@ -233,3 +233,32 @@ def test_side_stream_gradients_match_the_single_stream_step(tmp_path):
         g1 = res["single"][k]
         scale = float(g1.abs().max()) + 1e-20
         assert float((gs - g1).abs().max()) <= 2e-2 * scale, (k, float((gs - g1).abs().max()) / scale)
+
+
+def test_tensors_a_fold_never_materialises_hold_no_memory():
+    """ConvTranspose + concat + conv as one op (biu_foldt_*) never writes the ConvT output, nearest up-sampling + conv folded in all three
+    directions never writes the up-sampled tensor: their buffers (and gradient twins) are released at engine build, their Acts keep extents
+    and channel counts but a NULL pointer."""
+    from bio_image_unet_amd import engine as E
+    torch.manual_seed(0)
+    for mk, shape in ((lambda: B.UNet3D(1, 1, 16), (1, 1, 16, 32, 32)),
+                      (lambda: B.MultiOutputUnet3D(1, None, 16, use_interpolation=True), (1, 1, 16, 32, 32))):
+        m = mk().cuda()
+        m.set_compute_dtype(torch.bfloat16)
+        m.train()
+        x = torch.rand(*shape, device="cuda")
+        out = m(x)
+        t = out[1] if isinstance(out, tuple) else sum(v.float().mean() for v in out.values())
+        t.float().square().mean().backward()
+        torch.cuda.synchronize()
+        eng = list(m._engines.values())[-1][-1]
+        released = 0
+        for nd in eng.nodes:
+            if isinstance(nd, E.ConvTNode) and nd.folded_into is not None:
+                assert nd.y.buf.t is None and nd.y.buf.g is None and not nd.y._a.p
+                released += 1
+            if isinstance(nd, E.ResampleNode) and getattr(nd, "skip", False):
+                assert nd.y.buf.t is None and not nd.y._a.p
+                released += 1
+        assert released >= 2, released
+        assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
