@@ -191,21 +191,30 @@ static ReducePlan plan_reduce(i64 total_vox, int C, int max_blocks) {
     return p;
 }
 
+// Sum of (a0, a1) over the block's threads, left in d0[0] / d1[0] for thread 0: wave shuffles + one LDS exchange (these one-block-per-channel
+// kernels sit between every two convolutions of a step: the former 8-barrier LDS tree was most of their run time).  Fixed order: reproducible.
+__device__ __forceinline__ void bn_block_sum2(double a0, double a1, double* d0, double* d1) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); }
+    if ((threadIdx.x & 63) == 0) { d0[threadIdx.x >> 6] = a0; d1[threadIdx.x >> 6] = a1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t0 = d0[0], t1 = d1[0];
+        for (int w = 1; w < TPB / 64; ++w) { t0 += d0[w]; t1 += d1[w]; }
+        d0[0] = t0; d1[0] = t1;
+    }
+}
+
 // out0[c] = sum_b partial[b][c][0], out1[c] = sum_b partial[b][c][1]   (fp64 merge), one block per channel
 __global__ void k_partial_sum(const float* __restrict__ partial, int nblk, int C, float* out0, float* out1) {
-    __shared__ double d0[TPB], d1[TPB];
+    __shared__ double d0[TPB / 64], d1[TPB / 64];
     int c = blockIdx.x;
     double a0 = 0, a1 = 0;
     for (int b = threadIdx.x; b < nblk; b += TPB) {
         a0 += partial[((i64)b * C + c) * 2 + 0];
         a1 += partial[((i64)b * C + c) * 2 + 1];
     }
-    d0[threadIdx.x] = a0; d1[threadIdx.x] = a1;
-    __syncthreads();
-    for (int s = TPB / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s) { d0[threadIdx.x] += d0[threadIdx.x + s]; d1[threadIdx.x] += d1[threadIdx.x + s]; }
-        __syncthreads();
-    }
+    bn_block_sum2(a0, a1, d0, d1);                       // (totals in d0[0], d1[0], read by thread 0 below)
     if (threadIdx.x == 0) {
         if (out0) out0[c] = (float)d0[0];
         if (out1) out1[c] = (float)d1[0];
@@ -228,19 +237,14 @@ __global__ void k_bn_finalize(const float* __restrict__ partial, int nblk, int C
                               const float* gamma, const float* beta, float* running_mean, float* running_var,
                               float momentum, float eps, float* scale, float* shift, float* save_mean,
                               float* save_invstd) {
-    __shared__ double d0[TPB], d1[TPB];
+    __shared__ double d0[TPB / 64], d1[TPB / 64];
     int c = blockIdx.x;
     double a0 = 0, a1 = 0;
     for (int b = threadIdx.x; b < nblk; b += TPB) {
         a0 += partial[((i64)b * C + c) * 2 + 0];
         a1 += partial[((i64)b * C + c) * 2 + 1];
     }
-    d0[threadIdx.x] = a0; d1[threadIdx.x] = a1;
-    __syncthreads();
-    for (int s = TPB / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s) { d0[threadIdx.x] += d0[threadIdx.x + s]; d1[threadIdx.x] += d1[threadIdx.x + s]; }
-        __syncthreads();
-    }
+    bn_block_sum2(a0, a1, d0, d1);                       // (totals in d0[0], d1[0], read by thread 0 below)
     if (threadIdx.x == 0) {
         double mean = d0[0] / count;
         double var = d1[0] / count - mean * mean;
@@ -304,19 +308,14 @@ template <typename T> struct BnBwdF {
 __global__ void k_bn_bwd_finalize(const float* __restrict__ partial, int nblk, int C, double count,
                                   const float* scale, const float* mean, const float* invstd, float* dgamma,
                                   float* dbeta, float* A, float* B, float* Cc) {
-    __shared__ double d0[TPB], d1[TPB];
+    __shared__ double d0[TPB / 64], d1[TPB / 64];
     int c = blockIdx.x;
     double a0 = 0, a1 = 0;
     for (int b = threadIdx.x; b < nblk; b += TPB) {
         a0 += partial[((i64)b * C + c) * 2 + 0];
         a1 += partial[((i64)b * C + c) * 2 + 1];
     }
-    d0[threadIdx.x] = a0; d1[threadIdx.x] = a1;
-    __syncthreads();
-    for (int s = TPB / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s) { d0[threadIdx.x] += d0[threadIdx.x + s]; d1[threadIdx.x] += d1[threadIdx.x + s]; }
-        __syncthreads();
-    }
+    bn_block_sum2(a0, a1, d0, d1);                       // (totals in d0[0], d1[0], read by thread 0 below)
     if (threadIdx.x == 0) {
         double S1 = d0[0], S2 = d1[0];
         if (dbeta) dbeta[c] = (float)S1;
@@ -333,19 +332,14 @@ __global__ void k_bn_bwd_finalize(const float* __restrict__ partial, int nblk, i
 // eval-mode BatchNorm: the statistics are constants, dy = scale * dz
 __global__ void k_bn_bwd_finalize_eval(const float* __restrict__ partial, int nblk, int C, const float* scale, float* dgamma, float* dbeta,
                                        float* dbias, float* A, float* B, float* Cc) {
-    __shared__ double d0[TPB], d1[TPB];
+    __shared__ double d0[TPB / 64], d1[TPB / 64];
     int c = blockIdx.x;
     double a0 = 0, a1 = 0;
     for (int b = threadIdx.x; b < nblk; b += TPB) {
         a0 += partial[((i64)b * C + c) * 2 + 0];
         a1 += partial[((i64)b * C + c) * 2 + 1];
     }
-    d0[threadIdx.x] = a0; d1[threadIdx.x] = a1;
-    __syncthreads();
-    for (int s = TPB / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s) { d0[threadIdx.x] += d0[threadIdx.x + s]; d1[threadIdx.x] += d1[threadIdx.x + s]; }
-        __syncthreads();
-    }
+    bn_block_sum2(a0, a1, d0, d1);                       // (totals in d0[0], d1[0], read by thread 0 below)
     if (threadIdx.x == 0) {
         if (dbeta) dbeta[c] = (float)d0[0];
         if (dgamma) dgamma[c] = (float)d1[0];
